@@ -1,0 +1,340 @@
+// C ABI of libbnhip.so (see include/bnhip.h for the reference interfaces each entry point replaces).
+#include "../../include/bnhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "engine.h"
+#include "tflite_model.h"
+
+using namespace bnhip;
+
+struct bnhip_model {
+    Engine eng;
+};
+
+namespace {
+
+thread_local std::string g_err;
+std::mutex g_init_mu;
+int g_devices = -1;     // -1 = not initialised
+
+int set_err(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+// tiny extractor for {"key": <int>} options; absent -> def
+long json_int(const char* js, const char* key, long def) {
+    if (!js) return def;
+    std::string pat = std::string("\"") + key + "\"";
+    const char* p = strstr(js, pat.c_str());
+    if (!p) return def;
+    p += pat.size();
+    while (*p == ' ' || *p == ':' || *p == '\t') p++;
+    char* end = nullptr;
+    long v = strtol(p, &end, 10);
+    return end == p ? def : v;
+}
+
+bool is_gfx950(int dev) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bnhip_version(void) { return "bnhip 0.1 (gfx950)"; }
+const char* bnhip_last_error(void) { return g_err.c_str(); }
+
+int bnhip_init(int* n_devices) {
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    if (g_devices < 0) {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            if (n_devices) *n_devices = 0;
+            return set_err(BNHIP_E_NO_DEVICE, std::string("no HIP device available: ") + hipGetErrorString(e));
+        }
+        int usable = 0;
+        for (int d = 0; d < n; d++) if (is_gfx950(d)) usable++;
+        if (!usable) {
+            if (n_devices) *n_devices = 0;
+            return set_err(BNHIP_E_NO_DEVICE, "no gfx950 (MI355X) device found; this library ships gfx950 code objects only");
+        }
+        g_devices = n;
+    }
+    if (n_devices) *n_devices = g_devices;
+    return BNHIP_OK;
+}
+
+void bnhip_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    g_devices = -1;
+}
+
+int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, bnhip_model** out) {
+    if (!out) return set_err(BNHIP_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!blob || n_bytes == 0) return set_err(BNHIP_E_INVALID, "empty model blob");
+    // "plan_only": parse + plan on the CPU, no device touched (diagnostics / CPU-side tests); such a
+    // model answers info/describe and rejects predict calls.
+    const bool plan_only = json_int(opts_json, "plan_only", 0) != 0;
+    int device = (int)json_int(opts_json, "device", 0);
+    int max_batch = (int)json_int(opts_json, "max_batch", 256);
+    if (max_batch < 1 || max_batch > 4096) return set_err(BNHIP_E_INVALID, "max_batch must be in [1, 4096]");
+    if (!plan_only) {
+        int rc = bnhip_init(nullptr);
+        if (rc != BNHIP_OK) return rc;
+        if (device < 0 || device >= g_devices) return set_err(BNHIP_E_INVALID, "device ordinal out of range");
+        if (!is_gfx950(device)) return set_err(BNHIP_E_NO_DEVICE, "selected device is not gfx950");
+    }
+
+    TflModel tm;
+    std::string err;
+    if (!parse_tflite(blob, n_bytes, &tm, &err)) return set_err(BNHIP_E_MODEL, err);
+    bnhip_model* m = new (std::nothrow) bnhip_model();
+    if (!m) return set_err(BNHIP_E_NOMEM, "out of host memory");
+    int code = BNHIP_E_UNSUPPORTED;
+    if (!m->eng.build(tm, device, max_batch, plan_only, &err, &code)) {
+        delete m;
+        return set_err(code == BNHIP_OK ? BNHIP_E_UNSUPPORTED : code, err);
+    }
+    *out = m;
+    return BNHIP_OK;
+}
+
+int bnhip_model_info(const bnhip_model* m, int* n_samples, int* n_classes, int* emb_dim) {
+    if (!m) return set_err(BNHIP_E_INVALID, "model is NULL");
+    if (n_samples) *n_samples = m->eng.n_samples;
+    if (n_classes) *n_classes = m->eng.n_classes;
+    if (emb_dim) *emb_dim = m->eng.emb_dim;
+    return BNHIP_OK;
+}
+
+void bnhip_model_destroy(bnhip_model* m) {
+    if (!m) return;
+    if (m->eng.device >= 0) hipSetDevice(m->eng.device);
+    delete m;
+}
+
+int bnhip_set_stream(bnhip_model* m, void* hip_stream) {
+    if (!m || m->eng.device < 0) return set_err(BNHIP_E_INVALID, "model is NULL or plan-only");
+    Engine& e = m->eng;
+    hipSetDevice(e.device);
+    if (e.own_stream && e.stream) { hipStreamSynchronize(e.stream); hipStreamDestroy(e.stream); }
+    e.stream = reinterpret_cast<hipStream_t>(hip_stream);
+    e.own_stream = false;
+    return BNHIP_OK;
+}
+
+int bnhip_synchronize(bnhip_model* m) {
+    if (!m || m->eng.device < 0) return set_err(BNHIP_E_INVALID, "model is NULL or plan-only");
+    hipSetDevice(m->eng.device);
+    hipError_t e = hipStreamSynchronize(m->eng.stream);
+    if (e != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    return BNHIP_OK;
+}
+
+int bnhip_predict_device(bnhip_model* m, const float* d_samples, int n_clips, float* d_logits, float* d_emb) {
+    if (!m || !d_samples || !d_logits) return set_err(BNHIP_E_INVALID, "NULL argument");
+    if (n_clips <= 0) return set_err(BNHIP_E_INVALID, "n_clips must be positive");
+    Engine& e = m->eng;
+    if (e.device < 0) return set_err(BNHIP_E_INVALID, "plan-only model cannot run");
+    if (hipSetDevice(e.device) != hipSuccess) return set_err(BNHIP_E_RUNTIME, "hipSetDevice failed");
+    std::string err;
+    for (int off = 0; off < n_clips; off += e.max_batch) {
+        int n = std::min(e.max_batch, n_clips - off);
+        if (!e.run(d_samples + (size_t)off * e.n_samples, n, d_logits + (size_t)off * e.n_classes,
+                   d_emb ? d_emb + (size_t)off * e.emb_dim : nullptr, &err))
+            return set_err(BNHIP_E_RUNTIME, err);
+    }
+    return BNHIP_OK;
+}
+
+static int predict_host(bnhip_model* m, const void* src, bool pcm16, int n_clips, float* logits, float* emb) {
+    if (!m || !src || !logits) return set_err(BNHIP_E_INVALID, "NULL argument");
+    if (n_clips <= 0) return set_err(BNHIP_E_INVALID, "n_clips must be positive");
+    Engine& e = m->eng;
+    if (e.device < 0) return set_err(BNHIP_E_INVALID, "plan-only model cannot run");
+    if (emb && !e.emb_dim) return set_err(BNHIP_E_INVALID, "model has no embedding output");
+    if (hipSetDevice(e.device) != hipSuccess) return set_err(BNHIP_E_RUNTIME, "hipSetDevice failed");
+    std::string err;
+    if (pcm16 && !e.d_stage_pcm) {
+        if (hipMalloc((void**)&e.d_stage_pcm, (size_t)e.max_batch * e.n_samples * 2) != hipSuccess)
+            return set_err(BNHIP_E_NOMEM, "device allocation failed (pcm staging)");
+    }
+    for (int off = 0; off < n_clips; off += e.max_batch) {
+        int n = std::min(e.max_batch, n_clips - off);
+        size_t cnt = (size_t)n * e.n_samples;
+        hipError_t he;
+        if (pcm16) {
+            he = hipMemcpyAsync(e.d_stage_pcm, (const int16_t*)src + (size_t)off * e.n_samples, cnt * 2,
+                                hipMemcpyHostToDevice, e.stream);
+            if (he == hipSuccess) launch_pcm16_to_f32(e.d_stage_pcm, e.d_stage_in, cnt, e.stream);
+        } else {
+            he = hipMemcpyAsync(e.d_stage_in, (const float*)src + (size_t)off * e.n_samples, cnt * 4,
+                                hipMemcpyHostToDevice, e.stream);
+        }
+        if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("H2D copy: ") + hipGetErrorString(he));
+        if (!e.run(e.d_stage_in, n, e.d_stage_logits, emb ? e.d_stage_emb : nullptr, &err))
+            return set_err(BNHIP_E_RUNTIME, err);
+        he = hipMemcpyAsync(logits + (size_t)off * e.n_classes, e.d_stage_logits, (size_t)n * e.n_classes * 4,
+                            hipMemcpyDeviceToHost, e.stream);
+        if (he == hipSuccess && emb)
+            he = hipMemcpyAsync(emb + (size_t)off * e.emb_dim, e.d_stage_emb, (size_t)n * e.emb_dim * 4,
+                                hipMemcpyDeviceToHost, e.stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(e.stream);
+        if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("D2H copy/sync: ") + hipGetErrorString(he));
+    }
+    return BNHIP_OK;
+}
+
+int bnhip_predict(bnhip_model* m, const float* samples, int n_clips, float* logits, float* emb) {
+    return predict_host(m, samples, false, n_clips, logits, emb);
+}
+
+int bnhip_predict_pcm16(bnhip_model* m, const int16_t* pcm, int n_clips, float* logits, float* emb) {
+    return predict_host(m, pcm, true, n_clips, logits, emb);
+}
+
+static int ensure_topk(Engine& e, int k) {
+    if (k <= e.topk_cap) return BNHIP_OK;
+    if (e.d_topk_conf) hipFree(e.d_topk_conf);
+    if (e.d_topk_idx) hipFree(e.d_topk_idx);
+    e.d_topk_conf = nullptr; e.d_topk_idx = nullptr; e.topk_cap = 0;
+    if (hipMalloc((void**)&e.d_topk_conf, (size_t)e.max_batch * k * 4) != hipSuccess ||
+        hipMalloc((void**)&e.d_topk_idx, (size_t)e.max_batch * k * 4) != hipSuccess)
+        return set_err(BNHIP_E_NOMEM, "device allocation failed (top-k)");
+    e.topk_cap = k;
+    return BNHIP_OK;
+}
+
+int bnhip_postprocess_topk(bnhip_model* m, const float* logits, int n_clips, int n_classes, int activation,
+                           double sensitivity, int k, float* out_conf, int32_t* out_idx) {
+    if (!m || !logits || !out_conf || !out_idx) return set_err(BNHIP_E_INVALID, "NULL argument");
+    Engine& e = m->eng;
+    if (n_clips <= 0 || k <= 0) return set_err(BNHIP_E_INVALID, "n_clips and k must be positive");
+    if (e.device < 0) return set_err(BNHIP_E_INVALID, "plan-only model cannot run");
+    if (n_classes != e.n_classes) return set_err(BNHIP_E_INVALID, "n_classes does not match the model");
+    if (activation < 0 || activation > 2) return set_err(BNHIP_E_INVALID, "unknown activation");
+    if (n_classes * 4 > 150 * 1024) return set_err(BNHIP_E_UNSUPPORTED, "too many classes for the LDS top-k");
+    hipSetDevice(e.device);
+    int kk = std::min(k, n_classes);
+    int rc = ensure_topk(e, kk);
+    if (rc) return rc;
+    for (int off = 0; off < n_clips; off += e.max_batch) {
+        int n = std::min(e.max_batch, n_clips - off);
+        hipError_t he = hipMemcpyAsync(e.d_stage_logits, logits + (size_t)off * n_classes, (size_t)n * n_classes * 4,
+                                       hipMemcpyHostToDevice, e.stream);
+        if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("H2D copy: ") + hipGetErrorString(he));
+        launch_activation(e.d_stage_logits, e.d_post_conf, n, n_classes, activation, sensitivity, e.stream);
+        launch_topk(e.d_post_conf, n, n_classes, kk, e.d_topk_conf, e.d_topk_idx, e.stream);
+        hipMemcpyAsync(out_conf + (size_t)off * kk, e.d_topk_conf, (size_t)n * kk * 4, hipMemcpyDeviceToHost, e.stream);
+        hipMemcpyAsync(out_idx + (size_t)off * kk, e.d_topk_idx, (size_t)n * kk * 4, hipMemcpyDeviceToHost, e.stream);
+        he = hipStreamSynchronize(e.stream);
+        if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("postprocess: ") + hipGetErrorString(he));
+    }
+    return BNHIP_OK;
+}
+
+int bnhip_predict_topk(bnhip_model* m, const float* samples, int n_clips, int activation, double sensitivity, int k,
+                       float* out_conf, int32_t* out_idx) {
+    if (!m || !samples || !out_conf || !out_idx) return set_err(BNHIP_E_INVALID, "NULL argument");
+    Engine& e = m->eng;
+    if (n_clips <= 0 || k <= 0) return set_err(BNHIP_E_INVALID, "n_clips and k must be positive");
+    if (activation < 0 || activation > 2) return set_err(BNHIP_E_INVALID, "unknown activation");
+    if (e.n_classes * 4 > 150 * 1024) return set_err(BNHIP_E_UNSUPPORTED, "too many classes for the LDS top-k");
+    if (e.device < 0) return set_err(BNHIP_E_INVALID, "plan-only model cannot run");
+    hipSetDevice(e.device);
+    int kk = std::min(k, e.n_classes);
+    int rc = ensure_topk(e, kk);
+    if (rc) return rc;
+    std::string err;
+    for (int off = 0; off < n_clips; off += e.max_batch) {
+        int n = std::min(e.max_batch, n_clips - off);
+        hipError_t he = hipMemcpyAsync(e.d_stage_in, samples + (size_t)off * e.n_samples, (size_t)n * e.n_samples * 4,
+                                       hipMemcpyHostToDevice, e.stream);
+        if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("H2D copy: ") + hipGetErrorString(he));
+        if (!e.run(e.d_stage_in, n, e.d_stage_logits, nullptr, &err)) return set_err(BNHIP_E_RUNTIME, err);
+        launch_activation(e.d_stage_logits, e.d_post_conf, n, e.n_classes, activation, sensitivity, e.stream);
+        launch_topk(e.d_post_conf, n, e.n_classes, kk, e.d_topk_conf, e.d_topk_idx, e.stream);
+        hipMemcpyAsync(out_conf + (size_t)off * kk, e.d_topk_conf, (size_t)n * kk * 4, hipMemcpyDeviceToHost, e.stream);
+        hipMemcpyAsync(out_idx + (size_t)off * kk, e.d_topk_idx, (size_t)n * kk * 4, hipMemcpyDeviceToHost, e.stream);
+        he = hipStreamSynchronize(e.stream);
+        if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("predict_topk: ") + hipGetErrorString(he));
+    }
+    return BNHIP_OK;
+}
+
+int bnhip_us_frame_cv(int device, const double* samples, int n_clips, int n, int sample_rate, int fft_size, int hop,
+                      int split_hz, double* cv, int32_t* ok) {
+    if (!samples || !cv || !ok || n_clips <= 0) return set_err(BNHIP_E_INVALID, "NULL/empty argument");
+    // guards: internal/audiocore/ultrasonic/filter.go:21-37
+    bool valid = !(n < fft_size || sample_rate <= 0 || fft_size < 2 || hop <= 0) && (fft_size & (fft_size - 1)) == 0 &&
+                 !(split_hz < 0 || split_hz >= sample_rate / 2);
+    int frames = valid ? 1 + (n - fft_size) / hop : 0;
+    if (!valid || frames < 2) {
+        for (int i = 0; i < n_clips; i++) { cv[i] = 0.0; ok[i] = 0; }
+        return BNHIP_OK;
+    }
+    if ((size_t)fft_size * 16 > 160 * 1024 - 256) return set_err(BNHIP_E_UNSUPPORTED, "FFT size exceeds the LDS-resident limit (8192)");
+    int rc = bnhip_init(nullptr);
+    if (rc) return rc;
+    if (device < 0 || device >= g_devices) return set_err(BNHIP_E_INVALID, "device ordinal out of range");
+    hipSetDevice(device);
+    double bin_width = (double)sample_rate / (double)fft_size;
+    int split_bin = (int)((double)split_hz / bin_width);
+    double *d_s = nullptr, *d_p = nullptr, *d_cv = nullptr;
+    hipError_t he = hipMalloc((void**)&d_s, (size_t)n_clips * n * 8);
+    if (he == hipSuccess) he = hipMalloc((void**)&d_p, (size_t)n_clips * frames * 8);
+    if (he == hipSuccess) he = hipMalloc((void**)&d_cv, (size_t)n_clips * 8);
+    if (he == hipSuccess) he = hipMemcpy(d_s, samples, (size_t)n_clips * n * 8, hipMemcpyHostToDevice);
+    if (he == hipSuccess) {
+        launch_us_frame_power(d_s, n_clips, n, fft_size, hop, frames, split_bin, d_p, nullptr);
+        launch_us_cv(d_p, n_clips, frames, d_cv, nullptr);
+        he = hipMemcpy(cv, d_cv, (size_t)n_clips * 8, hipMemcpyDeviceToHost);
+    }
+    if (d_s) hipFree(d_s);
+    if (d_p) hipFree(d_p);
+    if (d_cv) hipFree(d_cv);
+    if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("us_frame_cv: ") + hipGetErrorString(he));
+    for (int i = 0; i < n_clips; i++) ok[i] = 1;
+    return BNHIP_OK;
+}
+
+int bnhip_profile_enable(bnhip_model* m, int on) {
+    if (!m) return set_err(BNHIP_E_INVALID, "model is NULL");
+    m->eng.profiling = on != 0;
+    return BNHIP_OK;
+}
+
+static int copy_out(const std::string& s, char* buf, size_t cap) {
+    if (buf && cap) {
+        size_t n = std::min(cap - 1, s.size());
+        memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return (int)s.size() + 1;
+}
+
+int bnhip_profile_read(bnhip_model* m, char* buf, size_t cap) {
+    if (!m || m->eng.device < 0) return set_err(BNHIP_E_INVALID, "model is NULL or plan-only");
+    hipSetDevice(m->eng.device);
+    return copy_out(m->eng.profile_read(), buf, cap);
+}
+
+int bnhip_model_describe(const bnhip_model* m, char* buf, size_t cap) {
+    if (!m) return set_err(BNHIP_E_INVALID, "model is NULL");
+    return copy_out(m->eng.describe(), buf, cap);
+}
+
+}  // extern "C"

@@ -1,0 +1,919 @@
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <sstream>
+
+#include "../../include/bnhip.h"
+
+namespace bnhip {
+
+#define HIPCHK(call)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            *err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+            return false;                                                                      \
+        }                                                                                      \
+    } while (0)
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Planner {
+    const TflModel& m;
+    std::vector<int> producer;                 // tensor -> op index (-1: const / input)
+    std::vector<std::vector<int>> consumers;   // tensor -> op indices
+    std::vector<int> uses;                     // consumer count + graph outputs
+    std::vector<char> absorbed;                // op consumed by a fusion
+    std::string err;
+    int code = BNHIP_E_UNSUPPORTED;
+
+    explicit Planner(const TflModel& mm) : m(mm) {
+        int nt = (int)m.tensors.size();
+        producer.assign(nt, -1);
+        consumers.assign(nt, {});
+        uses.assign(nt, 0);
+        absorbed.assign(m.ops.size(), 0);
+        for (int i = 0; i < (int)m.ops.size(); i++) {
+            for (int o : m.ops[i].outputs) producer[o] = i;
+            for (int t : m.ops[i].inputs)
+                if (t >= 0) { consumers[t].push_back(i); uses[t]++; }
+        }
+        for (int t : m.outputs) uses[t]++;
+    }
+    bool is_const(int t) const { return t >= 0 && m.tensors[t].data != nullptr; }
+    const TflTensor& T(int t) const { return m.tensors[t]; }
+    bool fail(const std::string& s) { if (err.empty()) err = s; return false; }
+
+    static bool shape_op(int code) { return code == OP_RESHAPE || code == OP_EXPAND_DIMS || code == OP_SQUEEZE; }
+
+    int skip_up(int t) {          // walk producers through pure shape ops
+        while (t >= 0 && producer[t] >= 0 && shape_op(m.ops[producer[t]].code)) {
+            absorbed[producer[t]] = 1;
+            t = m.ops[producer[t]].inputs[0];
+        }
+        return t;
+    }
+    int skip_down(int t) {        // walk single consumers through pure shape ops
+        while (consumers[t].size() == 1 && shape_op(m.ops[consumers[t][0]].code)) {
+            absorbed[consumers[t][0]] = 1;
+            t = m.ops[consumers[t][0]].outputs[0];
+        }
+        return t;
+    }
+    int only_consumer(int t) const { return consumers[t].size() == 1 ? consumers[t][0] : -1; }
+    // scalar float const?
+    bool const_scalar(int t, float* v) const {
+        if (!is_const(t) || T(t).type != TT_FLOAT32 || T(t).numel() != 1) return false;
+        *v = T(t).f32()[0];
+        return true;
+    }
+    // binary op with one const-scalar operand: returns the other operand
+    int bin_const(const TflOp& o, float* c, bool* const_is_rhs = nullptr) const {
+        if (o.inputs.size() != 2) return -1;
+        if (const_scalar(o.inputs[1], c)) { if (const_is_rhs) *const_is_rhs = true; return o.inputs[0]; }
+        if (const_scalar(o.inputs[0], c)) { if (const_is_rhs) *const_is_rhs = false; return o.inputs[1]; }
+        return -1;
+    }
+};
+
+struct FrontendMatch {
+    int L = 0, Lfft = 0, hop = 0, F = 0, n_mels = 0;
+    std::vector<float> window;
+    int mel_tensor = -1;     // const [n_mels, nbins]
+    float p1 = 1.f, p2 = 1.f, eps = 0.f, norm_sub = 0.f, norm_mul = 1.f;
+    bool reverse = false;
+    int out_tensor = -1;     // [1, n_mels, F, 1]
+};
+
+// Recognise one MelSpec branch around RFFT2D op `ri` (see header comment in synth_model.py for the graph).
+bool match_frontend(Planner& P, int ri, FrontendMatch* fm) {
+    const TflModel& m = P.m;
+    const TflOp& R = m.ops[ri];
+    if (R.inputs.size() != 2 || !P.is_const(R.inputs[1]) || P.T(R.inputs[1]).numel() != 2)
+        return P.fail("RFFT2D: fft_length must be a constant [2]");
+    const int32_t* fl = P.T(R.inputs[1]).i32();
+    if (fl[0] != 1) return P.fail("RFFT2D: only 1-D transforms (fft_length[0]==1) are supported");
+    fm->Lfft = fl[1];
+    P.absorbed[ri] = 1;
+
+    // ---- upstream: window MUL <- framing GATHER <- normalisation chain <- graph input
+    int t = P.skip_up(R.inputs[0]);
+    int pi = P.producer[t];
+    int frames_t = t;
+    if (pi >= 0 && m.ops[pi].code == OP_MUL) {
+        const TflOp& mu = m.ops[pi];
+        int wc = P.is_const(mu.inputs[1]) ? 1 : (P.is_const(mu.inputs[0]) ? 0 : -1);
+        if (wc < 0) return P.fail("front-end: window MUL without a constant operand");
+        const TflTensor& wt = P.T(mu.inputs[wc]);
+        if (wt.type != TT_FLOAT32) return P.fail("front-end: window must be float32");
+        fm->window.assign(wt.f32(), wt.f32() + wt.numel());
+        frames_t = mu.inputs[1 - wc];
+        P.absorbed[pi] = 1;
+    }
+    t = P.skip_up(frames_t);
+    pi = P.producer[t];
+    if (pi < 0 || m.ops[pi].code != OP_GATHER) return P.fail("front-end: framing pattern (GATHER) not found");
+    {
+        const TflOp& ga = m.ops[pi];
+        if (ga.axis != 1 || ga.batch_dims != 0 || !P.is_const(ga.inputs[1]) || P.T(ga.inputs[1]).shape.size() != 2)
+            return P.fail("front-end: unsupported GATHER framing");
+        const TflTensor& sel = P.T(ga.inputs[1]);
+        const TflTensor& par = P.T(ga.inputs[0]);
+        if (par.shape.size() != 3) return P.fail("front-end: GATHER params must be [1, n_sub, sub]");
+        int sub = par.shape[2], F = sel.shape[0], Q = sel.shape[1];
+        const int32_t* sv = sel.i32();
+        int step = F > 1 ? sv[Q] - sv[0] : 1;
+        for (int f = 0; f < F; f++)
+            for (int q = 0; q < Q; q++)
+                if (sv[f * Q + q] != f * step + q) return P.fail("front-end: GATHER selector is not a sliding window");
+        fm->F = F; fm->hop = step * sub; fm->L = Q * sub;
+        P.absorbed[pi] = 1;
+        t = P.skip_up(ga.inputs[0]);
+    }
+    if (fm->window.empty()) fm->window.assign(fm->L, 1.0f);
+    if ((int)fm->window.size() != fm->L) return P.fail("front-end: window length != frame length");
+    if (fm->L > fm->Lfft) return P.fail("front-end: frame length > fft length");
+
+    // normalisation: MUL(SUB(DIV(SUB(x, REDUCE_MIN x), ADD(REDUCE_MAX(.), eps)), c_sub), c_mul)
+    {
+        int p_mul = P.producer[t];
+        if (p_mul < 0 || m.ops[p_mul].code != OP_MUL) return P.fail("front-end: normalisation (MUL) not found");
+        int n2 = P.bin_const(m.ops[p_mul], &fm->norm_mul);
+        if (n2 < 0) return P.fail("front-end: normalisation MUL needs a scalar constant");
+        int p_sub = P.producer[n2];
+        bool rhs = false;
+        if (p_sub < 0 || m.ops[p_sub].code != OP_SUB) return P.fail("front-end: normalisation (SUB c) not found");
+        int nm = P.bin_const(m.ops[p_sub], &fm->norm_sub, &rhs);
+        if (nm < 0 || !rhs) return P.fail("front-end: normalisation SUB needs a scalar constant rhs");
+        int p_div = P.producer[nm];
+        if (p_div < 0 || m.ops[p_div].code != OP_DIV) return P.fail("front-end: normalisation (DIV) not found");
+        int s1 = m.ops[p_div].inputs[0], dn = m.ops[p_div].inputs[1];
+        int p_add = P.producer[dn];
+        if (p_add < 0 || m.ops[p_add].code != OP_ADD) return P.fail("front-end: normalisation (ADD eps) not found");
+        int mx = P.bin_const(m.ops[p_add], &fm->eps);
+        if (mx < 0) return P.fail("front-end: normalisation ADD needs a scalar constant");
+        int p_max = P.producer[mx];
+        if (p_max < 0 || m.ops[p_max].code != OP_REDUCE_MAX || m.ops[p_max].inputs[0] != s1)
+            return P.fail("front-end: normalisation (REDUCE_MAX of shifted signal) not found");
+        int p_s1 = P.producer[s1];
+        if (p_s1 < 0 || m.ops[p_s1].code != OP_SUB) return P.fail("front-end: normalisation (SUB min) not found");
+        int x = m.ops[p_s1].inputs[0], mn = m.ops[p_s1].inputs[1];
+        int p_min = P.producer[mn];
+        if (p_min < 0 || m.ops[p_min].code != OP_REDUCE_MIN || m.ops[p_min].inputs[0] != x)
+            return P.fail("front-end: normalisation (REDUCE_MIN) not found");
+        if (x != m.inputs[0]) return P.fail("front-end: normalisation does not start at the graph input");
+        for (int op : {p_mul, p_sub, p_div, p_add, p_max, p_s1, p_min}) P.absorbed[op] = 1;
+    }
+
+    // ---- downstream: real part -> mel matmul -> POW(s) -> REVERSE -> TRANSPOSE -> [1, n_mels, F, 1]
+    t = P.skip_down(R.outputs[0]);
+    int ci = P.only_consumer(t);
+    if (ci < 0) return P.fail("front-end: STFT output must have one consumer");
+    if (m.ops[ci].code == OP_COMPLEX_ABS) {
+        P.code = BNHIP_E_UNSUPPORTED;
+        return P.fail("front-end: magnitude STFT (COMPLEX_ABS) variant is not implemented; only the real-part (CAST) graph");
+    }
+    if (!(m.ops[ci].code == OP_CAST || m.ops[ci].code == OP_REAL)) return P.fail("front-end: expected CAST/REAL after RFFT2D");
+    P.absorbed[ci] = 1;
+    t = P.skip_down(m.ops[ci].outputs[0]);
+    ci = P.only_consumer(t);
+    if (ci < 0 || m.ops[ci].code != OP_FULLY_CONNECTED) return P.fail("front-end: mel projection (FULLY_CONNECTED) not found");
+    {
+        const TflOp& fc = m.ops[ci];
+        if (!P.is_const(fc.inputs[1]) || (fc.inputs.size() > 2 && fc.inputs[2] >= 0))
+            return P.fail("front-end: mel projection must have constant weights and no bias");
+        const TflTensor& w = P.T(fc.inputs[1]);
+        if (w.shape.size() != 2 || w.shape[1] != fm->Lfft / 2 + 1 || w.type != TT_FLOAT32)
+            return P.fail("front-end: mel matrix shape mismatch");
+        fm->mel_tensor = fc.inputs[1];
+        fm->n_mels = w.shape[0];
+        P.absorbed[ci] = 1;
+        t = P.skip_down(fc.outputs[0]);
+    }
+    int npow = 0;
+    while ((ci = P.only_consumer(t)) >= 0 && m.ops[ci].code == OP_POW && npow < 2) {
+        float e;
+        if (!P.const_scalar(m.ops[ci].inputs[1], &e)) return P.fail("front-end: POW exponent must be a scalar constant");
+        (npow == 0 ? fm->p1 : fm->p2) = e;
+        npow++;
+        P.absorbed[ci] = 1;
+        t = P.skip_down(m.ops[ci].outputs[0]);
+    }
+    ci = P.only_consumer(t);
+    if (ci >= 0 && m.ops[ci].code == OP_REVERSE_V2) {
+        const TflTensor& ax = P.T(m.ops[ci].inputs[1]);
+        int rank = (int)P.T(m.ops[ci].inputs[0]).shape.size();
+        if (!ax.data || ax.numel() != 1 || ((ax.i32()[0] + rank) % rank) != rank - 1)
+            return P.fail("front-end: REVERSE_V2 must flip the mel axis");
+        fm->reverse = true;
+        P.absorbed[ci] = 1;
+        t = P.skip_down(m.ops[ci].outputs[0]);
+        ci = P.only_consumer(t);
+    }
+    if (ci < 0 || m.ops[ci].code != OP_TRANSPOSE) return P.fail("front-end: TRANSPOSE to [mel, time] not found");
+    {
+        const TflTensor& pm = P.T(m.ops[ci].inputs[1]);
+        if (!pm.data || pm.numel() != 3 || pm.i32()[0] != 0 || pm.i32()[1] != 2 || pm.i32()[2] != 1)
+            return P.fail("front-end: unsupported TRANSPOSE permutation");
+        P.absorbed[ci] = 1;
+        t = P.skip_down(m.ops[ci].outputs[0]);
+    }
+    const auto& os = P.T(t).shape;
+    if (os.size() != 4 || os[0] != 1 || os[1] != fm->n_mels || os[2] != fm->F || os[3] != 1)
+        return P.fail("front-end: unexpected spectrogram tensor shape");
+    fm->out_tensor = t;
+    return true;
+}
+
+// G[n][m'] = w[n] * sum_k cos(2 pi k n / Lfft) * Mel[k][m]   (fp64 accumulate, rounded once to fp32)
+std::vector<float> build_G(const Planner& P, const FrontendMatch& fm, int Lp, int NTP) {
+    const int nb = fm.Lfft / 2 + 1, nm = fm.n_mels, N = fm.Lfft;
+    const float* melT = P.T(fm.mel_tensor).f32();      // [n_mels][nbins]
+    std::vector<double> ctab(N);
+    for (int i = 0; i < N; i++) ctab[i] = std::cos(2.0 * M_PI * (double)i / (double)N);
+    std::vector<int> krows;                             // bins with any non-zero mel weight (DFT truncation)
+    for (int k = 0; k < nb; k++) {
+        bool nz = false;
+        for (int mm = 0; mm < nm && !nz; mm++) nz = melT[(size_t)mm * nb + k] != 0.0f;
+        if (nz) krows.push_back(k);
+    }
+    std::vector<double> melk(krows.size() * (size_t)nm);
+    for (size_t r = 0; r < krows.size(); r++)
+        for (int mm = 0; mm < nm; mm++) melk[r * nm + mm] = (double)melT[(size_t)mm * nb + krows[r]];
+    std::vector<float> G((size_t)Lp * NTP, 0.0f);
+    std::vector<double> row(nm);
+    for (int n = 0; n < fm.L; n++) {
+        std::fill(row.begin(), row.end(), 0.0);
+        for (size_t r = 0; r < krows.size(); r++) {
+            double c = ctab[(size_t)(((long long)krows[r] * n) % N)];
+            const double* mk = &melk[r * nm];
+            for (int mm = 0; mm < nm; mm++) row[mm] += c * mk[mm];
+        }
+        double w = (double)fm.window[n];
+        for (int mo = 0; mo < nm; mo++) {
+            int mm = fm.reverse ? nm - 1 - mo : mo;
+            G[(size_t)n * NTP + mo] = (float)(w * row[mm]);
+        }
+    }
+    return G;
+}
+
+}  // namespace
+
+// ================================================================================================ build
+Engine::~Engine() {
+    if (device >= 0) hipSetDevice(device);
+    for (auto& e : prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (auto e : ev_pool) hipEventDestroy(e);
+    for (void* p : {(void*)act_arena, (void*)w_arena, (void*)d_stage_in, (void*)d_stage_logits, (void*)d_stage_emb,
+                    (void*)d_stage_pcm, (void*)d_post_conf, (void*)d_topk_conf, (void*)d_topk_idx})
+        if (p) hipFree(p);
+    if (own_stream && stream) hipStreamDestroy(stream);
+}
+
+bool Engine::build(const TflModel& m, int dev, int maxb, bool plan_only, std::string* err, int* code) {
+    device = dev;
+    max_batch = maxb;
+    *code = BNHIP_E_UNSUPPORTED;
+    Planner P(m);
+
+    const TflTensor& tin = m.tensors[m.inputs[0]];
+    if (tin.type != TT_FLOAT32 || tin.shape.size() != 2 || tin.shape[0] != 1) {
+        *err = "graph input must be float32 [1, n_samples]";
+        return false;
+    }
+    n_samples = tin.shape[1];
+
+    // ---------------------------------------------------------------- front-end
+    std::vector<FrontendMatch> fms;
+    for (int i = 0; i < (int)m.ops.size(); i++)
+        if (m.ops[i].code == OP_RFFT2D) {
+            FrontendMatch fm;
+            if (!match_frontend(P, i, &fm)) { *err = P.err; *code = P.code; return false; }
+            fms.push_back(fm);
+        }
+    if (fms.empty()) { *err = "no STFT front-end (RFFT2D) found in graph: unsupported model family"; return false; }
+    int spec_tensor = -1;
+    std::vector<int> chan_of(fms.size(), 0);
+    {
+        int cc = P.only_consumer(fms[0].out_tensor);
+        if (fms.size() == 1 && (cc < 0 || m.ops[cc].code != OP_CONCATENATION)) {
+            spec_tensor = fms[0].out_tensor;
+        } else {
+            if (cc < 0 || m.ops[cc].code != OP_CONCATENATION || m.ops[cc].axis != 3) {
+                *err = "front-end: spectrogram channels must be concatenated on axis 3";
+                return false;
+            }
+            const TflOp& cat = m.ops[cc];
+            if (cat.inputs.size() != fms.size()) { *err = "front-end: concat arity != number of STFT branches"; return false; }
+            for (size_t i = 0; i < fms.size(); i++) {
+                auto it = std::find(cat.inputs.begin(), cat.inputs.end(), fms[i].out_tensor);
+                if (it == cat.inputs.end()) { *err = "front-end: STFT branch does not feed the concat"; return false; }
+                chan_of[i] = (int)(it - cat.inputs.begin());
+            }
+            P.absorbed[cc] = 1;
+            spec_tensor = cat.outputs[0];
+        }
+    }
+    C_spec = (int)fms.size();
+    for (auto& fm : fms)
+        if (fm.n_mels != fms[0].n_mels || fm.F != fms[0].F) { *err = "front-end: branches disagree on [mel, time] shape"; return false; }
+
+    // ---------------------------------------------------------------- weights arena (host image first)
+    std::vector<float> wimg;
+    auto wpush = [&](const float* src, size_t n) -> size_t {
+        size_t off = align_up(wimg.size(), 64);       // 256-byte alignment
+        wimg.resize(off + n);
+        memcpy(&wimg[off], src, n * sizeof(float));
+        return off;
+    };
+    std::vector<std::pair<const float**, size_t>> wfix;   // pointer slots to patch after upload
+    std::map<int, size_t> wcache;                      // tflite tensor -> offset (plain upload)
+    auto wconst = [&](int t) -> size_t {
+        auto it = wcache.find(t);
+        if (it != wcache.end()) return it->second;
+        size_t off = wpush(m.tensors[t].f32(), m.tensors[t].numel());
+        wcache[t] = off;
+        return off;
+    };
+
+    // values
+    std::map<int, int> tv;    // tflite tensor -> value id
+    auto new_val = [&](int tfl, size_t elems) {
+        Value v; v.tfl = tfl; v.elems = elems;
+        vals.push_back(v);
+        return (int)vals.size() - 1;
+    };
+    v_input = new_val(m.inputs[0], n_samples);
+    vals[v_input].external = true;
+    tv[m.inputs[0]] = v_input;
+    v_mm = new_val(-1, 2);
+
+    std::vector<size_t> step_w[4];   // per-step weight offsets (SIZE_MAX = none)
+    auto add_step = [&](Step s, size_t o0 = SIZE_MAX, size_t o1 = SIZE_MAX, size_t o2 = SIZE_MAX, size_t o3 = SIZE_MAX) {
+        steps.push_back(s);
+        step_w[0].push_back(o0); step_w[1].push_back(o1); step_w[2].push_back(o2); step_w[3].push_back(o3);
+    };
+
+    // front-end steps
+    {
+        Step s; s.kind = S_MINMAX; s.name = "clip_minmax"; s.kclass = "clip_minmax"; s.in0 = v_input; s.out = v_mm;
+        s.bytes = (double)n_samples * 4;
+        add_step(s);
+        int v_spec = new_val(spec_tensor, (size_t)fms[0].n_mels * fms[0].F * C_spec);
+        tv[spec_tensor] = v_spec;
+        for (size_t i = 0; i < fms.size(); i++) {
+            const FrontendMatch& fm = fms[i];
+            FrontSpec fs;
+            fs.L = fm.L; fs.Lfft = fm.Lfft; fs.hop = fm.hop; fs.F = fm.F; fs.n_mels = fm.n_mels; fs.c = chan_of[i];
+            fs.Lp = (int)align_up(fm.L, kFrontendKC);
+            fs.NTP = (int)align_up(fm.n_mels, 16);
+            if (fs.NTP > 128) { *err = "front-end: more than 128 mel bins unsupported"; return false; }
+            if (fm.eps != fms[0].eps || fm.norm_sub != fms[0].norm_sub || fm.norm_mul != fms[0].norm_mul) {
+                *err = "front-end: branches use different normalisation constants";
+                return false;
+            }
+            fs.p1 = fm.p1; fs.p2 = fm.p2; fs.eps = fm.eps; fs.norm_sub = fm.norm_sub; fs.norm_mul = fm.norm_mul;
+            if (frontend_lds_bytes(fs.L, fs.Lp, fs.hop, fs.NTP) > 160 * 1024) {
+                *err = "front-end: frame tile does not fit in LDS";
+                return false;
+            }
+            std::vector<float> G = build_G(P, fm, fs.Lp, fs.NTP);
+            size_t goff = wpush(G.data(), G.size());
+            specs.push_back(fs);
+            Step f; f.kind = S_FRONTEND; f.name = "melspec" + std::to_string(i); f.kclass = "frontend";
+            f.in0 = v_input; f.in1 = v_mm; f.out = v_spec; f.spec = (int)specs.size() - 1;
+            f.flops = 2.0 * fm.F * fs.L * fm.n_mels;
+            f.bytes = (double)n_samples * 4 + (double)fm.F * fm.n_mels * 4;
+            add_step(f, goff);
+        }
+    }
+
+    // ---------------------------------------------------------------- CNN ops
+    auto hwc = [&](int t, int* H, int* W, int* C) -> bool {
+        const auto& s = m.tensors[t].shape;
+        if (s.size() == 4 && s[0] == 1) { *H = s[1]; *W = s[2]; *C = s[3]; return true; }
+        if (s.size() == 2 && s[0] == 1) { *H = 1; *W = 1; *C = s[1]; return true; }
+        return false;
+    };
+    auto map_act = [&](int fused) -> int {
+        switch (fused) { case 0: return ACT_NONE; case 1: return ACT_RELU; case 3: return ACT_RELU6; default: return -1; }
+    };
+    // trailing swish / sigmoid detection on tensor y produced by op `oi`; returns final tensor and act
+    auto trailing_act = [&](int y, int* act) -> int {
+        if (P.consumers[y].size() == 2 && P.uses[y] == 2) {
+            int a = P.consumers[y][0], b = P.consumers[y][1];
+            int lg = m.ops[a].code == OP_LOGISTIC ? a : (m.ops[b].code == OP_LOGISTIC ? b : -1);
+            int mu = lg == a ? b : a;
+            if (lg >= 0 && m.ops[mu].code == OP_MUL && m.ops[mu].act == 0) {
+                int sgt = m.ops[lg].outputs[0];
+                const auto& mi = m.ops[mu].inputs;
+                bool ok = P.uses[sgt] == 1 && ((mi[0] == y && mi[1] == sgt) || (mi[1] == y && mi[0] == sgt));
+                if (ok) { P.absorbed[lg] = 1; P.absorbed[mu] = 1; *act = ACT_SWISH; return m.ops[mu].outputs[0]; }
+            }
+        } else if (P.uses[y] == 1 && P.consumers[y].size() == 1 && m.ops[P.consumers[y][0]].code == OP_LOGISTIC) {
+            int lg = P.consumers[y][0];
+            P.absorbed[lg] = 1; *act = ACT_SIGMOID; return m.ops[lg].outputs[0];
+        }
+        return y;
+    };
+    struct ScaledAlias { int v_data; int v_scale; };
+    std::map<int, ScaledAlias> scaled;   // tflite tensor (SE MUL output) -> (data value, scale value)
+
+    for (int oi = 0; oi < (int)m.ops.size(); oi++) {
+        if (P.absorbed[oi]) continue;
+        const TflOp& o = m.ops[oi];
+        const std::string oname = m.tensors[o.outputs[0]].name;
+        auto need_val = [&](int t) -> int {
+            auto it = tv.find(t);
+            return it == tv.end() ? -1 : it->second;
+        };
+        switch (o.code) {
+            case OP_CONV_2D: {
+                int in_t = o.inputs[0];
+                if (!P.is_const(o.inputs[1])) { *err = "CONV_2D with non-constant filter"; return false; }
+                const TflTensor& w = m.tensors[o.inputs[1]];
+                int H, W, C, Ho, Wo, Co;
+                if (!hwc(in_t, &H, &W, &C) || !hwc(o.outputs[0], &Ho, &Wo, &Co) || w.shape.size() != 4 || w.shape[3] != C) {
+                    *err = "CONV_2D: unsupported shapes at " + oname; return false;
+                }
+                int kh = w.shape[1], kw = w.shape[2];
+                int act = map_act(o.act);
+                if (act < 0) { *err = "CONV_2D: unsupported fused activation"; return false; }
+                int outt = o.outputs[0];
+                if (act == ACT_NONE) outt = trailing_act(outt, &act);
+                size_t boff = (o.inputs.size() > 2 && o.inputs[2] >= 0) ? wconst(o.inputs[2]) : SIZE_MAX;
+                bool pw = kh == 1 && kw == 1 && o.stride_h == 1 && o.stride_w == 1;
+                Step s; s.name = oname; s.H = H; s.W = W; s.C = C; s.Ho = Ho; s.Wo = Wo; s.Co = Co; s.act = act;
+                if (pw) {
+                    s.kind = S_PW; s.kclass = "pw_gemm";
+                    auto sc = scaled.find(in_t);
+                    if (sc != scaled.end()) { s.in0 = sc->second.v_data; s.in1 = sc->second.v_scale; }
+                    else s.in0 = need_val(in_t);
+                    if (s.in0 < 0) { *err = "CONV_2D: input has no value: " + oname; return false; }
+                    // residual ADD fusion
+                    if (P.uses[outt] == 1 && P.consumers[outt].size() == 1) {
+                        int ai = P.consumers[outt][0];
+                        const TflOp& ad = m.ops[ai];
+                        if (ad.code == OP_ADD && ad.act == 0 && !P.absorbed[ai]) {
+                            int other = ad.inputs[0] == outt ? ad.inputs[1] : ad.inputs[0];
+                            int vo = need_val(other);
+                            if (vo >= 0 && m.tensors[other].shape == m.tensors[outt].shape) {
+                                s.in2 = vo; P.absorbed[ai] = 1; outt = ad.outputs[0];
+                            }
+                        }
+                    }
+                    s.flops = 2.0 * H * W * C * Co;
+                    s.bytes = 4.0 * ((double)H * W * C + (double)H * W * Co * (s.in2 >= 0 ? 2 : 1));
+                    s.wbytes = 4.0 * C * Co;
+                    s.out = new_val(outt, (size_t)Ho * Wo * Co);
+                    tv[outt] = s.out;
+                    add_step(s, wconst(o.inputs[1]), boff);
+                } else {
+                    if (o.dil_h != 1 || o.dil_w != 1 || (Co & 3)) { *err = "CONV_2D: unsupported dilation/channels at " + oname; return false; }
+                    s.kind = S_CONV_DIRECT; s.kclass = "conv_direct";
+                    s.in0 = need_val(in_t);
+                    if (s.in0 < 0) { *err = "CONV_2D: input has no value: " + oname; return false; }
+                    s.kh = kh; s.kw = kw; s.sh = o.stride_h; s.sw = o.stride_w;
+                    if (o.padding == 0) {   // SAME
+                        int th = std::max((Ho - 1) * s.sh + kh - H, 0), tw = std::max((Wo - 1) * s.sw + kw - W, 0);
+                        s.pt = th / 2; s.pl = tw / 2;
+                    }
+                    // re-lay OHWI -> [kh][kw][Cin][Cout]
+                    std::vector<float> wt((size_t)kh * kw * C * Co);
+                    const float* ws = w.f32();
+                    for (int oc = 0; oc < Co; oc++)
+                        for (int i = 0; i < kh; i++)
+                            for (int j = 0; j < kw; j++)
+                                for (int ic = 0; ic < C; ic++)
+                                    wt[(((size_t)i * kw + j) * C + ic) * Co + oc] = ws[(((size_t)oc * kh + i) * kw + j) * C + ic];
+                    s.flops = 2.0 * Ho * Wo * Co * kh * kw * C;
+                    s.bytes = 4.0 * ((double)H * W * C + (double)Ho * Wo * Co);
+                    s.out = new_val(outt, (size_t)Ho * Wo * Co);
+                    tv[outt] = s.out;
+                    add_step(s, wpush(wt.data(), wt.size()), boff);
+                }
+                break;
+            }
+            case OP_DEPTHWISE_CONV_2D: {
+                int in_t = o.inputs[0];
+                const TflTensor& w = m.tensors[o.inputs[1]];
+                int H, W, C, Ho, Wo, Co;
+                if (!P.is_const(o.inputs[1]) || !hwc(in_t, &H, &W, &C) || !hwc(o.outputs[0], &Ho, &Wo, &Co) ||
+                    w.shape.size() != 4 || w.shape[3] != C || Co != C || o.depth_multiplier != 1 || o.dil_h != 1 || o.dil_w != 1) {
+                    *err = "DEPTHWISE_CONV_2D: unsupported configuration at " + oname; return false;
+                }
+                int act = map_act(o.act);
+                if (act < 0) { *err = "DEPTHWISE_CONV_2D: unsupported fused activation"; return false; }
+                int outt = o.outputs[0];
+                if (act == ACT_NONE) outt = trailing_act(outt, &act);
+                Step s; s.kind = S_DW; s.kclass = "dwconv"; s.name = oname;
+                s.in0 = need_val(in_t);
+                if (s.in0 < 0) { *err = "DEPTHWISE_CONV_2D: input has no value"; return false; }
+                s.H = H; s.W = W; s.C = C; s.Ho = Ho; s.Wo = Wo; s.Co = C; s.act = act;
+                s.kh = w.shape[1]; s.kw = w.shape[2]; s.sh = o.stride_h; s.sw = o.stride_w;
+                if (o.padding == 0) {
+                    int th = std::max((Ho - 1) * s.sh + s.kh - H, 0), tw = std::max((Wo - 1) * s.sw + s.kw - W, 0);
+                    s.pt = th / 2; s.pl = tw / 2;
+                }
+                s.flops = 2.0 * Ho * Wo * C * s.kh * s.kw;
+                s.bytes = 4.0 * ((double)H * W * C + (double)Ho * Wo * C);
+                s.out = new_val(outt, (size_t)Ho * Wo * C);
+                tv[outt] = s.out;
+                size_t boff = (o.inputs.size() > 2 && o.inputs[2] >= 0) ? wconst(o.inputs[2]) : SIZE_MAX;
+                add_step(s, wconst(o.inputs[1]), boff);
+                break;
+            }
+            case OP_MEAN: {
+                int in_t = o.inputs[0];
+                int H, W, C;
+                const TflTensor& ax = m.tensors[o.inputs[1]];
+                bool ok = hwc(in_t, &H, &W, &C) && ax.data && ax.numel() == 2 &&
+                          ((ax.i32()[0] == 1 && ax.i32()[1] == 2) || (ax.i32()[0] == 2 && ax.i32()[1] == 1));
+                if (!ok) { *err = "MEAN: only spatial (axes 1,2) means are supported at " + oname; return false; }
+                int vin = need_val(in_t);
+                if (vin < 0) { *err = "MEAN: input has no value"; return false; }
+                int S = mean_splits(H * W);
+                Step mp; mp.kind = S_MEAN_PARTIAL; mp.kclass = "mean"; mp.name = oname + "/partial";
+                mp.in0 = vin; mp.H = H; mp.W = W; mp.C = C; mp.S = S;
+                mp.out = new_val(-1, (size_t)S * C);
+                mp.bytes = 4.0 * H * W * C;
+                // squeeze-excite pattern?
+                bool se = false;
+                int mt = o.outputs[0];
+                do {
+                    if (P.uses[mt] != 1) break;
+                    int c1 = P.only_consumer(mt);
+                    if (c1 < 0 || m.ops[c1].code != OP_CONV_2D || !P.is_const(m.ops[c1].inputs[1])) break;
+                    const TflTensor& w1 = m.tensors[m.ops[c1].inputs[1]];
+                    if (w1.shape.size() != 4 || w1.shape[1] != 1 || w1.shape[2] != 1 || w1.shape[3] != C || m.ops[c1].act != 0) break;
+                    int y1 = m.ops[c1].outputs[0];
+                    // peek activation without absorbing yet
+                    std::vector<char> save = P.absorbed;
+                    int act1 = ACT_NONE, act2 = ACT_NONE;
+                    int r = trailing_act(y1, &act1);
+                    int c2 = P.uses[r] == 1 ? P.only_consumer(r) : -1;
+                    if (c2 < 0 || m.ops[c2].code != OP_CONV_2D || !P.is_const(m.ops[c2].inputs[1]) || m.ops[c2].act != 0) { P.absorbed = save; break; }
+                    const TflTensor& w2 = m.tensors[m.ops[c2].inputs[1]];
+                    int Cr = w1.shape[0];
+                    if (w2.shape.size() != 4 || w2.shape[1] != 1 || w2.shape[2] != 1 || w2.shape[3] != Cr || w2.shape[0] != C) { P.absorbed = save; break; }
+                    int e = trailing_act(m.ops[c2].outputs[0], &act2);
+                    int mu = P.uses[e] == 1 ? P.only_consumer(e) : -1;
+                    if (mu < 0 || m.ops[mu].code != OP_MUL || m.ops[mu].act != 0) { P.absorbed = save; break; }
+                    int other = m.ops[mu].inputs[0] == e ? m.ops[mu].inputs[1] : m.ops[mu].inputs[0];
+                    if (other != in_t) { P.absorbed = save; break; }
+                    // matched
+                    P.absorbed[c1] = 1; P.absorbed[c2] = 1; P.absorbed[mu] = 1;
+                    add_step(mp);
+                    Step ss; ss.kind = S_SE; ss.kclass = "se"; ss.name = oname + "/se";
+                    ss.in0 = mp.out; ss.H = H; ss.W = W; ss.C = C; ss.Cr = Cr; ss.S = S; ss.act = act1; ss.act2 = act2;
+                    ss.out = new_val(e, (size_t)C);
+                    tv[e] = ss.out;
+                    ss.flops = 4.0 * C * Cr;
+                    size_t b1 = (m.ops[c1].inputs.size() > 2 && m.ops[c1].inputs[2] >= 0) ? wconst(m.ops[c1].inputs[2]) : SIZE_MAX;
+                    size_t b2 = (m.ops[c2].inputs.size() > 2 && m.ops[c2].inputs[2] >= 0) ? wconst(m.ops[c2].inputs[2]) : SIZE_MAX;
+                    add_step(ss, wconst(m.ops[c1].inputs[1]), b1, wconst(m.ops[c2].inputs[1]), b2);
+                    int u = m.ops[mu].outputs[0];
+                    int pc = P.uses[u] == 1 ? P.only_consumer(u) : -1;
+                    bool fold = false;
+                    if (pc >= 0 && m.ops[pc].code == OP_CONV_2D && P.is_const(m.ops[pc].inputs[1]) && m.ops[pc].inputs[0] == u) {
+                        const TflTensor& wp = m.tensors[m.ops[pc].inputs[1]];
+                        fold = wp.shape.size() == 4 && wp.shape[1] == 1 && wp.shape[2] == 1 && m.ops[pc].stride_h == 1 &&
+                               m.ops[pc].stride_w == 1 && (C % 4) == 0;
+                    }
+                    if (fold) {
+                        scaled[u] = ScaledAlias{vin, ss.out};
+                    } else {
+                        Step bs; bs.kind = S_BINARY; bs.kclass = "elementwise"; bs.name = m.tensors[u].name;
+                        bs.in0 = vin; bs.in1 = ss.out; bs.op = 1; bs.mode = 1; bs.H = H; bs.W = W; bs.C = C;
+                        bs.out = new_val(u, (size_t)H * W * C); tv[u] = bs.out;
+                        bs.bytes = 8.0 * H * W * C;
+                        add_step(bs);
+                    }
+                    se = true;
+                } while (0);
+                if (!se) {
+                    add_step(mp);
+                    Step mf; mf.kind = S_MEAN_FINISH; mf.kclass = "mean"; mf.name = oname;
+                    mf.in0 = mp.out; mf.H = H; mf.W = W; mf.C = C; mf.S = S;
+                    mf.out = new_val(mt, (size_t)C); tv[mt] = mf.out;
+                    add_step(mf);
+                }
+                break;
+            }
+            case OP_FULLY_CONNECTED: {
+                int in_t = o.inputs[0];
+                int H, W, C;
+                if (!P.is_const(o.inputs[1]) || !hwc(in_t, &H, &W, &C) || H * W != 1) { *err = "FULLY_CONNECTED: unsupported input at " + oname; return false; }
+                const TflTensor& w = m.tensors[o.inputs[1]];
+                if (w.shape.size() != 2 || w.shape[1] != C) { *err = "FULLY_CONNECTED: weight shape mismatch"; return false; }
+                int act = map_act(o.act);
+                if (act < 0) { *err = "FULLY_CONNECTED: unsupported fused activation"; return false; }
+                int outt = o.outputs[0];
+                if (act == ACT_NONE && std::find(m.outputs.begin(), m.outputs.end(), outt) == m.outputs.end())
+                    outt = trailing_act(outt, &act);
+                Step s; s.kind = S_PW; s.kclass = "pw_gemm"; s.name = oname;
+                s.in0 = need_val(in_t);
+                if (s.in0 < 0) { *err = "FULLY_CONNECTED: input has no value"; return false; }
+                s.H = 1; s.W = 1; s.C = C; s.Ho = 1; s.Wo = 1; s.Co = w.shape[0]; s.act = act;
+                s.flops = 2.0 * C * s.Co;
+                s.bytes = 4.0 * (C + s.Co);
+                s.wbytes = 4.0 * C * s.Co;
+                s.out = new_val(outt, (size_t)s.Co); tv[outt] = s.out;
+                size_t boff = (o.inputs.size() > 2 && o.inputs[2] >= 0) ? wconst(o.inputs[2]) : SIZE_MAX;
+                add_step(s, wconst(o.inputs[1]), boff);
+                break;
+            }
+            case OP_LOGISTIC: case OP_RELU: case OP_RELU6: case OP_HARD_SWISH: {
+                int vin = need_val(o.inputs[0]);
+                if (vin < 0) { *err = std::string(op_name(o.code)) + ": input has no value"; return false; }
+                Step s; s.kind = S_UNARY; s.kclass = "elementwise"; s.name = oname; s.in0 = vin;
+                s.act = o.code == OP_LOGISTIC ? ACT_SIGMOID : o.code == OP_RELU ? ACT_RELU : o.code == OP_RELU6 ? ACT_RELU6 : ACT_HARD_SWISH;
+                s.out = new_val(o.outputs[0], vals[vin].elems); tv[o.outputs[0]] = s.out;
+                s.bytes = 8.0 * vals[vin].elems;
+                add_step(s);
+                break;
+            }
+            case OP_ADD: case OP_MUL: case OP_SUB: {
+                int act = map_act(o.act);
+                if (act < 0) { *err = "binary op: unsupported fused activation"; return false; }
+                int a = o.inputs[0], b = o.inputs[1];
+                int va = need_val(a), vb = need_val(b);
+                if (va < 0 && vb >= 0 && o.code != OP_SUB) { std::swap(a, b); std::swap(va, vb); }
+                if (va < 0) { *err = std::string(op_name(o.code)) + ": no activation operand at " + oname; return false; }
+                Step s; s.kind = S_BINARY; s.kclass = "elementwise"; s.name = oname; s.act = act;
+                s.op = o.code == OP_ADD ? 0 : (o.code == OP_MUL ? 1 : 2);
+                s.in0 = va;
+                int H, W, C;
+                if (!hwc(a, &H, &W, &C)) { *err = "binary op: unsupported shape"; return false; }
+                s.H = H; s.W = W; s.C = C;
+                size_t coff = SIZE_MAX;
+                if (vb >= 0) {
+                    s.in1 = vb;
+                    if (vals[vb].elems == vals[va].elems) s.mode = 0;
+                    else if (vals[vb].elems == (size_t)C) s.mode = 1;
+                    else { *err = "binary op: unsupported broadcast at " + oname; return false; }
+                } else {
+                    float c;
+                    if (!P.const_scalar(b, &c)) { *err = "binary op: unsupported constant operand at " + oname; return false; }
+                    s.mode = 2; coff = wconst(b);
+                }
+                s.out = new_val(o.outputs[0], vals[va].elems); tv[o.outputs[0]] = s.out;
+                s.bytes = 4.0 * vals[va].elems * (s.mode == 0 ? 3 : 2);
+                add_step(s, coff);
+                break;
+            }
+            case OP_RESHAPE: case OP_SQUEEZE: case OP_EXPAND_DIMS: {
+                int vin = need_val(o.inputs[0]);
+                if (vin < 0) { *err = std::string(op_name(o.code)) + ": input has no value"; return false; }
+                if (m.tensors[o.outputs[0]].numel() != vals[vin].elems) { *err = "reshape changes element count"; return false; }
+                tv[o.outputs[0]] = vin;   // contiguous alias
+                break;
+            }
+            default:
+                *err = std::string("unsupported operator ") + op_name(o.code) + " (code " + std::to_string(o.code) + ") at " + oname;
+                return false;
+        }
+    }
+
+    // ---------------------------------------------------------------- outputs
+    {
+        int lt = m.outputs[0];
+        auto it = tv.find(lt);
+        if (it == tv.end()) { *err = "graph output 0 was not produced by a supported op"; return false; }
+        v_logits = it->second;
+        n_classes = (int)vals[v_logits].elems;
+        vals[v_logits].external = true;
+        if (m.outputs.size() > 1) {
+            auto ie = tv.find(m.outputs[1]);
+            if (ie == tv.end()) { *err = "graph output 1 (embedding) was not produced by a supported op"; return false; }
+            v_emb = ie->second;
+            emb_dim = (int)vals[v_emb].elems;
+        }
+    }
+
+    // ---------------------------------------------------------------- liveness + arena
+    for (int si = 0; si < (int)steps.size(); si++) {
+        for (int v : {steps[si].in0, steps[si].in1, steps[si].in2, steps[si].out}) {
+            if (v < 0) continue;
+            if (vals[v].first < 0) vals[v].first = si;
+            vals[v].last = si;
+        }
+    }
+    if (v_emb >= 0) vals[v_emb].last = (int)steps.size();      // keep until copy-out
+    {
+        struct Block { size_t off, size; };
+        std::vector<Block> free_list;
+        size_t top = 0;
+        std::vector<std::vector<int>> born(steps.size() + 1), dies(steps.size() + 2);
+        for (int v = 0; v < (int)vals.size(); v++) {
+            if (vals[v].external || vals[v].first < 0) continue;
+            born[vals[v].first].push_back(v);
+            dies[std::min<size_t>(vals[v].last + 1, steps.size() + 1)].push_back(v);
+        }
+        for (size_t si = 0; si <= steps.size(); si++) {
+            for (int v : dies[si]) {
+                free_list.push_back(Block{vals[v].offset, align_up(vals[v].elems * 4 * (size_t)max_batch, 256)});
+                // coalesce
+                std::sort(free_list.begin(), free_list.end(), [](const Block& a, const Block& b) { return a.off < b.off; });
+                std::vector<Block> merged;
+                for (auto& b : free_list) {
+                    if (!merged.empty() && merged.back().off + merged.back().size == b.off) merged.back().size += b.size;
+                    else merged.push_back(b);
+                }
+                free_list.swap(merged);
+            }
+            if (si == steps.size()) break;
+            for (int v : born[si]) {
+                size_t need = align_up(vals[v].elems * 4 * (size_t)max_batch, 256);
+                int best = -1;
+                for (int i = 0; i < (int)free_list.size(); i++)
+                    if (free_list[i].size >= need && (best < 0 || free_list[i].size < free_list[best].size)) best = i;
+                if (best >= 0) {
+                    vals[v].offset = free_list[best].off;
+                    free_list[best].off += need; free_list[best].size -= need;
+                    if (free_list[best].size == 0) free_list.erase(free_list.begin() + best);
+                } else {
+                    // extend the arena top (absorb a trailing free block if adjacent)
+                    if (!free_list.empty() && free_list.back().off + free_list.back().size == top) {
+                        vals[v].offset = free_list.back().off;
+                        top = vals[v].offset + need;
+                        free_list.pop_back();
+                    } else {
+                        vals[v].offset = top; top += need;
+                    }
+                }
+            }
+        }
+        act_bytes = top;
+    }
+
+    // ---------------------------------------------------------------- device allocation
+    w_bytes = wimg.size() * sizeof(float);
+    if (plan_only) { device = -1; *code = BNHIP_OK; return true; }   // CPU-side planning only (tests, describe)
+    *code = BNHIP_E_RUNTIME;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    own_stream = true;
+    HIPCHK(hipMalloc((void**)&w_arena, std::max<size_t>(w_bytes, 256)));
+    HIPCHK(hipMemcpy(w_arena, wimg.data(), w_bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&act_arena, std::max<size_t>(act_bytes, 256)));
+    for (size_t si = 0; si < steps.size(); si++) {
+        const float** slots[4] = {&steps[si].w0, &steps[si].w1, &steps[si].w2, &steps[si].w3};
+        for (int k = 0; k < 4; k++)
+            if (step_w[k][si] != SIZE_MAX) *slots[k] = reinterpret_cast<const float*>(w_arena) + step_w[k][si];
+        if (steps[si].kind == S_FRONTEND) specs[steps[si].spec].G = steps[si].w0;
+    }
+    HIPCHK(hipMalloc((void**)&d_stage_in, (size_t)max_batch * n_samples * 4));
+    HIPCHK(hipMalloc((void**)&d_stage_logits, (size_t)max_batch * n_classes * 4));
+    HIPCHK(hipMalloc((void**)&d_post_conf, (size_t)max_batch * n_classes * 4));
+    if (emb_dim) HIPCHK(hipMalloc((void**)&d_stage_emb, (size_t)max_batch * emb_dim * 4));
+    *code = BNHIP_OK;
+    return true;
+}
+
+// ================================================================================================ run
+float* Engine::vptr(int v, const float* d_in, float* d_logits, float* d_emb) const {
+    if (v < 0) return nullptr;
+    if (v == v_input) return const_cast<float*>(d_in);
+    if (v == v_logits) return d_logits;
+    (void)d_emb;
+    return reinterpret_cast<float*>(act_arena + vals[v].offset);
+}
+
+hipEvent_t Engine::get_event() {
+    if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+}
+
+bool Engine::run(const float* d_in, int n, float* d_logits, float* d_emb, std::string* err) {
+    if (n <= 0 || n > max_batch) { *err = "batch size out of range"; return false; }
+    for (int si = 0; si < (int)steps.size(); si++) {
+        const Step& s = steps[si];
+        float* in0 = vptr(s.in0, d_in, d_logits, d_emb);
+        float* in1 = vptr(s.in1, d_in, d_logits, d_emb);
+        float* in2 = vptr(s.in2, d_in, d_logits, d_emb);
+        float* out = vptr(s.out, d_in, d_logits, d_emb);
+        ProfEntry pe{};
+        if (profiling) { pe.a = get_event(); pe.b = get_event(); pe.step = si; pe.n = n; hipEventRecord(pe.a, stream); }
+        switch (s.kind) {
+            case S_MINMAX:
+                launch_clip_minmax(in0, n, n_samples, specs[0].eps, reinterpret_cast<float2*>(out), stream);
+                break;
+            case S_FRONTEND: {
+                const FrontSpec& fs = specs[s.spec];
+                FrontendParams p;
+                p.x = in0; p.mm = reinterpret_cast<const float2*>(in1); p.G = fs.G; p.out = out;
+                p.n_samples = n_samples; p.L = fs.L; p.Lp = fs.Lp; p.hop = fs.hop; p.F = fs.F; p.n_mels = fs.n_mels;
+                p.NTP = fs.NTP; p.C = C_spec; p.c = fs.c; p.norm_sub = fs.norm_sub; p.norm_mul = fs.norm_mul;
+                p.p1 = fs.p1; p.p2 = fs.p2; p.n_clips = n;
+                launch_frontend(p, stream);
+                break;
+            }
+            case S_CONV_DIRECT: {
+                ConvParams p{in0, s.w0, s.w1, out, n, s.H, s.W, s.C, s.Ho, s.Wo, s.Co, s.kh, s.kw, s.sh, s.sw, s.pt, s.pl, s.act};
+                launch_conv_direct(p, stream);
+                break;
+            }
+            case S_PW: {
+                PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act};
+                launch_pw_gemm(p, stream);
+                break;
+            }
+            case S_DW: {
+                DwParams p{in0, s.w0, s.w1, out, n, s.H, s.W, s.C, s.Ho, s.Wo, s.kh, s.kw, s.sh, s.sw, s.pt, s.pl, s.act};
+                launch_dwconv(p, stream);
+                break;
+            }
+            case S_MEAN_PARTIAL:
+                launch_mean_partial(in0, out, n, s.H * s.W, s.C, s.S, stream);
+                break;
+            case S_MEAN_FINISH:
+                launch_mean_finish(in0, out, n, s.H * s.W, s.C, s.S, stream);
+                break;
+            case S_SE: {
+                SeParams p{in0, s.S, s.H * s.W, s.w0, s.w1, s.w2, s.w3, out, n, s.C, s.Cr, s.act, s.act2};
+                launch_se(p, stream);
+                break;
+            }
+            case S_UNARY:
+                launch_unary(in0, out, vals[s.in0].elems * (size_t)n, s.act, stream);
+                break;
+            case S_BINARY:
+                launch_binary(in0, s.mode == 2 ? s.w0 : in1, out, vals[s.in0].elems * (size_t)n, s.op, s.mode, s.H * s.W, s.C,
+                              s.act, stream);
+                break;
+        }
+        if (profiling) { hipEventRecord(pe.b, stream); prof.push_back(pe); }
+    }
+    if (d_emb && v_emb >= 0) {
+        hipError_t e = hipMemcpyAsync(d_emb, vptr(v_emb, d_in, d_logits, d_emb), (size_t)n * emb_dim * 4,
+                                      hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) { *err = std::string("emb copy: ") + hipGetErrorString(e); return false; }
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { *err = std::string("kernel launch: ") + hipGetErrorString(e); return false; }
+    return true;
+}
+
+// ================================================================================================ describe / profile
+static void jesc(std::ostringstream& os, const std::string& s) {
+    for (char c : s) { if (c == '"' || c == '\\') os << '\\'; os << c; }
+}
+
+std::string Engine::describe() const {
+    std::ostringstream os;
+    os << "{\"n_samples\":" << n_samples << ",\"n_classes\":" << n_classes << ",\"emb_dim\":" << emb_dim
+       << ",\"max_batch\":" << max_batch << ",\"act_arena_bytes\":" << act_bytes << ",\"weight_bytes\":" << w_bytes
+       << ",\"specs\":[";
+    for (size_t i = 0; i < specs.size(); i++) {
+        const FrontSpec& f = specs[i];
+        os << (i ? "," : "") << "{\"frame_length\":" << f.L << ",\"fft_length\":" << f.Lfft << ",\"hop\":" << f.hop
+           << ",\"frames\":" << f.F << ",\"n_mels\":" << f.n_mels << ",\"channel\":" << f.c << ",\"p1\":" << f.p1
+           << ",\"p2\":" << f.p2 << "}";
+    }
+    os << "],\"steps\":[";
+    for (size_t i = 0; i < steps.size(); i++) {
+        const Step& s = steps[i];
+        os << (i ? "," : "") << "{\"i\":" << i << ",\"kernel\":\"" << s.kclass << "\",\"name\":\"";
+        jesc(os, s.name);
+        os << "\",\"H\":" << s.H << ",\"W\":" << s.W << ",\"C\":" << s.C << ",\"Co\":" << s.Co << ",\"k\":" << s.kh
+           << ",\"stride\":" << s.sh << ",\"act\":" << s.act << ",\"fused_scale\":" << (s.kind == S_PW && s.in1 >= 0 ? 1 : 0)
+           << ",\"fused_res\":" << (s.kind == S_PW && s.in2 >= 0 ? 1 : 0) << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << ",\"wbytes\":" << s.wbytes << "}";
+    }
+    os << "]}";
+    return os.str();
+}
+
+std::string Engine::profile_read() {
+    hipStreamSynchronize(stream);
+    struct Agg { double ms = 0, flops = 0, bytes = 0; long launches = 0; };
+    std::map<std::string, Agg> agg;
+    std::vector<std::string> order;
+    for (auto& e : prof) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, e.a, e.b);
+        const Step& s = steps[e.step];
+        if (!agg.count(s.kclass)) order.push_back(s.kclass);
+        Agg& a = agg[s.kclass];
+        a.ms += ms; a.launches++; a.flops += s.flops * e.n; a.bytes += s.bytes * e.n + s.wbytes;
+        ev_pool.push_back(e.a); ev_pool.push_back(e.b);
+    }
+    prof.clear();
+    std::ostringstream os;
+    os << "[";
+    for (size_t i = 0; i < order.size(); i++) {
+        const Agg& a = agg[order[i]];
+        os << (i ? "," : "") << "{\"kernel\":\"" << order[i] << "\",\"launches\":" << a.launches << ",\"ms\":" << a.ms
+           << ",\"flops\":" << a.flops << ",\"bytes\":" << a.bytes << "}";
+    }
+    os << "]";
+    return os.str();
+}
+
+}  // namespace bnhip

@@ -1,0 +1,91 @@
+// Graph planner + executor: TFLite op graph -> fused gfx950 kernel plan.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "tflite_model.h"
+
+namespace bnhip {
+
+enum StepKind { S_MINMAX, S_FRONTEND, S_CONV_DIRECT, S_PW, S_DW, S_MEAN_PARTIAL, S_MEAN_FINISH, S_SE, S_UNARY, S_BINARY };
+
+struct Step {
+    StepKind kind;
+    std::string name;        // graph op name (for describe/profile)
+    const char* kclass;      // kernel class for profile aggregation
+    // value ids (indices into Engine::vals) ; -1 = none
+    int in0 = -1, in1 = -1, in2 = -1, out = -1;
+    // weights (device pointers into the weight arena)
+    const float *w0 = nullptr, *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;
+    // geometry per clip
+    int H = 0, W = 0, C = 0, Ho = 0, Wo = 0, Co = 0, kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0;
+    int act = 0, act2 = 0, op = 0, mode = 0, S = 1, Cr = 0;
+    // front-end
+    int spec = -1;
+    // accounting per clip
+    double flops = 0, bytes = 0, wbytes = 0;   // wbytes: weight bytes per launch
+};
+
+struct Value {               // an activation tensor (per clip geometry)
+    int tfl = -1;            // tflite tensor id (or -1 for internal scratch)
+    size_t elems = 0;        // floats per clip
+    size_t offset = 0;       // byte offset in the activation arena (for max_batch)
+    int first = -1, last = -1;   // step liveness
+    bool external = false;   // bound at run time (graph input / outputs)
+};
+
+struct FrontSpec {
+    int L, Lp, Lfft, hop, F, n_mels, NTP, c;
+    float p1, p2, eps, norm_sub, norm_mul;
+    const float* G = nullptr;    // device
+};
+
+struct ProfEntry { hipEvent_t a, b; int step; int n; };
+
+class Engine {
+  public:
+    ~Engine();
+    // returns false and sets err (+ code: BNHIP_E_*) on failure
+    bool build(const TflModel& m, int device, int max_batch, bool plan_only, std::string* err, int* code);
+    bool run(const float* d_in, int n, float* d_logits, float* d_emb, std::string* err);
+
+    int device = 0, max_batch = 256;
+    int n_samples = 0, n_classes = 0, emb_dim = 0, C_spec = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool profiling = false;
+
+    std::vector<Step> steps;
+    std::vector<Value> vals;
+    std::vector<FrontSpec> specs;
+    int v_input = -1, v_logits = -1, v_emb = -1, v_mm = -1;
+
+    // staging for host-pointer API
+    float* d_stage_in = nullptr;      // [max_batch, n_samples]
+    float* d_stage_logits = nullptr;  // [max_batch, n_classes]
+    float* d_stage_emb = nullptr;     // [max_batch, emb_dim]
+    int16_t* d_stage_pcm = nullptr;
+    float* d_post_conf = nullptr;     // [max_batch, n_classes]
+    float* d_topk_conf = nullptr;
+    int32_t* d_topk_idx = nullptr;
+    int topk_cap = 0;
+
+    std::string describe() const;
+    std::string profile_read();
+
+  private:
+    char* act_arena = nullptr;
+    size_t act_bytes = 0;
+    char* w_arena = nullptr;
+    size_t w_bytes = 0;
+    std::vector<ProfEntry> prof;
+    std::vector<hipEvent_t> ev_pool;
+    float* vptr(int v, const float* d_in, float* d_logits, float* d_emb) const;
+    hipEvent_t get_event();
+};
+
+}  // namespace bnhip

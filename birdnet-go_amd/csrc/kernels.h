@@ -1,0 +1,83 @@
+// Launch wrappers for the gfx950 kernels in kernels.hip.  All tensors are fp32, activations NHWC.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace bnhip {
+
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 3, ACT_SWISH = 100, ACT_SIGMOID = 101, ACT_HARD_SWISH = 102 };
+
+// ---- ingest
+void launch_pcm16_to_f32(const int16_t* pcm, float* out, size_t n, hipStream_t s);
+
+// ---- front-end
+// per-clip (min, max(x-min)+eps) as TFLite's REDUCE_MIN/SUB/REDUCE_MAX/ADD chain produces them
+void launch_clip_minmax(const float* x, int n_clips, int n_samples, float eps, float2* mm, hipStream_t s);
+
+struct FrontendParams {
+    const float* x;        // [B, n_samples] raw clip
+    const float2* mm;      // [B] (min, range+eps)
+    const float* G;        // [Lp, NTP] folded window*DFT-real*mel matrix, rows >= L are zero
+    float* out;            // [B, n_mels, F, C]
+    int n_samples, L, Lp, hop, F, n_mels, NTP, C, c;   // c = channel index written
+    float norm_sub, norm_mul;   // (x-min)/range - norm_sub) * norm_mul
+    float p1, p2;          // y = pow(pow(v, p1), p2); p2 == 1 => single pow
+    int n_clips;
+};
+void launch_frontend(const FrontendParams& p, hipStream_t s);
+size_t frontend_lds_bytes(int L, int Lp, int hop, int NTP);
+constexpr int kFrontendKC = 32;   // K-chunk of the front-end GEMM (G rows per LDS stage)
+
+// ---- CNN
+struct ConvParams {       // direct conv, small Cin (stem)
+    const float* in; const float* w /*[kh][kw][Cin][Cout]*/; const float* bias; float* out;
+    int B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, pt, pl, act;
+};
+void launch_conv_direct(const ConvParams& p, hipStream_t s);
+
+struct PwParams {         // pointwise conv / fully-connected as GEMM: out[M,N] = act(A[M,K] W[N,K]^T + b) (+res)
+    const float* A; const float* W; const float* bias; const float* ascale; const float* res; float* out;
+    int M, N, K, HW, act;
+};
+void launch_pw_gemm(const PwParams& p, hipStream_t s);
+
+struct DwParams {
+    const float* in; const float* w /*[kh][kw][C]*/; const float* bias; float* out;
+    int B, H, W, C, Ho, Wo, kh, kw, sh, sw, pt, pl, act;
+};
+void launch_dwconv(const DwParams& p, hipStream_t s);
+
+// mean over H*W: in [B,HW,C] -> partial [B,S,C] (sums), S = number of pixel splits
+int mean_splits(int HW);
+void launch_mean_partial(const float* in, float* partial, int B, int HW, int C, int S, hipStream_t s);
+// finish: out[b][c] = sum_s partial[b][s][c] / HW
+void launch_mean_finish(const float* partial, float* out, int B, int HW, int C, int S, hipStream_t s);
+
+struct SeParams {         // squeeze-excite FCs on pooled sums
+    const float* partial; int S; int HW;         // pooled sums [B,S,C]
+    const float* w1; const float* b1;            // [Cr, C], [Cr]
+    const float* w2; const float* b2;            // [C, Cr], [C]
+    float* scale;                                // [B, C]
+    int B, C, Cr, act1, act2;
+};
+void launch_se(const SeParams& p, hipStream_t s);
+
+// ---- generic fallbacks (unfused graphs)
+void launch_unary(const float* in, float* out, size_t n, int act, hipStream_t s);
+// mode 0: same shape; mode 1: b is [B,1,1,C] broadcast over HW (a is [B,HW,C]); mode 2: b scalar
+void launch_binary(const float* a, const float* b, float* out, size_t n, int op /*0 add 1 mul 2 sub*/, int mode,
+                   int HW, int C, int act, hipStream_t s);
+
+// ---- post-processing
+// activation 0: float32(1/(1+exp(-sens*float64(x)))); 1: softmax (f32 max-sub, f64 exp, f32 sum); 2: f32-div sigmoid
+void launch_activation(const float* logits, float* conf, int n_clips, int n_classes, int activation, double sens,
+                       hipStream_t s);
+void launch_topk(const float* conf, int n_clips, int n_classes, int k, float* out_conf, int32_t* out_idx,
+                 hipStream_t s);
+
+// ---- ultrasonic frame-CV (float64)
+void launch_us_frame_power(const double* samples, int n_clips, int n, int fft_size, int hop, int frames,
+                           int split_bin, double* powers /*[n_clips, frames]*/, hipStream_t s);
+void launch_us_cv(const double* powers, int n_clips, int frames, double* cv, hipStream_t s);
+
+}  // namespace bnhip

@@ -1,0 +1,735 @@
+// gfx950 (CDNA4 / MI355X) kernels for the BirdNET inference hot path.  fp32 throughout (the
+// reference documents f16 as fatal for v2.4: internal/classifier/model_openvino.go:99-103);
+// contractions run on the f32-input MFMA (v_mfma_f32_16x16x4_f32), whose result is bit-for-bit a
+// k-ordered fmaf chain, so numerics are those of a plain fp32 CPU kernel.
+//
+// Layouts: activations NHWC fp32; pointwise/FC weights [N][K] (TFLite OHWI with 1x1 == [Cout][Cin]),
+// depthwise weights [kh][kw][C], stem weights re-laid to [kh][kw][Cin][Cout] at plan time.
+#include "kernels.h"
+
+#include <cmath>
+
+namespace bnhip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return fmaxf(v, 0.0f);
+        case ACT_RELU6: return fminf(fmaxf(v, 0.0f), 6.0f);
+        case ACT_SWISH: { float s = 1.0f / (1.0f + expf(-v)); return v * s; }   // LOGISTIC then MUL, as the graph does
+        case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        case ACT_HARD_SWISH: return v * fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) / 6.0f;
+        default: return v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ ingest
+// internal/analysis/process.go:491-495: float32(int16)/32768
+__global__ void k_pcm16_to_f32(const int16_t* __restrict__ pcm, float* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = (float)pcm[i] / 32768.0f;
+}
+void launch_pcm16_to_f32(const int16_t* pcm, float* out, size_t n, hipStream_t s) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_pcm16_to_f32, dim3(blocks), dim3(256), 0, s, pcm, out, n);
+}
+
+// ------------------------------------------------------------------------------------------ front-end
+// One block per clip: min(x) and fl(max(x)-min)+eps, i.e. REDUCE_MIN -> SUB -> REDUCE_MAX -> ADD eps.
+__global__ __launch_bounds__(1024) void k_clip_minmax(const float* __restrict__ x, int n_samples, float eps,
+                                                      float2* __restrict__ mm) {
+    const float* xc = x + (size_t)blockIdx.x * n_samples;
+    float mn = INFINITY, mx = -INFINITY;
+    if ((n_samples & 3) == 0 && ((((size_t)blockIdx.x * n_samples) & 3) == 0)) {
+        const float4* x4 = reinterpret_cast<const float4*>(xc);
+        for (int i = threadIdx.x; i < n_samples / 4; i += blockDim.x) {
+            float4 v = x4[i];
+            mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
+            mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+        }
+    } else {
+        for (int i = threadIdx.x; i < n_samples; i += blockDim.x) { float v = xc[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    }
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_down(mn, o, 64)); mx = fmaxf(mx, __shfl_down(mx, o, 64)); }
+    __shared__ float smn[16], smx[16];
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { smn[w] = mn; smx[w] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int nw = blockDim.x >> 6;
+        for (int i = 1; i < nw; i++) { mn = fminf(mn, smn[i]); mx = fmaxf(mx, smx[i]); }
+        float range = mx - mn;          // == max_i fl(x_i - mn): rounding is monotone
+        mm[blockIdx.x] = make_float2(mn, range + eps);
+    }
+}
+void launch_clip_minmax(const float* x, int n_clips, int n_samples, float eps, float2* mm, hipStream_t s) {
+    hipLaunchKernelGGL(k_clip_minmax, dim3(n_clips), dim3(1024), 0, s, x, n_samples, eps, mm);
+}
+
+// Fused normalise -> frame -> (window * real-DFT * mel) -> x^p1 -> x^p2 -> NHWC store.
+// Because the graph keeps only the REAL part of the STFT (CAST complex64->float32) and applies the
+// mel matrix before squaring, everything up to the first POW is linear in the normalised signal:
+//   mel[f, m] = sum_n xn[f*hop + n] * G[n, m],  G = diag(hann) * cos(2*pi*k*n/N) * Mel  (built in fp64 on host)
+// so the whole stage is one strided-window GEMM on the f32 MFMA: A rows are overlapping windows of the
+// LDS-resident clip segment (never materialised), B = G streamed from L2 in 32-row chunks.
+// Block: 64 frames x (16*NT) mel columns, 4 waves, wave w owns frames [16w,16w+16) x all NT tiles.
+#define FE_FT 64
+#define FE_KC 32
+template <int NT>
+__global__ __launch_bounds__(256) void k_frontend(FrontendParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NTP = NT * 16;
+    constexpr int GS = NTP + 16;                 // LDS row stride of a G chunk: k-rows land 16 banks apart
+    constexpr int GQ = (NT + 1) / 2;             // float4 per thread per chunk
+    const int seg_len = (FE_FT - 1) * p.hop + p.Lp;
+    float* seg = smem;
+    float* Gs = smem + ((seg_len + 3) & ~3);
+
+    const int b = blockIdx.y;
+    const int f0 = blockIdx.x * FE_FT;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+
+    // ---- stage + normalise the clip segment ((x - min) / (range+eps) - 0.5) * 2, exactly the graph's op order
+    {
+        const float2 mm = p.mm[b];
+        const float* xc = p.x + (size_t)b * p.n_samples;
+        const int s0 = f0 * p.hop;
+        for (int i = tid; i < seg_len; i += 256) {
+            int g = s0 + i;
+            float v = 0.0f;
+            if (g < p.n_samples) {
+                float t = xc[g] - mm.x;
+                t = t / mm.y;
+                t = t - p.norm_sub;
+                v = t * p.norm_mul;
+            }
+            seg[i] = v;
+        }
+    }
+
+    const float4* G4 = reinterpret_cast<const float4*>(p.G);
+    float4 greg[GQ];
+    auto gload = [&](int chunk) {
+#pragma unroll
+        for (int q = 0; q < GQ; q++) {
+            int idx = tid + 256 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < FE_KC * (NTP / 4)) v = G4[(size_t)chunk * FE_KC * (NTP / 4) + idx];
+            greg[q] = v;
+        }
+    };
+    auto gstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < GQ; q++) {
+            int idx = tid + 256 * q;
+            if (idx < FE_KC * (NTP / 4)) {
+                int r = idx / (NTP / 4), c4 = idx % (NTP / 4);
+                *reinterpret_cast<float4*>(&Gs[buf * FE_KC * GS + r * GS + 4 * c4]) = greg[q];
+            }
+        }
+    };
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = p.Lp / FE_KC;
+    gload(0);
+    gstore(0);
+    __syncthreads();
+    const float* arow = seg + (16 * wave + li) * p.hop + kq;
+    for (int ch = 0; ch < nchunks; ch++) {
+        if (ch + 1 < nchunks) gload(ch + 1);
+        const float* gb = Gs + (ch & 1) * FE_KC * GS + kq * GS + li;
+        const float* ab = arow + ch * FE_KC;
+#pragma unroll
+        for (int kk = 0; kk < FE_KC / 4; kk++) {
+            float a = ab[kk * 4];
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                float bv = gb[kk * 4 * GS + t * 16];
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[t], 0, 0, 0);
+            }
+        }
+        if (ch + 1 < nchunks) gstore((ch + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[i = frame 4*kq + r][j = mel li]
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        int m = t * 16 + li;
+        if (m >= p.n_mels) continue;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int f = f0 + 16 * wave + 4 * kq + r;
+            if (f >= p.F) continue;
+            float v = acc[t][r];
+            float y = (p.p1 == 2.0f) ? v * v : powf(v, p.p1);
+            if (p.p2 != 1.0f) y = powf(y, p.p2);
+            p.out[(((size_t)b * p.n_mels + m) * p.F + f) * p.C + p.c] = y;
+        }
+    }
+}
+
+size_t frontend_lds_bytes(int L, int Lp, int hop, int NTP) {
+    (void)L;
+    int seg_len = (FE_FT - 1) * hop + Lp;
+    return (size_t)(((seg_len + 3) & ~3) + 2 * FE_KC * (NTP + 16)) * sizeof(float);
+}
+
+template <int NT>
+static void launch_frontend_nt(const FrontendParams& p, hipStream_t s) {
+    size_t lds = frontend_lds_bytes(p.L, p.Lp, p.hop, p.NTP);
+    static bool attr_set[9] = {};
+    if (!attr_set[NT]) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frontend<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+        attr_set[NT] = true;
+    }
+    dim3 grid((p.F + FE_FT - 1) / FE_FT, p.n_clips);
+    hipLaunchKernelGGL(k_frontend<NT>, grid, dim3(256), lds, s, p);
+}
+void launch_frontend(const FrontendParams& p, hipStream_t s) {
+    switch (p.NTP / 16) {
+        case 1: launch_frontend_nt<1>(p, s); break; case 2: launch_frontend_nt<2>(p, s); break;
+        case 3: launch_frontend_nt<3>(p, s); break; case 4: launch_frontend_nt<4>(p, s); break;
+        case 5: launch_frontend_nt<5>(p, s); break; case 6: launch_frontend_nt<6>(p, s); break;
+        case 7: launch_frontend_nt<7>(p, s); break; case 8: launch_frontend_nt<8>(p, s); break;
+        default: break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ direct conv (stem)
+// thread = (output pixel, group of 4 output channels); weights [kh][kw][Cin][Cout].
+__global__ __launch_bounds__(256) void k_conv_direct(ConvParams p) {
+    const int C4 = p.Cout >> 2;
+    size_t total = (size_t)p.B * p.Ho * p.Wo * C4;
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    int c4 = (int)(idx % C4);
+    size_t pix = idx / C4;
+    int wo = (int)(pix % p.Wo);
+    int ho = (int)((pix / p.Wo) % p.Ho);
+    int b = (int)(pix / ((size_t)p.Wo * p.Ho));
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* w4 = reinterpret_cast<const float4*>(p.w);
+    for (int i = 0; i < p.kh; i++) {
+        int hi = ho * p.sh - p.pt + i;
+        if (hi < 0 || hi >= p.H) continue;
+        for (int j = 0; j < p.kw; j++) {
+            int wi = wo * p.sw - p.pl + j;
+            if (wi < 0 || wi >= p.W) continue;
+            const float* ip = p.in + (((size_t)b * p.H + hi) * p.W + wi) * p.Cin;
+            const float4* wp = w4 + (size_t)((i * p.kw + j) * p.Cin) * C4 + c4;
+            for (int ci = 0; ci < p.Cin; ci++) {
+                float x = ip[ci];
+                float4 w = wp[(size_t)ci * C4];
+                acc.x = fmaf(x, w.x, acc.x); acc.y = fmaf(x, w.y, acc.y);
+                acc.z = fmaf(x, w.z, acc.z); acc.w = fmaf(x, w.w, acc.w);
+            }
+        }
+    }
+    if (p.bias) {
+        float4 bv = reinterpret_cast<const float4*>(p.bias)[c4];
+        acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
+    }
+    acc.x = apply_act(acc.x, p.act); acc.y = apply_act(acc.y, p.act);
+    acc.z = apply_act(acc.z, p.act); acc.w = apply_act(acc.w, p.act);
+    reinterpret_cast<float4*>(p.out)[idx] = acc;
+}
+void launch_conv_direct(const ConvParams& p, hipStream_t s) {
+    size_t total = (size_t)p.B * p.Ho * p.Wo * (p.Cout >> 2);
+    hipLaunchKernelGGL(k_conv_direct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+}
+
+// ------------------------------------------------------------------------------------------ pointwise GEMM
+// out[M,N] = act(A[M,K] * W[N,K]^T + bias[N]) (+ res[M,N]); optional per-(batch,k) scale on A (squeeze-excite
+// MUL folded into the consumer's operand load).  f32 MFMA 16x16x4 with the roles swapped (W rows feed
+// the MFMA "A" side, activation rows the "B" side) so each lane ends up holding 4 consecutive output
+// channels of one row -> one 16-byte store per tile.
+// Block 128 rows x (16*NT) cols, 4 waves, wave w owns rows [32w,32w+32).  BK = 32, LDS row stride 40 floats:
+// with ds_read_b128 fragment loads the (row*10 + kq) 16-byte slot pattern is conflict-free for every
+// 16-lane service group.  K is consumed in permuted order inside each 16-wide slab (lane kq holds
+// k = 4kq..4kq+3, MFMA step s pairs element s of both operands) - a fixed reordering of the fp32 sum.
+#define PW_BM 128
+#define PW_BK 32
+#define PW_LS 40
+template <int NT>
+__global__ __launch_bounds__(256) void k_pw_gemm(PwParams p) {
+    __shared__ __attribute__((aligned(16))) float Xs[PW_BM * PW_LS];
+    __shared__ __attribute__((aligned(16))) float Ws[NT * 16 * PW_LS];
+    constexpr int WQ = (NT + 1) / 2;             // float4 per thread for the W tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * PW_BM;
+    const int n0 = blockIdx.y * (NT * 16);
+    const int K = p.K;
+
+    float4 xreg[4], wreg[WQ];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int idx = tid + 256 * q;
+            int row = idx >> 3, c4 = idx & 7;
+            int m = m0 + row, k = k0 + 4 * c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < p.M && k < K) {
+                v = *reinterpret_cast<const float4*>(p.A + (size_t)m * K + k);
+                if (p.ascale) {
+                    float4 sc = *reinterpret_cast<const float4*>(p.ascale + (size_t)(m / p.HW) * K + k);
+                    v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+                }
+            }
+            xreg[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < WQ; q++) {
+            int idx = tid + 256 * q;
+            int row = idx >> 3, c4 = idx & 7;
+            int n = n0 + row, k = k0 + 4 * c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < NT * 16 && n < p.N && k < K) v = *reinterpret_cast<const float4*>(p.W + (size_t)n * K + k);
+            wreg[q] = v;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int idx = tid + 256 * q;
+            *reinterpret_cast<float4*>(&Xs[(idx >> 3) * PW_LS + 4 * (idx & 7)]) = xreg[q];
+        }
+#pragma unroll
+        for (int q = 0; q < WQ; q++) {
+            int idx = tid + 256 * q;
+            if ((idx >> 3) < NT * 16) *reinterpret_cast<float4*>(&Ws[(idx >> 3) * PW_LS + 4 * (idx & 7)]) = wreg[q];
+        }
+    };
+
+    f32x4 acc[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; t++) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    gload(0);
+    for (int k0 = 0; k0 < K; k0 += PW_BK) {
+        lstore();
+        __syncthreads();
+        if (k0 + PW_BK < K) gload(k0 + PW_BK);
+#pragma unroll
+        for (int t16 = 0; t16 < 2; t16++) {
+            f32x4 xf[2], wf[NT];
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+                xf[mt] = *reinterpret_cast<const f32x4*>(&Xs[(32 * wave + 16 * mt + li) * PW_LS + 16 * t16 + 4 * kq]);
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+                wf[t] = *reinterpret_cast<const f32x4*>(&Ws[(16 * t + li) * PW_LS + 16 * t16 + 4 * kq]);
+#pragma unroll
+            for (int sidx = 0; sidx < 4; sidx++) {
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][sidx], xf[0][sidx], acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][sidx], xf[1][sidx], acc[t][1], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[i = n 4*kq + r][j = m li]
+    const bool vec_ok = (p.N & 3) == 0;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+        int m = m0 + 32 * wave + 16 * mt + li;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            int n = n0 + 16 * t + 4 * kq;
+            if (n >= p.N) continue;
+            f32x4 v = acc[t][mt];
+            if (vec_ok) {
+                if (p.bias) { float4 bv = *reinterpret_cast<const float4*>(p.bias + n); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
+                v[0] = apply_act(v[0], p.act); v[1] = apply_act(v[1], p.act);
+                v[2] = apply_act(v[2], p.act); v[3] = apply_act(v[3], p.act);
+                if (p.res) { float4 rv = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.N + n); v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
+                *reinterpret_cast<float4*>(p.out + (size_t)m * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (n + r >= p.N) break;
+                    float x = v[r];
+                    if (p.bias) x += p.bias[n + r];
+                    x = apply_act(x, p.act);
+                    if (p.res) x += p.res[(size_t)m * p.N + n + r];
+                    p.out[(size_t)m * p.N + n + r] = x;
+                }
+            }
+        }
+    }
+}
+
+// scalar fallback for K not a multiple of 4 (never hit by EfficientNet-style graphs; kept for drop-in safety)
+__global__ void k_pw_naive(PwParams p) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)p.M * p.N) return;
+    int n = (int)(idx % p.N);
+    size_t m = idx / p.N;
+    float acc = 0.f;
+    for (int k = 0; k < p.K; k++) {
+        float a = p.A[m * p.K + k];
+        if (p.ascale) a *= p.ascale[(m / p.HW) * p.K + k];
+        acc = fmaf(a, p.W[(size_t)n * p.K + k], acc);
+    }
+    if (p.bias) acc += p.bias[n];
+    acc = apply_act(acc, p.act);
+    if (p.res) acc += p.res[idx];
+    p.out[idx] = acc;
+}
+
+static int pick_nt(int N) {
+    // minimise padded columns, prefer wider tiles on ties
+    int best = 1; long best_cost = -1;
+    for (int nt = 1; nt <= 8; nt++) {
+        int bn = nt * 16;
+        long cols = (long)((N + bn - 1) / bn) * bn;
+        if (best_cost < 0 || cols < best_cost || (cols == best_cost && nt > best)) { best = nt; best_cost = cols; }
+    }
+    return best;
+}
+
+void launch_pw_gemm(const PwParams& p, hipStream_t s) {
+    if ((p.K & 3) != 0) {
+        size_t total = (size_t)p.M * p.N;
+        hipLaunchKernelGGL(k_pw_naive, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+        return;
+    }
+    int nt = pick_nt(p.N);
+    dim3 grid((p.M + PW_BM - 1) / PW_BM, (p.N + nt * 16 - 1) / (nt * 16));
+    switch (nt) {
+        case 1: hipLaunchKernelGGL(k_pw_gemm<1>, grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL(k_pw_gemm<2>, grid, dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL(k_pw_gemm<3>, grid, dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL(k_pw_gemm<4>, grid, dim3(256), 0, s, p); break;
+        case 5: hipLaunchKernelGGL(k_pw_gemm<5>, grid, dim3(256), 0, s, p); break;
+        case 6: hipLaunchKernelGGL(k_pw_gemm<6>, grid, dim3(256), 0, s, p); break;
+        case 7: hipLaunchKernelGGL(k_pw_gemm<7>, grid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL(k_pw_gemm<8>, grid, dim3(256), 0, s, p); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ depthwise conv
+// thread = (output pixel, 4 channels). HBM-bound: each input element is re-read k*k/(s*s) times from L1/L2.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_dwconv(DwParams p) {
+    const int CV = p.C / VEC;
+    size_t total = (size_t)p.B * p.Ho * p.Wo * CV;
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    int cv = (int)(idx % CV);
+    size_t pix = idx / CV;
+    int wo = (int)(pix % p.Wo);
+    int ho = (int)((pix / p.Wo) % p.Ho);
+    int b = (int)(pix / ((size_t)p.Wo * p.Ho));
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) acc[v] = 0.f;
+    for (int i = 0; i < p.kh; i++) {
+        int hi = ho * p.sh - p.pt + i;
+        if (hi < 0 || hi >= p.H) continue;
+        for (int j = 0; j < p.kw; j++) {
+            int wi = wo * p.sw - p.pl + j;
+            if (wi < 0 || wi >= p.W) continue;
+            const float* ip = p.in + (((size_t)b * p.H + hi) * p.W + wi) * p.C + (size_t)cv * VEC;
+            const float* wp = p.w + (size_t)(i * p.kw + j) * p.C + (size_t)cv * VEC;
+            if (VEC == 4) {
+                float4 x = *reinterpret_cast<const float4*>(ip);
+                float4 w = *reinterpret_cast<const float4*>(wp);
+                acc[0] = fmaf(x.x, w.x, acc[0]); acc[1 % VEC] = fmaf(x.y, w.y, acc[1 % VEC]);
+                acc[2 % VEC] = fmaf(x.z, w.z, acc[2 % VEC]); acc[3 % VEC] = fmaf(x.w, w.w, acc[3 % VEC]);
+            } else {
+                acc[0] = fmaf(ip[0], wp[0], acc[0]);
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; v++) {
+        float x = acc[v];
+        if (p.bias) x += p.bias[cv * VEC + v];
+        acc[v] = apply_act(x, p.act);
+    }
+    if (VEC == 4) reinterpret_cast<float4*>(p.out)[idx] = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
+    else p.out[idx] = acc[0];
+}
+void launch_dwconv(const DwParams& p, hipStream_t s) {
+    if ((p.C & 3) == 0) {
+        size_t total = (size_t)p.B * p.Ho * p.Wo * (p.C / 4);
+        hipLaunchKernelGGL(k_dwconv<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+    } else {
+        size_t total = (size_t)p.B * p.Ho * p.Wo * p.C;
+        hipLaunchKernelGGL(k_dwconv<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ spatial mean
+// Deterministic two-stage reduction (no float atomics): partial[b][s][c] = sum over the s-th pixel slab.
+#define MEAN_SLAB 512
+int mean_splits(int HW) { return (HW + MEAN_SLAB - 1) / MEAN_SLAB; }
+
+__global__ __launch_bounds__(256) void k_mean_partial(const float* __restrict__ in, float* __restrict__ partial,
+                                                      int HW, int C, int S) {
+    __shared__ float red[256];
+    const int b = blockIdx.z, sp = blockIdx.y;
+    const int CW = blockDim.x, PY = blockDim.y;
+    const int c = blockIdx.x * CW + threadIdx.x;
+    const int p0 = sp * MEAN_SLAB, p1 = min(HW, p0 + MEAN_SLAB);
+    float acc = 0.f;
+    if (c < C)
+        for (int px = p0 + threadIdx.y; px < p1; px += PY) acc += in[((size_t)b * HW + px) * C + c];
+    red[threadIdx.y * CW + threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.y == 0 && c < C) {
+        float sum = 0.f;
+        for (int y = 0; y < PY; y++) sum += red[y * CW + threadIdx.x];
+        partial[((size_t)b * S + sp) * C + c] = sum;
+    }
+}
+void launch_mean_partial(const float* in, float* partial, int B, int HW, int C, int S, hipStream_t s) {
+    int CW = C < 64 ? C : 64;
+    int PY = 256 / CW; if (PY < 1) PY = 1;
+    dim3 grid((C + CW - 1) / CW, S, B);
+    hipLaunchKernelGGL(k_mean_partial, grid, dim3(CW, PY), 0, s, in, partial, HW, C, S);
+}
+__global__ void k_mean_finish(const float* __restrict__ partial, float* __restrict__ out, int B, int HW, int C, int S) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * C) return;
+    int c = (int)(idx % C); size_t b = idx / C;
+    float sum = 0.f;
+    for (int sidx = 0; sidx < S; sidx++) sum += partial[(b * S + sidx) * C + c];
+    out[idx] = sum / (float)HW;
+}
+void launch_mean_finish(const float* partial, float* out, int B, int HW, int C, int S, hipStream_t s) {
+    size_t total = (size_t)B * C;
+    hipLaunchKernelGGL(k_mean_finish, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, partial, out, B, HW, C, S);
+}
+
+// ------------------------------------------------------------------------------------------ squeeze-excite
+// One block per clip: mean -> FC(Cr)+act1 -> FC(C)+act2 -> scale[b][c].
+__global__ __launch_bounds__(256) void k_se(SeParams p) {
+    extern __shared__ float sm[];
+    float* mean = sm;            // [C]
+    float* r = sm + p.C;         // [Cr]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < p.C; c += 256) {
+        float sum = 0.f;
+        for (int sidx = 0; sidx < p.S; sidx++) sum += p.partial[((size_t)b * p.S + sidx) * p.C + c];
+        mean[c] = sum / (float)p.HW;
+    }
+    __syncthreads();
+    for (int j = wave; j < p.Cr; j += 4) {
+        float acc = 0.f;
+        for (int c = lane; c < p.C; c += 64) acc = fmaf(p.w1[(size_t)j * p.C + c], mean[c], acc);
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if (lane == 0) r[j] = apply_act(acc + (p.b1 ? p.b1[j] : 0.f), p.act1);
+    }
+    __syncthreads();
+    for (int c = tid; c < p.C; c += 256) {
+        float acc = 0.f;
+        for (int j = 0; j < p.Cr; j++) acc = fmaf(p.w2[(size_t)c * p.Cr + j], r[j], acc);
+        p.scale[(size_t)b * p.C + c] = apply_act(acc + (p.b2 ? p.b2[c] : 0.f), p.act2);
+    }
+}
+void launch_se(const SeParams& p, hipStream_t s) {
+    size_t lds = (size_t)(p.C + p.Cr) * sizeof(float);
+    hipLaunchKernelGGL(k_se, dim3(p.B), dim3(256), lds, s, p);
+}
+
+// ------------------------------------------------------------------------------------------ generic elementwise
+__global__ void k_unary(const float* __restrict__ in, float* __restrict__ out, size_t n, int act) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = apply_act(in[i], act);
+}
+void launch_unary(const float* in, float* out, size_t n, int act, hipStream_t s) {
+    size_t blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_unary, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n, act);
+}
+__global__ void k_binary(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n,
+                         int op, int mode, int HW, int C, int act) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float y = mode == 0 ? b[i] : (mode == 2 ? b[0] : b[(i / ((size_t)HW * C)) * C + (i % C)]);
+        float x = a[i];
+        float v = op == 0 ? x + y : (op == 1 ? x * y : x - y);
+        out[i] = apply_act(v, act);
+    }
+}
+void launch_binary(const float* a, const float* b, float* out, size_t n, int op, int mode, int HW, int C, int act,
+                   hipStream_t s) {
+    size_t blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_binary, dim3((unsigned)blocks), dim3(256), 0, s, a, b, out, n, op, mode, HW, C, act);
+}
+
+// ------------------------------------------------------------------------------------------ post-processing
+// classifier/analyze.go:113-115,197-208 (mode 0); onnx/postprocess.go:8-10 (mode 2)
+__global__ void k_sigmoid(const float* __restrict__ x, float* __restrict__ out, size_t n, int mode, double sens) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (mode == 0) out[i] = (float)(1.0 / (1.0 + exp(-sens * (double)x[i])));
+    else out[i] = 1.0f / (1.0f + (float)exp((double)(-x[i])));
+}
+// classifier/perch_onnx.go:315-335: f32 max, e = float32(exp(float64(x - m))), f32 sum in index order, divide
+__global__ __launch_bounds__(256) void k_softmax(const float* __restrict__ x, float* __restrict__ out, int n) {
+    __shared__ float red[4];
+    __shared__ float s_sum;
+    const float* xr = x + (size_t)blockIdx.x * n;
+    float* orow = out + (size_t)blockIdx.x * n;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, xr[i]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    for (int i = threadIdx.x; i < n; i += 256) orow[i] = (float)exp((double)(xr[i] - m));
+    __syncthreads();
+    if (threadIdx.x == 0) {          // sequential f32 sum in index order == the Go loop, bit for bit
+        float sum = 0.f;
+        for (int i = 0; i < n; i++) sum += orow[i];
+        s_sum = sum;
+    }
+    __syncthreads();
+    float sum = s_sum;
+    for (int i = threadIdx.x; i < n; i += 256) orow[i] = orow[i] / sum;
+}
+void launch_activation(const float* logits, float* conf, int n_clips, int n_classes, int activation, double sens,
+                       hipStream_t s) {
+    if (activation == 1) {
+        hipLaunchKernelGGL(k_softmax, dim3(n_clips), dim3(256), 0, s, logits, conf, n_classes);
+    } else {
+        size_t n = (size_t)n_clips * n_classes;
+        hipLaunchKernelGGL(k_sigmoid, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, logits, conf, n, activation, sens);
+    }
+}
+
+// top-k by confidence, descending; ties resolved to the lower label index (the reference's order for
+// ties is implementation-defined: analyze.go:120-124 uses the unstable sort.Slice).
+__global__ __launch_bounds__(256) void k_topk(const float* __restrict__ conf, int n, int k, float* __restrict__ oc,
+                                              int32_t* __restrict__ oi) {
+    extern __shared__ float v[];
+    __shared__ float rv[4];
+    __shared__ int ri[4];
+    const float* row = conf + (size_t)blockIdx.x * n;
+    for (int i = threadIdx.x; i < n; i += 256) v[i] = row[i];
+    __syncthreads();
+    int kk = k < n ? k : n;
+    for (int r = 0; r < kk; r++) {
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            float x = v[i];
+            if (x > best || (x == best && i < bi)) { best = x; bi = i; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            float ob = __shfl_down(best, o, 64); int oidx = __shfl_down(bi, o, 64);
+            if (ob > best || (ob == best && oidx < bi)) { best = ob; bi = oidx; }
+        }
+        if ((threadIdx.x & 63) == 0) { rv[threadIdx.x >> 6] = best; ri[threadIdx.x >> 6] = bi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; w++)
+                if (rv[w] > best || (rv[w] == best && ri[w] < bi)) { best = rv[w]; bi = ri[w]; }
+            oc[(size_t)blockIdx.x * k + r] = best;
+            oi[(size_t)blockIdx.x * k + r] = bi;
+            if (bi >= 0 && bi < n) v[bi] = -INFINITY;
+        }
+        __syncthreads();
+    }
+}
+void launch_topk(const float* conf, int n_clips, int n_classes, int k, float* out_conf, int32_t* out_idx,
+                 hipStream_t s) {
+    hipLaunchKernelGGL(k_topk, dim3(n_clips), dim3(256), (size_t)n_classes * sizeof(float), s, conf, n_classes, k,
+                       out_conf, out_idx);
+}
+
+// ------------------------------------------------------------------------------------------ ultrasonic frame-CV
+// internal/audiocore/ultrasonic/filter.go:20-66 in float64.  One block per (frame, clip); the 8192-point
+// complex128 FFT lives entirely in LDS (128 KiB of the CU's 160 KiB): bit-reversed load with the symmetric
+// Hann window applied, radix-2 DIT stages with directly evaluated twiddles (the Go code's w *= wn recurrence
+// only adds rounding noise), then the one-sided power sum above the split bin.
+__global__ __launch_bounds__(1024) void k_us_frame_power(const double* __restrict__ samples, int n, int fft, int hop,
+                                                         int frames, int split_bin, int log2n,
+                                                         double* __restrict__ powers) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // re[fft], im[fft]
+    double* re = lds; double* im = lds + fft;
+    __shared__ double red[16];
+    const int frame = blockIdx.x, clip = blockIdx.y;
+    const double* x = samples + (size_t)clip * n + (size_t)frame * hop;
+    const double tw = 6.283185307179586476925286766559 / (double)(fft - 1);
+    for (int i = threadIdx.x; i < fft; i += blockDim.x) {
+        double w = 0.5 * (1.0 - cos(tw * (double)i));        // filter.go:139-145
+        unsigned j = __brev((unsigned)i) >> (32 - log2n);
+        re[j] = x[i] * w; im[j] = 0.0;
+    }
+    __syncthreads();
+    for (int size = 2; size <= fft; size <<= 1) {
+        int half = size >> 1;
+        double ang = -6.283185307179586476925286766559 / (double)size;
+        for (int t = threadIdx.x; t < fft / 2; t += blockDim.x) {
+            int k = t & (half - 1);
+            int i0 = ((t - k) << 1) + k, i1 = i0 + half;
+            double s, c; sincos(ang * (double)k, &s, &c);
+            double vr = c * re[i1] - s * im[i1], vi = c * im[i1] + s * re[i1];
+            double ur = re[i0], ui = im[i0];
+            re[i0] = ur + vr; im[i0] = ui + vi; re[i1] = ur - vr; im[i1] = ui - vi;
+        }
+        __syncthreads();
+    }
+    const int nyq = fft / 2;
+    double pw = 0.0;
+    for (int b = split_bin + threadIdx.x; b <= nyq; b += blockDim.x) {
+        double q = re[b] * re[b] + im[b] * im[b];
+        if (b > 0 && b < nyq) q *= 2.0;
+        pw += q;
+    }
+    for (int o = 32; o > 0; o >>= 1) pw += __shfl_down(pw, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pw;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sum = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) sum += red[w];
+        powers[(size_t)clip * frames + frame] = sum;
+    }
+}
+void launch_us_frame_power(const double* samples, int n_clips, int n, int fft_size, int hop, int frames, int split_bin,
+                           double* powers, hipStream_t s) {
+    int log2n = 0; while ((1 << log2n) < fft_size) log2n++;
+    size_t lds = (size_t)fft_size * 2 * sizeof(double);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_us_frame_power), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024 - 256);
+    int threads = fft_size / 2 < 1024 ? (fft_size / 2 < 64 ? 64 : fft_size / 2) : 1024;
+    hipLaunchKernelGGL(k_us_frame_power, dim3(frames, n_clips), dim3(threads), lds, s, samples, n, fft_size, hop,
+                       frames, split_bin, log2n, powers);
+}
+// filter.go:76-97, sequential like the Go loop
+__global__ void k_us_cv(const double* __restrict__ powers, int frames, double* __restrict__ cv) {
+    if (threadIdx.x != 0) return;
+    const double* p = powers + (size_t)blockIdx.x * frames;
+    double n = (double)frames, sum = 0.0;
+    if (frames < 2) { cv[blockIdx.x] = 0.0; return; }
+    for (int i = 0; i < frames; i++) sum += p[i];
+    double mean = sum / n;
+    if (mean <= 0.0) { cv[blockIdx.x] = 0.0; return; }
+    double sq = 0.0;
+    for (int i = 0; i < frames; i++) { double d = p[i] - mean; sq += d * d; }
+    cv[blockIdx.x] = sqrt(sq / n) / mean;
+}
+void launch_us_cv(const double* powers, int n_clips, int frames, double* cv, hipStream_t s) {
+    hipLaunchKernelGGL(k_us_cv, dim3(n_clips), dim3(64), 0, s, powers, frames, cv);
+}
+
+}  // namespace bnhip

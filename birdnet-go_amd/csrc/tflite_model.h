@@ -1,0 +1,63 @@
+// Minimal, bounds-checked reader for TFLite flatbuffers (float models).
+//
+// The reference passes its classifier backend the model as an in-memory byte slice
+// (internal/classifier/birdnet.go:1195-1246 -> internal/inference/tflite/classifier.go:38-41), so the
+// container is part of the drop-in boundary.  Schema: TensorFlow Lite 2.17.1 schema.fbs (third-party).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace bnhip {
+
+enum TensorType : int { TT_FLOAT32 = 0, TT_FLOAT16 = 1, TT_INT32 = 2, TT_UINT8 = 3, TT_INT64 = 4,
+                        TT_COMPLEX64 = 8, TT_INT8 = 9 };
+
+// BuiltinOperator codes (subset)
+enum OpCode : int {
+    OP_ADD = 0, OP_AVERAGE_POOL_2D = 1, OP_CONCATENATION = 2, OP_CONV_2D = 3, OP_DEPTHWISE_CONV_2D = 4,
+    OP_FULLY_CONNECTED = 9, OP_LOGISTIC = 14, OP_MAX_POOL_2D = 17, OP_MUL = 18, OP_RELU = 19, OP_RELU6 = 21,
+    OP_RESHAPE = 22, OP_SOFTMAX = 25, OP_PAD = 34, OP_GATHER = 36, OP_TRANSPOSE = 39, OP_MEAN = 40,
+    OP_SUB = 41, OP_DIV = 42, OP_SQUEEZE = 43, OP_STRIDED_SLICE = 45, OP_CAST = 53, OP_EXPAND_DIMS = 70,
+    OP_SUM = 74, OP_POW = 78, OP_REDUCE_MAX = 82, OP_REDUCE_MIN = 89, OP_REVERSE_V2 = 105,
+    OP_HARD_SWISH = 117, OP_BATCH_MATMUL = 126, OP_RFFT2D = 131, OP_IMAG = 133, OP_REAL = 134,
+    OP_COMPLEX_ABS = 135
+};
+const char* op_name(int code);
+
+struct TflTensor {
+    std::string name;
+    std::vector<int> shape;
+    int type = 0;
+    const uint8_t* data = nullptr;   // points into the caller's blob (valid during model_create only)
+    size_t nbytes = 0;
+    size_t numel() const { size_t n = 1; for (int d : shape) n *= (size_t)d; return n; }
+    const float* f32() const { return reinterpret_cast<const float*>(data); }
+    const int32_t* i32() const { return reinterpret_cast<const int32_t*>(data); }
+};
+
+struct TflOp {
+    int code = -1;
+    std::vector<int> inputs, outputs;
+    // decoded option fields (only those relevant to `code` are meaningful)
+    int padding = 0, stride_w = 1, stride_h = 1, dil_w = 1, dil_h = 1, act = 0, depth_multiplier = 1;
+    int filter_w = 0, filter_h = 0;
+    int axis = 0, batch_dims = 0;
+    bool keep_dims = false, keep_num_dims = false, adj_x = false, adj_y = false;
+    int in_type = 0, out_type = 0;
+    float beta = 1.0f;
+    std::vector<int> new_shape, squeeze_dims;
+};
+
+struct TflModel {
+    std::string description;
+    std::vector<TflTensor> tensors;
+    std::vector<TflOp> ops;
+    std::vector<int> inputs, outputs;
+};
+
+// Parses `blob`; returns false and fills `err` on malformed input. Never reads out of bounds.
+bool parse_tflite(const void* blob, size_t n, TflModel* out, std::string* err);
+
+}  // namespace bnhip

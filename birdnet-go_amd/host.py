@@ -1,0 +1,248 @@
+"""Host-side mirror of the reference's backend interface over the C ABI (ctypes).
+
+Mirrors, name for name, the Go seam this engine drops in behind:
+  inference.Classifier          internal/inference/backend.go:8-19   -> HipClassifier.predict/num_species/close
+  inference.EmbeddingExtractor  internal/inference/backend.go:21-29  -> HipClassifier.predict_with_embeddings
+  onnx.Classifier.PredictBatch  internal/inference/onnx/classifier.go:372-430 -> HipClassifier.predict_batch
+  (*BirdNET).Predict post-proc  internal/classifier/analyze.go:25-110 -> BirdNET.predict (sigmoid(sens) + top-10)
+Error behaviour follows the reference: size mismatch is an error (tflite/classifier.go:102-104), the
+"backend unavailable" condition is a distinct sentinel so callers can fall back
+(openvino/openvino.go:26-31 ErrOpenVINOUnavailable), and nothing ever silently falls back to a CPU path.
+
+This file is plumbing for tests/bench in this repo (Go is not installed here); the production
+binding is the cgo file under go/ (see INTEGRATION.md).
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbnhip.so")
+
+BNHIP_OK, E_INVALID, E_NO_DEVICE, E_MODEL, E_UNSUPPORTED, E_RUNTIME, E_NOMEM = 0, -1, -2, -3, -4, -5, -6
+
+SYMBOLS = ["bnhip_init", "bnhip_shutdown", "bnhip_model_create", "bnhip_model_info", "bnhip_predict",
+           "bnhip_predict_pcm16", "bnhip_predict_device", "bnhip_postprocess_topk", "bnhip_predict_topk",
+           "bnhip_us_frame_cv", "bnhip_set_stream", "bnhip_synchronize", "bnhip_profile_enable",
+           "bnhip_profile_read", "bnhip_model_describe", "bnhip_model_destroy", "bnhip_last_error",
+           "bnhip_version"]
+
+
+class HipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"bnhip error {code}: {msg}")
+        self.code = code
+
+
+class ErrHIPUnavailable(HipError):
+    """Sentinel like openvino.ErrOpenVINOUnavailable: library missing / no gfx950 device."""
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads libbnhip.so; fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ErrHIPUnavailable(E_NO_DEVICE, f"{p} not built (run `python -c 'import __graft_entry__ as g; g.build()'`)")
+    lib = C.CDLL(p)
+    lib.bnhip_last_error.restype = C.c_char_p
+    lib.bnhip_version.restype = C.c_char_p
+    lib.bnhip_model_create.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_void_p)]
+    lib.bnhip_model_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.bnhip_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.bnhip_predict_pcm16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.bnhip_predict_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.bnhip_postprocess_topk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                           C.c_void_p, C.c_void_p]
+    lib.bnhip_predict_topk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p,
+                                       C.c_void_p]
+    lib.bnhip_us_frame_cv.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p]
+    lib.bnhip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.bnhip_synchronize.argtypes = [C.c_void_p]
+    lib.bnhip_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    lib.bnhip_profile_read.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.bnhip_model_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.bnhip_model_destroy.argtypes = [C.c_void_p]
+    lib.bnhip_init.argtypes = [C.POINTER(C.c_int)]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(lib, rc):
+    if rc != BNHIP_OK:
+        msg = (lib.bnhip_last_error() or b"").decode("utf-8", "replace")
+        raise (ErrHIPUnavailable if rc == E_NO_DEVICE else HipError)(rc, msg)
+
+
+def init():
+    """-> number of devices (InitOV analogue, backend_openvino.go:477)."""
+    lib = load_library()
+    n = C.c_int(0)
+    _check(lib, lib.bnhip_init(C.byref(n)))
+    return n.value
+
+
+class HipClassifier:
+    """inference.Classifier + EmbeddingExtractor over libbnhip.so.  NOT thread-safe (backend.go:7)."""
+
+    def __init__(self, model_bytes: bytes, device=0, max_batch=256, plan_only=False):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        opts = json.dumps({"device": device, "max_batch": max_batch, "plan_only": int(plan_only)}).encode()
+        buf = (C.c_char * len(model_bytes)).from_buffer_copy(model_bytes)
+        _check(self._lib, self._lib.bnhip_model_create(C.cast(buf, C.c_void_p), len(model_bytes), opts, C.byref(self._h)))
+        ns, nc, ed = C.c_int(), C.c_int(), C.c_int()
+        _check(self._lib, self._lib.bnhip_model_info(self._h, C.byref(ns), C.byref(nc), C.byref(ed)))
+        self.n_samples, self._n_classes, self.emb_dim = ns.value, nc.value, ed.value
+        self.max_batch = max_batch
+
+    # ---- inference.Classifier
+    def predict(self, samples):
+        """Predict(samples []float32) ([]float32, error): raw logits for ONE clip."""
+        x = np.ascontiguousarray(samples, np.float32).reshape(-1)
+        if x.size != self.n_samples:
+            raise HipError(E_INVALID, f"input size mismatch: expected {self.n_samples} samples, got {x.size}")
+        return self.predict_batch(x, 1)[0]
+
+    def num_species(self):
+        return self._n_classes
+
+    def close(self):
+        if self._h:
+            self._lib.bnhip_model_destroy(self._h)
+            self._h = C.c_void_p()
+
+    # ---- inference.EmbeddingExtractor
+    def predict_with_embeddings(self, samples):
+        x = np.ascontiguousarray(samples, np.float32).reshape(-1)
+        if x.size != self.n_samples:
+            raise HipError(E_INVALID, f"input size mismatch: expected {self.n_samples} samples, got {x.size}")
+        if not self.emb_dim:
+            return self.predict(x), None
+        lg, em = self.predict_batch(x, 1, want_embeddings=True)
+        return lg[0], em[0]
+
+    # ---- onnx.Classifier.PredictBatch shape: flat [B*N] in, [B, classes] out
+    def predict_batch(self, flat, batch_size, want_embeddings=False):
+        self._alive()
+        x = np.ascontiguousarray(flat, np.float32).reshape(-1)
+        if batch_size <= 0 or x.size != batch_size * self.n_samples:
+            raise HipError(E_INVALID, f"input size mismatch: expected {batch_size * self.n_samples} samples, got {x.size}")
+        logits = np.empty((batch_size, self._n_classes), np.float32)
+        emb = np.empty((batch_size, self.emb_dim), np.float32) if (want_embeddings and self.emb_dim) else None
+        _check(self._lib, self._lib.bnhip_predict(self._h, x.ctypes.data, batch_size, logits.ctypes.data,
+                                                  emb.ctypes.data if emb is not None else None))
+        return (logits, emb) if want_embeddings else logits
+
+    def predict_pcm16(self, pcm, batch_size):
+        self._alive()
+        x = np.ascontiguousarray(pcm, np.int16).reshape(-1)
+        if x.size != batch_size * self.n_samples:
+            raise HipError(E_INVALID, f"input size mismatch: expected {batch_size * self.n_samples} samples, got {x.size}")
+        logits = np.empty((batch_size, self._n_classes), np.float32)
+        _check(self._lib, self._lib.bnhip_predict_pcm16(self._h, x.ctypes.data, batch_size, logits.ctypes.data, None))
+        return logits
+
+    def predict_device(self, d_samples_ptr, n_clips, d_logits_ptr, d_emb_ptr=None):
+        self._alive()
+        _check(self._lib, self._lib.bnhip_predict_device(self._h, d_samples_ptr, n_clips, d_logits_ptr, d_emb_ptr))
+
+    def postprocess_topk(self, logits, k=10, activation=0, sensitivity=1.0):
+        self._alive()
+        lg = np.ascontiguousarray(logits, np.float32).reshape(-1, self._n_classes)
+        kk = min(k, self._n_classes)
+        conf = np.empty((lg.shape[0], kk), np.float32)
+        idx = np.empty((lg.shape[0], kk), np.int32)
+        _check(self._lib, self._lib.bnhip_postprocess_topk(self._h, lg.ctypes.data, lg.shape[0], self._n_classes,
+                                                           activation, sensitivity, k, conf.ctypes.data, idx.ctypes.data))
+        return conf, idx
+
+    def predict_topk(self, flat, batch_size, k=10, activation=0, sensitivity=1.0):
+        self._alive()
+        x = np.ascontiguousarray(flat, np.float32).reshape(-1)
+        if x.size != batch_size * self.n_samples:
+            raise HipError(E_INVALID, f"input size mismatch: expected {batch_size * self.n_samples} samples, got {x.size}")
+        kk = min(k, self._n_classes)
+        conf = np.empty((batch_size, kk), np.float32)
+        idx = np.empty((batch_size, kk), np.int32)
+        _check(self._lib, self._lib.bnhip_predict_topk(self._h, x.ctypes.data, batch_size, activation, sensitivity, k,
+                                                       conf.ctypes.data, idx.ctypes.data))
+        return conf, idx
+
+    # ---- plumbing
+    def set_stream(self, hip_stream_ptr):
+        _check(self._lib, self._lib.bnhip_set_stream(self._h, hip_stream_ptr))
+
+    def synchronize(self):
+        _check(self._lib, self._lib.bnhip_synchronize(self._h))
+
+    def profile_enable(self, on=True):
+        _check(self._lib, self._lib.bnhip_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        buf = C.create_string_buffer(1 << 16)
+        rc = self._lib.bnhip_profile_read(self._h, buf, len(buf))
+        if rc < 0:
+            _check(self._lib, rc)
+        return json.loads(buf.value.decode())
+
+    def describe(self):
+        need = self._lib.bnhip_model_describe(self._h, None, 0)
+        if need < 0:
+            _check(self._lib, need)
+        buf = C.create_string_buffer(need + 16)
+        self._lib.bnhip_model_describe(self._h, buf, len(buf))
+        return json.loads(buf.value.decode())
+
+    def _alive(self):
+        if not self._h:
+            raise HipError(E_INVALID, "classifier is closed")
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def us_frame_cv(samples, sample_rate, fft_size=8192, hop=4096, split_hz=20000, device=0):
+    """ultrasonic.ComputeUSFrameCV (filter.go:20) for a batch: samples [B, n] float64 -> (cv[B], ok[B])."""
+    lib = load_library()
+    s = np.ascontiguousarray(samples, np.float64)
+    if s.ndim == 1:
+        s = s[None, :]
+    cv = np.zeros(s.shape[0], np.float64)
+    ok = np.zeros(s.shape[0], np.int32)
+    _check(lib, lib.bnhip_us_frame_cv(device, s.ctypes.data, s.shape[0], s.shape[1], sample_rate, fft_size, hop,
+                                      split_hz, cv.ctypes.data, ok.ctypes.data))
+    return cv, ok.astype(bool)
+
+
+class BirdNET:
+    """(*BirdNET).Predict (classifier/analyze.go:25-110): backend logits -> sigmoid(sensitivity) ->
+    label pairing -> top-10, with the post-processing on device."""
+
+    TOP_K = 10  # defaultTopKResults
+
+    def __init__(self, classifier: HipClassifier, labels, sensitivity=1.0):
+        if len(labels) != classifier.num_species():
+            # validateModelAndLabels, classifier/birdnet.go:1248-1256
+            raise HipError(E_INVALID, f"label count {len(labels)} != model outputs {classifier.num_species()}")
+        self.classifier, self.labels, self.sensitivity = classifier, list(labels), float(sensitivity)
+
+    def predict(self, samples):
+        conf, idx = self.classifier.predict_topk(np.asarray(samples, np.float32), 1, self.TOP_K, 0, self.sensitivity)
+        return [(self.labels[i], float(c)) for c, i in zip(conf[0], idx[0])]
+
+    def predict_batch(self, flat, batch_size):
+        conf, idx = self.classifier.predict_topk(flat, batch_size, self.TOP_K, 0, self.sensitivity)
+        return [[(self.labels[i], float(c)) for c, i in zip(cr, ir)] for cr, ir in zip(conf, idx)]

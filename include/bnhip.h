@@ -1,0 +1,117 @@
+/*
+ * bnhip.h — C ABI of libbnhip.so, the MI355X-native (gfx950) BirdNET inference engine.
+ *
+ * This is the drop-in boundary for birdnet-go's classifier backend seam
+ *   internal/inference/backend.go:8-29   (inference.Classifier / EmbeddingExtractor)
+ * i.e. exactly what a cgo backend `internal/inference/hip/backend_hip.go` (build tag `hip`) binds,
+ * shaped after the reference's own native-accelerator precedent, the OpenVINO cgo shim
+ *   internal/inference/openvino/backend_openvino.go:16-413 (C preamble), :443-832 (Go side).
+ * Plain pointers and sizes only; no C++/torch types.  All functions return 0 on success or a
+ * negative BNHIP_E_* code; bnhip_last_error() returns a thread-local message (the OpenVINO shim
+ * keeps thread-local error strings too: backend_openvino.go:100,325).
+ *
+ * Threading contract (same as the reference's backends, backend.go:7 "NOT goroutine-safe; callers
+ * must synchronize"): a bnhip_model may be used by one thread at a time.  Every entry point calls
+ * hipSetDevice for the model's device first, so the Go side does not need runtime.LockOSThread
+ * for correctness (HIP's current device is thread-local; cf. backend_openvino.go:478-481).
+ */
+#ifndef BNHIP_H
+#define BNHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bnhip_model bnhip_model;
+
+enum {
+    BNHIP_OK = 0,
+    BNHIP_E_INVALID = -1,      /* bad argument (NULL, size mismatch) — CategoryValidation */
+    BNHIP_E_NO_DEVICE = -2,    /* no usable gfx950 device / HIP runtime — maps to ErrHIPUnavailable */
+    BNHIP_E_MODEL = -3,        /* model bytes are not a TFLite flatbuffer / corrupt */
+    BNHIP_E_UNSUPPORTED = -4,  /* graph uses an op/pattern the engine does not implement: caller falls back */
+    BNHIP_E_RUNTIME = -5,      /* HIP runtime error during alloc/launch/copy */
+    BNHIP_E_NOMEM = -6
+};
+
+/* Process-global runtime init; idempotent, retryable after failure
+ * (replaces InitOV, backend_openvino.go:477-506).  Returns the number of usable devices in
+ * *n_devices (nullable). */
+int bnhip_init(int* n_devices);
+
+/* Releases process-global state (replaces DestroyOV, backend_openvino.go:512-536). */
+void bnhip_shutdown(void);
+
+/* Build a classifier from in-memory TFLite model bytes — the same byte slice the reference hands to
+ * NewTFLiteClassifier(modelData []byte, ...) (internal/inference/tflite/classifier.go:38).  The blob
+ * is consumed during the call and may be freed afterwards (classifier.go:37).
+ * opts_json (nullable): {"device":0,"max_batch":256}.  */
+int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, bnhip_model** out);
+
+/* n_samples: exact input length per clip (tflite/classifier.go:100-104); n_classes: size of the logits
+ * output read from the model, not the label list (inference/openvino.go:72-81); emb_dim: 0 when the
+ * graph exposes no embedding output (EmbeddingExtractor, backend.go:21-29). */
+int bnhip_model_info(const bnhip_model* m, int* n_samples, int* n_classes, int* emb_dim);
+
+/* Classifier.Predict / PredictWithEmbeddings / onnx PredictBatch (onnx/classifier.go:372-430).
+ * samples: host float32 [n_clips * n_samples], copied before return (process.go:280-291 contract).
+ * logits:  host float32 [n_clips * n_classes] raw pre-activation logits in label order.
+ * emb:     nullable host float32 [n_clips * emb_dim].
+ * Blocking. */
+int bnhip_predict(bnhip_model* m, const float* samples, int n_clips, float* logits, float* emb);
+
+/* Same, with 16-bit little-endian PCM input converted on device: float32(s)/32768
+ * (internal/analysis/process.go:479-497, audiocore/convert/pcm.go:226-237). */
+int bnhip_predict_pcm16(bnhip_model* m, const int16_t* pcm, int n_clips, float* logits, float* emb);
+
+/* Device-resident variant: all pointers are device memory on the model's device; work is enqueued on
+ * the model's stream and NOT synchronised (call bnhip_synchronize). Used by the throughput harness so
+ * timing starts with inputs already in HBM. */
+int bnhip_predict_device(bnhip_model* m, const float* d_samples, int n_clips, float* d_logits, float* d_emb);
+
+/* Post-processing on device for a batch of logits already on the host:
+ * conf = float32(1/(1+exp(-sensitivity*float64(x))))  (classifier/analyze.go:113-115,197-208), then
+ * top-k by confidence, descending (analyze.go:220-253).  activation: 0 = sigmoid(sensitivity),
+ * 1 = softmax (perch_onnx.go:315-335), 2 = plain float32-division sigmoid (onnx/postprocess.go:8-10).
+ * out_conf/out_idx: [n_clips * k]. */
+int bnhip_postprocess_topk(bnhip_model* m, const float* logits, int n_clips, int n_classes, int activation,
+                           double sensitivity, int k, float* out_conf, int32_t* out_idx);
+
+/* Fused convenience: predict + activation + top-k without the logits leaving the device. */
+int bnhip_predict_topk(bnhip_model* m, const float* samples, int n_clips, int activation, double sensitivity,
+                       int k, float* out_conf, int32_t* out_idx);
+
+/* Ultrasonic frame-CV filter (internal/audiocore/ultrasonic/filter.go:20-66), float64 throughout.
+ * samples: host float64 [n_clips * n] (int16/32768 as float64, convert/pcm.go:108-113).
+ * cv/ok: [n_clips]. device: HIP device ordinal. */
+int bnhip_us_frame_cv(int device, const double* samples, int n_clips, int n, int sample_rate, int fft_size,
+                      int hop, int split_hz, double* cv, int32_t* ok);
+
+/* Stream plumbing for hosts that own a HIP stream (bench harness: torch's current stream). */
+int bnhip_set_stream(bnhip_model* m, void* hip_stream);
+int bnhip_synchronize(bnhip_model* m);
+
+/* Per-kernel timing (the reference has no per-operator profile wired: doc/PROFILING.md:491-540).
+ * When enabled every launch is bracketed by HIP events on the model stream; bnhip_profile_read
+ * synchronises and writes a JSON array [{"kernel":..,"launches":..,"ms":..,"flops":..,"bytes":..},..]
+ * into buf (NUL-terminated, truncated to cap) and resets the counters. Returns bytes needed. */
+int bnhip_profile_enable(bnhip_model* m, int on);
+int bnhip_profile_read(bnhip_model* m, char* buf, size_t cap);
+
+/* Plan description (JSON) for diagnostics/DESIGN tables: one entry per launch with shapes,
+ * algorithmic flops and bytes. Returns bytes needed. */
+int bnhip_model_describe(const bnhip_model* m, char* buf, size_t cap);
+
+/* Idempotent; frees device memory now (BirdNET.Delete, classifier/birdnet.go:972-984). */
+void bnhip_model_destroy(bnhip_model* m);
+
+const char* bnhip_last_error(void);
+const char* bnhip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BNHIP_H */
