@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""Throughput bench for the BirdNET v2.4 hot path on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under torch.distributed.run, one rank
+per GPU).  A *step* = one pass of the whole hot path (per-clip normalise -> fused mel front-end ->
+CNN -> species head, raw logits out) over one batch of 256 synthetic 3 s / 48 kHz clips per GPU
+(BASELINE.json configs[1]: "BirdNET v2.4 fp32, batch 256x3s@48kHz synthetic sine+noise").  Inputs are
+resident in HBM before the timed region.  Prints ONE JSON line on rank 0 with `roofline` (dominant
+kernel, measured with HIP events on the launch stream inside the timed region) and `cpu_baseline`
+(the numpy/BLAS oracle restatement timed on this box's host cores; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=0, help="clips in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--no-profile", action="store_true", help="disable per-kernel HIP-event timing")
+    return ap.parse_args()
+
+
+def cpu_baseline(blob, n_samples, sample_rate, n_clips_hint):
+    """Oracle restatement ("port") timed on the host cores: bounded sample of the same workload."""
+    from oracle.interp import Interpreter
+    from birdnet_go_amd import synth_model as sm
+    import torch
+
+    cores = os.cpu_count() or 1
+    threads = torch.get_num_threads()
+    it = Interpreter(blob)
+    x1 = sm.synth_clips(2, n_samples, sample_rate)
+    t0 = time.time()
+    it.invoke(x1)                      # warm-up + probe
+    per_clip = (time.time() - t0) / 2
+    n = n_clips_hint or int(max(8, min(256, 15.0 / max(per_clip, 1e-3))))
+    n = (n + 7) // 8 * 8
+    x = sm.synth_clips(n, n_samples, sample_rate)
+    t0 = time.time()
+    for i in range(0, n, 8):
+        it.invoke(x[i:i + 8])
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"{n} clips of the config-2 generator through the numpy/OpenBLAS oracle (fp32), "
+                      f"batches of 8, {dt:.1f} s wall; BLAS threads={threads} of {cores} host cores; "
+                      "restatement baseline - NOT TFLite (no TFLite runtime or real weights in this environment)"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import birdnet_go_amd  # noqa: F401
+    from birdnet_go_amd import host, shard, synth_model as sm
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists by design)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = sm.SynthConfig()
+    # frozen weights: built once on rank 0, broadcast over RCCL/xGMI (the only collective on this path)
+    if world > 1:
+        blob = sm.build_model(cfg) if rank == 0 else None
+        blob = shard.broadcast_model_bytes(blob, src=0, device=dev)
+    else:
+        blob = sm.build_model(cfg)
+
+    B = args.batch
+    clf = host.HipClassifier(blob, device=local_rank, max_batch=B)
+    lo, _ = shard.shard_range(B * world, rank, world)       # weak scaling: B clips per rank, distinct seeds
+    x_host = sm.synth_clips(B, cfg.n_samples, cfg.sample_rate, first=lo)
+    x = torch.from_numpy(x_host).to(dev)
+    logits = torch.empty((B, clf.num_species()), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    clf.set_stream(stream.cuda_stream)
+
+    def step():
+        clf.predict_device(x.data_ptr(), B, logits.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if not args.no_profile:
+        clf.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    prof = clf.profile_read() if not args.no_profile else []
+    clf.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ok = bool(torch.isfinite(logits).all().item())
+    if rank == 0:
+        total_clips = B * world * args.steps
+        out = {
+            "metric": "3s-48kHz clips/sec (whole node), BirdNET v2.4", "value": total_clips / dt, "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic sine+noise clips (SURVEY 8d cfg 2); random-init BirdNET-v2.4-topology weights "
+                    "(real .tflite absent from the reference snapshot)",
+            "config": {"workload": "BASELINE configs[1]: BirdNET v2.4 fp32, batch 256 x 3 s @ 48 kHz per GPU, "
+                                   "mel front-end + CNN + head on device, raw logits out",
+                       "batch_per_gpu": B, "n_samples": cfg.n_samples, "n_classes": clf.num_species(),
+                       "sharding": f"clips index-contiguous over {world} rank(s); weights broadcast once"},
+            "finite_outputs": ok,
+        }
+        if prof:
+            prof = sorted(prof, key=lambda r: -r["ms"])
+            dom = prof[0]
+            per_launch_ms = dom["ms"] / dom["launches"]
+            if dom["kernel"] in ("pw_gemm", "frontend"):
+                ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+                roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None}
+            else:
+                ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+                roof = {"kernel": dom["kernel"], "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS,
+                        "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None}
+            roof["launches"] = dom["launches"]
+            roof["avg_launch_ms"] = per_launch_ms
+            roof["share_of_kernel_time"] = dom["ms"] / sum(r["ms"] for r in prof)
+            out["roofline"] = roof
+            out["kernels"] = [{"kernel": r["kernel"], "ms_per_step": r["ms"] / args.steps,
+                               "launches_per_step": r["launches"] / args.steps,
+                               "tflops": r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] else 0.0,
+                               "gbs": r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] else 0.0} for r in prof]
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(blob, cfg.n_samples, cfg.sample_rate, args.cpu_clips)
+        print(json.dumps(out))
+    clf.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -104,6 +104,7 @@ int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, 
     bnhip_model* m = new (std::nothrow) bnhip_model();
     if (!m) return set_err(BNHIP_E_NOMEM, "out of host memory");
     int code = BNHIP_E_UNSUPPORTED;
+    m->eng.no_reuse = json_int(opts_json, "debug_no_reuse", 0) != 0;
     if (!m->eng.build(tm, device, max_batch, plan_only, &err, &code)) {
         delete m;
         return set_err(code == BNHIP_OK ? BNHIP_E_UNSUPPORTED : code, err);
@@ -309,6 +310,22 @@ int bnhip_us_frame_cv(int device, const double* samples, int n_clips, int n, int
     if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("us_frame_cv: ") + hipGetErrorString(he));
     for (int i = 0; i < n_clips; i++) ok[i] = 1;
     return BNHIP_OK;
+}
+
+int bnhip_debug_fetch(bnhip_model* m, int tensor_index, int n_clips, float* out, size_t cap_floats) {
+    if (!m || !out || m->eng.device < 0) return set_err(BNHIP_E_INVALID, "NULL argument or plan-only model");
+    Engine& e = m->eng;
+    auto it = e.tensor_value.find(tensor_index);
+    if (it == e.tensor_value.end()) return set_err(BNHIP_E_INVALID, "tensor is not materialised by the plan (fused away)");
+    const Value& v = e.vals[it->second];
+    if (v.external) return set_err(BNHIP_E_INVALID, "tensor is bound externally (graph input/logits)");
+    size_t n = v.elems * (size_t)n_clips;
+    if (n > cap_floats || n_clips > e.max_batch) return set_err(BNHIP_E_INVALID, "buffer too small");
+    hipSetDevice(e.device);
+    hipStreamSynchronize(e.stream);
+    if (hipMemcpy(out, e.value_ptr(it->second), n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return set_err(BNHIP_E_RUNTIME, "debug fetch copy failed");
+    return (int)v.elems;
 }
 
 int bnhip_profile_enable(bnhip_model* m, int on) {

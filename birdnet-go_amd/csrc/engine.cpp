@@ -697,6 +697,7 @@ bool Engine::build(const TflModel& m, int dev, int maxb, bool plan_only, std::st
         }
     }
 
+    tensor_value = tv;
     // ---------------------------------------------------------------- liveness + arena
     for (int si = 0; si < (int)steps.size(); si++) {
         for (int v : {steps[si].in0, steps[si].in1, steps[si].in2, steps[si].out}) {
@@ -732,6 +733,7 @@ bool Engine::build(const TflModel& m, int dev, int maxb, bool plan_only, std::st
             for (int v : born[si]) {
                 size_t need = align_up(vals[v].elems * 4 * (size_t)max_batch, 256);
                 int best = -1;
+                if (no_reuse) free_list.clear();
                 for (int i = 0; i < (int)free_list.size(); i++)
                     if (free_list[i].size >= need && (best < 0 || free_list[i].size < free_list[best].size)) best = i;
                 if (best >= 0) {

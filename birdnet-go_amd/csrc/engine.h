@@ -54,6 +54,9 @@ class Engine {
     bool run(const float* d_in, int n, float* d_logits, float* d_emb, std::string* err);
 
     int device = 0, max_batch = 256;
+    bool no_reuse = false;              // diagnostics: every activation keeps its own buffer
+    std::map<int, int> tensor_value;    // tflite tensor index -> value id (diagnostics)
+    const float* value_ptr(int v) const { return reinterpret_cast<const float*>(act_arena + vals[v].offset); }
     int n_samples = 0, n_classes = 0, emb_dim = 0, C_spec = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;

@@ -27,7 +27,7 @@ SYMBOLS = ["bnhip_init", "bnhip_shutdown", "bnhip_model_create", "bnhip_model_in
            "bnhip_predict_pcm16", "bnhip_predict_device", "bnhip_postprocess_topk", "bnhip_predict_topk",
            "bnhip_us_frame_cv", "bnhip_set_stream", "bnhip_synchronize", "bnhip_profile_enable",
            "bnhip_profile_read", "bnhip_model_describe", "bnhip_model_destroy", "bnhip_last_error",
-           "bnhip_version"]
+           "bnhip_version", "bnhip_debug_fetch"]
 
 
 class HipError(RuntimeError):
@@ -94,10 +94,11 @@ def init():
 class HipClassifier:
     """inference.Classifier + EmbeddingExtractor over libbnhip.so.  NOT thread-safe (backend.go:7)."""
 
-    def __init__(self, model_bytes: bytes, device=0, max_batch=256, plan_only=False):
+    def __init__(self, model_bytes: bytes, device=0, max_batch=256, plan_only=False, debug_no_reuse=False):
         self._lib = load_library()
         self._h = C.c_void_p()
-        opts = json.dumps({"device": device, "max_batch": max_batch, "plan_only": int(plan_only)}).encode()
+        opts = json.dumps({"device": device, "max_batch": max_batch, "plan_only": int(plan_only),
+                           "debug_no_reuse": int(debug_no_reuse)}).encode()
         buf = (C.c_char * len(model_bytes)).from_buffer_copy(model_bytes)
         _check(self._lib, self._lib.bnhip_model_create(C.cast(buf, C.c_void_p), len(model_bytes), opts, C.byref(self._h)))
         ns, nc, ed = C.c_int(), C.c_int(), C.c_int()
@@ -202,6 +203,15 @@ class HipClassifier:
         buf = C.create_string_buffer(need + 16)
         self._lib.bnhip_model_describe(self._h, buf, len(buf))
         return json.loads(buf.value.decode())
+
+    def debug_fetch(self, tensor_index, n_clips, max_floats_per_clip):
+        out = np.empty(n_clips * max_floats_per_clip, np.float32)
+        lib = self._lib
+        lib.bnhip_debug_fetch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        rc = lib.bnhip_debug_fetch(self._h, tensor_index, n_clips, out.ctypes.data, out.size)
+        if rc < 0:
+            _check(lib, rc)
+        return out[:rc * n_clips].reshape(n_clips, rc)
 
     def _alive(self):
         if not self._h:

@@ -48,7 +48,8 @@ void bnhip_shutdown(void);
 /* Build a classifier from in-memory TFLite model bytes — the same byte slice the reference hands to
  * NewTFLiteClassifier(modelData []byte, ...) (internal/inference/tflite/classifier.go:38).  The blob
  * is consumed during the call and may be freed afterwards (classifier.go:37).
- * opts_json (nullable): {"device":0,"max_batch":256}.  */
+ * opts_json (nullable): {"device":0,"max_batch":256,"plan_only":0,"debug_no_reuse":0}; plan_only builds the
+ * kernel plan on the CPU without touching a device (info/describe work, predict is rejected).  */
 int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, bnhip_model** out);
 
 /* n_samples: exact input length per clip (tflite/classifier.go:100-104); n_classes: size of the logits
@@ -104,6 +105,11 @@ int bnhip_profile_read(bnhip_model* m, char* buf, size_t cap);
 /* Plan description (JSON) for diagnostics/DESIGN tables: one entry per launch with shapes,
  * algorithmic flops and bytes. Returns bytes needed. */
 int bnhip_model_describe(const bnhip_model* m, char* buf, size_t cap);
+
+/* Diagnostics: copy the activation produced for TFLite tensor `tensor_index` by the LAST run of
+ * n_clips clips to host. Only meaningful for models created with {"debug_no_reuse":1} (otherwise the
+ * arena slot may already have been recycled). Returns floats per clip, or a negative error. */
+int bnhip_debug_fetch(bnhip_model* m, int tensor_index, int n_clips, float* out, size_t cap_floats);
 
 /* Idempotent; frees device memory now (BirdNET.Delete, classifier/birdnet.go:972-984). */
 void bnhip_model_destroy(bnhip_model* m);

@@ -6,6 +6,10 @@
  *
  * Each function cites the reference file:line it follows (paths relative to /root/reference).
  */
+#define _USE_MATH_DEFINES
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>

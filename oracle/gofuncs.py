@@ -16,7 +16,7 @@ _SRC = os.path.join(_HERE, "c", "oracle.c")
 
 def build(force=False):
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
-        subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off",
+        subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-fPIC", "-shared", "-ffp-contract=off",
                                "-o", _SO, _SRC, "-lm"])
     return _SO
 
