@@ -230,8 +230,8 @@ bool match_frontend(Planner& P, int ri, FrontendMatch* fm) {
     return true;
 }
 
-// G[n][m'] = w[n] * sum_k cos(2 pi k n / Lfft) * Mel[k][m]   (fp64 accumulate, rounded once to fp32)
-std::vector<float> build_G(const Planner& P, const FrontendMatch& fm, int Lp, int NTP) {
+// G[n][m'] = sum_k cos(2 pi k n / Lfft) * Mel[k][m]   (fp64; the window is applied separately in fp32)
+std::vector<double> build_G(const Planner& P, const FrontendMatch& fm, int Lp, int NTP) {
     const int nb = fm.Lfft / 2 + 1, nm = fm.n_mels, N = fm.Lfft;
     const float* melT = P.T(fm.mel_tensor).f32();      // [n_mels][nbins]
     std::vector<double> ctab(N);
@@ -245,7 +245,7 @@ std::vector<float> build_G(const Planner& P, const FrontendMatch& fm, int Lp, in
     std::vector<double> melk(krows.size() * (size_t)nm);
     for (size_t r = 0; r < krows.size(); r++)
         for (int mm = 0; mm < nm; mm++) melk[r * nm + mm] = (double)melT[(size_t)mm * nb + krows[r]];
-    std::vector<float> G((size_t)Lp * NTP, 0.0f);
+    std::vector<double> G((size_t)Lp * NTP, 0.0);
     std::vector<double> row(nm);
     for (int n = 0; n < fm.L; n++) {
         std::fill(row.begin(), row.end(), 0.0);
@@ -254,10 +254,9 @@ std::vector<float> build_G(const Planner& P, const FrontendMatch& fm, int Lp, in
             const double* mk = &melk[r * nm];
             for (int mm = 0; mm < nm; mm++) row[mm] += c * mk[mm];
         }
-        double w = (double)fm.window[n];
         for (int mo = 0; mo < nm; mo++) {
             int mm = fm.reverse ? nm - 1 - mo : mo;
-            G[(size_t)n * NTP + mo] = (float)(w * row[mm]);
+            G[(size_t)n * NTP + mo] = row[mm];
         }
     }
     return G;
@@ -383,14 +382,17 @@ bool Engine::build(const TflModel& m, int dev, int maxb, bool plan_only, std::st
                 *err = "front-end: frame tile does not fit in LDS";
                 return false;
             }
-            std::vector<float> G = build_G(P, fm, fs.Lp, fs.NTP);
-            size_t goff = wpush(G.data(), G.size());
+            std::vector<double> G = build_G(P, fm, fs.Lp, fs.NTP);
+            size_t goff = wpush(reinterpret_cast<const float*>(G.data()), G.size() * 2);   // fp64 image, 256-B aligned
+            std::vector<float> wpad(fs.Lp, 0.0f);
+            std::copy(fm.window.begin(), fm.window.end(), wpad.begin());
+            size_t woff = wpush(wpad.data(), wpad.size());
             specs.push_back(fs);
             Step f; f.kind = S_FRONTEND; f.name = "melspec" + std::to_string(i); f.kclass = "frontend";
             f.in0 = v_input; f.in1 = v_mm; f.out = v_spec; f.spec = (int)specs.size() - 1;
             f.flops = 2.0 * fm.F * fs.L * fm.n_mels;
             f.bytes = (double)n_samples * 4 + (double)fm.F * fm.n_mels * 4;
-            add_step(f, goff);
+            add_step(f, goff, woff);
         }
     }
 
@@ -769,7 +771,10 @@ bool Engine::build(const TflModel& m, int dev, int maxb, bool plan_only, std::st
         const float** slots[4] = {&steps[si].w0, &steps[si].w1, &steps[si].w2, &steps[si].w3};
         for (int k = 0; k < 4; k++)
             if (step_w[k][si] != SIZE_MAX) *slots[k] = reinterpret_cast<const float*>(w_arena) + step_w[k][si];
-        if (steps[si].kind == S_FRONTEND) specs[steps[si].spec].G = steps[si].w0;
+        if (steps[si].kind == S_FRONTEND) {
+            specs[steps[si].spec].G = reinterpret_cast<const double*>(steps[si].w0);
+            specs[steps[si].spec].window = steps[si].w1;
+        }
     }
     HIPCHK(hipMalloc((void**)&d_stage_in, (size_t)max_batch * n_samples * 4));
     HIPCHK(hipMalloc((void**)&d_stage_logits, (size_t)max_batch * n_classes * 4));
@@ -810,7 +815,7 @@ bool Engine::run(const float* d_in, int n, float* d_logits, float* d_emb, std::s
             case S_FRONTEND: {
                 const FrontSpec& fs = specs[s.spec];
                 FrontendParams p;
-                p.x = in0; p.mm = reinterpret_cast<const float2*>(in1); p.G = fs.G; p.out = out;
+                p.x = in0; p.mm = reinterpret_cast<const float2*>(in1); p.G = fs.G; p.window = fs.window; p.out = out;
                 p.n_samples = n_samples; p.L = fs.L; p.Lp = fs.Lp; p.hop = fs.hop; p.F = fs.F; p.n_mels = fs.n_mels;
                 p.NTP = fs.NTP; p.C = C_spec; p.c = fs.c; p.norm_sub = fs.norm_sub; p.norm_mul = fs.norm_mul;
                 p.p1 = fs.p1; p.p2 = fs.p2; p.n_clips = n;

@@ -41,7 +41,8 @@ struct Value {               // an activation tensor (per clip geometry)
 struct FrontSpec {
     int L, Lp, Lfft, hop, F, n_mels, NTP, c;
     float p1, p2, eps, norm_sub, norm_mul;
-    const float* G = nullptr;    // device
+    const double* G = nullptr;   // device, fp64
+    const float* window = nullptr;
 };
 
 struct ProfEntry { hipEvent_t a, b; int step; int n; };

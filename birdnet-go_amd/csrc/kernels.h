@@ -17,7 +17,8 @@ void launch_clip_minmax(const float* x, int n_clips, int n_samples, float eps, f
 struct FrontendParams {
     const float* x;        // [B, n_samples] raw clip
     const float2* mm;      // [B] (min, range+eps)
-    const float* G;        // [Lp, NTP] folded window*DFT-real*mel matrix, rows >= L are zero
+    const double* G;       // [Lp, NTP] folded DFT-real*mel matrix (fp64), rows >= L are zero
+    const float* window;   // [Lp] analysis window (zeros beyond L)
     float* out;            // [B, n_mels, F, C]
     int n_samples, L, Lp, hop, F, n_mels, NTP, C, c;   // c = channel index written
     float norm_sub, norm_mul;   // (x-min)/range - norm_sub) * norm_mul

@@ -1,0 +1,145 @@
+"""Model container + planner, CPU only: writer -> (oracle reader | C++ reader via plan_only)."""
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+from birdnet_go_amd import host, synth_model as sm, tflite_schema as S
+from birdnet_go_amd.tflite_build import GraphBuilder
+from oracle.interp import Interpreter
+from oracle.tflite_reader import read_model
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_writer_is_deterministic_and_matches_golden_digest(tiny_blob, tiny_cfg):
+    assert sm.build_model(tiny_cfg) == tiny_blob
+    g = np.load(os.path.join(GOLD, "tiny_logits.npz"))
+    assert hashlib.sha256(tiny_blob).digest() == g["sha256"].tobytes()
+
+
+def test_oracle_reader_roundtrip(tiny_blob, tiny_cfg):
+    m = read_model(tiny_blob)
+    assert m.tensors[m.inputs[0]].shape == [1, tiny_cfg.n_samples]
+    assert m.tensors[m.outputs[0]].shape == [1, tiny_cfg.n_classes]
+    names = [o.name for o in m.ops]
+    for need in ("RFFT2D", "GATHER", "CAST", "FULLY_CONNECTED", "POW", "REVERSE_V2", "TRANSPOSE", "CONCATENATION",
+                 "CONV_2D", "DEPTHWISE_CONV_2D", "MEAN", "LOGISTIC", "MUL", "ADD"):
+        assert need in names
+    # weights survive bit-exactly
+    w = [t for t in m.tensors if t.name == "stem/w"][0]
+    rng = np.random.default_rng(tiny_cfg.seed)
+    want = rng.standard_normal((tiny_cfg.stem, 3, 3, 2)).astype(np.float32) * np.float32(1.6 / np.sqrt(18))
+    assert np.array_equal(w.data, want)
+
+
+def test_oracle_matches_golden(tiny_blob, tiny_cfg):
+    g = np.load(os.path.join(GOLD, "tiny_logits.npz"))
+    x = sm.synth_clips(3, tiny_cfg.n_samples, tiny_cfg.sample_rate)
+    got = Interpreter(tiny_blob).invoke(x)[0]
+    # BLAS summation order may differ between hosts: tolerance, not bit-equality
+    assert np.abs(got - g["logits_f32"]).max() < 2e-5
+    assert np.abs(got - g["logits_f64"]).max() < 2e-5
+
+
+def test_oracle_batch_equals_single(tiny_blob, tiny_cfg):
+    x = sm.synth_clips(3, tiny_cfg.n_samples, tiny_cfg.sample_rate)
+    it = Interpreter(tiny_blob)
+    whole = it.invoke(x)[0]
+    for i in range(3):
+        assert np.abs(it.invoke(x[i])[0][0] - whole[i]).max() < 1e-5
+
+
+def test_oracle_input_size_mismatch(tiny_blob):
+    with pytest.raises(ValueError, match="input size mismatch"):
+        Interpreter(tiny_blob).invoke(np.zeros(100, np.float32))
+
+
+def test_frontend_equals_direct_numpy_stft(tiny_blob, tiny_cfg):
+    """The graph front-end == a direct numpy restatement of MelSpecLayerSimple (real-part STFT)."""
+    m = read_model(tiny_blob)
+    x = sm.synth_clips(2, tiny_cfg.n_samples, tiny_cfg.sample_rate)
+    keep = {}
+    Interpreter(m, "f64").invoke(x, keep=keep)
+    cat = [o for o in m.ops if o.name == "CONCATENATION"][0]
+    spec = keep[cat.outputs[0]]
+    xn = x.astype(np.float64)
+    xn = xn - xn.min(1, keepdims=True)
+    xn = xn / (xn.max(1, keepdims=True) + np.float64(np.float32(1e-6)))
+    xn = (xn - 0.5) * 2.0
+    for c, sp in enumerate(tiny_cfg.specs):
+        F = sm.n_frames(tiny_cfg.n_samples, sp.frame_length, sp.frame_step)
+        idx = np.arange(F)[:, None] * sp.frame_step + np.arange(sp.frame_length)[None, :]
+        fr = xn[:, idx] * sm.hann_periodic(sp.frame_length).astype(np.float64)
+        re = np.fft.rfft(fr, axis=-1).real
+        mel = sm.mel_weight_matrix(tiny_cfg.n_mels, sp.frame_length // 2 + 1, tiny_cfg.sample_rate, sp.fmin, sp.fmax)
+        v = re @ mel.astype(np.float64)
+        expo = np.float64(np.float32(1.0 / (1.0 + np.exp(tiny_cfg.mag_scale))))
+        y = np.power(np.power(v, 2.0), expo)
+        want = np.transpose(y[:, :, ::-1], (0, 2, 1))
+        assert np.allclose(spec[..., c], want, rtol=1e-4, atol=1e-5)
+
+
+def test_cpp_reader_and_planner_fuse_everything(built_lib, full_blob):
+    clf = host.HipClassifier(full_blob, plan_only=True)
+    assert (clf.n_samples, clf.num_species(), clf.emb_dim) == (144000, 6522, 0)
+    d = clf.describe()
+    kinds = [s["kernel"] for s in d["steps"]]
+    assert kinds.count("frontend") == 2 and kinds.count("clip_minmax") == 1
+    assert "elementwise" not in kinds, "an op fell back to the unfused elementwise path"
+    assert kinds.count("se") == 16 and kinds.count("dwconv") == 16
+    pw = [s for s in d["steps"] if s["kernel"] == "pw_gemm"]
+    assert sum(s["fused_scale"] for s in pw) == 16 and sum(s["fused_res"] for s in pw) == 9
+    assert d["specs"][0]["hop"] == 278 and d["specs"][1]["hop"] == 280 and d["specs"][0]["frames"] == 511
+    assert abs(d["specs"][0]["p2"] - 1.0 / (1.0 + np.exp(1.23))) < 1e-6
+    with pytest.raises(host.HipError, match="plan-only"):
+        clf.predict(np.zeros(144000, np.float32))
+    clf.close()
+
+
+def test_cpp_reader_embedding_output(built_lib):
+    blob = sm.build_model(sm.tiny_config(emit_embeddings=True))
+    clf = host.HipClassifier(blob, plan_only=True)
+    assert clf.emb_dim == 64 and clf.num_species() == 50
+    clf.close()
+
+
+def test_cpp_reader_rejects_garbage(built_lib, tiny_blob):
+    with pytest.raises(host.HipError) as e:
+        host.HipClassifier(b"\x00" * 64, plan_only=True)
+    assert e.value.code == host.E_MODEL
+    # truncated file: must fail cleanly (bounds-checked), never crash
+    for cut in (9, 64, 1000, len(tiny_blob) // 2, len(tiny_blob) - 5000):
+        with pytest.raises(host.HipError):
+            host.HipClassifier(tiny_blob[:cut], plan_only=True)
+    # corrupted offsets
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        b = bytearray(tiny_blob)
+        for p in rng.integers(8, 4096, 8):
+            b[p] ^= 0xFF
+        try:
+            host.HipClassifier(bytes(b), plan_only=True).close()
+        except host.HipError:
+            pass
+
+
+def test_unsupported_graph_reports_op(built_lib):
+    g = GraphBuilder()
+    x = g.tensor([1, 1000], name="INPUT")
+    y = g.op("SOFTMAX", [x], [1, 1000], dict(beta=1.0))
+    blob = g.finish([x], [y])
+    with pytest.raises(host.HipError) as e:
+        host.HipClassifier(blob, plan_only=True)
+    assert e.value.code == host.E_UNSUPPORTED
+
+
+def test_magnitude_frontend_is_reported_unsupported(built_lib):
+    blob = sm.build_model(sm.tiny_config(complex_mode="abs"))
+    with pytest.raises(host.HipError, match="COMPLEX_ABS") as e:
+        host.HipClassifier(blob, plan_only=True)
+    assert e.value.code == host.E_UNSUPPORTED
+    # ...while the oracle executes it generically
+    assert np.isfinite(Interpreter(blob).invoke(sm.synth_clips(1, 12000))[0]).all()
