@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=0, help="clips in the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-profile", action="store_true", help="disable per-kernel HIP-event timing")
+    ap.add_argument("--detail", action="store_true", help="print a per-launch table to stderr")
     return ap.parse_args()
 
 
@@ -117,7 +118,13 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    prof = clf.profile_read() if not args.no_profile else []
+    prof, prof_steps = clf.profile_read(per_step=True) if not args.no_profile else ([], [])
+    if args.detail and rank == 0:
+        for r in prof_steps:
+            ms = r["ms"] / r["launches"]
+            print(f"{r['step']:3d} {r['kernel']:12s} {r['name']:28s} {ms * 1e3:8.1f} us  "
+                  f"{r['flops'] / r['launches'] / (ms * 1e-3) / 1e12:6.1f} TF  {r['bytes'] / r['launches'] / (ms * 1e-3) / 1e9:7.0f} GB/s",
+                  file=sys.stderr)
     clf.profile_enable(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)

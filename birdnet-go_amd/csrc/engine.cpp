@@ -541,9 +541,24 @@ bool Engine::build(const TflModel& m, int dev, int maxb, bool plan_only, std::st
                 int vin = need_val(in_t);
                 if (vin < 0) { *err = "MEAN: input has no value"; return false; }
                 int S = mean_splits(H * W);
+                bool fused_sum = false;
                 Step mp; mp.kind = S_MEAN_PARTIAL; mp.kclass = "mean"; mp.name = oname + "/partial";
-                mp.in0 = vin; mp.H = H; mp.W = W; mp.C = C; mp.S = S;
-                mp.out = new_val(-1, (size_t)S * C);
+                mp.in0 = vin; mp.H = H; mp.W = W; mp.C = C;
+                if (!steps.empty() && steps.back().kind == S_DW && steps.back().out == vin) {
+                    // the producer is a depthwise conv: let it emit the per-slab channel sums itself
+                    const Step& d = steps.back();
+                    DwParams dp{nullptr, nullptr, nullptr, nullptr, 1, d.H, d.W, d.C, d.Ho, d.Wo, d.kh, d.kw, d.sh, d.sw, d.pt, d.pl, d.act};
+                    int slabs = dwconv_sum_slabs(dp);
+                    if (slabs > 0) {
+                        S = slabs;
+                        fused_sum = true;
+                        mp.out = new_val(-1, (size_t)S * C);
+                        steps.back().out2 = mp.out;
+                        steps.back().S = S;
+                    }
+                }
+                mp.S = S;
+                if (!fused_sum) mp.out = new_val(-1, (size_t)S * C);
                 mp.bytes = 4.0 * H * W * C;
                 // squeeze-excite pattern?
                 bool se = false;
@@ -571,7 +586,7 @@ bool Engine::build(const TflModel& m, int dev, int maxb, bool plan_only, std::st
                     if (other != in_t) { P.absorbed = save; break; }
                     // matched
                     P.absorbed[c1] = 1; P.absorbed[c2] = 1; P.absorbed[mu] = 1;
-                    add_step(mp);
+                    if (!fused_sum) add_step(mp);
                     Step ss; ss.kind = S_SE; ss.kclass = "se"; ss.name = oname + "/se";
                     ss.in0 = mp.out; ss.H = H; ss.W = W; ss.C = C; ss.Cr = Cr; ss.S = S; ss.act = act1; ss.act2 = act2;
                     ss.out = new_val(e, (size_t)C);
@@ -600,7 +615,7 @@ bool Engine::build(const TflModel& m, int dev, int maxb, bool plan_only, std::st
                     se = true;
                 } while (0);
                 if (!se) {
-                    add_step(mp);
+                    if (!fused_sum) add_step(mp);
                     Step mf; mf.kind = S_MEAN_FINISH; mf.kclass = "mean"; mf.name = oname;
                     mf.in0 = mp.out; mf.H = H; mf.W = W; mf.C = C; mf.S = S;
                     mf.out = new_val(mt, (size_t)C); tv[mt] = mf.out;
@@ -702,7 +717,7 @@ bool Engine::build(const TflModel& m, int dev, int maxb, bool plan_only, std::st
     tensor_value = tv;
     // ---------------------------------------------------------------- liveness + arena
     for (int si = 0; si < (int)steps.size(); si++) {
-        for (int v : {steps[si].in0, steps[si].in1, steps[si].in2, steps[si].out}) {
+        for (int v : {steps[si].in0, steps[si].in1, steps[si].in2, steps[si].out, steps[si].out2}) {
             if (v < 0) continue;
             if (vals[v].first < 0) vals[v].first = si;
             vals[v].last = si;
@@ -834,7 +849,7 @@ bool Engine::run(const float* d_in, int n, float* d_logits, float* d_emb, std::s
             }
             case S_DW: {
                 DwParams p{in0, s.w0, s.w1, out, n, s.H, s.W, s.C, s.Ho, s.Wo, s.kh, s.kw, s.sh, s.sw, s.pt, s.pl, s.act};
-                launch_dwconv(p, stream);
+                launch_dwconv(p, vptr(s.out2, d_in, d_logits, d_emb), stream);
                 break;
             }
             case S_MEAN_PARTIAL:
@@ -891,7 +906,7 @@ std::string Engine::describe() const {
         jesc(os, s.name);
         os << "\",\"H\":" << s.H << ",\"W\":" << s.W << ",\"C\":" << s.C << ",\"Co\":" << s.Co << ",\"k\":" << s.kh
            << ",\"stride\":" << s.sh << ",\"act\":" << s.act << ",\"fused_scale\":" << (s.kind == S_PW && s.in1 >= 0 ? 1 : 0)
-           << ",\"fused_res\":" << (s.kind == S_PW && s.in2 >= 0 ? 1 : 0) << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << ",\"wbytes\":" << s.wbytes << "}";
+           << ",\"fused_res\":" << (s.kind == S_PW && s.in2 >= 0 ? 1 : 0) << ",\"fused_sum\":" << (s.out2 >= 0 ? 1 : 0) << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << ",\"wbytes\":" << s.wbytes << "}";
     }
     os << "]}";
     return os.str();
@@ -902,6 +917,7 @@ std::string Engine::profile_read() {
     struct Agg { double ms = 0, flops = 0, bytes = 0; long launches = 0; };
     std::map<std::string, Agg> agg;
     std::vector<std::string> order;
+    std::vector<Agg> per_step(steps.size());
     for (auto& e : prof) {
         float ms = 0;
         hipEventElapsedTime(&ms, e.a, e.b);
@@ -909,6 +925,8 @@ std::string Engine::profile_read() {
         if (!agg.count(s.kclass)) order.push_back(s.kclass);
         Agg& a = agg[s.kclass];
         a.ms += ms; a.launches++; a.flops += s.flops * e.n; a.bytes += s.bytes * e.n + s.wbytes;
+        Agg& ps = per_step[e.step];
+        ps.ms += ms; ps.launches++; ps.flops += s.flops * e.n; ps.bytes += s.bytes * e.n + s.wbytes;
         ev_pool.push_back(e.a); ev_pool.push_back(e.b);
     }
     prof.clear();
@@ -918,6 +936,13 @@ std::string Engine::profile_read() {
         const Agg& a = agg[order[i]];
         os << (i ? "," : "") << "{\"kernel\":\"" << order[i] << "\",\"launches\":" << a.launches << ",\"ms\":" << a.ms
            << ",\"flops\":" << a.flops << ",\"bytes\":" << a.bytes << "}";
+    }
+    for (size_t i = 0; i < steps.size(); i++) {
+        const Agg& a = per_step[i];
+        if (!a.launches) continue;
+        os << ",{\"step\":" << i << ",\"kernel\":\"" << steps[i].kclass << "\",\"name\":\"";
+        jesc(os, steps[i].name);
+        os << "\",\"launches\":" << a.launches << ",\"ms\":" << a.ms << ",\"flops\":" << a.flops << ",\"bytes\":" << a.bytes << "}";
     }
     os << "]";
     return os.str();

@@ -18,7 +18,7 @@ struct Step {
     std::string name;        // graph op name (for describe/profile)
     const char* kclass;      // kernel class for profile aggregation
     // value ids (indices into Engine::vals) ; -1 = none
-    int in0 = -1, in1 = -1, in2 = -1, out = -1;
+    int in0 = -1, in1 = -1, in2 = -1, out = -1, out2 = -1;
     // weights (device pointers into the weight arena)
     const float *w0 = nullptr, *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;
     // geometry per clip

@@ -46,7 +46,10 @@ struct DwParams {
     const float* in; const float* w /*[kh][kw][C]*/; const float* bias; float* out;
     int B, H, W, C, Ho, Wo, kh, kw, sh, sw, pt, pl, act;
 };
-void launch_dwconv(const DwParams& p, hipStream_t s);
+// partial (nullable): [B, dwconv_sum_slabs(p), C] per-slab channel sums of the OUTPUT (fused squeeze-excite mean);
+// dwconv_sum_slabs returns 0 when the shape has no tiled kernel (then no fused sums are available).
+int dwconv_sum_slabs(const DwParams& p);
+void launch_dwconv(const DwParams& p, float* partial, hipStream_t s);
 
 // mean over H*W: in [B,HW,C] -> partial [B,S,C] (sums), S = number of pixel splits
 int mean_splits(int HW);

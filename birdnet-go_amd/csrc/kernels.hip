@@ -434,7 +434,107 @@ void launch_pw_gemm(const PwParams& p, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------ depthwise conv
-// thread = (output pixel, 4 channels). HBM-bound: each input element is re-read k*k/(s*s) times from L1/L2.
+// XCD-aware logical block id: the dispatcher places block b on XCD b % 8; remapping so that each XCD walks a
+// contiguous range of logical blocks keeps halo rows / shared operand panels in ONE XCD's L2 (bijective form).
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    unsigned q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// Register-tiled depthwise conv: a thread owns 4 channels x (TH x TW) output pixels, so each input
+// row segment it loads is reused across the TW horizontal and up to K vertical taps (HBM/L2 traffic per
+// output drops from K*K loads to ~((TH-1)S+K)((TW-1)S+K)/(TH*TW)).  Threads are laid out channel-fastest
+// (coalesced float4), tiles row-major; blocks are XCD-remapped so vertically adjacent tiles of a clip share an
+// L2.  Optionally emits deterministic per-block channel sums for the squeeze-excite mean (no second pass over
+// the tensor, no float atomics): partial[b][tile_chunk][c].
+template <int K, int S, int TH, int TW>
+__global__ __launch_bounds__(256) void k_dwconv_t(DwParams p, int CX, int PY, int tiles_w, int tiles, int tchunks,
+                                                  int cchunks, unsigned nblk, float* __restrict__ partial) {
+    __shared__ float red[256 * 4];
+    const unsigned L = xcd_remap(blockIdx.x, nblk);
+    const int bpc = tchunks * cchunks;
+    const int b = L / bpc;
+    const int rest = L % bpc;
+    const int tc = rest / cchunks, cc = rest % cchunks;
+    const int tx = threadIdx.x % CX, ty = threadIdx.x / CX;
+    const int c4 = cc * CX + tx;
+    const int C4 = p.C >> 2;
+    const int tile = tc * PY + ty;
+    const bool live = c4 < C4 && tile < tiles && ty < PY;
+    float4 acc[TH][TW];
+#pragma unroll
+    for (int a = 0; a < TH; a++)
+#pragma unroll
+        for (int c = 0; c < TW; c++) acc[a][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int th0 = live ? (tile / tiles_w) * TH : 0, tw0 = live ? (tile % tiles_w) * TW : 0;
+    if (live) {
+        constexpr int RW = (TW - 1) * S + K;       // input columns per row segment
+        constexpr int RH = (TH - 1) * S + K;       // input rows
+        const int hi0 = th0 * S - p.pt, wi0 = tw0 * S - p.pl;
+        const float4* in4 = reinterpret_cast<const float4*>(p.in) + (size_t)b * p.H * p.W * C4 + c4;
+        const float4* w4 = reinterpret_cast<const float4*>(p.w) + c4;
+#pragma unroll
+        for (int r = 0; r < RH; r++) {
+            const int hi = hi0 + r;
+            if (hi < 0 || hi >= p.H) continue;
+            float4 x[RW];
+#pragma unroll
+            for (int c = 0; c < RW; c++) {
+                int wi = wi0 + c;
+                x[c] = (wi >= 0 && wi < p.W) ? in4[((size_t)hi * p.W + wi) * C4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int a = 0; a < TH; a++) {
+                const int i = r - a * S;            // kernel row feeding output row a from input row r
+                if (i < 0 || i >= K) continue;
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                    const float4 w = w4[(size_t)(i * K + j) * C4];
+#pragma unroll
+                    for (int c = 0; c < TW; c++) {
+                        const float4 xv = x[c * S + j];
+                        acc[a][c].x = fmaf(xv.x, w.x, acc[a][c].x); acc[a][c].y = fmaf(xv.y, w.y, acc[a][c].y);
+                        acc[a][c].z = fmaf(xv.z, w.z, acc[a][c].z); acc[a][c].w = fmaf(xv.w, w.w, acc[a][c].w);
+                    }
+                }
+            }
+        }
+    }
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        float4 bv = p.bias ? reinterpret_cast<const float4*>(p.bias)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4* out4 = reinterpret_cast<float4*>(p.out) + (size_t)b * p.Ho * p.Wo * C4 + c4;
+#pragma unroll
+        for (int a = 0; a < TH; a++) {
+            int ho = th0 + a;
+            if (ho >= p.Ho) continue;
+#pragma unroll
+            for (int c = 0; c < TW; c++) {
+                int wo = tw0 + c;
+                if (wo >= p.Wo) continue;
+                float4 v = acc[a][c];
+                v.x = apply_act(v.x + bv.x, p.act); v.y = apply_act(v.y + bv.y, p.act);
+                v.z = apply_act(v.z + bv.z, p.act); v.w = apply_act(v.w + bv.w, p.act);
+                out4[((size_t)ho * p.Wo + wo) * C4] = v;
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+        }
+    }
+    if (partial) {
+        reinterpret_cast<float4*>(red)[threadIdx.x] = sum;
+        __syncthreads();
+        if (ty == 0 && c4 < C4) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int y = 0; y < PY; y++) {
+                float4 v = reinterpret_cast<float4*>(red)[y * CX + tx];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            reinterpret_cast<float4*>(partial)[((size_t)b * tchunks + tc) * C4 + c4] = t;
+        }
+    }
+}
+
+// generic fallback: thread = (output pixel, 4 or 1 channels)
 template <int VEC>
 __global__ __launch_bounds__(256) void k_dwconv(DwParams p) {
     const int CV = p.C / VEC;
@@ -457,26 +557,59 @@ __global__ __launch_bounds__(256) void k_dwconv(DwParams p) {
             if (wi < 0 || wi >= p.W) continue;
             const float* ip = p.in + (((size_t)b * p.H + hi) * p.W + wi) * p.C + (size_t)cv * VEC;
             const float* wp = p.w + (size_t)(i * p.kw + j) * p.C + (size_t)cv * VEC;
-            if (VEC == 4) {
-                float4 x = *reinterpret_cast<const float4*>(ip);
-                float4 w = *reinterpret_cast<const float4*>(wp);
-                acc[0] = fmaf(x.x, w.x, acc[0]); acc[1 % VEC] = fmaf(x.y, w.y, acc[1 % VEC]);
-                acc[2 % VEC] = fmaf(x.z, w.z, acc[2 % VEC]); acc[3 % VEC] = fmaf(x.w, w.w, acc[3 % VEC]);
-            } else {
-                acc[0] = fmaf(ip[0], wp[0], acc[0]);
-            }
+#pragma unroll
+            for (int v = 0; v < VEC; v++) acc[v] = fmaf(ip[v], wp[v], acc[v]);
         }
     }
 #pragma unroll
     for (int v = 0; v < VEC; v++) {
         float x = acc[v];
         if (p.bias) x += p.bias[cv * VEC + v];
-        acc[v] = apply_act(x, p.act);
+        p.out[idx * VEC + v] = apply_act(x, p.act);
     }
-    if (VEC == 4) reinterpret_cast<float4*>(p.out)[idx] = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
-    else p.out[idx] = acc[0];
 }
-void launch_dwconv(const DwParams& p, hipStream_t s) {
+
+static void dw_geometry(const DwParams& p, int TH, int TW, int* CX, int* PY, int* tiles_w, int* tiles, int* tchunks,
+                        int* cchunks) {
+    int C4 = p.C / 4;
+    *CX = C4 < 64 ? C4 : 64;
+    *PY = 256 / *CX;
+    *tiles_w = (p.Wo + TW - 1) / TW;
+    *tiles = *tiles_w * ((p.Ho + TH - 1) / TH);
+    if (*PY > *tiles) *PY = *tiles;
+    *tchunks = (*tiles + *PY - 1) / *PY;
+    *cchunks = (C4 + *CX - 1) / *CX;
+}
+static bool dw_tiled_shape(const DwParams& p, int* TH, int* TW) {
+    if ((p.C & 3) || p.kh != p.kw || p.sh != p.sw) return false;
+    if (p.kh == 3 && p.sh == 1) { *TH = 2; *TW = 4; return true; }
+    if (p.kh == 3 && p.sh == 2) { *TH = 2; *TW = 2; return true; }
+    if (p.kh == 5 && p.sh == 1) { *TH = 2; *TW = 4; return true; }
+    if (p.kh == 5 && p.sh == 2) { *TH = 1; *TW = 2; return true; }
+    return false;
+}
+int dwconv_sum_slabs(const DwParams& p) {
+    int TH, TW, CX, PY, tw, t, tch, cch;
+    if (!dw_tiled_shape(p, &TH, &TW)) return 0;
+    dw_geometry(p, TH, TW, &CX, &PY, &tw, &t, &tch, &cch);
+    return tch;
+}
+void launch_dwconv(const DwParams& p, float* partial, hipStream_t s) {
+    int TH, TW;
+    if (dw_tiled_shape(p, &TH, &TW)) {
+        int CX, PY, tiles_w, tiles, tchunks, cchunks;
+        dw_geometry(p, TH, TW, &CX, &PY, &tiles_w, &tiles, &tchunks, &cchunks);
+        unsigned nblk = (unsigned)p.B * tchunks * cchunks;
+        dim3 block(CX * PY < 64 ? 64 : CX * PY);
+#define DW_LAUNCH(K_, S_, TH_, TW_) hipLaunchKernelGGL((k_dwconv_t<K_, S_, TH_, TW_>), dim3(nblk), block, 0, s, p, CX, PY, \
+                                                       tiles_w, tiles, tchunks, cchunks, nblk, partial)
+        if (p.kh == 3 && p.sh == 1) DW_LAUNCH(3, 1, 2, 4);
+        else if (p.kh == 3) DW_LAUNCH(3, 2, 2, 2);
+        else if (p.sh == 1) DW_LAUNCH(5, 1, 2, 4);
+        else DW_LAUNCH(5, 2, 1, 2);
+#undef DW_LAUNCH
+        return;
+    }
     if ((p.C & 3) == 0) {
         size_t total = (size_t)p.B * p.Ho * p.Wo * (p.C / 4);
         hipLaunchKernelGGL(k_dwconv<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);

@@ -189,12 +189,15 @@ class HipClassifier:
     def profile_enable(self, on=True):
         _check(self._lib, self._lib.bnhip_profile_enable(self._h, int(on)))
 
-    def profile_read(self):
-        buf = C.create_string_buffer(1 << 16)
+    def profile_read(self, per_step=False):
+        """Per-kernel-class timing rows; with per_step=True returns (classes, steps)."""
+        buf = C.create_string_buffer(1 << 18)
         rc = self._lib.bnhip_profile_read(self._h, buf, len(buf))
         if rc < 0:
             _check(self._lib, rc)
-        return json.loads(buf.value.decode())
+        rows = json.loads(buf.value.decode())
+        classes = [r for r in rows if "step" not in r]
+        return (classes, [r for r in rows if "step" in r]) if per_step else classes
 
     def describe(self):
         need = self._lib.bnhip_model_describe(self._h, None, 0)

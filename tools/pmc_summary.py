@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Per-kernel PMC sums from rocprofv3 rocpd databases (one db per --pmc pass).
+Usage: python tools/pmc_summary.py <db> [<db> ...]   -> CSV on stdout (kernel, dispatches, avg_us, counter sums per dispatch)"""
+import re
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"\(.*\)$", "", name)
+    return name.replace("void ", "").replace("bnhip::", "")[:48]
+
+
+def load(path):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if "kernel_dispatch" in t][0]
+    ks = [t for t in tabs if "kernel_symbol" in t][0]
+    pm = [t for t in tabs if "pmc_event" in t][0]
+    ip = [t for t in tabs if "info_pmc" in t][0]
+    # per dispatch: name, grid, duration
+    disp = {}
+    for eid, name, gx, gy, gz, wx, st, en in cur.execute(
+            f"select d.event_id, s.display_name, d.grid_size_x, d.grid_size_y, d.grid_size_z, d.workgroup_size_x, d.start, d.end "
+            f"from {kd} d join {ks} s on d.kernel_id = s.id"):
+        disp[eid] = (short(name), gx * gy * gz // max(wx, 1), en - st)
+    vals = defaultdict(lambda: defaultdict(float))
+    for eid, cname, v in cur.execute(f"select e.event_id, p.name, e.value from {pm} e join {ip} p on e.pmc_id = p.id"):
+        vals[eid][cname] += v
+    return disp, vals
+
+
+def main():
+    agg = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(int)
+    dur = defaultdict(float)
+    counters = []
+    for path in sys.argv[1:]:
+        disp, vals = load(path)
+        seen = set()
+        for eid, (name, blocks, d) in disp.items():
+            if eid not in vals:
+                continue
+            key = name
+            for c, v in vals[eid].items():
+                agg[key][c] += v
+                if c not in counters:
+                    counters.append(c)
+            if (path, key) not in seen:
+                seen.add((path, key))
+        # duration/count from the first db only
+        if path == sys.argv[1]:
+            for eid, (name, blocks, d) in disp.items():
+                cnt[name] += 1
+                dur[name] += d
+    print("kernel,dispatches,avg_us," + ",".join(f"{c}_per_dispatch" for c in counters))
+    for k in sorted(agg, key=lambda k: -dur[k]):
+        if not cnt[k]:
+            continue
+        print(f"\"{k}\",{cnt[k]},{dur[k] / cnt[k] / 1e3:.1f}," + ",".join(f"{agg[k].get(c, 0) / cnt[k]:.4g}" for c in counters))
+
+
+if __name__ == "__main__":
+    main()
