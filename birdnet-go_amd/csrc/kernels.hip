@@ -8,20 +8,32 @@
 #include "kernels.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace bnhip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// sigmoid via the hardware exp2/rcp units (v_exp_f32 / v_rcp_f32, ~1 ulp each).  TFLite's own LOGISTIC
+// kernels are polynomial approximations of similar accuracy, so this stays inside fp32 noise.
+__device__ __forceinline__ float fast_sigmoid(float v) { return __frcp_rn(1.0f + __expf(-v)); }
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case ACT_RELU: return fmaxf(v, 0.0f);
         case ACT_RELU6: return fminf(fmaxf(v, 0.0f), 6.0f);
-        case ACT_SWISH: { float s = 1.0f / (1.0f + expf(-v)); return v * s; }   // LOGISTIC then MUL, as the graph does
-        case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        case ACT_SWISH: return v * fast_sigmoid(v);          // LOGISTIC then MUL, as the graph does
+        case ACT_SIGMOID: return fast_sigmoid(v);
         case ACT_HARD_SWISH: return v * fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) / 6.0f;
         default: return v;
     }
+}
+
+// XCD-aware logical block id: the dispatcher places block b on XCD b % 8; remapping so that each XCD walks a
+// contiguous range of logical blocks keeps halo rows / shared operand panels in ONE XCD's L2 (bijective form).
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    unsigned q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
 // ------------------------------------------------------------------------------------------ ingest
@@ -271,33 +283,44 @@ void launch_conv_direct(const ConvParams& p, hipStream_t s) {
 #define PW_BM 128
 #define PW_BK 32
 #define PW_LS 40
-template <int NT>
-__global__ __launch_bounds__(256) void k_pw_gemm(PwParams p) {
-    __shared__ __attribute__((aligned(16))) float Xs[PW_BM * PW_LS];
-    __shared__ __attribute__((aligned(16))) float Ws[NT * 16 * PW_LS];
+template <int NT, bool SC>
+__global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigned nblk) {
+    // operand tiles (the epilogue re-uses the array as per-wave output staging).  SC: squeeze-excite scale on A.
+    constexpr bool DB = false;   // double-buffering measured neutral on this chip for these shapes; kept for experiments
+    constexpr int TILE = (PW_BM + NT * 16) * PW_LS;
+    __shared__ __attribute__((aligned(16))) float lds[(DB ? 2 : 1) * TILE];
     constexpr int WQ = (NT + 1) / 2;             // float4 per thread for the W tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
-    const int m0 = blockIdx.x * PW_BM;
-    const int n0 = blockIdx.y * (NT * 16);
+    // XCD-aware order: N-blocks fastest so the blocks that share an activation tile sit on one XCD's L2
+    const unsigned L = xcd_remap(blockIdx.x, nblk);
+    const int m0 = (int)(L / nblk_n) * PW_BM;
+    const int n0 = (int)(L % nblk_n) * (NT * 16);
     const int K = p.K;
 
-    float4 xreg[4], wreg[WQ];
+    float4 xreg[4], wreg[WQ], sreg[SC ? 4 : 1];
+    int srow[SC ? 4 : 1];                        // batch index of each staged row (for the per-(batch,k) scale)
+    if (SC) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int m = m0 + ((tid + 256 * q) >> 3);
+            srow[SC ? q : 0] = (m < p.M ? m : 0) / p.HW;
+        }
+    }
+    // all global loads of a slab are issued back-to-back (scale included); the multiply happens at LDS-store time
     auto gload = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             int idx = tid + 256 * q;
             int row = idx >> 3, c4 = idx & 7;
             int m = m0 + row, k = k0 + 4 * c4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < p.M && k < K) {
                 v = *reinterpret_cast<const float4*>(p.A + (size_t)m * K + k);
-                if (p.ascale) {
-                    float4 sc = *reinterpret_cast<const float4*>(p.ascale + (size_t)(m / p.HW) * K + k);
-                    v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
-                }
+                if (SC) sc = *reinterpret_cast<const float4*>(p.ascale + (size_t)srow[SC ? q : 0] * K + k);
             }
             xreg[q] = v;
+            if (SC) sreg[SC ? q : 0] = sc;
         }
 #pragma unroll
         for (int q = 0; q < WQ; q++) {
@@ -309,11 +332,15 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p) {
             wreg[q] = v;
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int buf) {
+        float* Xs = lds + buf * TILE;
+        float* Ws = Xs + PW_BM * PW_LS;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             int idx = tid + 256 * q;
-            *reinterpret_cast<float4*>(&Xs[(idx >> 3) * PW_LS + 4 * (idx & 7)]) = xreg[q];
+            float4 v = xreg[q];
+            if (SC) { float4 sc = sreg[SC ? q : 0]; v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+            *reinterpret_cast<float4*>(&Xs[(idx >> 3) * PW_LS + 4 * (idx & 7)]) = v;
         }
 #pragma unroll
         for (int q = 0; q < WQ; q++) {
@@ -326,11 +353,16 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p) {
 #pragma unroll
     for (int t = 0; t < NT; t++) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
+    // software pipeline: slab s computes from LDS buffer s&1 while slab s+1 moves registers -> the other
+    // buffer and slab s+2's global loads are in flight; one barrier per slab.
+    const int nslab = (K + PW_BK - 1) / PW_BK;
     gload(0);
-    for (int k0 = 0; k0 < K; k0 += PW_BK) {
-        lstore();
-        __syncthreads();
-        if (k0 + PW_BK < K) gload(k0 + PW_BK);
+    lstore(0);
+    if (nslab > 1) gload(PW_BK);
+    __syncthreads();
+    for (int sl = 0; sl < nslab; sl++) {
+        const float* Xs = lds + (DB ? (sl & 1) : 0) * TILE;
+        const float* Ws = Xs + PW_BM * PW_LS;
 #pragma unroll
         for (int t16 = 0; t16 < 2; t16++) {
             f32x4 xf[2], wf[NT];
@@ -349,38 +381,59 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p) {
                 }
             }
         }
+        if (sl + 1 < nslab) {
+            if (!DB) __syncthreads();          // single buffer: everyone must be done reading it
+            lstore(DB ? ((sl + 1) & 1) : 0);
+            if (sl + 2 < nslab) gload((sl + 2) * PW_BK);
+        }
         __syncthreads();
     }
 
-    // ---- epilogue: D[i = n 4*kq + r][j = m li]
+    // ---- epilogue.  D[i = n 4*kq + r][j = m li]: the lane holds 4 consecutive channels of one row.  Bias and
+    // activation are applied in registers, the 16 x (16*NT) sub-tile is staged through this wave's private LDS
+    // slice, and written out row-contiguously (full 64*NT-byte runs per row instead of 64-byte pieces); the
+    // residual is read with the same coalesced pattern.
+    constexpr int BN = NT * 16;
+    constexpr int CS = BN + 4;                    // staging row stride (floats), keeps 16-byte alignment
+    float* stage = lds + wave * (16 * CS);        // 4 waves x 16 x CS floats fits in one operand tile
     const bool vec_ok = (p.N & 3) == 0;
 #pragma unroll
     for (int mt = 0; mt < 2; mt++) {
-        int m = m0 + 32 * wave + 16 * mt + li;
-        if (m >= p.M) continue;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             int n = n0 + 16 * t + 4 * kq;
-            if (n >= p.N) continue;
             f32x4 v = acc[t][mt];
-            if (vec_ok) {
-                if (p.bias) { float4 bv = *reinterpret_cast<const float4*>(p.bias + n); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
-                v[0] = apply_act(v[0], p.act); v[1] = apply_act(v[1], p.act);
-                v[2] = apply_act(v[2], p.act); v[3] = apply_act(v[3], p.act);
-                if (p.res) { float4 rv = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.N + n); v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
-                *reinterpret_cast<float4*>(p.out + (size_t)m * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
+            if (p.bias) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    if (n + r >= p.N) break;
-                    float x = v[r];
-                    if (p.bias) x += p.bias[n + r];
-                    x = apply_act(x, p.act);
-                    if (p.res) x += p.res[(size_t)m * p.N + n + r];
-                    p.out[(size_t)m * p.N + n + r] = x;
+                for (int r = 0; r < 4; r++) if (n + r < p.N) v[r] += p.bias[n + r];
+            }
+            v[0] = apply_act(v[0], p.act); v[1] = apply_act(v[1], p.act);
+            v[2] = apply_act(v[2], p.act); v[3] = apply_act(v[3], p.act);
+            *reinterpret_cast<f32x4*>(&stage[li * CS + 16 * t + 4 * kq]) = v;
+        }
+        // wave-private region: the wave's own LDS writes are visible to it once the LDS counter drains
+        __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        const int mbase = m0 + 32 * wave + 16 * mt;
+#pragma unroll
+        for (int q = 0; q < (16 * (BN / 4) + 63) / 64; q++) {
+            int idx = lane + 64 * q;
+            int row = idx / (BN / 4), c4 = idx % (BN / 4);
+            int m = mbase + row, n = n0 + 4 * c4;
+            if (row < 16 && m < p.M && n < p.N) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * CS + 4 * c4]);
+                float* op = p.out + (size_t)m * p.N + n;
+                if (vec_ok) {
+                    if (p.res) { float4 rv = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.N + n); v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
+                    *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (n + r < p.N) op[r] = v[r] + (p.res ? p.res[(size_t)m * p.N + n + r] : 0.f);
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -402,14 +455,23 @@ __global__ void k_pw_naive(PwParams p) {
     p.out[idx] = acc;
 }
 
-static int pick_nt(int N) {
-    // minimise padded columns, prefer wider tiles on ties
-    int best = 1; long best_cost = -1;
-    for (int nt = 1; nt <= 8; nt++) {
-        int bn = nt * 16;
-        long cols = (long)((N + bn - 1) / bn) * bn;
-        if (best_cost < 0 || cols < best_cost || (cols == best_cost && nt > best)) { best = nt; best_cost = cols; }
+// Tile-width choice.  Measured on MI355X (tests/micro sweep, late-layer shapes at batch 256): NT <= 4 keeps
+// the kernel at <= 112 VGPRs (4 waves/SIMD) and beats the wider tiles (134-158 VGPRs, 2 waves/SIMD) by
+// 10-45 % even where they pad less, so: widest NT in 1..4 whose padded width is within 15 % of the best.
+static int pick_nt(int M, int N) {
+    (void)M;
+    long best_cols = -1;
+    for (int nt = 1; nt <= 4; nt++) {
+        long cols = (long)((N + nt * 16 - 1) / (nt * 16)) * nt * 16;
+        if (best_cols < 0 || cols < best_cols) best_cols = cols;
     }
+    int best = 1;
+    for (int nt = 1; nt <= 4; nt++) {
+        long cols = (long)((N + nt * 16 - 1) / (nt * 16)) * nt * 16;
+        if (cols * 100 <= best_cols * 115) best = nt;
+    }
+    const char* ov = getenv("BNHIP_PW_NT");
+    if (ov && atoi(ov) >= 1 && atoi(ov) <= 8) best = atoi(ov);
     return best;
 }
 
@@ -419,28 +481,18 @@ void launch_pw_gemm(const PwParams& p, hipStream_t s) {
         hipLaunchKernelGGL(k_pw_naive, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
         return;
     }
-    int nt = pick_nt(p.N);
-    dim3 grid((p.M + PW_BM - 1) / PW_BM, (p.N + nt * 16 - 1) / (nt * 16));
-    switch (nt) {
-        case 1: hipLaunchKernelGGL(k_pw_gemm<1>, grid, dim3(256), 0, s, p); break;
-        case 2: hipLaunchKernelGGL(k_pw_gemm<2>, grid, dim3(256), 0, s, p); break;
-        case 3: hipLaunchKernelGGL(k_pw_gemm<3>, grid, dim3(256), 0, s, p); break;
-        case 4: hipLaunchKernelGGL(k_pw_gemm<4>, grid, dim3(256), 0, s, p); break;
-        case 5: hipLaunchKernelGGL(k_pw_gemm<5>, grid, dim3(256), 0, s, p); break;
-        case 6: hipLaunchKernelGGL(k_pw_gemm<6>, grid, dim3(256), 0, s, p); break;
-        case 7: hipLaunchKernelGGL(k_pw_gemm<7>, grid, dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL(k_pw_gemm<8>, grid, dim3(256), 0, s, p); break;
-    }
+    int nt = pick_nt(p.M, p.N);
+    int nblk_n = (p.N + nt * 16 - 1) / (nt * 16);
+    unsigned nblk = (unsigned)((p.M + PW_BM - 1) / PW_BM) * nblk_n;
+    dim3 grid(nblk);
+    const bool sc = p.ascale != nullptr;
+#define PW_CASE(NT_) case NT_: if (sc) hipLaunchKernelGGL((k_pw_gemm<NT_, true>), grid, dim3(256), 0, s, p, nblk_n, nblk); \
+                     else hipLaunchKernelGGL((k_pw_gemm<NT_, false>), grid, dim3(256), 0, s, p, nblk_n, nblk); break;
+    switch (nt) { PW_CASE(1) PW_CASE(2) PW_CASE(3) PW_CASE(4) PW_CASE(5) PW_CASE(6) PW_CASE(7) default: PW_CASE(8) }
+#undef PW_CASE
 }
 
 // ------------------------------------------------------------------------------------------ depthwise conv
-// XCD-aware logical block id: the dispatcher places block b on XCD b % 8; remapping so that each XCD walks a
-// contiguous range of logical blocks keeps halo rows / shared operand panels in ONE XCD's L2 (bijective form).
-__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
-    unsigned q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
 // Register-tiled depthwise conv: a thread owns 4 channels x (TH x TW) output pixels, so each input
 // row segment it loads is reused across the TW horizontal and up to K vertical taps (HBM/L2 traffic per
 // output drops from K*K loads to ~((TH-1)S+K)((TW-1)S+K)/(TH*TW)).  Threads are laid out channel-fastest
