@@ -594,7 +594,14 @@ bool Engine::build(const TflModel& m, int dev, int maxb, bool plan_only, std::st
                     ss.flops = 4.0 * C * Cr;
                     size_t b1 = (m.ops[c1].inputs.size() > 2 && m.ops[c1].inputs[2] >= 0) ? wconst(m.ops[c1].inputs[2]) : SIZE_MAX;
                     size_t b2 = (m.ops[c2].inputs.size() > 2 && m.ops[c2].inputs[2] >= 0) ? wconst(m.ops[c2].inputs[2]) : SIZE_MAX;
-                    add_step(ss, wconst(m.ops[c1].inputs[1]), b1, wconst(m.ops[c2].inputs[1]), b2);
+                    // second FC transposed [C][Cr] -> [Cr][C] so the kernel reads it coalesced
+                    std::vector<float> w2t((size_t)C * Cr);
+                    {
+                        const float* w2s = w2.f32();
+                        for (int cc = 0; cc < C; cc++)
+                            for (int jj = 0; jj < Cr; jj++) w2t[(size_t)jj * C + cc] = w2s[(size_t)cc * Cr + jj];
+                    }
+                    add_step(ss, wconst(m.ops[c1].inputs[1]), b1, wpush(w2t.data(), w2t.size()), b2);
                     int u = m.ops[mu].outputs[0];
                     int pc = P.uses[u] == 1 ? P.only_consumer(u) : -1;
                     bool fold = false;

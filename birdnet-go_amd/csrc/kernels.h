@@ -60,7 +60,7 @@ void launch_mean_finish(const float* partial, float* out, int B, int HW, int C, 
 struct SeParams {         // squeeze-excite FCs on pooled sums
     const float* partial; int S; int HW;         // pooled sums [B,S,C]
     const float* w1; const float* b1;            // [Cr, C], [Cr]
-    const float* w2; const float* b2;            // [C, Cr], [C]
+    const float* w2; const float* b2;            // w2 TRANSPOSED to [Cr, C] at plan time; [C]
     float* scale;                                // [B, C]
     int B, C, Cr, act1, act2;
 };

@@ -97,12 +97,14 @@ void launch_clip_minmax(const float* x, int n_clips, int n_samples, float eps, f
 #define FE_FT 64
 #define FE_KC 32
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-template <int NT>
-__global__ __launch_bounds__(256) void k_frontend(FrontendParams p) {
+template <int NT, int WN>
+__global__ __launch_bounds__(256 * WN) void k_frontend(FrontendParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NTP = NT * 16;
+    constexpr int NTW = NT / WN;                 // mel tiles per wave (waves are 4 frame-groups x WN mel-groups)
+    constexpr int NTHR = 256 * WN;
     constexpr int GS = NTP + 16;                 // LDS row stride (doubles): k-rows land 32 banks apart for ds_read_b64
-    constexpr int GQ = (NT + 1) / 2;             // double4 (32 B) per thread per chunk
+    constexpr int GQ = (NT * 128 + NTHR - 1) / NTHR;   // double4 (32 B) per thread per chunk
     const int seg_len = (FE_FT - 1) * p.hop + p.Lp;
     float* seg = smem;
     float* win = smem + ((seg_len + 3) & ~3);
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void k_frontend(FrontendParams p) {
     const int b = blockIdx.y;
     const int f0 = blockIdx.x * FE_FT;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = (tid >> 6) & 3, nh = tid >> 8;
     const int li = lane & 15, kq = lane >> 4;
 
     // ---- stage + normalise the clip segment ((x - min) / (range+eps) - 0.5) * 2, exactly the graph's op order
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void k_frontend(FrontendParams p) {
         const float2 mm = p.mm[b];
         const float* xc = p.x + (size_t)b * p.n_samples;
         const int s0 = f0 * p.hop;
-        for (int i = tid; i < seg_len; i += 256) {
+        for (int i = tid; i < seg_len; i += NTHR) {
             int g = s0 + i;
             float v = 0.0f;
             if (g < p.n_samples) {
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void k_frontend(FrontendParams p) {
             }
             seg[i] = v;
         }
-        for (int i = tid; i < p.Lp; i += 256) win[i] = p.window[i];
+        for (int i = tid; i < p.Lp; i += NTHR) win[i] = p.window[i];
     }
 
     const double4* G4 = reinterpret_cast<const double4*>(p.G);
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void k_frontend(FrontendParams p) {
     auto gload = [&](int chunk) {
 #pragma unroll
         for (int q = 0; q < GQ; q++) {
-            int idx = tid + 256 * q;
+            int idx = tid + NTHR * q;
             double4 v = make_double4(0., 0., 0., 0.);
             if (idx < FE_KC * (NTP / 4)) v = G4[(size_t)chunk * FE_KC * (NTP / 4) + idx];
             greg[q] = v;
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void k_frontend(FrontendParams p) {
     auto gstore = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < GQ; q++) {
-            int idx = tid + 256 * q;
+            int idx = tid + NTHR * q;
             if (idx < FE_KC * (NTP / 4)) {
                 int r = idx / (NTP / 4), c4 = idx % (NTP / 4);
                 *reinterpret_cast<double4*>(&Gs[buf * FE_KC * GS + r * GS + 4 * c4]) = greg[q];
@@ -155,9 +157,9 @@ __global__ __launch_bounds__(256) void k_frontend(FrontendParams p) {
         }
     };
 
-    f64x4 acc[NT];
+    f64x4 acc[NTW];
 #pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = (f64x4){0., 0., 0., 0.};
+    for (int t = 0; t < NTW; t++) acc[t] = (f64x4){0., 0., 0., 0.};
 
     const int nchunks = p.Lp / FE_KC;
     gload(0);
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void k_frontend(FrontendParams p) {
     const float* arow = seg + (16 * wave + li) * p.hop + kq;
     for (int ch = 0; ch < nchunks; ch++) {
         if (ch + 1 < nchunks) gload(ch + 1);
-        const double* gb = Gs + (ch & 1) * FE_KC * GS + kq * GS + li;
+        const double* gb = Gs + (ch & 1) * FE_KC * GS + kq * GS + nh * NTW * 16 + li;
         const float* ab = arow + ch * FE_KC;
         const float* wb = win + ch * FE_KC + kq;
 #pragma unroll
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void k_frontend(FrontendParams p) {
             float xw = ab[kk * 4] * wb[kk * 4];          // fp32 product, rounded like the graph's window MUL
             double a = (double)xw;
 #pragma unroll
-            for (int t = 0; t < NT; t++) {
+            for (int t = 0; t < NTW; t++) {
                 double bv = gb[kk * 4 * GS + t * 16];
                 acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[t], 0, 0, 0);
             }
@@ -185,8 +187,8 @@ __global__ __launch_bounds__(256) void k_frontend(FrontendParams p) {
 
     // ---- epilogue: f64 C/D layout D[row = kq + 4*r][col = li]  (row = frame, col = mel)
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-        int m = t * 16 + li;
+    for (int t = 0; t < NTW; t++) {
+        int m = (nh * NTW + t) * 16 + li;
         if (m >= p.n_mels) continue;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -206,24 +208,26 @@ size_t frontend_lds_bytes(int L, int Lp, int hop, int NTP) {
     return (size_t)(((seg_len + 3) & ~3) + Lp) * sizeof(float) + (size_t)2 * FE_KC * (NTP + 16) * sizeof(double);
 }
 
-template <int NT>
+template <int NT, int WN>
 static void launch_frontend_nt(const FrontendParams& p, hipStream_t s) {
     size_t lds = frontend_lds_bytes(p.L, p.Lp, p.hop, p.NTP);
-    static bool attr_set[9] = {};
-    if (!attr_set[NT]) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frontend<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frontend<NT, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
-        attr_set[NT] = true;
+        attr_set = true;
     }
     dim3 grid((p.F + FE_FT - 1) / FE_FT, p.n_clips);
-    hipLaunchKernelGGL(k_frontend<NT>, grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((k_frontend<NT, WN>), grid, dim3(256 * WN), lds, s, p);
 }
 void launch_frontend(const FrontendParams& p, hipStream_t s) {
+    // even tile counts run 8 waves (two mel halves): two waves per SIMD keep the f64 matrix pipe fed while the
+    // partner waits on LDS
     switch (p.NTP / 16) {
-        case 1: launch_frontend_nt<1>(p, s); break; case 2: launch_frontend_nt<2>(p, s); break;
-        case 3: launch_frontend_nt<3>(p, s); break; case 4: launch_frontend_nt<4>(p, s); break;
-        case 5: launch_frontend_nt<5>(p, s); break; case 6: launch_frontend_nt<6>(p, s); break;
-        case 7: launch_frontend_nt<7>(p, s); break; case 8: launch_frontend_nt<8>(p, s); break;
+        case 1: launch_frontend_nt<1, 1>(p, s); break; case 2: launch_frontend_nt<2, 2>(p, s); break;
+        case 3: launch_frontend_nt<3, 1>(p, s); break; case 4: launch_frontend_nt<4, 2>(p, s); break;
+        case 5: launch_frontend_nt<5, 1>(p, s); break; case 6: launch_frontend_nt<6, 2>(p, s); break;
+        case 7: launch_frontend_nt<7, 1>(p, s); break; case 8: launch_frontend_nt<8, 2>(p, s); break;
         default: break;
     }
 }
@@ -714,34 +718,38 @@ void launch_mean_finish(const float* partial, float* out, int B, int HW, int C, 
 }
 
 // ------------------------------------------------------------------------------------------ squeeze-excite
-// One block per clip: mean -> FC(Cr)+act1 -> FC(C)+act2 -> scale[b][c].
-__global__ __launch_bounds__(256) void k_se(SeParams p) {
+// One block (16 waves) per clip: mean -> FC(Cr)+act1 -> FC(C)+act2 -> scale[b][c].
+// w1 [Cr][C] is read wave-per-output with coalesced float4 rows; w2t is the second FC transposed to [Cr][C]
+// at plan time so thread c reads it coalesced.
+__global__ __launch_bounds__(1024) void k_se(SeParams p) {
     extern __shared__ float sm[];
     float* mean = sm;            // [C]
     float* r = sm + p.C;         // [Cr]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int c = tid; c < p.C; c += 256) {
+    const float inv = 1.0f / (float)p.HW;
+    for (int c = tid; c < p.C; c += 1024) {
         float sum = 0.f;
         for (int sidx = 0; sidx < p.S; sidx++) sum += p.partial[((size_t)b * p.S + sidx) * p.C + c];
-        mean[c] = sum / (float)p.HW;
+        mean[c] = sum * inv;
     }
     __syncthreads();
-    for (int j = wave; j < p.Cr; j += 4) {
+    for (int j = wave; j < p.Cr; j += 16) {
         float acc = 0.f;
-        for (int c = lane; c < p.C; c += 64) acc = fmaf(p.w1[(size_t)j * p.C + c], mean[c], acc);
+        const float* wr = p.w1 + (size_t)j * p.C;
+        for (int c = lane; c < p.C; c += 64) acc = fmaf(wr[c], mean[c], acc);
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
         if (lane == 0) r[j] = apply_act(acc + (p.b1 ? p.b1[j] : 0.f), p.act1);
     }
     __syncthreads();
-    for (int c = tid; c < p.C; c += 256) {
+    for (int c = tid; c < p.C; c += 1024) {
         float acc = 0.f;
-        for (int j = 0; j < p.Cr; j++) acc = fmaf(p.w2[(size_t)c * p.Cr + j], r[j], acc);
+        for (int j = 0; j < p.Cr; j++) acc = fmaf(p.w2[(size_t)j * p.C + c], r[j], acc);
         p.scale[(size_t)b * p.C + c] = apply_act(acc + (p.b2 ? p.b2[c] : 0.f), p.act2);
     }
 }
 void launch_se(const SeParams& p, hipStream_t s) {
     size_t lds = (size_t)(p.C + p.Cr) * sizeof(float);
-    hipLaunchKernelGGL(k_se, dim3(p.B), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(k_se, dim3(p.B), dim3(1024), lds, s, p);
 }
 
 // ------------------------------------------------------------------------------------------ generic elementwise
