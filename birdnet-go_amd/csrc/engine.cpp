@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
@@ -424,6 +425,7 @@ bool Engine::build(const TflModel& m, int dev, int maxb, bool plan_only, std::st
         }
         return y;
     };
+    const bool fuse_expdw = !(getenv("BNHIP_NO_FUSE_EXPDW") && atoi(getenv("BNHIP_NO_FUSE_EXPDW")) != 0);
     struct ScaledAlias { int v_data; int v_scale; };
     std::map<int, ScaledAlias> scaled;   // tflite tensor (SE MUL output) -> (data value, scale value)
 
@@ -452,6 +454,41 @@ bool Engine::build(const TflModel& m, int dev, int maxb, bool plan_only, std::st
                 size_t boff = (o.inputs.size() > 2 && o.inputs[2] >= 0) ? wconst(o.inputs[2]) : SIZE_MAX;
                 bool pw = kh == 1 && kw == 1 && o.stride_h == 1 && o.stride_w == 1;
                 Step s; s.name = oname; s.H = H; s.W = W; s.C = C; s.Ho = Ho; s.Wo = Wo; s.Co = Co; s.act = act;
+                // ---- MBConv front half: 1x1 expand whose only consumer is a depthwise conv -> one fused kernel
+                if (pw && fuse_expdw && scaled.find(in_t) == scaled.end() && P.uses[outt] == 1 && P.consumers[outt].size() == 1) {
+                    int di = P.consumers[outt][0];
+                    const TflOp& d = m.ops[di];
+                    int dH, dW, dC, dHo, dWo, dCo;
+                    if (d.code == OP_DEPTHWISE_CONV_2D && !P.absorbed[di] && d.inputs[0] == outt && P.is_const(d.inputs[1]) &&
+                        hwc(outt, &dH, &dW, &dC) && hwc(d.outputs[0], &dHo, &dWo, &dCo) && dCo == dC && d.depth_multiplier == 1 &&
+                        d.dil_h == 1 && d.dil_w == 1 && d.stride_h == d.stride_w) {
+                        const TflTensor& wd = m.tensors[d.inputs[1]];
+                        int kd = wd.shape.size() == 4 ? wd.shape[1] : 0;
+                        int act_d = map_act(d.act);
+                        if (kd == wd.shape[2] && wd.shape[3] == dC && act_d >= 0 && expdw_supported(kd, d.stride_h, C, Co) &&
+                            need_val(in_t) >= 0) {
+                            int dout = d.outputs[0];
+                            if (act_d == ACT_NONE) dout = trailing_act(dout, &act_d);
+                            P.absorbed[di] = 1;
+                            Step f; f.kind = S_EXPAND_DW; f.kclass = "expand_dw"; f.name = oname + "+dw";
+                            f.in0 = need_val(in_t);
+                            f.H = H; f.W = W; f.C = C; f.Co = Co; f.Ho = dHo; f.Wo = dWo; f.kh = kd; f.kw = kd;
+                            f.sh = d.stride_h; f.sw = d.stride_w; f.act = act; f.act2 = act_d;
+                            if (d.padding == 0) {
+                                int th = std::max((dHo - 1) * f.sh + kd - dH, 0), tw = std::max((dWo - 1) * f.sw + kd - dW, 0);
+                                f.pt = th / 2; f.pl = tw / 2;
+                            }
+                            f.flops = 2.0 * H * W * C * Co + 2.0 * dHo * dWo * Co * kd * kd;
+                            f.bytes = 4.0 * ((double)H * W * C + (double)dHo * dWo * Co);
+                            f.wbytes = 4.0 * (C * Co + kd * kd * Co);
+                            f.out = new_val(dout, (size_t)dHo * dWo * Co);
+                            tv[dout] = f.out;
+                            size_t bd = (d.inputs.size() > 2 && d.inputs[2] >= 0) ? wconst(d.inputs[2]) : SIZE_MAX;
+                            add_step(f, wconst(o.inputs[1]), boff, wconst(d.inputs[1]), bd);
+                            break;
+                        }
+                    }
+                }
                 if (pw) {
                     s.kind = S_PW; s.kclass = "pw_gemm";
                     auto sc = scaled.find(in_t);
@@ -544,7 +581,17 @@ bool Engine::build(const TflModel& m, int dev, int maxb, bool plan_only, std::st
                 bool fused_sum = false;
                 Step mp; mp.kind = S_MEAN_PARTIAL; mp.kclass = "mean"; mp.name = oname + "/partial";
                 mp.in0 = vin; mp.H = H; mp.W = W; mp.C = C;
-                if (!steps.empty() && steps.back().kind == S_DW && steps.back().out == vin) {
+                if (!steps.empty() && steps.back().kind == S_EXPAND_DW && steps.back().out == vin) {
+                    const Step& d = steps.back();
+                    int slabs = expdw_sum_slabs(d.kh, d.sh, d.Ho, d.Wo);
+                    if (slabs > 0) {
+                        S = slabs;
+                        fused_sum = true;
+                        mp.out = new_val(-1, (size_t)S * C);
+                        steps.back().out2 = mp.out;
+                        steps.back().S = S;
+                    }
+                } else if (!steps.empty() && steps.back().kind == S_DW && steps.back().out == vin) {
                     // the producer is a depthwise conv: let it emit the per-slab channel sums itself
                     const Step& d = steps.back();
                     DwParams dp{nullptr, nullptr, nullptr, nullptr, 1, d.H, d.W, d.C, d.Ho, d.Wo, d.kh, d.kw, d.sh, d.sw, d.pt, d.pl, d.act};
@@ -859,6 +906,10 @@ bool Engine::run(const float* d_in, int n, float* d_logits, float* d_emb, std::s
                 launch_dwconv(p, vptr(s.out2, d_in, d_logits, d_emb), stream);
                 break;
             }
+            case S_EXPAND_DW:
+                launch_expand_dw(in0, s.w0, s.w1, s.w2, s.w3, out, vptr(s.out2, d_in, d_logits, d_emb), n, s.H, s.W, s.C, s.Co,
+                                 s.Ho, s.Wo, s.kh, s.sh, s.pt, s.pl, s.act, s.act2, stream);
+                break;
             case S_MEAN_PARTIAL:
                 launch_mean_partial(in0, out, n, s.H * s.W, s.C, s.S, stream);
                 break;

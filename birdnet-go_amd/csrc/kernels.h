@@ -51,6 +51,13 @@ struct DwParams {
 int dwconv_sum_slabs(const DwParams& p);
 void launch_dwconv(const DwParams& p, float* partial, hipStream_t s);
 
+// fused MBConv front half: y = act_d(dwconv(act_e(x We^T + be)) + bd); partial (nullable) [B, slabs, Cmid]
+bool expdw_supported(int k, int s, int Cin, int Cmid);
+int expdw_sum_slabs(int k, int s, int Ho, int Wo);
+void launch_expand_dw(const float* x, const float* we, const float* be, const float* wd, const float* bd, float* y,
+                      float* partial, int B, int H, int W, int Cin, int Cmid, int Ho, int Wo, int k, int s, int pt,
+                      int pl, int act_e, int act_d, hipStream_t st);
+
 // mean over H*W: in [B,HW,C] -> partial [B,S,C] (sums), S = number of pixel splits
 int mean_splits(int HW);
 void launch_mean_partial(const float* in, float* partial, int B, int HW, int C, int S, hipStream_t s);

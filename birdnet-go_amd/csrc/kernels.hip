@@ -675,6 +675,246 @@ void launch_dwconv(const DwParams& p, float* partial, hipStream_t s) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ fused expand + depthwise
+// MBConv front half in one kernel: y = act_d(dw_kxk(act_e(x * We^T + be)) + bd), plus the per-tile channel sums
+// the squeeze-excite mean needs.  The 6x-expanded tensor (the largest activation of every block, ~40 % of all
+// HBM traffic when materialised) lives only in LDS.
+//   block = (clip, TOH x TOW output tile, 32-channel chunk of the expanded width)
+//   phase 1: E[pixel][32] = expand over the tile's input footprint ((TOH-1)S+K) x ((TOW-1)S+K), as an f32-MFMA
+//            GEMM whose rows are the *in-image* footprint pixels (halo outside the image is zero padding of the
+//            expanded tensor and is never computed); K-slabs of 32 input channels staged like k_pw_gemm.
+//   phase 2: depthwise taps from LDS, 32 thread-tiles (4 x 8) x 8 channel quads, bias + activation, store, sums.
+struct ExpDwParams {
+    const float* x; const float* we; const float* be; const float* wd; const float* bd;
+    float* y; float* partial;
+    int B, H, W, Cin, Cmid, Ho, Wo, pt, pl, act_e, act_d, tiles_h, tiles_w, cchunks;
+};
+#define ED_XS 40     // X/W slab row stride (floats): conflict-free ds_read_b128 fragments (see k_pw_gemm)
+#define ED_ES 36     // E row stride (floats)
+template <int K, int S, int TOH, int TOW>
+__global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk) {
+    constexpr int TIH = (TOH - 1) * S + K, TIW = (TOW - 1) * S + K;
+    constexpr int NPIX = TIH * TIW, NPIXP = (NPIX + 15) / 16 * 16;
+    constexpr int JT = NPIXP / 16, JTW = (JT + 3) / 4;
+    constexpr int XQ = (NPIXP * 8 + 255) / 256;
+    constexpr int SH = TOH / 4, SW = TOW / 8;                 // outputs per thread in phase 2 (thread-tiles are 4 x 8)
+    constexpr int RW = (SW - 1) * S + K;
+    __shared__ __attribute__((aligned(16))) float lds[NPIXP * ED_XS + 32 * ED_XS];
+    float* Xs = lds;                       // [NPIXP][40] slab of footprint pixels; later aliased by E [NPIX][36]
+    float* Ws = lds + NPIXP * ED_XS;       // [32][40] slab of expand weights; later aliased by the sum scratch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+
+    const unsigned L = xcd_remap(blockIdx.x, nblk);
+    const int tiles = p.tiles_h * p.tiles_w;
+    const int bpc = tiles * p.cchunks;
+    const int b = L / bpc, rest = L % bpc;
+    const int tile = rest / p.cchunks, cc = rest % p.cchunks;
+    const int oh0 = (tile / p.tiles_w) * TOH, ow0 = (tile % p.tiles_w) * TOW;
+    const int ih0 = oh0 * S - p.pt, iw0 = ow0 * S - p.pl;
+    // in-image part of the footprint
+    const int vh0 = max(ih0, 0), vh1 = min(ih0 + TIH, p.H), vw0 = max(iw0, 0), vw1 = min(iw0 + TIW, p.W);
+    const int vw = vw1 - vw0, nvalid = (vh1 - vh0) * vw;
+    const int nvp = (nvalid + 15) & ~15;
+    const int Cin = p.Cin;
+    const int n_base = cc * 32;
+
+    // per-thread gather offsets of the pixels this thread stages (constant over K-slabs)
+    int xoff[XQ];
+#pragma unroll
+    for (int q = 0; q < XQ; q++) {
+        int idx = tid + 256 * q;
+        int j = idx >> 3;
+        xoff[q] = -1;
+        if (j < nvalid) {
+            int r = j / vw, c = j - r * vw;
+            xoff[q] = (((b * p.H + vh0 + r) * p.W) + vw0 + c) * Cin + 4 * (idx & 7);
+        }
+    }
+    float4 xreg[XQ], wreg;
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < XQ; q++) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int k = k0 + 4 * ((tid + 256 * q) & 7);
+            if (xoff[q] >= 0 && k < Cin) v = *reinterpret_cast<const float4*>(p.x + (size_t)xoff[q] + k0);
+            xreg[q] = v;
+        }
+        {
+            int row = tid >> 3, k = k0 + 4 * (tid & 7);
+            int n = n_base + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < p.Cmid && k < Cin) v = *reinterpret_cast<const float4*>(p.we + (size_t)n * Cin + k);
+            wreg = v;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < XQ; q++) {
+            int idx = tid + 256 * q;
+            if (idx < nvp * 8) *reinterpret_cast<float4*>(&Xs[(idx >> 3) * ED_XS + 4 * (idx & 7)]) = xreg[q];
+        }
+        *reinterpret_cast<float4*>(&Ws[(tid >> 3) * ED_XS + 4 * (tid & 7)]) = wreg;
+    };
+
+    f32x4 acc[JTW][2];
+#pragma unroll
+    for (int a = 0; a < JTW; a++) { acc[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    const int jtv = nvp >> 4;                 // live pixel tiles
+    gload(0);
+    for (int k0 = 0; k0 < Cin; k0 += 32) {
+        lstore();
+        __syncthreads();
+        if (k0 + 32 < Cin) gload(k0 + 32);
+#pragma unroll
+        for (int t16 = 0; t16 < 2; t16++) {
+            f32x4 wf[2];
+#pragma unroll
+            for (int it = 0; it < 2; it++)
+                wf[it] = *reinterpret_cast<const f32x4*>(&Ws[(16 * it + li) * ED_XS + 16 * t16 + 4 * kq]);
+#pragma unroll
+            for (int a = 0; a < JTW; a++) {
+                int jt = wave + 4 * a;
+                if (jt < jtv) {
+                    f32x4 xf = *reinterpret_cast<const f32x4*>(&Xs[(16 * jt + li) * ED_XS + 16 * t16 + 4 * kq]);
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; sidx++) {
+                        acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0][sidx], xf[sidx], acc[a][0], 0, 0, 0);
+                        acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1][sidx], xf[sidx], acc[a][1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- E <- act_e(acc + be), scattered to footprint coordinates; out-of-image footprint pixels stay zero
+    float* E = lds;
+    if (nvalid < NPIX) {
+        for (int i = tid; i < NPIX * ED_ES / 4; i += 256) reinterpret_cast<float4*>(E)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+    }
+    {
+        float4 bq[2];
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            int n = n_base + 16 * it + 4 * kq;
+            bq[it] = (p.be && n + 3 < p.Cmid) ? *reinterpret_cast<const float4*>(p.be + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int a = 0; a < JTW; a++) {
+            int j = 16 * (wave + 4 * a) + li;
+            if (j < nvalid) {
+                int r = j / vw, c = j - r * vw;
+                int e = ((vh0 - ih0 + r) * TIW + (vw0 - iw0 + c)) * ED_ES;
+#pragma unroll
+                for (int it = 0; it < 2; it++) {
+                    f32x4 v = acc[a][it];
+                    v[0] = apply_act(v[0] + bq[it].x, p.act_e); v[1] = apply_act(v[1] + bq[it].y, p.act_e);
+                    v[2] = apply_act(v[2] + bq[it].z, p.act_e); v[3] = apply_act(v[3] + bq[it].w, p.act_e);
+                    *reinterpret_cast<f32x4*>(&E[e + 16 * it + 4 * kq]) = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- depthwise from LDS
+    const int c4 = tid & 7, tt = tid >> 3;
+    const int ty = tt >> 3, tx = tt & 7;
+    const int n = n_base + 4 * c4;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < p.Cmid) {
+        float4 acc2[SH][SW];
+#pragma unroll
+        for (int a = 0; a < SH; a++)
+#pragma unroll
+            for (int c = 0; c < SW; c++) acc2[a][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* e0 = E + ((ty * SH * S) * TIW + tx * SW * S) * ED_ES + 4 * c4;
+        const float4* w4 = reinterpret_cast<const float4*>(p.wd + n);
+        const int C4 = p.Cmid >> 2;
+#pragma unroll 1
+        for (int i = 0; i < K; i++) {                 // kernel row (kept rolled: bounds the live weight registers)
+            float4 w[K];
+#pragma unroll
+            for (int j = 0; j < K; j++) w[j] = w4[(size_t)(i * K + j) * C4];
+#pragma unroll
+            for (int a = 0; a < SH; a++) {
+                float4 xr[RW];
+#pragma unroll
+                for (int c = 0; c < RW; c++) xr[c] = *reinterpret_cast<const float4*>(e0 + ((a * S + i) * TIW + c) * ED_ES);
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+#pragma unroll
+                    for (int c = 0; c < SW; c++) {
+                        const float4 xv = xr[c * S + j];
+                        acc2[a][c].x = fmaf(xv.x, w[j].x, acc2[a][c].x); acc2[a][c].y = fmaf(xv.y, w[j].y, acc2[a][c].y);
+                        acc2[a][c].z = fmaf(xv.z, w[j].z, acc2[a][c].z); acc2[a][c].w = fmaf(xv.w, w[j].w, acc2[a][c].w);
+                    }
+                }
+            }
+        }
+        float4 bv = p.bd ? *reinterpret_cast<const float4*>(p.bd + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < SH; a++) {
+            int oh = oh0 + ty * SH + a;
+            if (oh >= p.Ho) continue;
+#pragma unroll
+            for (int c = 0; c < SW; c++) {
+                int ow = ow0 + tx * SW + c;
+                if (ow >= p.Wo) continue;
+                float4 v = acc2[a][c];
+                v.x = apply_act(v.x + bv.x, p.act_d); v.y = apply_act(v.y + bv.y, p.act_d);
+                v.z = apply_act(v.z + bv.z, p.act_d); v.w = apply_act(v.w + bv.w, p.act_d);
+                *reinterpret_cast<float4*>(p.y + (((size_t)b * p.Ho + oh) * p.Wo + ow) * p.Cmid + n) = v;
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+        }
+    }
+    if (p.partial) {
+        float4* red = reinterpret_cast<float4*>(Ws);          // 256 float4 = 4 KiB <= 32*40*4 B
+        red[tid] = sum;
+        __syncthreads();
+        if (tid < 8 && n_base + 4 * tid < p.Cmid) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int y = 0; y < 32; y++) { float4 v = red[y * 8 + tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            *reinterpret_cast<float4*>(p.partial + ((size_t)b * tiles + tile) * p.Cmid + n_base + 4 * tid) = t;
+        }
+    }
+}
+
+static bool expdw_tile(int k, int s, int Ho, int* toh, int* tow) {
+    if (!((k == 3 || k == 5) && (s == 1 || s == 2))) return false;
+    if (s == 2) { *toh = 4; *tow = 8; return true; }
+    *toh = Ho > 4 ? 8 : 4;     // short images: one 8-row tile (only in-image footprint rows are computed)
+    *tow = 16;
+    return true;
+}
+int expdw_sum_slabs(int k, int s, int Ho, int Wo) {
+    int toh, tow;
+    if (!expdw_tile(k, s, Ho, &toh, &tow)) return 0;
+    return ((Ho + toh - 1) / toh) * ((Wo + tow - 1) / tow);
+}
+bool expdw_supported(int k, int s, int Cin, int Cmid) {
+    int toh, tow;
+    return expdw_tile(k, s, 8, &toh, &tow) && (Cin & 3) == 0 && (Cmid & 3) == 0;
+}
+void launch_expand_dw(const float* x, const float* we, const float* be, const float* wd, const float* bd, float* y,
+                      float* partial, int B, int H, int W, int Cin, int Cmid, int Ho, int Wo, int k, int s, int pt,
+                      int pl, int act_e, int act_d, hipStream_t st) {
+    int toh, tow;
+    expdw_tile(k, s, Ho, &toh, &tow);
+    ExpDwParams p{x, we, be, wd, bd, y, partial, B, H, W, Cin, Cmid, Ho, Wo, pt, pl, act_e, act_d,
+                  (Ho + toh - 1) / toh, (Wo + tow - 1) / tow, (Cmid + 31) / 32};
+    unsigned nblk = (unsigned)B * p.tiles_h * p.tiles_w * p.cchunks;
+#define ED_LAUNCH(K_, S_, TH_, TW_) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_>), dim3(nblk), dim3(256), 0, st, p, nblk)
+    if (s == 2) { if (k == 3) ED_LAUNCH(3, 2, 4, 8); else ED_LAUNCH(5, 2, 4, 8); }
+    else if (toh == 8) { if (k == 3) ED_LAUNCH(3, 1, 8, 16); else ED_LAUNCH(5, 1, 8, 16); }
+    else { if (k == 3) ED_LAUNCH(3, 1, 4, 16); else ED_LAUNCH(5, 1, 4, 16); }
+#undef ED_LAUNCH
+}
+
 // ------------------------------------------------------------------------------------------ spatial mean
 // Deterministic two-stage reduction (no float atomics): partial[b][s][c] = sum over the s-th pixel slab.
 #define MEAN_SLAB 512
