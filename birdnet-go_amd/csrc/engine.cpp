@@ -232,7 +232,7 @@ bool match_frontend(Planner& P, int ri, FrontendMatch* fm) {
 }
 
 // G[n][m'] = sum_k cos(2 pi k n / Lfft) * Mel[k][m]   (fp64; the window is applied separately in fp32)
-std::vector<double> build_G(const Planner& P, const FrontendMatch& fm, int Lp, int NTP) {
+std::vector<double> build_G(const Planner& P, const FrontendMatch& fm, int Kp, int NTP) {
     const int nb = fm.Lfft / 2 + 1, nm = fm.n_mels, N = fm.Lfft;
     const float* melT = P.T(fm.mel_tensor).f32();      // [n_mels][nbins]
     std::vector<double> ctab(N);
@@ -246,9 +246,9 @@ std::vector<double> build_G(const Planner& P, const FrontendMatch& fm, int Lp, i
     std::vector<double> melk(krows.size() * (size_t)nm);
     for (size_t r = 0; r < krows.size(); r++)
         for (int mm = 0; mm < nm; mm++) melk[r * nm + mm] = (double)melT[(size_t)mm * nb + krows[r]];
-    std::vector<double> G((size_t)Lp * NTP, 0.0);
+    std::vector<double> G((size_t)Kp * NTP, 0.0);     // rows n' = 0..Lfft/2 (cos symmetry folds the rest)
     std::vector<double> row(nm);
-    for (int n = 0; n < fm.L; n++) {
+    for (int n = 0; n <= fm.Lfft / 2; n++) {
         std::fill(row.begin(), row.end(), 0.0);
         for (size_t r = 0; r < krows.size(); r++) {
             double c = ctab[(size_t)(((long long)krows[r] * n) % N)];
@@ -371,7 +371,7 @@ bool Engine::build(const TflModel& m, int dev, int maxb, bool plan_only, std::st
             const FrontendMatch& fm = fms[i];
             FrontSpec fs;
             fs.L = fm.L; fs.Lfft = fm.Lfft; fs.hop = fm.hop; fs.F = fm.F; fs.n_mels = fm.n_mels; fs.c = chan_of[i];
-            fs.Lp = (int)align_up(fm.L, kFrontendKC);
+            fs.Kp = (int)align_up(fm.Lfft / 2 + 1, kFrontendKC);
             fs.NTP = (int)align_up(fm.n_mels, 16);
             if (fs.NTP > 128) { *err = "front-end: more than 128 mel bins unsupported"; return false; }
             if (fm.eps != fms[0].eps || fm.norm_sub != fms[0].norm_sub || fm.norm_mul != fms[0].norm_mul) {
@@ -379,19 +379,24 @@ bool Engine::build(const TflModel& m, int dev, int maxb, bool plan_only, std::st
                 return false;
             }
             fs.p1 = fm.p1; fs.p2 = fm.p2; fs.eps = fm.eps; fs.norm_sub = fm.norm_sub; fs.norm_mul = fm.norm_mul;
-            if (frontend_lds_bytes(fs.L, fs.Lp, fs.hop, fs.NTP) > 160 * 1024) {
+            if (frontend_lds_bytes(fs.Lfft, fs.Kp, fs.hop, fs.NTP) > 160 * 1024) {
                 *err = "front-end: frame tile does not fit in LDS";
                 return false;
             }
-            std::vector<double> G = build_G(P, fm, fs.Lp, fs.NTP);
+            std::vector<double> G = build_G(P, fm, fs.Kp, fs.NTP);
             size_t goff = wpush(reinterpret_cast<const float*>(G.data()), G.size() * 2);   // fp64 image, 256-B aligned
-            std::vector<float> wpad(fs.Lp, 0.0f);
-            std::copy(fm.window.begin(), fm.window.end(), wpad.begin());
+            // w[n'] for n' = 0..Lfft/2, then the mirror weights w[Lfft-n'] (0 when n' = 0, n' = Lfft/2, or beyond the frame)
+            std::vector<float> wpad((size_t)2 * fs.Kp, 0.0f);
+            for (int n = 0; n <= fm.Lfft / 2; n++) {
+                if (n < fm.L) wpad[n] = fm.window[n];
+                int mi = fm.Lfft - n;
+                if (n > 0 && mi != n && mi < fm.L) wpad[fs.Kp + n] = fm.window[mi];
+            }
             size_t woff = wpush(wpad.data(), wpad.size());
             specs.push_back(fs);
             Step f; f.kind = S_FRONTEND; f.name = "melspec" + std::to_string(i); f.kclass = "frontend";
             f.in0 = v_input; f.in1 = v_mm; f.out = v_spec; f.spec = (int)specs.size() - 1;
-            f.flops = 2.0 * fm.F * fs.L * fm.n_mels;
+            f.flops = 2.0 * fm.F * (fm.Lfft / 2 + 1) * fm.n_mels;
             f.bytes = (double)n_samples * 4 + (double)fm.F * fm.n_mels * 4;
             add_step(f, goff, woff);
         }
@@ -885,7 +890,7 @@ bool Engine::run(const float* d_in, int n, float* d_logits, float* d_emb, std::s
                 const FrontSpec& fs = specs[s.spec];
                 FrontendParams p;
                 p.x = in0; p.mm = reinterpret_cast<const float2*>(in1); p.G = fs.G; p.window = fs.window; p.out = out;
-                p.n_samples = n_samples; p.L = fs.L; p.Lp = fs.Lp; p.hop = fs.hop; p.F = fs.F; p.n_mels = fs.n_mels;
+                p.n_samples = n_samples; p.L = fs.L; p.Lfft = fs.Lfft; p.Kp = fs.Kp; p.hop = fs.hop; p.F = fs.F; p.n_mels = fs.n_mels;
                 p.NTP = fs.NTP; p.C = C_spec; p.c = fs.c; p.norm_sub = fs.norm_sub; p.norm_mul = fs.norm_mul;
                 p.p1 = fs.p1; p.p2 = fs.p2; p.n_clips = n;
                 launch_frontend(p, stream);

@@ -39,7 +39,7 @@ struct Value {               // an activation tensor (per clip geometry)
 };
 
 struct FrontSpec {
-    int L, Lp, Lfft, hop, F, n_mels, NTP, c;
+    int L, Kp, Lfft, hop, F, n_mels, NTP, c;
     float p1, p2, eps, norm_sub, norm_mul;
     const double* G = nullptr;   // device, fp64
     const float* window = nullptr;

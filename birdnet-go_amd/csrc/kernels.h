@@ -17,16 +17,16 @@ void launch_clip_minmax(const float* x, int n_clips, int n_samples, float eps, f
 struct FrontendParams {
     const float* x;        // [B, n_samples] raw clip
     const float2* mm;      // [B] (min, range+eps)
-    const double* G;       // [Lp, NTP] folded DFT-real*mel matrix (fp64), rows >= L are zero
-    const float* window;   // [Lp] analysis window (zeros beyond L)
+    const double* G;       // [Kp, NTP] folded DFT-real*mel matrix (fp64), rows n' = 0..Lfft/2 (then zero padding)
+    const float* window;   // [2*Kp]: w[n'] then w[Lfft-n'] (0 where the mirror sample does not exist)
     float* out;            // [B, n_mels, F, C]
-    int n_samples, L, Lp, hop, F, n_mels, NTP, C, c;   // c = channel index written
+    int n_samples, L, Lfft, Kp, hop, F, n_mels, NTP, C, c;   // c = channel index written; Kp = roundup(Lfft/2+1, 32)
     float norm_sub, norm_mul;   // (x-min)/range - norm_sub) * norm_mul
     float p1, p2;          // y = pow(pow(v, p1), p2); p2 == 1 => single pow
     int n_clips;
 };
 void launch_frontend(const FrontendParams& p, hipStream_t s);
-size_t frontend_lds_bytes(int L, int Lp, int hop, int NTP);
+size_t frontend_lds_bytes(int Lfft, int Kp, int hop, int NTP);
 constexpr int kFrontendKC = 32;   // K-chunk of the front-end GEMM (G rows per LDS stage)
 
 // ---- CNN

@@ -93,6 +93,9 @@ void launch_clip_minmax(const float* x, int n_clips, int n_samples, float eps, f
 // runs on the f64 MFMA (v_mfma_f64_16x16x4_f64) with G held in fp64, while the window product is
 // rounded to fp32 first exactly as the graph's MUL does.  A rows are overlapping windows of the
 // LDS-resident clip segment (never materialised), B = G streamed from L2 in 32-row chunks.
+// cos(2*pi*k*(N-n)/N) = cos(2*pi*k*n/N) makes G symmetric in n, so the windowed frame is folded first,
+//   a[n'] = double(fl32(x[n']*w[n'])) + double(fl32(x[N-n']*w[N-n']))   (exact in fp64), n' = 0..N/2,
+// halving the contraction length (K = N/2+1) at no cost in accuracy.
 // Block: 64 frames x (16*NT) mel columns, 4 waves, wave w owns frames [16w,16w+16) x all NT tiles.
 #define FE_FT 64
 #define FE_KC 32
@@ -105,10 +108,11 @@ __global__ __launch_bounds__(256 * WN) void k_frontend(FrontendParams p) {
     constexpr int NTHR = 256 * WN;
     constexpr int GS = NTP + 16;                 // LDS row stride (doubles): k-rows land 32 banks apart for ds_read_b64
     constexpr int GQ = (NT * 128 + NTHR - 1) / NTHR;   // double4 (32 B) per thread per chunk
-    const int seg_len = (FE_FT - 1) * p.hop + p.Lp;
+    const int seg_len = (FE_FT - 1) * p.hop + p.Lfft + 4;   // +4: the n'=0 mirror reads one past the frame (weight 0)
     float* seg = smem;
-    float* win = smem + ((seg_len + 3) & ~3);
-    double* Gs = reinterpret_cast<double*>(win + p.Lp);   // Lp is a multiple of 32 -> 16-byte aligned
+    float* win = smem + ((seg_len + 3) & ~3);                // [Kp] window at n'
+    float* win2 = win + p.Kp;                                // [Kp] window at the mirror index (0 where there is none)
+    double* Gs = reinterpret_cast<double*>(win2 + p.Kp);     // Kp is a multiple of 32 -> 16-byte aligned
 
     const int b = blockIdx.y;
     const int f0 = blockIdx.x * FE_FT;
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(256 * WN) void k_frontend(FrontendParams p) {
         for (int i = tid; i < seg_len; i += NTHR) {
             int g = s0 + i;
             float v = 0.0f;
-            if (g < p.n_samples) {
+            if (g < p.n_samples && i < seg_len - 4) {
                 float t = xc[g] - mm.x;
                 t = t / mm.y;
                 t = t - p.norm_sub;
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(256 * WN) void k_frontend(FrontendParams p) {
             }
             seg[i] = v;
         }
-        for (int i = tid; i < p.Lp; i += NTHR) win[i] = p.window[i];
+        for (int i = tid; i < p.Kp; i += NTHR) { win[i] = p.window[i]; win2[i] = p.window[p.Kp + i]; }
     }
 
     const double4* G4 = reinterpret_cast<const double4*>(p.G);
@@ -161,20 +165,24 @@ __global__ __launch_bounds__(256 * WN) void k_frontend(FrontendParams p) {
 #pragma unroll
     for (int t = 0; t < NTW; t++) acc[t] = (f64x4){0., 0., 0., 0.};
 
-    const int nchunks = p.Lp / FE_KC;
+    const int nchunks = p.Kp / FE_KC;
     gload(0);
     gstore(0);
     __syncthreads();
-    const float* arow = seg + (16 * wave + li) * p.hop + kq;
+    const float* arow = seg + (16 * wave + li) * p.hop + kq;                 // x[f*hop + n']
+    const float* mrow = seg + (16 * wave + li) * p.hop + p.Lfft - kq;        // x[f*hop + N - n']
     for (int ch = 0; ch < nchunks; ch++) {
         if (ch + 1 < nchunks) gload(ch + 1);
         const double* gb = Gs + (ch & 1) * FE_KC * GS + kq * GS + nh * NTW * 16 + li;
         const float* ab = arow + ch * FE_KC;
+        const float* mb = mrow - ch * FE_KC;
         const float* wb = win + ch * FE_KC + kq;
+        const float* wb2 = win2 + ch * FE_KC + kq;
 #pragma unroll
         for (int kk = 0; kk < FE_KC / 4; kk++) {
-            float xw = ab[kk * 4] * wb[kk * 4];          // fp32 product, rounded like the graph's window MUL
-            double a = (double)xw;
+            float xw = ab[kk * 4] * wb[kk * 4];          // fp32 products, rounded like the graph's window MUL
+            float xm = mb[-kk * 4] * wb2[kk * 4];
+            double a = (double)xw + (double)xm;          // exact fold in fp64
 #pragma unroll
             for (int t = 0; t < NTW; t++) {
                 double bv = gb[kk * 4 * GS + t * 16];
@@ -202,15 +210,14 @@ __global__ __launch_bounds__(256 * WN) void k_frontend(FrontendParams p) {
     }
 }
 
-size_t frontend_lds_bytes(int L, int Lp, int hop, int NTP) {
-    (void)L;
-    int seg_len = (FE_FT - 1) * hop + Lp;
-    return (size_t)(((seg_len + 3) & ~3) + Lp) * sizeof(float) + (size_t)2 * FE_KC * (NTP + 16) * sizeof(double);
+size_t frontend_lds_bytes(int Lfft, int Kp, int hop, int NTP) {
+    int seg_len = (FE_FT - 1) * hop + Lfft + 4;
+    return (size_t)(((seg_len + 3) & ~3) + 2 * Kp) * sizeof(float) + (size_t)2 * FE_KC * (NTP + 16) * sizeof(double);
 }
 
 template <int NT, int WN>
 static void launch_frontend_nt(const FrontendParams& p, hipStream_t s) {
-    size_t lds = frontend_lds_bytes(p.L, p.Lp, p.hop, p.NTP);
+    size_t lds = frontend_lds_bytes(p.Lfft, p.Kp, p.hop, p.NTP);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frontend<NT, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
