@@ -696,19 +696,22 @@ struct ExpDwParams {
     float* y; float* partial;
     int B, H, W, Cin, Cmid, Ho, Wo, pt, pl, act_e, act_d, tiles_h, tiles_w, cchunks;
 };
-#define ED_XS 40     // X/W slab row stride (floats): conflict-free ds_read_b128 fragments (see k_pw_gemm)
 #define ED_ES 36     // E row stride (floats)
+// Phase 1 feeds the MFMA straight from global memory: every footprint pixel row belongs to exactly one wave
+// (not shared across waves), so staging it through LDS would only add a write pass and two barriers per slab
+// (the guide's "operand streamed once per block and not shared -> load straight to VGPRs" case).  Each lane
+// loads its own fragment: pixel li of tile jt, input channels 16*t16 + 4*kq .. +3 (one float4); the K order
+// inside a 16-wide slab is permuted exactly as in k_pw_gemm.  The 32 x K weight panel is tiny and L1/L2 resident.
 template <int K, int S, int TOH, int TOW>
 __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk) {
     constexpr int TIH = (TOH - 1) * S + K, TIW = (TOW - 1) * S + K;
     constexpr int NPIX = TIH * TIW, NPIXP = (NPIX + 15) / 16 * 16;
     constexpr int JT = NPIXP / 16, JTW = (JT + 3) / 4;
-    constexpr int XQ = (NPIXP * 8 + 255) / 256;
     constexpr int SH = TOH / 4, SW = TOW / 8;                 // outputs per thread in phase 2 (thread-tiles are 4 x 8)
     constexpr int RW = (SW - 1) * S + K;
-    __shared__ __attribute__((aligned(16))) float lds[NPIXP * ED_XS + 32 * ED_XS];
-    float* Xs = lds;                       // [NPIXP][40] slab of footprint pixels; later aliased by E [NPIX][36]
-    float* Ws = lds + NPIXP * ED_XS;       // [32][40] slab of expand weights; later aliased by the sum scratch
+    __shared__ __attribute__((aligned(16))) float lds[NPIX * ED_ES + 1024];
+    float* E = lds;                                                      // [NPIX][36] expanded footprint
+    float4* red = reinterpret_cast<float4*>(lds + NPIX * ED_ES);         // [256] sum scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
 
@@ -719,89 +722,66 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
     const int tile = rest / p.cchunks, cc = rest % p.cchunks;
     const int oh0 = (tile / p.tiles_w) * TOH, ow0 = (tile % p.tiles_w) * TOW;
     const int ih0 = oh0 * S - p.pt, iw0 = ow0 * S - p.pl;
-    // in-image part of the footprint
-    const int vh0 = max(ih0, 0), vh1 = min(ih0 + TIH, p.H), vw0 = max(iw0, 0), vw1 = min(iw0 + TIW, p.W);
-    const int vw = vw1 - vw0, nvalid = (vh1 - vh0) * vw;
-    const int nvp = (nvalid + 15) & ~15;
+    // footprint rows are compacted to the in-image range [vr0, vr1); columns keep the compile-time width TIW
+    // (out-of-image columns are masked): GEMM row j <-> footprint pixel (vr0 + j / TIW, j % TIW), constant divisors
+    const int vr0 = max(ih0, 0) - ih0, vr1 = min(ih0 + TIH, p.H) - ih0;
+    const int nvalid = (vr1 - vr0) * TIW;
+    const int jtv = (nvalid + 15) >> 4;
     const int Cin = p.Cin;
     const int n_base = cc * 32;
 
-    // per-thread gather offsets of the pixels this thread stages (constant over K-slabs)
-    int xoff[XQ];
-#pragma unroll
-    for (int q = 0; q < XQ; q++) {
-        int idx = tid + 256 * q;
-        int j = idx >> 3;
-        xoff[q] = -1;
-        if (j < nvalid) {
-            int r = j / vw, c = j - r * vw;
-            xoff[q] = (((b * p.H + vh0 + r) * p.W) + vw0 + c) * Cin + 4 * (idx & 7);
-        }
+    if (nvalid < NPIX) {      // rows outside the image are zero padding of the expanded tensor
+        for (int i = tid; i < vr0 * TIW * (ED_ES / 4); i += 256) reinterpret_cast<float4*>(E)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = vr1 * TIW * (ED_ES / 4) + tid; i < NPIX * (ED_ES / 4); i += 256)
+            reinterpret_cast<float4*>(E)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    float4 xreg[XQ], wreg;
-    auto gload = [&](int k0) {
+
+    // this lane's pixel per owned tile (a): global offset (or -1) and validity
+    int xoff[JTW];
 #pragma unroll
-        for (int q = 0; q < XQ; q++) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            int k = k0 + 4 * ((tid + 256 * q) & 7);
-            if (xoff[q] >= 0 && k < Cin) v = *reinterpret_cast<const float4*>(p.x + (size_t)xoff[q] + k0);
-            xreg[q] = v;
-        }
-        {
-            int row = tid >> 3, k = k0 + 4 * (tid & 7);
-            int n = n_base + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < p.Cmid && k < Cin) v = *reinterpret_cast<const float4*>(p.we + (size_t)n * Cin + k);
-            wreg = v;
-        }
-    };
-    auto lstore = [&]() {
-#pragma unroll
-        for (int q = 0; q < XQ; q++) {
-            int idx = tid + 256 * q;
-            if (idx < nvp * 8) *reinterpret_cast<float4*>(&Xs[(idx >> 3) * ED_XS + 4 * (idx & 7)]) = xreg[q];
-        }
-        *reinterpret_cast<float4*>(&Ws[(tid >> 3) * ED_XS + 4 * (tid & 7)]) = wreg;
-    };
+    for (int a = 0; a < JTW; a++) {
+        int j = 16 * (wave + 4 * a) + li;
+        int r = j / TIW, c = j - r * TIW;
+        int iw = iw0 + c;
+        xoff[a] = (j < nvalid && iw >= 0 && iw < p.W) ? (((b * p.H + ih0 + vr0 + r) * p.W) + iw) * Cin + 4 * kq : -1;
+    }
+    const float* wrow0 = p.we + (size_t)min(n_base + li, p.Cmid - 1) * Cin + 4 * kq;
+    const float* wrow1 = p.we + (size_t)min(n_base + 16 + li, p.Cmid - 1) * Cin + 4 * kq;
 
     f32x4 acc[JTW][2];
 #pragma unroll
     for (int a = 0; a < JTW; a++) { acc[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-    const int jtv = nvp >> 4;                 // live pixel tiles
-    gload(0);
-    for (int k0 = 0; k0 < Cin; k0 += 32) {
-        lstore();
-        __syncthreads();
-        if (k0 + 32 < Cin) gload(k0 + 32);
+    // (a two-slab register prefetch was measured: the extra VGPRs cost more occupancy than the overlap buys)
+    for (int k0 = 0; k0 < Cin; k0 += 16) {
+        const bool kin = k0 + 4 * kq < Cin;       // Cin is a multiple of 4
+        f32x4 wf0 = (f32x4){0.f, 0.f, 0.f, 0.f}, wf1 = wf0;
+        if (kin) {
+            float4 t0 = *reinterpret_cast<const float4*>(wrow0 + k0), t1 = *reinterpret_cast<const float4*>(wrow1 + k0);
+            wf0 = (f32x4){t0.x, t0.y, t0.z, t0.w}; wf1 = (f32x4){t1.x, t1.y, t1.z, t1.w};
+        }
+        f32x4 xf[JTW];
 #pragma unroll
-        for (int t16 = 0; t16 < 2; t16++) {
-            f32x4 wf[2];
+        for (int a = 0; a < JTW; a++) {
+            xf[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (xoff[a] >= 0 && kin) {
+                float4 t = *reinterpret_cast<const float4*>(p.x + (size_t)xoff[a] + k0);
+                xf[a] = (f32x4){t.x, t.y, t.z, t.w};
+            }
+        }
 #pragma unroll
-            for (int it = 0; it < 2; it++)
-                wf[it] = *reinterpret_cast<const f32x4*>(&Ws[(16 * it + li) * ED_XS + 16 * t16 + 4 * kq]);
+        for (int a = 0; a < JTW; a++) {
+            if (wave + 4 * a < jtv) {
 #pragma unroll
-            for (int a = 0; a < JTW; a++) {
-                int jt = wave + 4 * a;
-                if (jt < jtv) {
-                    f32x4 xf = *reinterpret_cast<const f32x4*>(&Xs[(16 * jt + li) * ED_XS + 16 * t16 + 4 * kq]);
-#pragma unroll
-                    for (int sidx = 0; sidx < 4; sidx++) {
-                        acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0][sidx], xf[sidx], acc[a][0], 0, 0, 0);
-                        acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1][sidx], xf[sidx], acc[a][1], 0, 0, 0);
-                    }
+                for (int sidx = 0; sidx < 4; sidx++) {
+                    acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf0[sidx], xf[a][sidx], acc[a][0], 0, 0, 0);
+                    acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf1[sidx], xf[a][sidx], acc[a][1], 0, 0, 0);
                 }
             }
         }
-        __syncthreads();
     }
 
-    // ---- E <- act_e(acc + be), scattered to footprint coordinates; out-of-image footprint pixels stay zero
-    float* E = lds;
-    if (nvalid < NPIX) {
-        for (int i = tid; i < NPIX * ED_ES / 4; i += 256) reinterpret_cast<float4*>(E)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        __syncthreads();
-    }
+    // ---- E <- act_e(acc + be) at footprint coordinates (masked columns are zero)
     {
         float4 bq[2];
 #pragma unroll
@@ -813,13 +793,13 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
         for (int a = 0; a < JTW; a++) {
             int j = 16 * (wave + 4 * a) + li;
             if (j < nvalid) {
-                int r = j / vw, c = j - r * vw;
-                int e = ((vh0 - ih0 + r) * TIW + (vw0 - iw0 + c)) * ED_ES;
+                int e = (vr0 * TIW + j) * ED_ES;
 #pragma unroll
                 for (int it = 0; it < 2; it++) {
                     f32x4 v = acc[a][it];
                     v[0] = apply_act(v[0] + bq[it].x, p.act_e); v[1] = apply_act(v[1] + bq[it].y, p.act_e);
                     v[2] = apply_act(v[2] + bq[it].z, p.act_e); v[3] = apply_act(v[3] + bq[it].w, p.act_e);
+                    if (xoff[a] < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
                     *reinterpret_cast<f32x4*>(&E[e + 16 * it + 4 * kq]) = v;
                 }
             }
@@ -880,7 +860,6 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
         }
     }
     if (p.partial) {
-        float4* red = reinterpret_cast<float4*>(Ws);          // 256 float4 = 4 KiB <= 32*40*4 B
         red[tid] = sum;
         __syncthreads();
         if (tid < 8 && n_base + 4 * tid < p.Cmid) {
@@ -905,7 +884,9 @@ int expdw_sum_slabs(int k, int s, int Ho, int Wo) {
 }
 bool expdw_supported(int k, int s, int Cin, int Cmid) {
     int toh, tow;
-    return expdw_tile(k, s, 8, &toh, &tow) && (Cin & 3) == 0 && (Cmid & 3) == 0;
+    // measured on MI355X at batch 256: beyond ~128 input channels the unpipelined K loop of the fused kernel loses
+    // to the separate pw_gemm + dwconv pair (b13-b16 of the B0 stack: 126 us vs 176 us), so those stay unfused
+    return expdw_tile(k, s, 8, &toh, &tow) && (Cin & 3) == 0 && (Cmid & 3) == 0 && Cin <= 128;
 }
 void launch_expand_dw(const float* x, const float* we, const float* be, const float* wd, const float* bd, float* y,
                       float* partial, int B, int H, int W, int Cin, int Cmid, int Ho, int Wo, int k, int s, int pt,
