@@ -709,9 +709,10 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
     constexpr int JT = NPIXP / 16, JTW = (JT + 3) / 4;
     constexpr int SH = TOH / 4, SW = TOW / 8;                 // outputs per thread in phase 2 (thread-tiles are 4 x 8)
     constexpr int RW = (SW - 1) * S + K;
-    __shared__ __attribute__((aligned(16))) float lds[NPIX * ED_ES + 1024];
+    __shared__ __attribute__((aligned(16))) float lds[NPIX * ED_ES + 1024 + K * K * 32];
     float* E = lds;                                                      // [NPIX][36] expanded footprint
     float4* red = reinterpret_cast<float4*>(lds + NPIX * ED_ES);         // [256] sum scratch
+    float4* wds = reinterpret_cast<float4*>(lds + NPIX * ED_ES + 1024);  // [K*K][8] depthwise taps of this chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
 
@@ -730,6 +731,12 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
     const int Cin = p.Cin;
     const int n_base = cc * 32;
 
+    // depthwise taps for this 32-channel chunk -> LDS now (latency hides behind phase 1; read after the barrier)
+    if (tid < K * K * 8) {
+        int tap = tid >> 3, q = tid & 7;
+        int nq = cc * 32 + 4 * q;
+        wds[tid] = nq < p.Cmid ? *reinterpret_cast<const float4*>(p.wd + (size_t)tap * p.Cmid + nq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (nvalid < NPIX) {      // rows outside the image are zero padding of the expanded tensor
         for (int i = tid; i < vr0 * TIW * (ED_ES / 4); i += 256) reinterpret_cast<float4*>(E)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = vr1 * TIW * (ED_ES / 4) + tid; i < NPIX * (ED_ES / 4); i += 256)
@@ -752,15 +759,13 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
 #pragma unroll
     for (int a = 0; a < JTW; a++) { acc[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-    // (a two-slab register prefetch was measured: the extra VGPRs cost more occupancy than the overlap buys)
-    for (int k0 = 0; k0 < Cin; k0 += 16) {
+    auto fload = [&](int k0, f32x4& wf0, f32x4& wf1, f32x4 (&xf)[JTW]) {
         const bool kin = k0 + 4 * kq < Cin;       // Cin is a multiple of 4
-        f32x4 wf0 = (f32x4){0.f, 0.f, 0.f, 0.f}, wf1 = wf0;
+        wf0 = (f32x4){0.f, 0.f, 0.f, 0.f}; wf1 = wf0;
         if (kin) {
             float4 t0 = *reinterpret_cast<const float4*>(wrow0 + k0), t1 = *reinterpret_cast<const float4*>(wrow1 + k0);
             wf0 = (f32x4){t0.x, t0.y, t0.z, t0.w}; wf1 = (f32x4){t1.x, t1.y, t1.z, t1.w};
         }
-        f32x4 xf[JTW];
 #pragma unroll
         for (int a = 0; a < JTW; a++) {
             xf[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -769,6 +774,8 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
                 xf[a] = (f32x4){t.x, t.y, t.z, t.w};
             }
         }
+    };
+    auto fmma = [&](const f32x4& wf0, const f32x4& wf1, const f32x4 (&xf)[JTW]) {
 #pragma unroll
         for (int a = 0; a < JTW; a++) {
             if (wave + 4 * a < jtv) {
@@ -778,6 +785,25 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
                     acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf1[sidx], xf[a][sidx], acc[a][1], 0, 0, 0);
                 }
             }
+        }
+    };
+    if (Cin <= 16) {
+        f32x4 wA0, wA1, xA[JTW];
+        fload(0, wA0, wA1, xA);
+        fmma(wA0, wA1, xA);
+    } else if (Cin <= 32) {
+        // early blocks (Cin 17..32): both K slabs requested back-to-back -> one memory latency instead of two
+        f32x4 wA0, wA1, xA[JTW], wB0, wB1, xB[JTW];
+        fload(0, wA0, wA1, xA);
+        fload(16, wB0, wB1, xB);
+        fmma(wA0, wA1, xA);
+        fmma(wB0, wB1, xB);
+    } else {
+        // (a rolling two-slab register prefetch was measured here: the extra VGPRs cost more occupancy than it buys)
+        for (int k0 = 0; k0 < Cin; k0 += 16) {
+            f32x4 wf0, wf1, xf[JTW];
+            fload(k0, wf0, wf1, xf);
+            fmma(wf0, wf1, xf);
         }
     }
 
@@ -819,13 +845,11 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
 #pragma unroll
             for (int c = 0; c < SW; c++) acc2[a][c] = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* e0 = E + ((ty * SH * S) * TIW + tx * SW * S) * ED_ES + 4 * c4;
-        const float4* w4 = reinterpret_cast<const float4*>(p.wd + n);
-        const int C4 = p.Cmid >> 2;
 #pragma unroll 1
         for (int i = 0; i < K; i++) {                 // kernel row (kept rolled: bounds the live weight registers)
             float4 w[K];
 #pragma unroll
-            for (int j = 0; j < K; j++) w[j] = w4[(size_t)(i * K + j) * C4];
+            for (int j = 0; j < K; j++) w[j] = wds[(i * K + j) * 8 + c4];
 #pragma unroll
             for (int a = 0; a < SH; a++) {
                 float4 xr[RW];
