@@ -38,30 +38,88 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(blob, n_samples, sample_rate, n_clips_hint):
-    """Oracle restatement ("port") timed on the host cores: bounded sample of the same workload."""
-    from oracle.interp import Interpreter
+def pmc_traffic(kclass):
+    """HBM bytes per launch of a kernel class from the newest committed PMC pass (profiles/rNN_traffic.json, produced by
+    tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same bench; FETCH_SIZE
+    doubled per the gfx950 correction in MI355X_MICROARCH.md).  PMC cannot be collected inside the timed run itself."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    names = {"expand_dw": "k_expand_dw", "pw_gemm": "k_pw_gemm", "frontend": "k_frontend", "dwconv": "k_dwconv",
+             "conv_direct": "k_conv_direct", "se": "k_se"}
+    pref = names.get(kclass)
+    if not pref:
+        return None
+    data = json.load(open(files[-1]))
+    tot = n = 0
+    for k, v in data.items():
+        if k.startswith(pref):
+            tot += v["hbm_bytes_per_launch"] * v["dispatches"]
+            n += v["dispatches"]
+    if not n:
+        return None
+    return {"bytes_per_launch": tot / n, "source": os.path.relpath(files[-1], ROOT)}
+
+
+def cpu_worker_main(argv):
+    """`bench.py --cpu-worker <blob> <n_samples> <rate> <first> <count>`: one oracle process timing its share."""
+    blob_path, n_samples, sample_rate, first, count = argv[0], int(argv[1]), int(argv[2]), int(argv[3]), int(argv[4])
+    import birdnet_go_amd  # noqa: F401
     from birdnet_go_amd import synth_model as sm
-    import torch
+    from oracle.interp import Interpreter
+    it = Interpreter(open(blob_path, "rb").read())
+    x = sm.synth_clips(count, n_samples, sample_rate, first=first)
+    it.invoke(x[:1])                                    # warm-up
+    t0 = time.time()
+    for i in range(0, count, 2):
+        it.invoke(x[i:i + 2])
+    print(f"CPU_WORKER_SECONDS {time.time() - t0:.6f}")
+
+
+def cpu_baseline(blob, n_samples, sample_rate, n_clips_hint):
+    """Oracle restatement ("port") timed on the host cores: a bounded sample of the same workload, run as several
+    oracle processes x BLAS threads so the whole socket is used (a single numpy process cannot use 100+ cores)."""
+    import subprocess
+    import tempfile
 
     cores = os.cpu_count() or 1
-    threads = torch.get_num_threads()
-    it = Interpreter(blob)
-    x1 = sm.synth_clips(2, n_samples, sample_rate)
+    workers = max(1, min(32, cores // 4))
+    threads = max(1, cores // workers)
+    per_worker = max(2, (n_clips_hint or 8 * workers) // workers)
+    tmp = tempfile.NamedTemporaryFile(suffix=".tflite", delete=False)
+    tmp.write(blob)
+    tmp.close()
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OPENBLAS_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
     t0 = time.time()
-    it.invoke(x1)                      # warm-up + probe
-    per_clip = (time.time() - t0) / 2
-    n = n_clips_hint or int(max(8, min(256, 15.0 / max(per_clip, 1e-3))))
-    n = (n + 7) // 8 * 8
-    x = sm.synth_clips(n, n_samples, sample_rate)
-    t0 = time.time()
-    for i in range(0, n, 8):
-        it.invoke(x[i:i + 8])
-    dt = time.time() - t0
-    return {"value": n / dt, "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"{n} clips of the config-2 generator through the numpy/OpenBLAS oracle (fp32), "
-                      f"batches of 8, {dt:.1f} s wall; BLAS threads={threads} of {cores} host cores; "
-                      "restatement baseline - NOT TFLite (no TFLite runtime or real weights in this environment)"}
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", tmp.name, str(n_samples),
+                               str(sample_rate), str(100000 + w * per_worker), str(per_worker)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True)
+             for w in range(workers)]
+    times = []
+    try:
+        for pr in procs:
+            out, _ = pr.communicate(timeout=300)
+            for line in out.splitlines():
+                if line.startswith("CPU_WORKER_SECONDS"):
+                    times.append(float(line.split()[1]))
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        os.unlink(tmp.name)
+    wall = time.time() - t0
+    if len(times) != workers:
+        return {"value": None, "unit": "clips/s", "cores": cores, "kind": "port", "sample": "cpu baseline workers failed"}
+    n = workers * per_worker
+    busy = max(times)                                   # steady-state compute time (excludes process start-up/import)
+    return {"value": n / busy, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"{n} clips of the config-2 generator through the numpy/OpenBLAS fp32 oracle restatement: "
+                      f"{workers} processes x {threads} BLAS threads ({workers * threads} of {cores} host cores), "
+                      f"{busy:.1f} s compute ({wall:.1f} s incl. start-up); restatement baseline - NOT TFLite "
+                      "(no TFLite runtime or real weights exist in this environment)"}
 
 
 def main():
@@ -164,6 +222,10 @@ def main():
                 roof = {"kernel": dom["kernel"], "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS,
                         "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None}
             roof["flop_per_byte"] = intensity
+            tr = pmc_traffic(dom["kernel"])
+            if tr:
+                roof["traffic"] = tr["bytes_per_launch"]
+                roof["traffic_source"] = tr["source"]
             roof["launches"] = dom["launches"]
             roof["avg_launch_ms"] = per_launch_ms
             roof["share_of_kernel_time"] = dom["ms"] / sum(r["ms"] for r in prof)
@@ -181,4 +243,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        cpu_worker_main(sys.argv[2:])
+    else:
+        main()
