@@ -105,6 +105,7 @@ int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, 
     if (!m) return set_err(BNHIP_E_NOMEM, "out of host memory");
     int code = BNHIP_E_UNSUPPORTED;
     m->eng.no_reuse = json_int(opts_json, "debug_no_reuse", 0) != 0;
+    m->eng.autotune = json_int(opts_json, "autotune", 1) != 0;
     if (!m->eng.build(tm, device, max_batch, plan_only, &err, &code)) {
         delete m;
         return set_err(code == BNHIP_OK ? BNHIP_E_UNSUPPORTED : code, err);

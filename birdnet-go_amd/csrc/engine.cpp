@@ -854,8 +854,42 @@ bool Engine::build(const TflModel& m, int dev, int maxb, bool plan_only, std::st
     HIPCHK(hipMalloc((void**)&d_stage_logits, (size_t)max_batch * n_classes * 4));
     HIPCHK(hipMalloc((void**)&d_post_conf, (size_t)max_batch * n_classes * 4));
     if (emb_dim) HIPCHK(hipMalloc((void**)&d_stage_emb, (size_t)max_batch * emb_dim * 4));
+    if (autotune) autotune_pw();
     *code = BNHIP_OK;
     return true;
+}
+
+// Per-layer choice of the pw_gemm N-tile width: the best width depends on (M, N, K) through occupancy, grid size and
+// padding in ways no closed-form rule captured (late layers at batch 256 have as few as 288 blocks), so each
+// pointwise/FC step is timed once at create time on its real shapes and buffers (contents are irrelevant to timing).
+void Engine::autotune_pw() {
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    const int n = max_batch;
+    for (auto& s : steps) {
+        if (s.kind != S_PW || (s.C & 3)) continue;
+        float* in0 = vptr(s.in0, d_stage_in, d_stage_logits, nullptr);
+        float* in1 = vptr(s.in1, d_stage_in, d_stage_logits, nullptr);
+        float* in2 = vptr(s.in2, d_stage_in, d_stage_logits, nullptr);
+        float* out = vptr(s.out, d_stage_in, d_stage_logits, nullptr);
+        float best = 1e30f; int best_nt = 0;
+        for (int nt = 1; nt <= 4; nt++) {
+            long cols = (long)((s.Co + nt * 16 - 1) / (nt * 16)) * nt * 16;
+            if (cols * 100 > (long)((s.Co + 15) / 16 * 16) * 130) continue;         // skip absurd padding
+            PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, nt};
+            launch_pw_gemm(p, stream);                                             // warm-up
+            hipEventRecord(a, stream);
+            for (int r = 0; r < 3; r++) launch_pw_gemm(p, stream);
+            hipEventRecord(b, stream);
+            hipEventSynchronize(b);
+            float ms = 0; hipEventElapsedTime(&ms, a, b);
+            if (ms < best) { best = ms; best_nt = nt; }
+        }
+        s.nt = best_nt;
+    }
+    hipStreamSynchronize(stream);
+    hipEventDestroy(a); hipEventDestroy(b);
+    (void)hipGetLastError();
 }
 
 // ================================================================================================ run
@@ -902,7 +936,7 @@ bool Engine::run(const float* d_in, int n, float* d_logits, float* d_emb, std::s
                 break;
             }
             case S_PW: {
-                PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act};
+                PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, s.nt};
                 launch_pw_gemm(p, stream);
                 break;
             }
@@ -969,7 +1003,7 @@ std::string Engine::describe() const {
         jesc(os, s.name);
         os << "\",\"H\":" << s.H << ",\"W\":" << s.W << ",\"C\":" << s.C << ",\"Co\":" << s.Co << ",\"k\":" << s.kh
            << ",\"stride\":" << s.sh << ",\"act\":" << s.act << ",\"fused_scale\":" << (s.kind == S_PW && s.in1 >= 0 ? 1 : 0)
-           << ",\"fused_res\":" << (s.kind == S_PW && s.in2 >= 0 ? 1 : 0) << ",\"fused_sum\":" << (s.out2 >= 0 ? 1 : 0) << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << ",\"wbytes\":" << s.wbytes << "}";
+           << ",\"nt\":" << s.nt << ",\"fused_res\":" << (s.kind == S_PW && s.in2 >= 0 ? 1 : 0) << ",\"fused_sum\":" << (s.out2 >= 0 ? 1 : 0) << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << ",\"wbytes\":" << s.wbytes << "}";
     }
     os << "]}";
     return os.str();

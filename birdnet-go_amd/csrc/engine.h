@@ -24,6 +24,7 @@ struct Step {
     // geometry per clip
     int H = 0, W = 0, C = 0, Ho = 0, Wo = 0, Co = 0, kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0;
     int act = 0, act2 = 0, op = 0, mode = 0, S = 1, Cr = 0;
+    int nt = 0;              // pw_gemm tile width chosen by the create-time autotuner (0 = heuristic)
     // front-end
     int spec = -1;
     // accounting per clip
@@ -56,6 +57,8 @@ class Engine {
 
     int device = 0, max_batch = 256;
     bool no_reuse = false;              // diagnostics: every activation keeps its own buffer
+    bool autotune = true;               // time pw_gemm tile widths per layer at create time (a few ms)
+    void autotune_pw();
     std::map<int, int> tensor_value;    // tflite tensor index -> value id (diagnostics)
     const float* value_ptr(int v) const { return reinterpret_cast<const float*>(act_arena + vals[v].offset); }
     int n_samples = 0, n_classes = 0, emb_dim = 0, C_spec = 0;

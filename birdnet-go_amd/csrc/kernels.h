@@ -39,8 +39,10 @@ void launch_conv_direct(const ConvParams& p, hipStream_t s);
 struct PwParams {         // pointwise conv / fully-connected as GEMM: out[M,N] = act(A[M,K] W[N,K]^T + b) (+res)
     const float* A; const float* W; const float* bias; const float* ascale; const float* res; float* out;
     int M, N, K, HW, act;
+    int nt = 0;           // N-tile width in 16-column units (1..8); 0 = built-in heuristic
 };
 void launch_pw_gemm(const PwParams& p, hipStream_t s);
+int pw_default_nt(int M, int N);
 
 struct DwParams {
     const float* in; const float* w /*[kh][kw][C]*/; const float* bias; float* out;

@@ -486,13 +486,15 @@ static int pick_nt(int M, int N) {
     return best;
 }
 
+int pw_default_nt(int M, int N) { return pick_nt(M, N); }
+
 void launch_pw_gemm(const PwParams& p, hipStream_t s) {
     if ((p.K & 3) != 0) {
         size_t total = (size_t)p.M * p.N;
         hipLaunchKernelGGL(k_pw_naive, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
         return;
     }
-    int nt = pick_nt(p.M, p.N);
+    int nt = (p.nt >= 1 && p.nt <= 8) ? p.nt : pick_nt(p.M, p.N);
     int nblk_n = (p.N + nt * 16 - 1) / (nt * 16);
     unsigned nblk = (unsigned)((p.M + PW_BM - 1) / PW_BM) * nblk_n;
     dim3 grid(nblk);

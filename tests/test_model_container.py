@@ -89,9 +89,13 @@ def test_cpp_reader_and_planner_fuse_everything(built_lib, full_blob):
     kinds = [s["kernel"] for s in d["steps"]]
     assert kinds.count("frontend") == 2 and kinds.count("clip_minmax") == 1
     assert "elementwise" not in kinds, "an op fell back to the unfused elementwise path"
-    assert kinds.count("se") == 16 and kinds.count("dwconv") == 16
+    # 16 MBConv blocks: 11 with the fused expand+depthwise kernel (Cin <= 128), 5 plain depthwise (b1 + the 4 wide ones)
+    assert kinds.count("expand_dw") == 11 and kinds.count("dwconv") == 5 and kinds.count("se") == 16
+    # every squeeze-excite mean comes from sums emitted by the producing depthwise kernel; only the GAP uses the mean pass
+    assert sum(s["fused_sum"] for s in d["steps"]) == 16 and kinds.count("mean") == 2
     pw = [s for s in d["steps"] if s["kernel"] == "pw_gemm"]
     assert sum(s["fused_scale"] for s in pw) == 16 and sum(s["fused_res"] for s in pw) == 9
+    assert len(d["steps"]) == 60
     assert d["specs"][0]["hop"] == 278 and d["specs"][1]["hop"] == 280 and d["specs"][0]["frames"] == 511
     assert abs(d["specs"][0]["p2"] - 1.0 / (1.0 + np.exp(1.23))) < 1e-6
     with pytest.raises(host.HipError, match="plan-only"):
