@@ -7,6 +7,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <utility>
 
 #include "engine.h"
 #include "tflite_model.h"
@@ -106,7 +107,7 @@ int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, 
     int code = BNHIP_E_UNSUPPORTED;
     m->eng.no_reuse = json_int(opts_json, "debug_no_reuse", 0) != 0;
     m->eng.autotune = json_int(opts_json, "autotune", 1) != 0;
-    if (!m->eng.build(tm, device, max_batch, plan_only, &err, &code)) {
+    if (!m->eng.build(std::move(tm), device, max_batch, plan_only, &err, &code)) {
         delete m;
         return set_err(code == BNHIP_OK ? BNHIP_E_UNSUPPORTED : code, err);
     }

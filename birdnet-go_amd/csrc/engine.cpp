@@ -276,11 +276,39 @@ Engine::~Engine() {
     if (own_stream && stream) hipStreamDestroy(stream);
 }
 
-bool Engine::build(const TflModel& m, int dev, int maxb, bool plan_only, std::string* err, int* code) {
+static float half_to_float(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000) << 16, exp = (h >> 10) & 0x1f, man = h & 0x3ff, bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else { int e = -1; do { man <<= 1; e++; } while (!(man & 0x400)); bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ff) << 13); }
+    } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+    else bits = sign | ((exp + 112) << 23) | (man << 13);
+    float f; memcpy(&f, &bits, 4); return f;
+}
+
+bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* err, int* code) {
     device = dev;
     max_batch = maxb;
     *code = BNHIP_E_UNSUPPORTED;
+    // FP16-weight models (e.g. the reference's MData range-filter .tflite): DEQUANTIZE(const f16) -> f32 constant
+    std::vector<std::vector<float>> derived_consts;
+    std::vector<int> dequant_ops;
+    for (int i = 0; i < (int)m.ops.size(); i++) {
+        const TflOp& o = m.ops[i];
+        if (o.code != OP_DEQUANTIZE || o.inputs.empty() || o.outputs.empty()) continue;
+        TflTensor& src = m.tensors[o.inputs[0]];
+        if (!src.data || src.type != TT_FLOAT16) { *err = "DEQUANTIZE: only constant float16 inputs are supported"; return false; }
+        derived_consts.emplace_back(src.numel());
+        const uint16_t* h = reinterpret_cast<const uint16_t*>(src.data);
+        for (size_t k = 0; k < src.numel(); k++) derived_consts.back()[k] = half_to_float(h[k]);
+        TflTensor& dst = m.tensors[o.outputs[0]];
+        dst.data = reinterpret_cast<const uint8_t*>(derived_consts.back().data());
+        dst.nbytes = src.numel() * 4;
+        dst.type = TT_FLOAT32;
+        dequant_ops.push_back(i);
+    }
     Planner P(m);
+    for (int i : dequant_ops) P.absorbed[i] = 1;
 
     const TflTensor& tin = m.tensors[m.inputs[0]];
     if (tin.type != TT_FLOAT32 || tin.shape.size() != 2 || tin.shape[0] != 1) {
@@ -297,10 +325,12 @@ bool Engine::build(const TflModel& m, int dev, int maxb, bool plan_only, std::st
             if (!match_frontend(P, i, &fm)) { *err = P.err; *code = P.code; return false; }
             fms.push_back(fm);
         }
-    if (fms.empty()) { *err = "no STFT front-end (RFFT2D) found in graph: unsupported model family"; return false; }
+    // Graphs without an STFT are accepted when they are plain dense stacks on a [1,D] input: the bat heads
+    // (CustomClassifier, internal/inference/backend.go:31-52) and the range-filter meta-model (RangeFilter, :55-76).
+    const bool dense_only = fms.empty();
     int spec_tensor = -1;
     std::vector<int> chan_of(fms.size(), 0);
-    {
+    if (!dense_only) {
         int cc = P.only_consumer(fms[0].out_tensor);
         if (fms.size() == 1 && (cc < 0 || m.ops[cc].code != OP_CONCATENATION)) {
             spec_tensor = fms[0].out_tensor;
@@ -361,7 +391,7 @@ bool Engine::build(const TflModel& m, int dev, int maxb, bool plan_only, std::st
     };
 
     // front-end steps
-    {
+    if (!dense_only) {
         Step s; s.kind = S_MINMAX; s.name = "clip_minmax"; s.kclass = "clip_minmax"; s.in0 = v_input; s.out = v_mm;
         s.bytes = (double)n_samples * 4;
         add_step(s);

@@ -52,7 +52,7 @@ class Engine {
   public:
     ~Engine();
     // returns false and sets err (+ code: BNHIP_E_*) on failure
-    bool build(const TflModel& m, int device, int max_batch, bool plan_only, std::string* err, int* code);
+    bool build(TflModel m, int device, int max_batch, bool plan_only, std::string* err, int* code);
     bool run(const float* d_in, int n, float* d_logits, float* d_emb, std::string* err);
 
     int device = 0, max_batch = 256;

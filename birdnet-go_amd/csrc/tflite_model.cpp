@@ -8,7 +8,8 @@ const char* op_name(int code) {
     switch (code) {
         case OP_ADD: return "ADD"; case OP_AVERAGE_POOL_2D: return "AVERAGE_POOL_2D";
         case OP_CONCATENATION: return "CONCATENATION"; case OP_CONV_2D: return "CONV_2D";
-        case OP_DEPTHWISE_CONV_2D: return "DEPTHWISE_CONV_2D"; case OP_FULLY_CONNECTED: return "FULLY_CONNECTED";
+        case OP_DEPTHWISE_CONV_2D: return "DEPTHWISE_CONV_2D"; case OP_DEQUANTIZE: return "DEQUANTIZE";
+        case OP_FULLY_CONNECTED: return "FULLY_CONNECTED";
         case OP_LOGISTIC: return "LOGISTIC"; case OP_MAX_POOL_2D: return "MAX_POOL_2D"; case OP_MUL: return "MUL";
         case OP_RELU: return "RELU"; case OP_RELU6: return "RELU6"; case OP_RESHAPE: return "RESHAPE";
         case OP_SOFTMAX: return "SOFTMAX"; case OP_PAD: return "PAD"; case OP_GATHER: return "GATHER";

@@ -17,7 +17,7 @@ enum TensorType : int { TT_FLOAT32 = 0, TT_FLOAT16 = 1, TT_INT32 = 2, TT_UINT8 =
 // BuiltinOperator codes (subset)
 enum OpCode : int {
     OP_ADD = 0, OP_AVERAGE_POOL_2D = 1, OP_CONCATENATION = 2, OP_CONV_2D = 3, OP_DEPTHWISE_CONV_2D = 4,
-    OP_FULLY_CONNECTED = 9, OP_LOGISTIC = 14, OP_MAX_POOL_2D = 17, OP_MUL = 18, OP_RELU = 19, OP_RELU6 = 21,
+    OP_DEQUANTIZE = 6, OP_FULLY_CONNECTED = 9, OP_LOGISTIC = 14, OP_MAX_POOL_2D = 17, OP_MUL = 18, OP_RELU = 19, OP_RELU6 = 21,
     OP_RESHAPE = 22, OP_SOFTMAX = 25, OP_PAD = 34, OP_GATHER = 36, OP_TRANSPOSE = 39, OP_MEAN = 40,
     OP_SUB = 41, OP_DIV = 42, OP_SQUEEZE = 43, OP_STRIDED_SLICE = 45, OP_CAST = 53, OP_EXPAND_DIMS = 70,
     OP_SUM = 74, OP_POW = 78, OP_REDUCE_MAX = 82, OP_REDUCE_MIN = 89, OP_REVERSE_V2 = 105,

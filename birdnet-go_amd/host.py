@@ -240,6 +240,90 @@ def us_frame_cv(samples, sample_rate, fft_size=8192, hop=4096, split_hz=20000, d
     return cv, ok.astype(bool)
 
 
+def _sigmoid_f32div(x):
+    """onnx/postprocess.go:8-10: 1.0 / (1.0 + float32(exp(float64(-x)))), the division in float32."""
+    x = np.asarray(x, np.float32)
+    e = np.exp(-x.astype(np.float64)).astype(np.float32)
+    return (np.float32(1.0) / (np.float32(1.0) + e)).astype(np.float32)
+
+
+class CustomClassifier:
+    """inference.CustomClassifier (backend.go:31-52): secondary head on embedding vectors, e.g. a BattyBirdNET
+    regional classifier.  PredictEmbedding returns sigmoid-applied scores (custom_classifier.go:148-174)."""
+
+    def __init__(self, head_bytes: bytes, labels, device=0, max_batch=256):
+        self._clf = HipClassifier(head_bytes, device=device, max_batch=max_batch)
+        if len(labels) != self._clf.num_species():
+            raise HipError(E_INVALID, f"label count {len(labels)} != head outputs {self._clf.num_species()}")
+        self._labels = list(labels)
+
+    def predict_embedding(self, embeddings):
+        e = np.ascontiguousarray(embeddings, np.float32).reshape(-1)
+        if e.size != self.input_dim():
+            raise HipError(E_INVALID, f"input size mismatch: expected {self.input_dim()} values, got {e.size}")
+        return _sigmoid_f32div(self._clf.predict_batch(e, 1)[0])
+
+    def predict_embedding_batch(self, embeddings, batch_size):
+        return _sigmoid_f32div(self._clf.predict_batch(embeddings, batch_size))
+
+    def num_classes(self):
+        return self._clf.num_species()
+
+    def input_dim(self):
+        return self._clf.n_samples
+
+    def labels(self):
+        return list(self._labels)
+
+    def close(self):
+        self._clf.close()
+
+
+class RangeFilter:
+    """inference.RangeFilter / BatchRangeFilter (backend.go:55-76): [lat, lon, week] -> per-species occurrence."""
+
+    def __init__(self, model_bytes: bytes, device=0, max_batch=1024):
+        self._clf = HipClassifier(model_bytes, device=device, max_batch=max_batch)
+        if self._clf.n_samples != 3:
+            raise HipError(E_INVALID, f"range filter model must take 3 inputs, takes {self._clf.n_samples}")
+
+    def predict(self, latitude, longitude, week):
+        return self._clf.predict_batch(np.asarray([latitude, longitude, week], np.float32), 1)[0]
+
+    def predict_batch(self, inputs, batch_size):
+        x = np.ascontiguousarray(inputs, np.float32).reshape(-1)
+        if x.size != batch_size * 3:
+            raise HipError(E_INVALID, f"input size mismatch: expected {batch_size * 3} values, got {x.size}")
+        return self._clf.predict_batch(x, batch_size).reshape(-1)
+
+    def num_species(self):
+        return self._clf.num_species()
+
+    def close(self):
+        self._clf.close()
+
+
+class Bat:
+    """Bat.Predict (classifier/bat_onnx.go:220-342): v2.4 backbone -> 1024-d embedding -> regional head ->
+    plain sigmoid -> confidence threshold -> top-10.  The audio is 256 kHz material fed as if 48 kHz."""
+
+    TOP_K = 10
+
+    def __init__(self, backbone: HipClassifier, head: CustomClassifier, threshold=0.0):
+        if not backbone.emb_dim:
+            raise HipError(E_INVALID, "backbone model exposes no embedding output")
+        if head.input_dim() != backbone.emb_dim:
+            raise HipError(E_INVALID, f"head expects {head.input_dim()}-d embeddings, backbone yields {backbone.emb_dim}")
+        self.backbone, self.head, self.threshold = backbone, head, float(threshold)
+
+    def predict(self, samples):
+        _, emb = self.backbone.predict_with_embeddings(samples)
+        scores = self.head.predict_embedding(emb)
+        order = np.argsort(-scores, kind="stable")
+        labels = self.head.labels()
+        return [(labels[i], float(scores[i])) for i in order if scores[i] >= self.threshold][:self.TOP_K]
+
+
 class BirdNET:
     """(*BirdNET).Predict (classifier/analyze.go:25-110): backend logits -> sigmoid(sensitivity) ->
     label pairing -> top-10, with the post-processing on device."""

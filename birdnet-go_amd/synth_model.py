@@ -223,6 +223,42 @@ def build_model(cfg: SynthConfig = None) -> bytes:
     return g.finish([x], outs)
 
 
+def build_dense_model(dims, hidden_act="relu", final_sigmoid=False, fp16_weights=False, seed=7, name="dense_synth",
+                      input_scale=None):
+    """Dense-only graph on a [1, dims[0]] input: the shape of the reference's secondary models -
+    a BattyBirdNET regional head (1024 -> C logits; `internal/classifier/bat_onnx.go:282`,
+    `internal/inference/backend.go:31-52` CustomClassifier) and the range-filter meta-model
+    ([lat, lon, week] -> per-species occurrence, in-graph sigmoid; `backend.go:55-76`).  With
+    fp16_weights the constants are stored as float16 behind DEQUANTIZE ops, like the reference's
+    `BirdNET_GLOBAL_6K_V2.4_MData_Model_V2_FP16.tflite`."""
+    rng = np.random.default_rng(seed)
+    g = GraphBuilder(description=f"{name} seed={seed} (synthetic weights)")
+    x = g.tensor([1, dims[0]], name="INPUT")
+    t = x
+    for li in range(len(dims) - 1):
+        cin, cout = dims[li], dims[li + 1]
+        last = li == len(dims) - 2
+        w = (rng.standard_normal((cout, cin)) * (1.0 / np.sqrt(cin))).astype(np.float32)
+        if li == 0 and input_scale is not None:      # fold an input normalisation (e.g. lat/90, lon/180, week/48) into layer 0
+            w = (w / np.asarray(input_scale, np.float32)[None, :]).astype(np.float32)
+        b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+        if fp16_weights:
+            w16 = g.const(w.astype(np.float16), f"fc{li}/w_f16")
+            wt = g.op("DEQUANTIZE", [w16], [cout, cin], name=f"fc{li}/w")
+            b16 = g.const(b.astype(np.float16), f"fc{li}/b_f16")
+            bt = g.op("DEQUANTIZE", [b16], [cout], name=f"fc{li}/b")
+        else:
+            wt, bt = g.const(w, f"fc{li}/w"), g.const(b, f"fc{li}/b")
+        act = S.ACT_NONE if (last or hidden_act != "relu") else S.ACT_RELU
+        t = g.op("FULLY_CONNECTED", [t, wt, bt], [1, cout], dict(fused_activation_function=act), name=f"fc{li}")
+        if not last and hidden_act == "swish":
+            sg = g.op("LOGISTIC", [t], [1, cout])
+            t = g.op("MUL", [t, sg], [1, cout], {})
+    if final_sigmoid:
+        t = g.op("LOGISTIC", [t], [1, dims[-1]], name="OUTPUT")
+    return g.finish([x], [t])
+
+
 def synth_clips(n, n_samples=144000, sample_rate=48000, first=0):
     """BASELINE.json config-2 input: clip i = 0.5*sin(2*pi*f_i*t), f_i = 500+37*i Hz, plus
     N(0,0.05^2) noise from numpy default_rng(1234+i), clamped to [-1,1]."""

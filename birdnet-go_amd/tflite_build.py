@@ -4,7 +4,7 @@ import numpy as np
 from . import tflite_schema as S
 from .flatbuf_writer import Str, Table, Vec, build
 
-_DT = {np.dtype(np.float32): S.FLOAT32, np.dtype(np.int32): S.INT32,
+_DT = {np.dtype(np.float32): S.FLOAT32, np.dtype(np.float16): S.FLOAT16, np.dtype(np.int32): S.INT32,
        np.dtype(np.int64): S.INT64, np.dtype(np.complex64): S.COMPLEX64}
 
 

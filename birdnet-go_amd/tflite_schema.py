@@ -29,7 +29,7 @@ ACT_NONE, ACT_RELU, ACT_RELU_N1_TO_1, ACT_RELU6, ACT_TANH = 0, 1, 2, 3, 4
 
 # ---- BuiltinOperator codes (subset this engine understands)
 OP = dict(
-    ADD=0, AVERAGE_POOL_2D=1, CONCATENATION=2, CONV_2D=3, DEPTHWISE_CONV_2D=4,
+    ADD=0, AVERAGE_POOL_2D=1, CONCATENATION=2, CONV_2D=3, DEPTHWISE_CONV_2D=4, DEQUANTIZE=6,
     FULLY_CONNECTED=9, LOGISTIC=14, MAX_POOL_2D=17, MUL=18, RELU=19, RELU6=21, RESHAPE=22,
     SOFTMAX=25, PAD=34, GATHER=36, TRANSPOSE=39, MEAN=40, SUB=41, DIV=42, SQUEEZE=43,
     STRIDED_SLICE=45, CAST=53, EXPAND_DIMS=70, SUM=74, POW=78, REDUCE_MAX=82, REDUCE_MIN=89,
@@ -88,7 +88,7 @@ OPTION_FIELDS = dict(
 # which options table each builtin op carries
 OP_OPTIONS = dict(
     ADD="AddOptions", AVERAGE_POOL_2D="Pool2DOptions", CONCATENATION="ConcatenationOptions",
-    CONV_2D="Conv2DOptions", DEPTHWISE_CONV_2D="DepthwiseConv2DOptions",
+    CONV_2D="Conv2DOptions", DEPTHWISE_CONV_2D="DepthwiseConv2DOptions", DEQUANTIZE=None,
     FULLY_CONNECTED="FullyConnectedOptions", LOGISTIC=None, MAX_POOL_2D="Pool2DOptions",
     MUL="MulOptions", RELU=None, RELU6=None, RESHAPE="ReshapeOptions", SOFTMAX="SoftmaxOptions",
     PAD="PadOptions", GATHER="GatherOptions", TRANSPOSE="TransposeOptions", MEAN="ReducerOptions",

@@ -136,14 +136,14 @@ class Interpreter:
         self.fdt = np.float32 if precision == "f32" else np.float64
         self.cdt = np.complex64 if precision == "f32" else np.complex128
         inp = self.m.tensors[self.m.inputs[0]]
-        self.n_samples = int(inp.shape[-1])
+        self.n_samples = int(inp.shape[-1])       # clip length, or feature width for dense-only graphs
         self.out_dims = [int(self.m.tensors[o].shape[-1]) for o in self.m.outputs]
 
     def _const(self, idx):
         t = self.m.tensors[idx]
         if t.data is None:
             return None
-        if t.dtype == np.float32:
+        if t.dtype in (np.float32, np.float16):
             return t.data.astype(self.fdt)
         return t.data
 
@@ -176,6 +176,8 @@ class Interpreter:
                 y = conv2d(a[0], a[1], a[2] if len(a) > 2 else None, o)
             elif n == "DEPTHWISE_CONV_2D":
                 y = depthwise_conv2d(a[0], a[1], a[2] if len(a) > 2 else None, o)
+            elif n == "DEQUANTIZE":
+                y = np.asarray(a[0]).astype(fdt)      # float16 -> float32 (tflite dequantize.cc, kTfLiteFloat16 branch)
             elif n == "FULLY_CONNECTED":
                 w = a[1]
                 xin = a[0]

@@ -12,7 +12,7 @@ import numpy as np
 
 # slot numbers restated from TFLite schema.fbs (kept literal here on purpose: the oracle must not
 # share constants with the product package)
-_OPNAMES = {0: "ADD", 1: "AVERAGE_POOL_2D", 2: "CONCATENATION", 3: "CONV_2D", 4: "DEPTHWISE_CONV_2D",
+_OPNAMES = {0: "ADD", 1: "AVERAGE_POOL_2D", 2: "CONCATENATION", 3: "CONV_2D", 4: "DEPTHWISE_CONV_2D", 6: "DEQUANTIZE",
             9: "FULLY_CONNECTED", 14: "LOGISTIC", 17: "MAX_POOL_2D", 18: "MUL", 19: "RELU", 21: "RELU6",
             22: "RESHAPE", 25: "SOFTMAX", 34: "PAD", 36: "GATHER", 39: "TRANSPOSE", 40: "MEAN",
             41: "SUB", 42: "DIV", 43: "SQUEEZE", 45: "STRIDED_SLICE", 53: "CAST", 70: "EXPAND_DIMS",

@@ -147,3 +147,22 @@ def test_magnitude_frontend_is_reported_unsupported(built_lib):
     assert e.value.code == host.E_UNSUPPORTED
     # ...while the oracle executes it generically
     assert np.isfinite(Interpreter(blob).invoke(sm.synth_clips(1, 12000))[0]).all()
+
+
+def test_dense_only_graphs_plan(built_lib):
+    """Bat head (CustomClassifier) and FP16 range-filter (DEQUANTIZE) graphs: no STFT, plain FC stacks."""
+    head = sm.build_dense_model([1024, 30])
+    clf = host.HipClassifier(head, plan_only=True)
+    assert (clf.n_samples, clf.num_species(), clf.emb_dim) == (1024, 30, 0)
+    assert [s["kernel"] for s in clf.describe()["steps"]] == ["pw_gemm"]
+    rf = sm.build_dense_model([3, 64, 128, 6522], final_sigmoid=True, fp16_weights=True, input_scale=[90.0, 180.0, 48.0])
+    clf = host.HipClassifier(rf, plan_only=True)
+    assert (clf.n_samples, clf.num_species()) == (3, 6522)
+    assert [s["kernel"] for s in clf.describe()["steps"]] == ["pw_gemm"] * 3      # LOGISTIC folded into the last FC
+    # oracle executes the same file, fp16 constants included
+    x = np.array([[60.17, 24.94, 22.0], [-33.9, 151.2, 48.0]], np.float32)
+    y = Interpreter(rf).invoke(x)[0]
+    assert y.shape == (2, 6522) and (y > 0).all() and (y < 1).all()
+    m = read_model(rf)
+    w16 = [t for t in m.tensors if t.name == "fc0/w_f16"][0]
+    assert w16.dtype == np.float16 and w16.data.shape == (64, 3)

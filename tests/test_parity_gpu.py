@@ -223,3 +223,49 @@ def test_us_other_geometries():
         for i in range(2):
             want, wok = G.us_frame_cv(s[i], SR, fft, hop, 30000)
             assert ok[i] == wok and abs(cv[i] - want) <= 1e-9 * max(1.0, abs(want))
+
+
+# ---- secondary models: bat head (a12) and range filter (8f row 3) as dense-only graphs
+def test_bat_two_stage_pipeline(built_lib):
+    cfg = sm.tiny_config(emit_embeddings=True)
+    backbone_blob = sm.build_model(cfg)
+    head_blob = sm.build_dense_model([64, 30], seed=11)
+    backbone = host.HipClassifier(backbone_blob, max_batch=4)
+    labels = [f"Bat{i}" for i in range(30)]
+    head = host.CustomClassifier(head_blob, labels, max_batch=4)
+    assert (head.input_dim(), head.num_classes(), head.labels()[3]) == (64, 30, "Bat3")
+    bat = host.Bat(backbone, head, threshold=0.3)
+    x = sm.synth_clips(2, cfg.n_samples, cfg.sample_rate)
+    got = bat.predict(x[1])
+    # oracle pipeline: backbone embedding -> head logits -> float32-division sigmoid (onnx/postprocess.go:8-10)
+    emb = Interpreter(backbone_blob).invoke(x[1])[1][0]
+    scores = G.sigmoid_f32div(Interpreter(head_blob).invoke(emb[None, :])[0][0])
+    want = [(labels[i], float(scores[i])) for i in np.argsort(-scores, kind="stable") if scores[i] >= 0.3][:10]
+    assert [g[0] for g in got] == [w[0] for w in want]
+    assert np.allclose([g[1] for g in got], [w[1] for w in want], atol=1e-5)
+    with pytest.raises(host.HipError, match="input size mismatch"):
+        head.predict_embedding(np.zeros(63, np.float32))
+    with pytest.raises(host.HipError, match="label count"):
+        host.CustomClassifier(head_blob, labels[:5])
+    plain = host.HipClassifier(sm.build_model(sm.tiny_config()), max_batch=2)
+    with pytest.raises(host.HipError, match="no embedding output"):
+        host.Bat(plain, head)
+    for c in (backbone, plain):
+        c.close()
+    head.close()
+
+
+def test_range_filter_fp16_batch(built_lib):
+    blob = sm.build_dense_model([3, 64, 128, 6522], final_sigmoid=True, fp16_weights=True, input_scale=[90.0, 180.0, 48.0])
+    rf = host.RangeFilter(blob, max_batch=64)
+    assert rf.num_species() == 6522
+    rng = np.random.default_rng(3)
+    pts = np.stack([rng.uniform(-90, 90, 150), rng.uniform(-180, 180, 150), rng.integers(1, 49, 150)], 1).astype(np.float32)
+    got = rf.predict_batch(pts.reshape(-1), 150).reshape(150, 6522)       # 150 > max_batch: chunked
+    ref = Interpreter(blob).invoke(pts)[0]
+    assert np.abs(got - ref).max() < 2e-6
+    one = rf.predict(*pts[7])
+    assert np.array_equal(one, got[7])
+    with pytest.raises(host.HipError, match="input size mismatch"):
+        rf.predict_batch(np.zeros(7, np.float32), 2)
+    rf.close()
