@@ -336,6 +336,12 @@ int bnhip_profile_enable(bnhip_model* m, int on) {
     return BNHIP_OK;
 }
 
+int bnhip_profile_filter(bnhip_model* m, const char* kernel_class) {
+    if (!m) return set_err(BNHIP_E_INVALID, "model is NULL");
+    m->eng.profile_filter = kernel_class ? kernel_class : "";
+    return BNHIP_OK;
+}
+
 static int copy_out(const std::string& s, char* buf, size_t cap) {
     if (buf && cap) {
         size_t n = std::min(cap - 1, s.size());

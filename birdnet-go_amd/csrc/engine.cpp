@@ -945,7 +945,8 @@ bool Engine::run(const float* d_in, int n, float* d_logits, float* d_emb, std::s
         float* in2 = vptr(s.in2, d_in, d_logits, d_emb);
         float* out = vptr(s.out, d_in, d_logits, d_emb);
         ProfEntry pe{};
-        if (profiling) { pe.a = get_event(); pe.b = get_event(); pe.step = si; pe.n = n; hipEventRecord(pe.a, stream); }
+        const bool prof_this = profiling && (profile_filter.empty() || profile_filter == s.kclass);
+        if (prof_this) { pe.a = get_event(); pe.b = get_event(); pe.step = si; pe.n = n; hipEventRecord(pe.a, stream); }
         switch (s.kind) {
             case S_MINMAX:
                 launch_clip_minmax(in0, n, n_samples, specs[0].eps, reinterpret_cast<float2*>(out), stream);
@@ -998,7 +999,7 @@ bool Engine::run(const float* d_in, int n, float* d_logits, float* d_emb, std::s
                               s.act, stream);
                 break;
         }
-        if (profiling) { hipEventRecord(pe.b, stream); prof.push_back(pe); }
+        if (prof_this) { hipEventRecord(pe.b, stream); prof.push_back(pe); }
     }
     if (d_emb && v_emb >= 0) {
         hipError_t e = hipMemcpyAsync(d_emb, vptr(v_emb, d_in, d_logits, d_emb), (size_t)n * emb_dim * 4,

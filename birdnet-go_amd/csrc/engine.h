@@ -65,6 +65,7 @@ class Engine {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool profiling = false;
+    std::string profile_filter;      // non-empty: only launches of this kernel class are bracketed by events
 
     std::vector<Step> steps;
     std::vector<Value> vals;

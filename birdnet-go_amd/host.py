@@ -27,7 +27,7 @@ SYMBOLS = ["bnhip_init", "bnhip_shutdown", "bnhip_model_create", "bnhip_model_in
            "bnhip_predict_pcm16", "bnhip_predict_device", "bnhip_postprocess_topk", "bnhip_predict_topk",
            "bnhip_us_frame_cv", "bnhip_set_stream", "bnhip_synchronize", "bnhip_profile_enable",
            "bnhip_profile_read", "bnhip_model_describe", "bnhip_model_destroy", "bnhip_last_error",
-           "bnhip_version", "bnhip_debug_fetch"]
+           "bnhip_version", "bnhip_debug_fetch", "bnhip_profile_filter"]
 
 
 class HipError(RuntimeError):
@@ -69,6 +69,7 @@ def load_library(path=None):
     lib.bnhip_synchronize.argtypes = [C.c_void_p]
     lib.bnhip_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.bnhip_profile_read.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.bnhip_profile_filter.argtypes = [C.c_void_p, C.c_char_p]
     lib.bnhip_model_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     lib.bnhip_model_destroy.argtypes = [C.c_void_p]
     lib.bnhip_init.argtypes = [C.POINTER(C.c_int)]
@@ -188,6 +189,9 @@ class HipClassifier:
 
     def profile_enable(self, on=True):
         _check(self._lib, self._lib.bnhip_profile_enable(self._h, int(on)))
+
+    def profile_filter(self, kernel_class=None):
+        _check(self._lib, self._lib.bnhip_profile_filter(self._h, kernel_class.encode() if kernel_class else None))
 
     def profile_read(self, per_step=False):
         """Per-kernel-class timing rows; with per_step=True returns (classes, steps)."""

@@ -100,6 +100,9 @@ int bnhip_synchronize(bnhip_model* m);
  * synchronises and writes a JSON array [{"kernel":..,"launches":..,"ms":..,"flops":..,"bytes":..},..]
  * into buf (NUL-terminated, truncated to cap) and resets the counters. Returns bytes needed. */
 int bnhip_profile_enable(bnhip_model* m, int on);
+/* Restrict the event bracketing to one kernel class (e.g. "expand_dw"; NULL/"" = all): bracketing every launch costs
+ * ~7 % of a step (each event is a kernel boundary), bracketing only the dominant class ~1 %. */
+int bnhip_profile_filter(bnhip_model* m, const char* kernel_class);
 int bnhip_profile_read(bnhip_model* m, char* buf, size_t cap);
 
 /* Plan description (JSON) for diagnostics/DESIGN tables: one entry per launch with shapes,
