@@ -277,9 +277,57 @@ __global__ __launch_bounds__(256) void k_conv_direct(ConvParams p) {
     acc.z = apply_act(acc.z, p.act); acc.w = apply_act(acc.w, p.act);
     reinterpret_cast<float4*>(p.out)[idx] = acc;
 }
+// Compile-time (KH, KW, CIN) variant: every tap load is issued up front (the generic loop above is a chain of
+// dependent L1/L2 round trips: 18 serial loads per thread for the 3x3x2 stem made it latency-bound at 1 TB/s).
+template <int KH, int KW, int CIN>
+__global__ __launch_bounds__(256) void k_conv_direct_t(ConvParams p) {
+    const int C4 = p.Cout >> 2;
+    size_t total = (size_t)p.B * p.Ho * p.Wo * C4;
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    int c4 = (int)(idx % C4);
+    size_t pix = idx / C4;
+    int wo = (int)(pix % p.Wo);
+    int ho = (int)((pix / p.Wo) % p.Ho);
+    int b = (int)(pix / ((size_t)p.Wo * p.Ho));
+    float x[KH][KW][CIN];
+#pragma unroll
+    for (int i = 0; i < KH; i++) {
+        int hi = ho * p.sh - p.pt + i;
+#pragma unroll
+        for (int j = 0; j < KW; j++) {
+            int wi = wo * p.sw - p.pl + j;
+            bool ok = hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+            const float* ip = p.in + (((size_t)b * p.H + (ok ? hi : 0)) * p.W + (ok ? wi : 0)) * CIN;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ci++) x[i][j][ci] = ok ? ip[ci] : 0.f;
+        }
+    }
+    float4 acc = p.bias ? reinterpret_cast<const float4*>(p.bias)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* w4 = reinterpret_cast<const float4*>(p.w) + c4;
+#pragma unroll
+    for (int i = 0; i < KH; i++)
+#pragma unroll
+        for (int j = 0; j < KW; j++)
+#pragma unroll
+            for (int ci = 0; ci < CIN; ci++) {
+                float4 w = w4[(size_t)((i * KW + j) * CIN + ci) * C4];
+                float xv = x[i][j][ci];
+                a2.x = fmaf(xv, w.x, a2.x); a2.y = fmaf(xv, w.y, a2.y); a2.z = fmaf(xv, w.z, a2.z); a2.w = fmaf(xv, w.w, a2.w);
+            }
+    // same association as the generic kernel: sum of products first, bias added last
+    acc.x = apply_act(a2.x + acc.x, p.act); acc.y = apply_act(a2.y + acc.y, p.act);
+    acc.z = apply_act(a2.z + acc.z, p.act); acc.w = apply_act(a2.w + acc.w, p.act);
+    reinterpret_cast<float4*>(p.out)[idx] = acc;
+}
 void launch_conv_direct(const ConvParams& p, hipStream_t s) {
     size_t total = (size_t)p.B * p.Ho * p.Wo * (p.Cout >> 2);
-    hipLaunchKernelGGL(k_conv_direct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (p.kh == 3 && p.kw == 3 && p.Cin == 2) hipLaunchKernelGGL((k_conv_direct_t<3, 3, 2>), grid, dim3(256), 0, s, p);
+    else if (p.kh == 3 && p.kw == 3 && p.Cin == 1) hipLaunchKernelGGL((k_conv_direct_t<3, 3, 1>), grid, dim3(256), 0, s, p);
+    else if (p.kh == 3 && p.kw == 3 && p.Cin == 3) hipLaunchKernelGGL((k_conv_direct_t<3, 3, 3>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_conv_direct, grid, dim3(256), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------------ pointwise GEMM
@@ -973,8 +1021,9 @@ void launch_mean_finish(const float* partial, float* out, int B, int HW, int C, 
 
 // ------------------------------------------------------------------------------------------ squeeze-excite
 // One block (16 waves) per clip: mean -> FC(Cr)+act1 -> FC(C)+act2 -> scale[b][c].
-// w1 [Cr][C] is read wave-per-output with coalesced float4 rows; w2t is the second FC transposed to [Cr][C]
-// at plan time so thread c reads it coalesced.
+// w1 [Cr][C] is read wave-per-output with coalesced rows; w2t is the second FC transposed to [Cr][C] at plan
+// time so thread c reads it coalesced.  (Splitting a clip over 4 blocks that each redo mean+FC1 measured 2x slower:
+// the pass over the per-slab sums dominates.)
 __global__ __launch_bounds__(1024) void k_se(SeParams p) {
     extern __shared__ float sm[];
     float* mean = sm;            // [C]
