@@ -7,6 +7,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <vector>
 #include <utility>
 
 #include "engine.h"
@@ -49,6 +50,12 @@ bool is_gfx950(int dev) {
 }
 
 }  // namespace
+
+namespace bnhip {
+void resample_design(int L, int M, double beta, int half_factor, std::vector<float>* table, int* T_out, int* half_out);
+int launch_resample(const void* d_in, void* d_out, const float* d_table, bool pcm16, int n_clips, int n_in, int n_out, int L,
+                    int M, int T, int half, hipStream_t s);
+}
 
 extern "C" {
 
@@ -328,6 +335,63 @@ int bnhip_debug_fetch(bnhip_model* m, int tensor_index, int n_clips, float* out,
     if (hipMemcpy(out, e.value_ptr(it->second), n * 4, hipMemcpyDeviceToHost) != hipSuccess)
         return set_err(BNHIP_E_RUNTIME, "debug fetch copy failed");
     return (int)v.elems;
+}
+
+static int igcd(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+int bnhip_resample_length(int n_in, int rate_in, int rate_out) {
+    if (n_in <= 0 || rate_in <= 0 || rate_out <= 0) return 0;
+    int g = igcd(rate_in, rate_out);
+    long long L = rate_out / g, M = rate_in / g;
+    return (int)(((long long)n_in * L + M - 1) / M);
+}
+
+static int resample_impl(int device, const void* in, bool pcm16, int n_clips, int n_in, int rate_in, int rate_out, void* out,
+                         int n_out_cap, int* n_out) {
+    if (!in || !out || n_clips <= 0 || n_in <= 0 || rate_in <= 0 || rate_out <= 0)
+        return set_err(BNHIP_E_INVALID, "bad resample arguments");
+    const int no = bnhip_resample_length(n_in, rate_in, rate_out);
+    if (n_out) *n_out = no;
+    if (no > n_out_cap) return set_err(BNHIP_E_INVALID, "destination buffer too small");     // resample.go:137-144
+    const size_t esz = pcm16 ? 2 : 4;
+    if (rate_in == rate_out) {                                                              // NewResampler returns nil: passthrough
+        memcpy(out, in, (size_t)n_clips * n_in * esz);
+        return BNHIP_OK;
+    }
+    int rc = bnhip_init(nullptr);
+    if (rc) return rc;
+    if (device < 0 || device >= g_devices) return set_err(BNHIP_E_INVALID, "device ordinal out of range");
+    hipSetDevice(device);
+    int g = igcd(rate_in, rate_out), L = rate_out / g, M = rate_in / g, T = 0, half = 0;
+    std::vector<float> table;
+    resample_design(L, M, 5.0, 10, &table, &T, &half);
+    void *d_in = nullptr, *d_out = nullptr; float* d_tab = nullptr;
+    hipError_t he = hipMalloc(&d_in, (size_t)n_clips * n_in * esz);
+    if (he == hipSuccess) he = hipMalloc(&d_out, (size_t)n_clips * no * esz);
+    if (he == hipSuccess) he = hipMalloc((void**)&d_tab, table.size() * 4);
+    if (he == hipSuccess) he = hipMemcpy(d_in, in, (size_t)n_clips * n_in * esz, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemcpy(d_tab, table.data(), table.size() * 4, hipMemcpyHostToDevice);
+    int lrc = 0;
+    if (he == hipSuccess) {
+        lrc = launch_resample(d_in, d_out, d_tab, pcm16, n_clips, n_in, no, L, M, T, half, nullptr);
+        if (lrc == 0) he = hipMemcpy(out, d_out, (size_t)n_clips * no * esz, hipMemcpyDeviceToHost);
+    }
+    if (d_in) hipFree(d_in);
+    if (d_out) hipFree(d_out);
+    if (d_tab) hipFree(d_tab);
+    if (lrc) return set_err(BNHIP_E_UNSUPPORTED, "resample ratio needs a phase table larger than LDS");
+    if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("resample: ") + hipGetErrorString(he));
+    return BNHIP_OK;
+}
+
+int bnhip_resample_f32(int device, const float* in, int n_clips, int n_in, int rate_in, int rate_out, float* out, int n_out_cap,
+                       int* n_out) {
+    return resample_impl(device, in, false, n_clips, n_in, rate_in, rate_out, out, n_out_cap, n_out);
+}
+
+int bnhip_resample_pcm16(int device, const int16_t* in, int n_clips, int n_in, int rate_in, int rate_out, int16_t* out,
+                         int n_out_cap, int* n_out) {
+    return resample_impl(device, in, true, n_clips, n_in, rate_in, rate_out, out, n_out_cap, n_out);
 }
 
 int bnhip_profile_enable(bnhip_model* m, int on) {

@@ -27,7 +27,8 @@ SYMBOLS = ["bnhip_init", "bnhip_shutdown", "bnhip_model_create", "bnhip_model_in
            "bnhip_predict_pcm16", "bnhip_predict_device", "bnhip_postprocess_topk", "bnhip_predict_topk",
            "bnhip_us_frame_cv", "bnhip_set_stream", "bnhip_synchronize", "bnhip_profile_enable",
            "bnhip_profile_read", "bnhip_model_describe", "bnhip_model_destroy", "bnhip_last_error",
-           "bnhip_version", "bnhip_debug_fetch", "bnhip_profile_filter"]
+           "bnhip_version", "bnhip_debug_fetch", "bnhip_profile_filter", "bnhip_resample_length",
+           "bnhip_resample_f32", "bnhip_resample_pcm16"]
 
 
 class HipError(RuntimeError):
@@ -326,6 +327,45 @@ class Bat:
         order = np.argsort(-scores, kind="stable")
         labels = self.head.labels()
         return [(labels[i], float(scores[i])) for i in order if scores[i] >= self.threshold][:self.TOP_K]
+
+
+class Resampler:
+    """Resampler (internal/audiocore/resample/resample.go:57-172) on the GPU, stateless per clip.
+    `resample_to(pcm16)` keeps the reference's int16 edges; `resample_f32` is the float path."""
+
+    def __init__(self, from_rate, to_rate, device=0):
+        if from_rate <= 0 or to_rate <= 0:
+            raise HipError(E_INVALID, f"failed to create resampler from {from_rate} Hz to {to_rate} Hz")
+        self.from_rate, self.to_rate, self.device = int(from_rate), int(to_rate), device
+        self._lib = load_library()
+        self._lib.bnhip_resample_f32.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        self._lib.bnhip_resample_pcm16.argtypes = self._lib.bnhip_resample_f32.argtypes
+
+    def estimate_output(self, n_in):
+        return int(self._lib.bnhip_resample_length(int(n_in), self.from_rate, self.to_rate))
+
+    def _run(self, fn, x, dtype):
+        x = np.ascontiguousarray(x, dtype)
+        flat = x.ndim == 1
+        if flat:
+            x = x[None, :]
+        no = self.estimate_output(x.shape[1])
+        out = np.empty((x.shape[0], no), dtype)
+        n = C.c_int(0)
+        _check(self._lib, fn(self.device, x.ctypes.data, x.shape[0], x.shape[1], self.from_rate, self.to_rate,
+                             out.ctypes.data, no, C.byref(n)))
+        return out[0] if flat else out
+
+    def resample_f32(self, samples):
+        return self._run(self._lib.bnhip_resample_f32, samples, np.float32)
+
+    def resample_to(self, pcm16):
+        """int16 in -> int16 out (ResampleTo); accepts raw little-endian bytes or an int16 array."""
+        if isinstance(pcm16, (bytes, bytearray)):
+            if len(pcm16) % 2:
+                raise HipError(E_INVALID, f"input length {len(pcm16)} is not a multiple of 2 (16-bit PCM requires even byte count)")
+            return self._run(self._lib.bnhip_resample_pcm16, np.frombuffer(pcm16, "<i2"), np.int16).tobytes()
+        return self._run(self._lib.bnhip_resample_pcm16, pcm16, np.int16)
 
 
 class BirdNET:

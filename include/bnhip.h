@@ -91,6 +91,18 @@ int bnhip_predict_topk(bnhip_model* m, const float* samples, int n_clips, int ac
 int bnhip_us_frame_cv(int device, const double* samples, int n_clips, int n, int sample_rate, int fft_size,
                       int hop, int split_hz, double* cv, int32_t* ok);
 
+/* Polyphase resampler for the step upstream of the classifier (Resampler.ResampleTo, internal/audiocore/resample/
+ * resample.go:99-172).  Stateless per clip; n_out = ceil(n_in * rate_out / rate_in) (bnhip_resample_length); equal rates
+ * pass through (NewResampler returns nil, :58-60); a too-small destination is an error before any work (:137-144).
+ * The filter arithmetic of the reference lives in go-audio-resampler v1.7.0 (not in its tree, values unpinned), so the
+ * filter is this project's own spec = scipy.signal.resample_poly's default Kaiser design; the _pcm16 entry keeps the
+ * reference's edges: float32(int16)/32768 in, clamp +-1 and int16(f*32767) truncation out (:120-124,161-169). */
+int bnhip_resample_length(int n_in, int rate_in, int rate_out);
+int bnhip_resample_f32(int device, const float* in, int n_clips, int n_in, int rate_in, int rate_out, float* out,
+                       int n_out_cap, int* n_out);
+int bnhip_resample_pcm16(int device, const int16_t* in, int n_clips, int n_in, int rate_in, int rate_out, int16_t* out,
+                         int n_out_cap, int* n_out);
+
 /* Stream plumbing for hosts that own a HIP stream (bench harness: torch's current stream). */
 int bnhip_set_stream(bnhip_model* m, void* hip_stream);
 int bnhip_synchronize(bnhip_model* m);
