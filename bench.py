@@ -138,13 +138,18 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists by design)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # BENCH_FORCE_DIST=1 exercises the RCCL code path (init, broadcast, barrier, all-reduce) even on one GPU
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", device_id=dev)
 
     cfg = sm.SynthConfig()
     # frozen weights: built once on rank 0, broadcast over RCCL/xGMI (the only collective on this path)
-    if world > 1:
+    if use_dist:
         blob = sm.build_model(cfg) if rank == 0 else None
         blob = shard.broadcast_model_bytes(blob, src=0, device=dev)
     else:
@@ -179,14 +184,14 @@ def main():
         warm_prof, prof_steps = clf.profile_read(per_step=True)
         if warm_prof:
             clf.profile_filter(max(warm_prof, key=lambda r: r["ms"])["kernel"])
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     prof = clf.profile_read() if not args.no_profile else []
@@ -197,7 +202,7 @@ def main():
                   f"{r['flops'] / r['launches'] / (ms * 1e-3) / 1e12:6.1f} TF  {r['bytes'] / r['launches'] / (ms * 1e-3) / 1e9:7.0f} GB/s",
                   file=sys.stderr)
     clf.profile_enable(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -251,7 +256,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(blob, cfg.n_samples, cfg.sample_rate, args.cpu_clips)
         print(json.dumps(out))
     clf.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

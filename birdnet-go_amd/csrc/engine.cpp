@@ -51,16 +51,24 @@ struct Planner {
     bool fail(const std::string& s) { if (err.empty()) err = s; return false; }
 
     static bool shape_op(int code) { return code == OP_RESHAPE || code == OP_EXPAND_DIMS || code == OP_SQUEEZE; }
+    // tf.signal.frame slices the signal to a whole number of sub-frames first; when nothing is cut the
+    // STRIDED_SLICE is an identity and is treated like a reshape
+    bool identity_op(int oi) const {
+        const TflOp& o = m.ops[oi];
+        if (shape_op(o.code)) return true;
+        return o.code == OP_STRIDED_SLICE && !o.inputs.empty() && !o.outputs.empty() &&
+               m.tensors[o.inputs[0]].numel() == m.tensors[o.outputs[0]].numel();
+    }
 
     int skip_up(int t) {          // walk producers through pure shape ops
-        while (t >= 0 && producer[t] >= 0 && shape_op(m.ops[producer[t]].code)) {
+        while (t >= 0 && producer[t] >= 0 && identity_op(producer[t])) {
             absorbed[producer[t]] = 1;
             t = m.ops[producer[t]].inputs[0];
         }
         return t;
     }
     int skip_down(int t) {        // walk single consumers through pure shape ops
-        while (consumers[t].size() == 1 && shape_op(m.ops[consumers[t][0]].code)) {
+        while (consumers[t].size() == 1 && identity_op(consumers[t][0])) {
             absorbed[consumers[t][0]] = 1;
             t = m.ops[consumers[t][0]].outputs[0];
         }
