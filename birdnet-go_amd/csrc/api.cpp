@@ -182,29 +182,80 @@ static int predict_host(bnhip_model* m, const void* src, bool pcm16, int n_clips
         if (hipMalloc((void**)&e.d_stage_pcm, (size_t)e.max_batch * e.n_samples * 2) != hipSuccess)
             return set_err(BNHIP_E_NOMEM, "device allocation failed (pcm staging)");
     }
-    for (int off = 0; off < n_clips; off += e.max_batch) {
-        int n = std::min(e.max_batch, n_clips - off);
-        size_t cnt = (size_t)n * e.n_samples;
-        hipError_t he;
-        if (pcm16) {
-            he = hipMemcpyAsync(e.d_stage_pcm, (const int16_t*)src + (size_t)off * e.n_samples, cnt * 2,
-                                hipMemcpyHostToDevice, e.stream);
-            if (he == hipSuccess) launch_pcm16_to_f32(e.d_stage_pcm, e.d_stage_in, cnt, e.stream);
-        } else {
-            he = hipMemcpyAsync(e.d_stage_in, (const float*)src + (size_t)off * e.n_samples, cnt * 4,
-                                hipMemcpyHostToDevice, e.stream);
+    const int nchunks = (n_clips + e.max_batch - 1) / e.max_batch;
+    const bool pipelined = nchunks > 1 && !pcm16;
+    if (pipelined && !e.d_stage_in2) {       // second staging set, created on first use
+        hipError_t he = hipMalloc((void**)&e.d_stage_in2, (size_t)e.max_batch * e.n_samples * 4);
+        if (he == hipSuccess) he = hipMalloc((void**)&e.d_stage_logits2, (size_t)e.max_batch * e.n_classes * 4);
+        if (he == hipSuccess && e.emb_dim) he = hipMalloc((void**)&e.d_stage_emb2, (size_t)e.max_batch * e.emb_dim * 4);
+        if (he == hipSuccess) he = hipStreamCreateWithFlags(&e.copy_stream, hipStreamNonBlocking);
+        for (int i = 0; i < 2 && he == hipSuccess; i++) {
+            he = hipEventCreateWithFlags(&e.ev_copied[i], hipEventDisableTiming);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&e.ev_done[i], hipEventDisableTiming);
         }
-        if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("H2D copy: ") + hipGetErrorString(he));
-        if (!e.run(e.d_stage_in, n, e.d_stage_logits, emb ? e.d_stage_emb : nullptr, &err))
-            return set_err(BNHIP_E_RUNTIME, err);
-        he = hipMemcpyAsync(logits + (size_t)off * e.n_classes, e.d_stage_logits, (size_t)n * e.n_classes * 4,
-                            hipMemcpyDeviceToHost, e.stream);
-        if (he == hipSuccess && emb)
-            he = hipMemcpyAsync(emb + (size_t)off * e.emb_dim, e.d_stage_emb, (size_t)n * e.emb_dim * 4,
-                                hipMemcpyDeviceToHost, e.stream);
-        if (he == hipSuccess) he = hipStreamSynchronize(e.stream);
-        if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("D2H copy/sync: ") + hipGetErrorString(he));
+        if (he != hipSuccess) return set_err(BNHIP_E_NOMEM, std::string("staging allocation failed: ") + hipGetErrorString(he));
     }
+    if (!pipelined) {
+        for (int off = 0; off < n_clips; off += e.max_batch) {
+            int n = std::min(e.max_batch, n_clips - off);
+            size_t cnt = (size_t)n * e.n_samples;
+            hipError_t he;
+            if (pcm16) {
+                he = hipMemcpyAsync(e.d_stage_pcm, (const int16_t*)src + (size_t)off * e.n_samples, cnt * 2,
+                                    hipMemcpyHostToDevice, e.stream);
+                if (he == hipSuccess) launch_pcm16_to_f32(e.d_stage_pcm, e.d_stage_in, cnt, e.stream);
+            } else {
+                he = hipMemcpyAsync(e.d_stage_in, (const float*)src + (size_t)off * e.n_samples, cnt * 4,
+                                    hipMemcpyHostToDevice, e.stream);
+            }
+            if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("H2D copy: ") + hipGetErrorString(he));
+            if (!e.run(e.d_stage_in, n, e.d_stage_logits, emb ? e.d_stage_emb : nullptr, &err))
+                return set_err(BNHIP_E_RUNTIME, err);
+            he = hipMemcpyAsync(logits + (size_t)off * e.n_classes, e.d_stage_logits, (size_t)n * e.n_classes * 4,
+                                hipMemcpyDeviceToHost, e.stream);
+            if (he == hipSuccess && emb)
+                he = hipMemcpyAsync(emb + (size_t)off * e.emb_dim, e.d_stage_emb, (size_t)n * e.emb_dim * 4,
+                                    hipMemcpyDeviceToHost, e.stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(e.stream);
+            if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("D2H copy/sync: ") + hipGetErrorString(he));
+        }
+        return BNHIP_OK;
+    }
+    // ---- pipelined: the (host-blocking) pageable H2D of chunk i+1 runs on the copy stream while the compute stream is
+    // busy with chunk i; the D2H of chunk i-1 is issued after chunk i's kernels are queued.
+    float* din[2] = {e.d_stage_in, e.d_stage_in2};
+    float* dlog[2] = {e.d_stage_logits, e.d_stage_logits2};
+    float* demb[2] = {e.d_stage_emb, e.d_stage_emb2};
+    auto fail = [&](const std::string& what, hipError_t he) {
+        hipStreamSynchronize(e.stream); hipStreamSynchronize(e.copy_stream);
+        return set_err(BNHIP_E_RUNTIME, what + ": " + hipGetErrorString(he));
+    };
+    auto drain = [&](int c) -> hipError_t {      // copy chunk c's results to the caller (waits for its compute)
+        int off = c * e.max_batch, n = std::min(e.max_batch, n_clips - off), b = c & 1;
+        hipError_t he = hipStreamWaitEvent(e.copy_stream, e.ev_done[b], 0);
+        if (he == hipSuccess) he = hipMemcpyAsync(logits + (size_t)off * e.n_classes, dlog[b], (size_t)n * e.n_classes * 4,
+                                                  hipMemcpyDeviceToHost, e.copy_stream);
+        if (he == hipSuccess && emb)
+            he = hipMemcpyAsync(emb + (size_t)off * e.emb_dim, demb[b], (size_t)n * e.emb_dim * 4, hipMemcpyDeviceToHost,
+                                e.copy_stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(e.copy_stream);     // buffer b is free again afterwards
+        return he;
+    };
+    for (int c = 0; c < nchunks; c++) {
+        int off = c * e.max_batch, n = std::min(e.max_batch, n_clips - off), b = c & 1;
+        hipError_t he = hipMemcpyAsync(din[b], (const float*)src + (size_t)off * e.n_samples, (size_t)n * e.n_samples * 4,
+                                       hipMemcpyHostToDevice, e.copy_stream);
+        if (he == hipSuccess) he = hipEventRecord(e.ev_copied[b], e.copy_stream);
+        if (he == hipSuccess) he = hipStreamWaitEvent(e.stream, e.ev_copied[b], 0);
+        if (he != hipSuccess) return fail("H2D copy", he);
+        if (!e.run(din[b], n, dlog[b], emb ? demb[b] : nullptr, &err)) { hipStreamSynchronize(e.stream); return set_err(BNHIP_E_RUNTIME, err); }
+        he = hipEventRecord(e.ev_done[b], e.stream);
+        if (he != hipSuccess) return fail("event record", he);
+        if (c >= 1) { he = drain(c - 1); if (he != hipSuccess) return fail("D2H copy", he); }
+    }
+    hipError_t he = drain(nchunks - 1);
+    if (he == hipSuccess) he = hipStreamSynchronize(e.stream);
+    if (he != hipSuccess) return fail("D2H copy/sync", he);
     return BNHIP_OK;
 }
 

@@ -279,8 +279,11 @@ Engine::~Engine() {
     for (auto& e : prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto e : ev_pool) hipEventDestroy(e);
     for (void* p : {(void*)act_arena, (void*)w_arena, (void*)d_stage_in, (void*)d_stage_logits, (void*)d_stage_emb,
-                    (void*)d_stage_pcm, (void*)d_post_conf, (void*)d_topk_conf, (void*)d_topk_idx})
+                    (void*)d_stage_pcm, (void*)d_post_conf, (void*)d_topk_conf, (void*)d_topk_idx, (void*)d_stage_in2,
+                    (void*)d_stage_logits2, (void*)d_stage_emb2})
         if (p) hipFree(p);
+    for (int i = 0; i < 2; i++) { if (ev_copied[i]) hipEventDestroy(ev_copied[i]); if (ev_done[i]) hipEventDestroy(ev_done[i]); }
+    if (copy_stream) hipStreamDestroy(copy_stream);
     if (own_stream && stream) hipStreamDestroy(stream);
 }
 

@@ -76,6 +76,11 @@ class Engine {
     float* d_stage_in = nullptr;      // [max_batch, n_samples]
     float* d_stage_logits = nullptr;  // [max_batch, n_classes]
     float* d_stage_emb = nullptr;     // [max_batch, emb_dim]
+    // second staging set + copy stream: host-pointer calls with more than max_batch clips overlap the H2D copy of
+    // chunk i+1 with the compute of chunk i
+    float* d_stage_in2 = nullptr; float* d_stage_logits2 = nullptr; float* d_stage_emb2 = nullptr;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     int16_t* d_stage_pcm = nullptr;
     float* d_post_conf = nullptr;     // [max_batch, n_classes]
     float* d_topk_conf = nullptr;
