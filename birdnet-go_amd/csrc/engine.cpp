@@ -913,20 +913,22 @@ void Engine::autotune_pw() {
         float* in1 = vptr(s.in1, d_stage_in, d_stage_logits, nullptr);
         float* in2 = vptr(s.in2, d_stage_in, d_stage_logits, nullptr);
         float* out = vptr(s.out, d_stage_in, d_stage_logits, nullptr);
-        float best = 1e30f; int best_nt = 0;
-        for (int nt = 1; nt <= 4; nt++) {
-            long cols = (long)((s.Co + nt * 16 - 1) / (nt * 16)) * nt * 16;
-            if (cols * 100 > (long)((s.Co + 15) / 16 * 16) * 130) continue;         // skip absurd padding
-            PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, nt};
-            launch_pw_gemm(p, stream);                                             // warm-up
-            hipEventRecord(a, stream);
-            for (int r = 0; r < 3; r++) launch_pw_gemm(p, stream);
-            hipEventRecord(b, stream);
-            hipEventSynchronize(b);
-            float ms = 0; hipEventElapsedTime(&ms, a, b);
-            if (ms < best) { best = ms; best_nt = nt; }
+        float best = 1e30f; int best_nt = 0, best_wm = 0;
+        for (int wm = 2; wm >= 1; wm--) {
+            for (int nt = 1; nt <= 4; nt++) {
+                long cols = (long)((s.Co + nt * 16 - 1) / (nt * 16)) * nt * 16;
+                if (cols * 100 > (long)((s.Co + 15) / 16 * 16) * 130) continue;         // skip absurd padding
+                PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, nt, wm};
+                launch_pw_gemm(p, stream);                                             // warm-up
+                hipEventRecord(a, stream);
+                for (int r = 0; r < 3; r++) launch_pw_gemm(p, stream);
+                hipEventRecord(b, stream);
+                hipEventSynchronize(b);
+                float ms = 0; hipEventElapsedTime(&ms, a, b);
+                if (ms < best * 0.98f) { best = ms; best_nt = nt; best_wm = wm; }      // prefer the larger tile on ties
+            }
         }
-        s.nt = best_nt;
+        s.nt = best_nt; s.wm = best_wm;
     }
     hipStreamSynchronize(stream);
     hipEventDestroy(a); hipEventDestroy(b);
@@ -978,7 +980,7 @@ bool Engine::run(const float* d_in, int n, float* d_logits, float* d_emb, std::s
                 break;
             }
             case S_PW: {
-                PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, s.nt};
+                PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, s.nt, s.wm};
                 launch_pw_gemm(p, stream);
                 break;
             }
@@ -1045,7 +1047,7 @@ std::string Engine::describe() const {
         jesc(os, s.name);
         os << "\",\"H\":" << s.H << ",\"W\":" << s.W << ",\"C\":" << s.C << ",\"Co\":" << s.Co << ",\"k\":" << s.kh
            << ",\"stride\":" << s.sh << ",\"act\":" << s.act << ",\"fused_scale\":" << (s.kind == S_PW && s.in1 >= 0 ? 1 : 0)
-           << ",\"nt\":" << s.nt << ",\"fused_res\":" << (s.kind == S_PW && s.in2 >= 0 ? 1 : 0) << ",\"fused_sum\":" << (s.out2 >= 0 ? 1 : 0) << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << ",\"wbytes\":" << s.wbytes << "}";
+           << ",\"nt\":" << s.nt << ",\"wm\":" << s.wm << ",\"fused_res\":" << (s.kind == S_PW && s.in2 >= 0 ? 1 : 0) << ",\"fused_sum\":" << (s.out2 >= 0 ? 1 : 0) << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << ",\"wbytes\":" << s.wbytes << "}";
     }
     os << "]}";
     return os.str();

@@ -24,7 +24,7 @@ struct Step {
     // geometry per clip
     int H = 0, W = 0, C = 0, Ho = 0, Wo = 0, Co = 0, kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0;
     int act = 0, act2 = 0, op = 0, mode = 0, S = 1, Cr = 0;
-    int nt = 0;              // pw_gemm tile width chosen by the create-time autotuner (0 = heuristic)
+    int nt = 0, wm = 0;      // pw_gemm tile shape chosen by the create-time autotuner (0 = heuristic)
     // front-end
     int spec = -1;
     // accounting per clip

@@ -339,29 +339,31 @@ void launch_conv_direct(const ConvParams& p, hipStream_t s) {
 // with ds_read_b128 fragment loads the (row*10 + kq) 16-byte slot pattern is conflict-free for every
 // 16-lane service group.  K is consumed in permuted order inside each 16-wide slab (lane kq holds
 // k = 4kq..4kq+3, MFMA step s pairs element s of both operands) - a fixed reordering of the fp32 sum.
-#define PW_BM 128
+#define PW_BM 128      // largest row tile (WM = 2); WM = 1 gives 64-row tiles for small grids
 #define PW_BK 32
 #define PW_LS 40
-template <int NT, bool SC>
+template <int NT, bool SC, int WM>
 __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigned nblk) {
+    constexpr int BM = 64 * WM;                  // rows per block: 4 waves x (16*WM) rows
+    constexpr int XQ = BM / 32;                  // float4 per thread for the activation tile
     // operand tiles (the epilogue re-uses the array as per-wave output staging).  SC: squeeze-excite scale on A.
     constexpr bool DB = false;   // double-buffering measured neutral on this chip for these shapes; kept for experiments
-    constexpr int TILE = (PW_BM + NT * 16) * PW_LS;
+    constexpr int TILE = (BM + NT * 16) * PW_LS;
     __shared__ __attribute__((aligned(16))) float lds[(DB ? 2 : 1) * TILE];
     constexpr int WQ = (NT + 1) / 2;             // float4 per thread for the W tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     // XCD-aware order: N-blocks fastest so the blocks that share an activation tile sit on one XCD's L2
     const unsigned L = xcd_remap(blockIdx.x, nblk);
-    const int m0 = (int)(L / nblk_n) * PW_BM;
+    const int m0 = (int)(L / nblk_n) * BM;
     const int n0 = (int)(L % nblk_n) * (NT * 16);
     const int K = p.K;
 
-    float4 xreg[4], wreg[WQ], sreg[SC ? 4 : 1];
-    int srow[SC ? 4 : 1];                        // batch index of each staged row (for the per-(batch,k) scale)
+    float4 xreg[XQ], wreg[WQ], sreg[SC ? XQ : 1];
+    int srow[SC ? XQ : 1];                        // batch index of each staged row (for the per-(batch,k) scale)
     if (SC) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < XQ; q++) {
             int m = m0 + ((tid + 256 * q) >> 3);
             srow[SC ? q : 0] = (m < p.M ? m : 0) / p.HW;
         }
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
     // all global loads of a slab are issued back-to-back (scale included); the multiply happens at LDS-store time
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < XQ; q++) {
             int idx = tid + 256 * q;
             int row = idx >> 3, c4 = idx & 7;
             int m = m0 + row, k = k0 + 4 * c4;
@@ -393,9 +395,9 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
     };
     auto lstore = [&](int buf) {
         float* Xs = lds + buf * TILE;
-        float* Ws = Xs + PW_BM * PW_LS;
+        float* Ws = Xs + BM * PW_LS;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < XQ; q++) {
             int idx = tid + 256 * q;
             float4 v = xreg[q];
             if (SC) { float4 sc = sreg[SC ? q : 0]; v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
@@ -408,9 +410,11 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
         }
     };
 
-    f32x4 acc[NT][2];
+    f32x4 acc[NT][WM];
 #pragma unroll
-    for (int t = 0; t < NT; t++) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int mt = 0; mt < WM; mt++) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // software pipeline: slab s computes from LDS buffer s&1 while slab s+1 moves registers -> the other
     // buffer and slab s+2's global loads are in flight; one barrier per slab.
@@ -421,23 +425,23 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
     __syncthreads();
     for (int sl = 0; sl < nslab; sl++) {
         const float* Xs = lds + (DB ? (sl & 1) : 0) * TILE;
-        const float* Ws = Xs + PW_BM * PW_LS;
+        const float* Ws = Xs + BM * PW_LS;
 #pragma unroll
         for (int t16 = 0; t16 < 2; t16++) {
-            f32x4 xf[2], wf[NT];
+            f32x4 xf[WM], wf[NT];
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++)
-                xf[mt] = *reinterpret_cast<const f32x4*>(&Xs[(32 * wave + 16 * mt + li) * PW_LS + 16 * t16 + 4 * kq]);
+            for (int mt = 0; mt < WM; mt++)
+                xf[mt] = *reinterpret_cast<const f32x4*>(&Xs[(16 * WM * wave + 16 * mt + li) * PW_LS + 16 * t16 + 4 * kq]);
 #pragma unroll
             for (int t = 0; t < NT; t++)
                 wf[t] = *reinterpret_cast<const f32x4*>(&Ws[(16 * t + li) * PW_LS + 16 * t16 + 4 * kq]);
 #pragma unroll
             for (int sidx = 0; sidx < 4; sidx++) {
 #pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][sidx], xf[0][sidx], acc[t][0], 0, 0, 0);
-                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][sidx], xf[1][sidx], acc[t][1], 0, 0, 0);
-                }
+                for (int t = 0; t < NT; t++)
+#pragma unroll
+                    for (int mt = 0; mt < WM; mt++)
+                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][sidx], xf[mt][sidx], acc[t][mt], 0, 0, 0);
             }
         }
         if (sl + 1 < nslab) {
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
     float* stage = lds + wave * (16 * CS);        // 4 waves x 16 x CS floats fits in one operand tile
     const bool vec_ok = (p.N & 3) == 0;
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++) {
+    for (int mt = 0; mt < WM; mt++) {
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             int n = n0 + 16 * t + 4 * kq;
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
         // wave-private region: the wave's own LDS writes are visible to it once the LDS counter drains
         __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
-        const int mbase = m0 + 32 * wave + 16 * mt;
+        const int mbase = m0 + 16 * WM * wave + 16 * mt;
 #pragma unroll
         for (int q = 0; q < (16 * (BN / 4) + 63) / 64; q++) {
             int idx = lane + 64 * q;
@@ -543,13 +547,17 @@ void launch_pw_gemm(const PwParams& p, hipStream_t s) {
         return;
     }
     int nt = (p.nt >= 1 && p.nt <= 8) ? p.nt : pick_nt(p.M, p.N);
+    const int wm = p.wm == 1 ? 1 : 2;
+    const int bm = 64 * wm;
     int nblk_n = (p.N + nt * 16 - 1) / (nt * 16);
-    unsigned nblk = (unsigned)((p.M + PW_BM - 1) / PW_BM) * nblk_n;
+    unsigned nblk = (unsigned)((p.M + bm - 1) / bm) * nblk_n;
     dim3 grid(nblk);
     const bool sc = p.ascale != nullptr;
-#define PW_CASE(NT_) case NT_: if (sc) hipLaunchKernelGGL((k_pw_gemm<NT_, true>), grid, dim3(256), 0, s, p, nblk_n, nblk); \
-                     else hipLaunchKernelGGL((k_pw_gemm<NT_, false>), grid, dim3(256), 0, s, p, nblk_n, nblk); break;
+#define PW_LAUNCH(NT_, SC_, WM_) hipLaunchKernelGGL((k_pw_gemm<NT_, SC_, WM_>), grid, dim3(256), 0, s, p, nblk_n, nblk)
+#define PW_CASE(NT_) case NT_: if (sc) { if (wm == 1) PW_LAUNCH(NT_, true, 1); else PW_LAUNCH(NT_, true, 2); } \
+                     else { if (wm == 1) PW_LAUNCH(NT_, false, 1); else PW_LAUNCH(NT_, false, 2); } break;
     switch (nt) { PW_CASE(1) PW_CASE(2) PW_CASE(3) PW_CASE(4) PW_CASE(5) PW_CASE(6) PW_CASE(7) default: PW_CASE(8) }
+#undef PW_LAUNCH
 #undef PW_CASE
 }
 
