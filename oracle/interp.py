@@ -127,10 +127,38 @@ def _batch_reshape(x, shape, batch):
     raise ValueError(f"RESHAPE {x.shape} -> {shape} (batch {batch})")
 
 
-class Interpreter:
-    """Executes the graph for a batch of inputs (the graph itself is authored with batch 1)."""
+def _torch_conv(x, w, b, o, depthwise):
+    """Same op semantics as conv2d/depthwise_conv2d above, evaluated by torch's CPU convolution (oneDNN): used only for
+    the timed CPU baseline (bench.py cpu_baseline) where the numpy tap loops would understate what a CPU can do."""
+    import torch
+    import torch.nn.functional as F
+    N, H, W, C = x.shape
+    sh, sw = o.get("stride_h") or 1, o.get("stride_w") or 1
+    dh, dw = o.get("dil_h") or 1, o.get("dil_w") or 1
+    if depthwise:
+        kh, kw = w.shape[1], w.shape[2]
+        wt = torch.from_numpy(np.ascontiguousarray(np.transpose(w, (3, 0, 1, 2))))      # [C,1,kh,kw]
+        groups = C
+    else:
+        kh, kw = w.shape[1], w.shape[2]
+        wt = torch.from_numpy(np.ascontiguousarray(np.transpose(w, (0, 3, 1, 2))))      # [O,I,kh,kw]
+        groups = 1
+    Ho, pt, pb = _geom(H, kh, sh, dh, o.get("padding", 0))
+    Wo, pl, pr = _geom(W, kw, sw, dw, o.get("padding", 0))
+    xt = torch.from_numpy(np.ascontiguousarray(x)).permute(0, 3, 1, 2)
+    if pt or pb or pl or pr:
+        xt = F.pad(xt, (pl, pr, pt, pb))
+    y = F.conv2d(xt, wt, None if b is None else torch.from_numpy(np.ascontiguousarray(b)), stride=(sh, sw),
+                 dilation=(dh, dw), groups=groups)
+    return _act(y.permute(0, 2, 3, 1).contiguous().numpy(), o.get("act", 0))
 
-    def __init__(self, model, precision="f32"):
+
+class Interpreter:
+    """Executes the graph for a batch of inputs (the graph itself is authored with batch 1).
+    conv_backend="torch" swaps the two convolution ops for torch's CPU kernels (same semantics; fp32 only)."""
+
+    def __init__(self, model, precision="f32", conv_backend="numpy"):
+        self.conv_backend = conv_backend if precision == "f32" else "numpy"
         self.m = model if isinstance(model, Model) else read_model(model)
         assert precision in ("f32", "f64")
         self.fdt = np.float32 if precision == "f32" else np.float64
@@ -173,9 +201,15 @@ class Interpreter:
             o = op.opts
             n = op.name
             if n == "CONV_2D":
-                y = conv2d(a[0], a[1], a[2] if len(a) > 2 else None, o)
+                if self.conv_backend == "torch":
+                    y = _torch_conv(a[0], a[1], a[2] if len(a) > 2 else None, o, False)
+                else:
+                    y = conv2d(a[0], a[1], a[2] if len(a) > 2 else None, o)
             elif n == "DEPTHWISE_CONV_2D":
-                y = depthwise_conv2d(a[0], a[1], a[2] if len(a) > 2 else None, o)
+                if self.conv_backend == "torch":
+                    y = _torch_conv(a[0], a[1], a[2] if len(a) > 2 else None, o, True)
+                else:
+                    y = depthwise_conv2d(a[0], a[1], a[2] if len(a) > 2 else None, o)
             elif n == "DEQUANTIZE":
                 y = np.asarray(a[0]).astype(fdt)      # float16 -> float32 (tflite dequantize.cc, kTfLiteFloat16 branch)
             elif n == "FULLY_CONNECTED":
