@@ -114,6 +114,8 @@ int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, 
     int code = BNHIP_E_UNSUPPORTED;
     m->eng.no_reuse = json_int(opts_json, "debug_no_reuse", 0) != 0;
     m->eng.autotune = json_int(opts_json, "autotune", 1) != 0;
+    const char* genv = getenv("BNHIP_GRAPHS");           // experiment switch; the option wins when given
+    m->eng.use_graphs = json_int(opts_json, "graphs", genv ? atoi(genv) : 0) != 0;
     if (!m->eng.build(std::move(tm), device, max_batch, plan_only, &err, &code)) {
         delete m;
         return set_err(code == BNHIP_OK ? BNHIP_E_UNSUPPORTED : code, err);
@@ -140,6 +142,7 @@ int bnhip_set_stream(bnhip_model* m, void* hip_stream) {
     if (!m || m->eng.device < 0) return set_err(BNHIP_E_INVALID, "model is NULL or plan-only");
     Engine& e = m->eng;
     hipSetDevice(e.device);
+    e.drop_graphs();                                    // captured on the old stream
     if (e.own_stream && e.stream) { hipStreamSynchronize(e.stream); hipStreamDestroy(e.stream); }
     e.stream = reinterpret_cast<hipStream_t>(hip_stream);
     e.own_stream = false;

@@ -58,6 +58,8 @@ class Engine {
     int device = 0, max_batch = 256;
     bool no_reuse = false;              // diagnostics: every activation keeps its own buffer
     bool autotune = true;               // time pw_gemm tile widths per layer at create time (a few ms)
+    bool use_graphs = false;            // opt-in: replay the plan as a hipGraph once a (pointers, n) combination repeats (measured: no gain on ROCm 7.2)
+    void drop_graphs();
     void autotune_pw();
     std::map<int, int> tensor_value;    // tflite tensor index -> value id (diagnostics)
     const float* value_ptr(int v) const { return reinterpret_cast<const float*>(act_arena + vals[v].offset); }
@@ -91,6 +93,9 @@ class Engine {
     std::string profile_read();
 
   private:
+    struct GraphEntry { const float* in; float* logits; float* emb; int n; int seen; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;     // tiny cache: the host path always presents the same staging pointers
+    bool run_eager(const float* d_in, int n, float* d_logits, float* d_emb, std::string* err);
     char* act_arena = nullptr;
     size_t act_bytes = 0;
     char* w_arena = nullptr;

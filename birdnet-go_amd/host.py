@@ -96,11 +96,14 @@ def init():
 class HipClassifier:
     """inference.Classifier + EmbeddingExtractor over libbnhip.so.  NOT thread-safe (backend.go:7)."""
 
-    def __init__(self, model_bytes: bytes, device=0, max_batch=256, plan_only=False, debug_no_reuse=False):
+    def __init__(self, model_bytes: bytes, device=0, max_batch=256, plan_only=False, debug_no_reuse=False,
+                 graphs=None):
         self._lib = load_library()
         self._h = C.c_void_p()
-        opts = json.dumps({"device": device, "max_batch": max_batch, "plan_only": int(plan_only),
-                           "debug_no_reuse": int(debug_no_reuse)}).encode()
+        o = {"device": device, "max_batch": max_batch, "plan_only": int(plan_only), "debug_no_reuse": int(debug_no_reuse)}
+        if graphs is not None:
+            o["graphs"] = int(graphs)
+        opts = json.dumps(o).encode()
         buf = (C.c_char * len(model_bytes)).from_buffer_copy(model_bytes)
         _check(self._lib, self._lib.bnhip_model_create(C.cast(buf, C.c_void_p), len(model_bytes), opts, C.byref(self._h)))
         ns, nc, ed = C.c_int(), C.c_int(), C.c_int()

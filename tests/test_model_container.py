@@ -166,3 +166,11 @@ def test_dense_only_graphs_plan(built_lib):
     m = read_model(rf)
     w16 = [t for t in m.tensors if t.name == "fc0/w_f16"][0]
     assert w16.dtype == np.float16 and w16.data.shape == (64, 3)
+
+
+def test_oracle_torch_conv_backend_equals_numpy_ops(tiny_blob, tiny_cfg):
+    """bench.py's cpu_baseline runs the oracle with torch-CPU convolutions: same semantics as the numpy ops."""
+    x = sm.synth_clips(2, tiny_cfg.n_samples, tiny_cfg.sample_rate)
+    a = Interpreter(tiny_blob).invoke(x)[0]
+    b = Interpreter(tiny_blob, conv_backend="torch").invoke(x)[0]
+    assert np.abs(a - b).max() < 2e-5
