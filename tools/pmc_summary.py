@@ -1,6 +1,10 @@
 #!/usr/bin/env python
 """Per-kernel PMC sums from rocprofv3 rocpd databases (one db per --pmc pass).
-Usage: python tools/pmc_summary.py <db> [<db> ...]   -> CSV on stdout (kernel, dispatches, avg_us, counter sums per dispatch)"""
+Usage: python tools/pmc_summary.py [--traffic-json OUT] <db> [<db> ...]
+  -> CSV on stdout (kernel, dispatches, avg_us, counter sums per dispatch)
+  --traffic-json: also write {kernel: {dispatches, hbm_bytes_per_launch, fetch_kib_raw, write_kib}} where
+    hbm bytes = FETCH_SIZE[KiB] * 1024 * 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE[KiB] * 1024."""
+import json
 import re
 import sqlite3
 import sys
@@ -37,6 +41,12 @@ def main():
     cnt = defaultdict(int)
     dur = defaultdict(float)
     counters = []
+    argv = sys.argv[1:]
+    tj = None
+    if argv and argv[0] == "--traffic-json":
+        tj = argv[1]
+        argv = argv[2:]
+    sys.argv = [sys.argv[0]] + argv
     for path in sys.argv[1:]:
         disp, vals = load(path)
         seen = set()
@@ -60,6 +70,15 @@ def main():
         if not cnt[k]:
             continue
         print(f"\"{k}\",{cnt[k]},{dur[k] / cnt[k] / 1e3:.1f}," + ",".join(f"{agg[k].get(c, 0) / cnt[k]:.4g}" for c in counters))
+    if tj:
+        out = {}
+        for k in sorted(agg, key=lambda k: -dur[k]):
+            if not cnt[k] or not k.startswith("k_"):
+                continue
+            f = agg[k].get("FETCH_SIZE", 0) / cnt[k]
+            w = agg[k].get("WRITE_SIZE", 0) / cnt[k]
+            out[k] = {"dispatches": cnt[k], "hbm_bytes_per_launch": f * 1024 * 2 + w * 1024, "fetch_kib_raw": f, "write_kib": w}
+        json.dump(out, open(tj, "w"), indent=1)
 
 
 if __name__ == "__main__":
