@@ -16,7 +16,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // sigmoid via the hardware exp2/rcp units (v_exp_f32 / v_rcp_f32, ~1 ulp each).  TFLite's own LOGISTIC
 // kernels are polynomial approximations of similar accuracy, so this stays inside fp32 noise.
-__device__ __forceinline__ float fast_sigmoid(float v) { return __frcp_rn(1.0f + __expf(-v)); }
+// (__frcp_rn is NOT v_rcp_f32: it expands to the 10-instruction correctly-rounded division sequence.)
+__device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
@@ -27,6 +28,16 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case ACT_HARD_SWISH: return v * fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) / 6.0f;
         default: return v;
     }
+}
+
+// The activation code is uniform per launch.  Calling apply_act per element makes the compiler emit the whole
+// switch (compare/branch tree, plus hard-swish's IEEE division sequence) once per element; with_act() branches
+// once per call site and hands the body a branch-free functor (found in the ISA: ~170 s_branch per kernel before).
+template <typename Body>
+__device__ __forceinline__ void with_act(int act, Body&& body) {
+    if (act == ACT_SWISH) body([](float v) { return v * fast_sigmoid(v); });
+    else if (act == ACT_NONE) body([](float v) { return v; });
+    else body([act](float v) { return apply_act(v, act); });
 }
 
 // XCD-aware logical block id: the dispatcher places block b on XCD b % 8; remapping so that each XCD walks a
@@ -317,8 +328,9 @@ __global__ __launch_bounds__(256) void k_conv_direct_t(ConvParams p) {
                 a2.x = fmaf(xv, w.x, a2.x); a2.y = fmaf(xv, w.y, a2.y); a2.z = fmaf(xv, w.z, a2.z); a2.w = fmaf(xv, w.w, a2.w);
             }
     // same association as the generic kernel: sum of products first, bias added last
-    acc.x = apply_act(a2.x + acc.x, p.act); acc.y = apply_act(a2.y + acc.y, p.act);
-    acc.z = apply_act(a2.z + acc.z, p.act); acc.w = apply_act(a2.w + acc.w, p.act);
+    with_act(p.act, [&](auto f) {
+        acc.x = f(a2.x + acc.x); acc.y = f(a2.y + acc.y); acc.z = f(a2.z + acc.z); acc.w = f(a2.w + acc.w);
+    });
     reinterpret_cast<float4*>(p.out)[idx] = acc;
 }
 void launch_conv_direct(const ConvParams& p, hipStream_t s) {
@@ -460,20 +472,33 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
     constexpr int CS = BN + 4;                    // staging row stride (floats), keeps 16-byte alignment
     float* stage = lds + wave * (16 * CS);        // 4 waves x 16 x CS floats fits in one operand tile
     const bool vec_ok = (p.N & 3) == 0;
-#pragma unroll
-    for (int mt = 0; mt < WM; mt++) {
+    if (p.bias) {
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             int n = n0 + 16 * t + 4 * kq;
-            f32x4 v = acc[t][mt];
-            if (p.bias) {
+            f32x4 bq = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (vec_ok && n + 3 < p.N) { float4 t4 = *reinterpret_cast<const float4*>(p.bias + n); bq = (f32x4){t4.x, t4.y, t4.z, t4.w}; }
+            else {
 #pragma unroll
-                for (int r = 0; r < 4; r++) if (n + r < p.N) v[r] += p.bias[n + r];
+                for (int r = 0; r < 4; r++) if (n + r < p.N) bq[r] = p.bias[n + r];
             }
-            v[0] = apply_act(v[0], p.act); v[1] = apply_act(v[1], p.act);
-            v[2] = apply_act(v[2], p.act); v[3] = apply_act(v[3], p.act);
-            *reinterpret_cast<f32x4*>(&stage[li * CS + 16 * t + 4 * kq]) = v;
+#pragma unroll
+            for (int mt = 0; mt < WM; mt++) acc[t][mt] += bq;
         }
+    }
+    with_act(p.act, [&](auto f) {
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int mt = 0; mt < WM; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[t][mt][r] = f(acc[t][mt][r]);
+    });
+#pragma unroll
+    for (int mt = 0; mt < WM; mt++) {
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+            *reinterpret_cast<f32x4*>(&stage[li * CS + 16 * t + 4 * kq]) = acc[t][mt];
         // wave-private region: the wave's own LDS writes are visible to it once the LDS counter drains
         __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
@@ -625,6 +650,15 @@ __global__ __launch_bounds__(256) void k_dwconv_t(DwParams p, int CX, int PY, in
     if (live) {
         float4 bv = p.bias ? reinterpret_cast<const float4*>(p.bias)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
         float4* out4 = reinterpret_cast<float4*>(p.out) + (size_t)b * p.Ho * p.Wo * C4 + c4;
+        with_act(p.act, [&](auto f) {
+#pragma unroll
+            for (int a = 0; a < TH; a++)
+#pragma unroll
+                for (int c = 0; c < TW; c++) {
+                    float4& v = acc[a][c];
+                    v.x = f(v.x + bv.x); v.y = f(v.y + bv.y); v.z = f(v.z + bv.z); v.w = f(v.w + bv.w);
+                }
+        });
 #pragma unroll
         for (int a = 0; a < TH; a++) {
             int ho = th0 + a;
@@ -634,8 +668,6 @@ __global__ __launch_bounds__(256) void k_dwconv_t(DwParams p, int CX, int PY, in
                 int wo = tw0 + c;
                 if (wo >= p.Wo) continue;
                 float4 v = acc[a][c];
-                v.x = apply_act(v.x + bv.x, p.act); v.y = apply_act(v.y + bv.y, p.act);
-                v.z = apply_act(v.z + bv.z, p.act); v.w = apply_act(v.w + bv.w, p.act);
                 out4[((size_t)ho * p.Wo + wo) * C4] = v;
                 sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
             }
@@ -873,6 +905,15 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
             int n = n_base + 16 * it + 4 * kq;
             bq[it] = (p.be && n + 3 < p.Cmid) ? *reinterpret_cast<const float4*>(p.be + n) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        with_act(p.act_e, [&](auto f) {
+#pragma unroll
+            for (int a = 0; a < JTW; a++)
+#pragma unroll
+                for (int it = 0; it < 2; it++) {
+                    f32x4& v = acc[a][it];
+                    v[0] = f(v[0] + bq[it].x); v[1] = f(v[1] + bq[it].y); v[2] = f(v[2] + bq[it].z); v[3] = f(v[3] + bq[it].w);
+                }
+        });
 #pragma unroll
         for (int a = 0; a < JTW; a++) {
             int j = 16 * (wave + 4 * a) + li;
@@ -881,8 +922,6 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
 #pragma unroll
                 for (int it = 0; it < 2; it++) {
                     f32x4 v = acc[a][it];
-                    v[0] = apply_act(v[0] + bq[it].x, p.act_e); v[1] = apply_act(v[1] + bq[it].y, p.act_e);
-                    v[2] = apply_act(v[2] + bq[it].z, p.act_e); v[3] = apply_act(v[3] + bq[it].w, p.act_e);
                     if (xoff[a] < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
                     *reinterpret_cast<f32x4*>(&E[e + 16 * it + 4 * kq]) = v;
                 }
@@ -925,6 +964,15 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
             }
         }
         float4 bv = p.bd ? *reinterpret_cast<const float4*>(p.bd + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        with_act(p.act_d, [&](auto f) {
+#pragma unroll
+            for (int a = 0; a < SH; a++)
+#pragma unroll
+                for (int c = 0; c < SW; c++) {
+                    float4& v = acc2[a][c];
+                    v.x = f(v.x + bv.x); v.y = f(v.y + bv.y); v.z = f(v.z + bv.z); v.w = f(v.w + bv.w);
+                }
+        });
 #pragma unroll
         for (int a = 0; a < SH; a++) {
             int oh = oh0 + ty * SH + a;
@@ -934,8 +982,6 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
                 int ow = ow0 + tx * SW + c;
                 if (ow >= p.Wo) continue;
                 float4 v = acc2[a][c];
-                v.x = apply_act(v.x + bv.x, p.act_d); v.y = apply_act(v.y + bv.y, p.act_d);
-                v.z = apply_act(v.z + bv.z, p.act_d); v.w = apply_act(v.w + bv.w, p.act_d);
                 *reinterpret_cast<float4*>(p.y + (((size_t)b * p.Ho + oh) * p.Wo + ow) * p.Cmid + n) = v;
                 sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
             }

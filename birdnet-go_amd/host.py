@@ -19,7 +19,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbnhip.so")
+LIB_PATH = os.environ.get("BNHIP_LIB") or os.path.join(_HERE, "lib", "libbnhip.so")   # BNHIP_LIB: A/B a second build
 
 BNHIP_OK, E_INVALID, E_NO_DEVICE, E_MODEL, E_UNSUPPORTED, E_RUNTIME, E_NOMEM = 0, -1, -2, -3, -4, -5, -6
 
