@@ -530,8 +530,18 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                             f.wbytes = 4.0 * (C * Co + kd * kd * Co);
                             f.out = new_val(dout, (size_t)dHo * dWo * Co);
                             tv[dout] = f.out;
-                            size_t bd = (d.inputs.size() > 2 && d.inputs[2] >= 0) ? wconst(d.inputs[2]) : SIZE_MAX;
-                            add_step(f, wconst(o.inputs[1]), boff, wconst(d.inputs[1]), bd);
+                            // padded parameter copies: every load in k_expand_dw is unconditional (see kernels.hip)
+                            const int Kw = expdw_kw(C), Cp = expdw_cp(Co);
+                            std::vector<float> wep((size_t)Cp * Kw, 0.f), bep(Cp, 0.f), wdp((size_t)kd * kd * Cp, 0.f), bdp(Cp, 0.f);
+                            const float* wsrc = w.f32();
+                            for (int n = 0; n < Co; n++) memcpy(&wep[(size_t)n * Kw], wsrc + (size_t)n * C, (size_t)C * sizeof(float));
+                            if (o.inputs.size() > 2 && o.inputs[2] >= 0) memcpy(bep.data(), m.tensors[o.inputs[2]].f32(), (size_t)Co * sizeof(float));
+                            const float* dsrc = wd.f32();
+                            for (int t = 0; t < kd * kd; t++) memcpy(&wdp[(size_t)t * Cp], dsrc + (size_t)t * Co, (size_t)Co * sizeof(float));
+                            if (d.inputs.size() > 2 && d.inputs[2] >= 0) memcpy(bdp.data(), m.tensors[d.inputs[2]].f32(), (size_t)Co * sizeof(float));
+                            size_t o_we = wpush(wep.data(), wep.size()), o_be = wpush(bep.data(), bep.size());
+                            size_t o_wd = wpush(wdp.data(), wdp.size()), o_bd = wpush(bdp.data(), bdp.size());
+                            add_step(f, o_we, o_be, o_wd, o_bd);
                             break;
                         }
                     }

@@ -57,6 +57,9 @@ void launch_dwconv(const DwParams& p, float* partial, hipStream_t s);
 // fused MBConv front half: y = act_d(dwconv(act_e(x We^T + be)) + bd); partial (nullable) [B, slabs, Cmid]
 bool expdw_supported(int k, int s, int Cin, int Cmid);
 int expdw_sum_slabs(int k, int s, int Ho, int Wo);
+// parameters are the planner's padded copies: we [expdw_cp(Cmid)][expdw_kw(Cin)], be/bd [Cp], wd [k*k][Cp] (zeros beyond)
+int expdw_kw(int Cin);
+int expdw_cp(int Cmid);
 void launch_expand_dw(const float* x, const float* we, const float* be, const float* wd, const float* bd, float* y,
                       float* partial, int B, int H, int W, int Cin, int Cmid, int Ho, int Wo, int k, int s, int pt,
                       int pl, int act_e, int act_d, hipStream_t st);

@@ -784,7 +784,7 @@ void launch_dwconv(const DwParams& p, float* partial, hipStream_t s) {
 struct ExpDwParams {
     const float* x; const float* we; const float* be; const float* wd; const float* bd;
     float* y; float* partial;
-    int B, H, W, Cin, Cmid, Ho, Wo, pt, pl, act_e, act_d, tiles_h, tiles_w, cchunks;
+    int B, H, W, Cin, Cmid, Ho, Wo, pt, pl, act_e, act_d, tiles_h, tiles_w, cchunks, Kw, Cp;
 };
 #define ED_ES 36     // E row stride (floats)
 // Phase 1 feeds the MFMA straight from global memory: every footprint pixel row belongs to exactly one wave
@@ -792,6 +792,11 @@ struct ExpDwParams {
 // (the guide's "operand streamed once per block and not shared -> load straight to VGPRs" case).  Each lane
 // loads its own fragment: pixel li of tile jt, input channels 16*t16 + 4*kq .. +3 (one float4); the K order
 // inside a 16-wide slab is permuted exactly as in k_pw_gemm.  The 32 x K weight panel is tiny and L1/L2 resident.
+// The planner hands over padded parameters (expand weights [Cp][Kw], Kw = Cin rounded up to 16 with zero
+// columns, Cp = Cmid rounded up to 32; biases and taps padded to Cp) so that every load in the kernel is
+// unconditional: pixels outside the image read a clamped (valid) address and are masked when E is written, the
+// K tail multiplies finite activations by zero weights.  All small parameter loads (biases, taps) are issued at
+// the top so their latency overlaps phase 1 (ISA check: they used to sit behind s_waitcnt vmcnt(0) mid-kernel).
 template <int K, int S, int TOH, int TOW>
 __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk) {
     constexpr int TIH = (TOH - 1) * S + K, TIW = (TOW - 1) * S + K;
@@ -799,10 +804,10 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
     constexpr int JT = NPIXP / 16, JTW = (JT + 3) / 4;
     constexpr int SH = TOH / 4, SW = TOW / 8;                 // outputs per thread in phase 2 (thread-tiles are 4 x 8)
     constexpr int RW = (SW - 1) * S + K;
-    __shared__ __attribute__((aligned(16))) float lds[NPIX * ED_ES + 1024 + K * K * 32];
+    __shared__ __attribute__((aligned(16))) float lds[NPIX * ED_ES + 128 + K * K * 32];
     float* E = lds;                                                      // [NPIX][36] expanded footprint
-    float4* red = reinterpret_cast<float4*>(lds + NPIX * ED_ES);         // [256] sum scratch
-    float4* wds = reinterpret_cast<float4*>(lds + NPIX * ED_ES + 1024);  // [K*K][8] depthwise taps of this chunk
+    float4* red = reinterpret_cast<float4*>(lds + NPIX * ED_ES);         // [4 waves][8] sum scratch
+    float4* wds = reinterpret_cast<float4*>(lds + NPIX * ED_ES + 128);   // [K*K][8] depthwise taps of this chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
 
@@ -818,51 +823,50 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
     const int vr0 = max(ih0, 0) - ih0, vr1 = min(ih0 + TIH, p.H) - ih0;
     const int nvalid = (vr1 - vr0) * TIW;
     const int jtv = (nvalid + 15) >> 4;
-    const int Cin = p.Cin;
+    const int Cin = p.Cin, Kw = p.Kw;
     const int n_base = cc * 32;
 
-    // depthwise taps for this 32-channel chunk -> LDS now (latency hides behind phase 1; read after the barrier)
-    if (tid < K * K * 8) {
-        int tap = tid >> 3, q = tid & 7;
-        int nq = cc * 32 + 4 * q;
-        wds[tid] = nq < p.Cmid ? *reinterpret_cast<const float4*>(p.wd + (size_t)tap * p.Cmid + nq) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    // ---- small parameters first (registers; the taps go to LDS after phase 1)
+    const int c4 = tid & 7, tt = tid >> 3;
+    float4 wdreg = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < K * K * 8) wdreg = *reinterpret_cast<const float4*>(p.wd + (size_t)(tid >> 3) * p.Cp + n_base + 4 * (tid & 7));
+    const float4 bq0 = *reinterpret_cast<const float4*>(p.be + n_base + 4 * kq);
+    const float4 bq1 = *reinterpret_cast<const float4*>(p.be + n_base + 16 + 4 * kq);
+    const float4 bv = *reinterpret_cast<const float4*>(p.bd + n_base + 4 * c4);
+
     if (nvalid < NPIX) {      // rows outside the image are zero padding of the expanded tensor
         for (int i = tid; i < vr0 * TIW * (ED_ES / 4); i += 256) reinterpret_cast<float4*>(E)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = vr1 * TIW * (ED_ES / 4) + tid; i < NPIX * (ED_ES / 4); i += 256)
             reinterpret_cast<float4*>(E)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
-    // this lane's pixel per owned tile (a): global offset (or -1) and validity
+    // this lane's pixel per owned tile (a): clamped global offset + validity
     int xoff[JTW];
+    bool xin[JTW];
 #pragma unroll
     for (int a = 0; a < JTW; a++) {
         int j = 16 * (wave + 4 * a) + li;
         int r = j / TIW, c = j - r * TIW;
         int iw = iw0 + c;
-        xoff[a] = (j < nvalid && iw >= 0 && iw < p.W) ? (((b * p.H + ih0 + vr0 + r) * p.W) + iw) * Cin + 4 * kq : -1;
+        xin[a] = j < nvalid && iw >= 0 && iw < p.W;
+        int ihc = min(ih0 + vr0 + r, p.H - 1), iwc = min(max(iw, 0), p.W - 1);
+        xoff[a] = (((b * p.H + ihc) * p.W) + iwc) * Cin + 4 * kq;
     }
-    const float* wrow0 = p.we + (size_t)min(n_base + li, p.Cmid - 1) * Cin + 4 * kq;
-    const float* wrow1 = p.we + (size_t)min(n_base + 16 + li, p.Cmid - 1) * Cin + 4 * kq;
+    const float* wrow0 = p.we + (size_t)(n_base + li) * Kw + 4 * kq;
+    const float* wrow1 = wrow0 + (size_t)16 * Kw;
 
     f32x4 acc[JTW][2];
 #pragma unroll
     for (int a = 0; a < JTW; a++) { acc[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     auto fload = [&](int k0, f32x4& wf0, f32x4& wf1, f32x4 (&xf)[JTW]) {
-        const bool kin = k0 + 4 * kq < Cin;       // Cin is a multiple of 4
-        wf0 = (f32x4){0.f, 0.f, 0.f, 0.f}; wf1 = wf0;
-        if (kin) {
-            float4 t0 = *reinterpret_cast<const float4*>(wrow0 + k0), t1 = *reinterpret_cast<const float4*>(wrow1 + k0);
-            wf0 = (f32x4){t0.x, t0.y, t0.z, t0.w}; wf1 = (f32x4){t1.x, t1.y, t1.z, t1.w};
-        }
+        float4 t0 = *reinterpret_cast<const float4*>(wrow0 + k0), t1 = *reinterpret_cast<const float4*>(wrow1 + k0);
+        wf0 = (f32x4){t0.x, t0.y, t0.z, t0.w}; wf1 = (f32x4){t1.x, t1.y, t1.z, t1.w};
+        const int kx = (k0 + 4 * kq < Cin) ? k0 : -4 * kq;     // K tail: any in-bounds address (its weights are zero)
 #pragma unroll
         for (int a = 0; a < JTW; a++) {
-            xf[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (xoff[a] >= 0 && kin) {
-                float4 t = *reinterpret_cast<const float4*>(p.x + (size_t)xoff[a] + k0);
-                xf[a] = (f32x4){t.x, t.y, t.z, t.w};
-            }
+            float4 t = *reinterpret_cast<const float4*>(p.x + (size_t)xoff[a] + kx);
+            xf[a] = (f32x4){t.x, t.y, t.z, t.w};
         }
     };
     auto fmma = [&](const f32x4& wf0, const f32x4& wf1, const f32x4 (&xf)[JTW]) {
@@ -877,11 +881,11 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
             }
         }
     };
-    if (Cin <= 16) {
+    if (Kw <= 16) {
         f32x4 wA0, wA1, xA[JTW];
         fload(0, wA0, wA1, xA);
         fmma(wA0, wA1, xA);
-    } else if (Cin <= 32) {
+    } else if (Kw <= 32) {
         // early blocks (Cin 17..32): both K slabs requested back-to-back -> one memory latency instead of two
         f32x4 wA0, wA1, xA[JTW], wB0, wB1, xB[JTW];
         fload(0, wA0, wA1, xA);
@@ -890,7 +894,7 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
         fmma(wB0, wB1, xB);
     } else {
         // (a rolling two-slab register prefetch was measured here: the extra VGPRs cost more occupancy than it buys)
-        for (int k0 = 0; k0 < Cin; k0 += 16) {
+        for (int k0 = 0; k0 < Kw; k0 += 16) {
             f32x4 wf0, wf1, xf[JTW];
             fload(k0, wf0, wf1, xf);
             fmma(wf0, wf1, xf);
@@ -898,40 +902,29 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
     }
 
     // ---- E <- act_e(acc + be) at footprint coordinates (masked columns are zero)
-    {
-        float4 bq[2];
-#pragma unroll
-        for (int it = 0; it < 2; it++) {
-            int n = n_base + 16 * it + 4 * kq;
-            bq[it] = (p.be && n + 3 < p.Cmid) ? *reinterpret_cast<const float4*>(p.be + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        with_act(p.act_e, [&](auto f) {
-#pragma unroll
-            for (int a = 0; a < JTW; a++)
-#pragma unroll
-                for (int it = 0; it < 2; it++) {
-                    f32x4& v = acc[a][it];
-                    v[0] = f(v[0] + bq[it].x); v[1] = f(v[1] + bq[it].y); v[2] = f(v[2] + bq[it].z); v[3] = f(v[3] + bq[it].w);
-                }
-        });
+    with_act(p.act_e, [&](auto f) {
 #pragma unroll
         for (int a = 0; a < JTW; a++) {
-            int j = 16 * (wave + 4 * a) + li;
-            if (j < nvalid) {
-                int e = (vr0 * TIW + j) * ED_ES;
+            f32x4& v0 = acc[a][0];
+            f32x4& v1 = acc[a][1];
+            v0[0] = f(v0[0] + bq0.x); v0[1] = f(v0[1] + bq0.y); v0[2] = f(v0[2] + bq0.z); v0[3] = f(v0[3] + bq0.w);
+            v1[0] = f(v1[0] + bq1.x); v1[1] = f(v1[1] + bq1.y); v1[2] = f(v1[2] + bq1.z); v1[3] = f(v1[3] + bq1.w);
+        }
+    });
 #pragma unroll
-                for (int it = 0; it < 2; it++) {
-                    f32x4 v = acc[a][it];
-                    if (xoff[a] < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    *reinterpret_cast<f32x4*>(&E[e + 16 * it + 4 * kq]) = v;
-                }
-            }
+    for (int a = 0; a < JTW; a++) {
+        int j = 16 * (wave + 4 * a) + li;
+        if (j < nvalid) {
+            int e = (vr0 * TIW + j) * ED_ES + 4 * kq;
+            const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&E[e]) = xin[a] ? acc[a][0] : z;
+            *reinterpret_cast<f32x4*>(&E[e + 16]) = xin[a] ? acc[a][1] : z;
         }
     }
+    if (tid < K * K * 8) wds[tid] = wdreg;
     __syncthreads();
 
     // ---- depthwise from LDS
-    const int c4 = tid & 7, tt = tid >> 3;
     const int ty = tt >> 3, tx = tt & 7;
     const int n = n_base + 4 * c4;
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -963,7 +956,6 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
                 }
             }
         }
-        float4 bv = p.bd ? *reinterpret_cast<const float4*>(p.bd + n) : make_float4(0.f, 0.f, 0.f, 0.f);
         with_act(p.act_d, [&](auto f) {
 #pragma unroll
             for (int a = 0; a < SH; a++)
@@ -988,16 +980,25 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
         }
     }
     if (p.partial) {
-        red[tid] = sum;
+        // lanes with equal (lane & 7) hold the same channel quad: butterfly over the other lane bits, then 4 waves
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+            sum.x += __shfl_xor(sum.x, o, 64); sum.y += __shfl_xor(sum.y, o, 64);
+            sum.z += __shfl_xor(sum.z, o, 64); sum.w += __shfl_xor(sum.w, o, 64);
+        }
+        if (lane < 8) red[wave * 8 + lane] = sum;
         __syncthreads();
         if (tid < 8 && n_base + 4 * tid < p.Cmid) {
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int y = 0; y < 32; y++) { float4 v = red[y * 8 + tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            float4 t = red[tid];
+#pragma unroll
+            for (int w = 1; w < 4; w++) { float4 v = red[w * 8 + tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
             *reinterpret_cast<float4*>(p.partial + ((size_t)b * tiles + tile) * p.Cmid + n_base + 4 * tid) = t;
         }
     }
 }
 
+int expdw_kw(int Cin) { return (Cin + 15) / 16 * 16; }
+int expdw_cp(int Cmid) { return (Cmid + 31) / 32 * 32; }
 static bool expdw_tile(int k, int s, int Ho, int* toh, int* tow) {
     if (!((k == 3 || k == 5) && (s == 1 || s == 2))) return false;
     if (s == 2) { *toh = 4; *tow = 8; return true; }
@@ -1022,7 +1023,7 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
     int toh, tow;
     expdw_tile(k, s, Ho, &toh, &tow);
     ExpDwParams p{x, we, be, wd, bd, y, partial, B, H, W, Cin, Cmid, Ho, Wo, pt, pl, act_e, act_d,
-                  (Ho + toh - 1) / toh, (Wo + tow - 1) / tow, (Cmid + 31) / 32};
+                  (Ho + toh - 1) / toh, (Wo + tow - 1) / tow, (Cmid + 31) / 32, expdw_kw(Cin), expdw_cp(Cmid)};
     unsigned nblk = (unsigned)B * p.tiles_h * p.tiles_w * p.cchunks;
 #define ED_LAUNCH(K_, S_, TH_, TW_) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_>), dim3(nblk), dim3(256), 0, st, p, nblk)
     if (s == 2) { if (k == 3) ED_LAUNCH(3, 2, 4, 8); else ED_LAUNCH(5, 2, 4, 8); }
