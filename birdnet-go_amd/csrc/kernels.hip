@@ -136,16 +136,39 @@ __global__ __launch_bounds__(256 * WN) void k_frontend(FrontendParams p) {
         const float2 mm = p.mm[b];
         const float* xc = p.x + (size_t)b * p.n_samples;
         const int s0 = f0 * p.hop;
-        for (int i = tid; i < seg_len; i += NTHR) {
-            int g = s0 + i;
-            float v = 0.0f;
-            if (g < p.n_samples && i < seg_len - 4) {
-                float t = xc[g] - mm.x;
-                t = t / mm.y;
-                t = t - p.norm_sub;
-                v = t * p.norm_mul;
+        // all of this thread's loads are issued before the first use: the rolled one-load-per-iteration loop exposed
+        // the global latency ~38 times per block, and with one block per CU nothing else covers it
+        auto norm = [&](float x) { float t = x - mm.x; t = t / mm.y; t = t - p.norm_sub; return t * p.norm_mul; };
+        const int lim = min(seg_len - 4, p.n_samples - s0);      // samples of this segment that exist
+        if ((((size_t)xc & 15) | (s0 & 3)) == 0) {
+            constexpr int UN = 10;
+            const int nq = (seg_len + 3) >> 2;
+            for (int q0 = tid; q0 < nq; q0 += NTHR * UN) {
+                float4 v[UN];
+#pragma unroll
+                for (int u = 0; u < UN; u++) {
+                    int q = q0 + u * NTHR;
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (4 * q + 3 < lim) v[u] = *reinterpret_cast<const float4*>(xc + s0 + 4 * q);
+                    else if (4 * q < lim) {
+                        v[u].x = xc[s0 + 4 * q];
+                        if (4 * q + 1 < lim) v[u].y = xc[s0 + 4 * q + 1];
+                        if (4 * q + 2 < lim) v[u].z = xc[s0 + 4 * q + 2];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UN; u++) {
+                    int q = q0 + u * NTHR;
+                    if (q < nq) {
+                        float4 o;
+                        o.x = 4 * q < lim ? norm(v[u].x) : 0.f; o.y = 4 * q + 1 < lim ? norm(v[u].y) : 0.f;
+                        o.z = 4 * q + 2 < lim ? norm(v[u].z) : 0.f; o.w = 4 * q + 3 < lim ? norm(v[u].w) : 0.f;
+                        *reinterpret_cast<float4*>(seg + 4 * q) = o;
+                    }
+                }
             }
-            seg[i] = v;
+        } else {
+            for (int i = tid; i < seg_len; i += NTHR) seg[i] = i < lim ? norm(xc[s0 + i]) : 0.0f;
         }
         for (int i = tid; i < p.Kp; i += NTHR) { win[i] = p.window[i]; win2[i] = p.window[p.Kp + i]; }
     }
@@ -176,32 +199,62 @@ __global__ __launch_bounds__(256 * WN) void k_frontend(FrontendParams p) {
 #pragma unroll
     for (int t = 0; t < NTW; t++) acc[t] = (f64x4){0., 0., 0., 0.};
 
+    // Register pipeline, one chunk deep: while the 8*NTW MFMAs of chunk ch run from registers, the operands of
+    // chunk ch+1 are fetched from LDS (folded window products + G fragments) and G(ch+2) travels global -> regs ->
+    // LDS.  (ISA of the previous version: every k-step was ds_read -> s_waitcnt lgkmcnt(0) -> mfma, i.e. the LDS
+    // latency was exposed 8 times per chunk with only two waves per SIMD to cover it: 41 % of the f64 MFMA peak.)
+    constexpr int KS = FE_KC / 4;
     const int nchunks = p.Kp / FE_KC;
-    gload(0);
-    gstore(0);
-    __syncthreads();
     const float* arow = seg + (16 * wave + li) * p.hop + kq;                 // x[f*hop + n']
     const float* mrow = seg + (16 * wave + li) * p.hop + p.Lfft - kq;        // x[f*hop + N - n']
-    for (int ch = 0; ch < nchunks; ch++) {
-        if (ch + 1 < nchunks) gload(ch + 1);
+    auto fetch = [&](int ch, double (&av)[KS], double (&bm)[KS][NTW]) {
         const double* gb = Gs + (ch & 1) * FE_KC * GS + kq * GS + nh * NTW * 16 + li;
         const float* ab = arow + ch * FE_KC;
         const float* mb = mrow - ch * FE_KC;
         const float* wb = win + ch * FE_KC + kq;
         const float* wb2 = win2 + ch * FE_KC + kq;
 #pragma unroll
-        for (int kk = 0; kk < FE_KC / 4; kk++) {
+        for (int kk = 0; kk < KS; kk++) {
             float xw = ab[kk * 4] * wb[kk * 4];          // fp32 products, rounded like the graph's window MUL
             float xm = mb[-kk * 4] * wb2[kk * 4];
-            double a = (double)xw + (double)xm;          // exact fold in fp64
+            av[kk] = (double)xw + (double)xm;            // exact fold in fp64
 #pragma unroll
-            for (int t = 0; t < NTW; t++) {
-                double bv = gb[kk * 4 * GS + t * 16];
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[t], 0, 0, 0);
-            }
+            for (int t = 0; t < NTW; t++) bm[kk][t] = gb[kk * 4 * GS + t * 16];
         }
-        if (ch + 1 < nchunks) gstore((ch + 1) & 1);
+    };
+    auto mma = [&](const double (&av)[KS], const double (&bm)[KS][NTW]) {
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++)
+#pragma unroll
+            for (int t = 0; t < NTW; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bm[kk][t], acc[t], 0, 0, 0);
+    };
+    double a0[KS], b0[KS][NTW], a1[KS], b1[KS][NTW];
+    gload(0);
+    gstore(0);
+    if (nchunks > 1) gload(1);
+    __syncthreads();
+    fetch(0, a0, b0);
+    if (nchunks > 1) gstore(1);
+    __syncthreads();
+    // iteration invariant: (a0,b0) = chunk ch in registers, LDS buffer (ch+1)&1 = G(ch+1) visible to all
+    auto iter = [&](int ch, double (&ac)[KS], double (&bc)[KS][NTW], double (&an)[KS], double (&bn)[KS][NTW]) {
+        if (ch + 2 < nchunks) gload(ch + 2);
+        // unconditional (the last iteration re-reads its own chunk, unused) so that fetch and the MFMA burst share a
+        // basic block; the group barriers then interleave them: each 64-cycle f64 MFMA leaves 15 issue slots
+        fetch(min(ch + 1, nchunks - 1), an, bn);
+        mma(ac, bc);
+#pragma unroll
+        for (int i = 0; i < KS * NTW; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 LDS reads
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // 3 VALU
+        }
+        if (ch + 2 < nchunks) gstore(ch & 1);       // buffer ch&1 was last read (chunk ch) before the previous barrier
         __syncthreads();
+    };
+    for (int ch = 0; ch < nchunks; ch += 2) {
+        iter(ch, a0, b0, a1, b1);
+        if (ch + 1 < nchunks) iter(ch + 1, a1, b1, a0, b0);
     }
 
     // ---- epilogue: f64 C/D layout D[row = kq + 4*r][col = li]  (row = frame, col = mel)
