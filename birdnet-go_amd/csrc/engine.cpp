@@ -413,8 +413,8 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
             const FrontendMatch& fm = fms[i];
             FrontSpec fs;
             fs.L = fm.L; fs.Lfft = fm.Lfft; fs.hop = fm.hop; fs.F = fm.F; fs.n_mels = fm.n_mels; fs.c = chan_of[i];
-            fs.Kp = (int)align_up(fm.Lfft / 2 + 1, kFrontendKC);
             fs.NTP = (int)align_up(fm.n_mels, 16);
+            fs.Kp = (int)align_up(fm.Lfft / 2 + 1, frontend_kc(fm.Lfft, fm.hop, fs.NTP));
             if (fs.NTP > 128) { *err = "front-end: more than 128 mel bins unsupported"; return false; }
             if (fm.eps != fms[0].eps || fm.norm_sub != fms[0].norm_sub || fm.norm_mul != fms[0].norm_mul) {
                 *err = "front-end: branches use different normalisation constants";

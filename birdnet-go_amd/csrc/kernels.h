@@ -27,7 +27,7 @@ struct FrontendParams {
 };
 void launch_frontend(const FrontendParams& p, hipStream_t s);
 size_t frontend_lds_bytes(int Lfft, int Kp, int hop, int NTP);
-constexpr int kFrontendKC = 32;   // K-chunk of the front-end GEMM (G rows per LDS stage)
+int frontend_kc(int Lfft, int hop, int NTP);   // K-chunk of the front-end GEMM (G rows per LDS stage): 16 or 32; Kp is padded to it
 
 // ---- CNN
 struct ConvParams {       // direct conv, small Cin (stem)

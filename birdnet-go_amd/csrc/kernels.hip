@@ -8,6 +8,7 @@
 #include "kernels.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 namespace bnhip {
@@ -108,27 +109,34 @@ void launch_clip_minmax(const float* x, int n_clips, int n_samples, float eps, f
 //   a[n'] = double(fl32(x[n']*w[n'])) + double(fl32(x[N-n']*w[N-n']))   (exact in fp64), n' = 0..N/2,
 // halving the contraction length (K = N/2+1) at no cost in accuracy.
 // Block: 64 frames x (16*NT) mel columns, 4 waves, wave w owns frames [16w,16w+16) x all NT tiles.
-#define FE_FT 64
-#define FE_KC 32
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-template <int NT, int WN>
-__global__ __launch_bounds__(256 * WN) void k_frontend(FrontendParams p) {
+// Tile parameters: FT frames x all mel tiles per block, waves = (FT/16 frame groups) x (WN mel groups), G streamed
+// in KC-row chunks.  Two shapes are instantiated:
+//   <FT 32, KC 16>: ~80 KB of LDS -> two blocks per CU (measured 3 % faster than the 64-frame shape);
+//   <FT 64, KC 32|16>: fallback when the smaller shape's LDS does not allow two blocks anyway.
+// Measured ceilings on MI355X (tools/ubench/mfma_f64*.hip): the f64 MFMA sustains 68 TF with two waves per SIMD and
+// nothing else; FP VALU work does NOT overlap it (2 v_mul_f32 per MFMA -> 54 TF, 8 -> 49 TF; integer VALU is free) and
+// an LDS read consumed right away costs far more (1 per MFMA -> 57 TF, 4 -> 38 TF).  This kernel needs 5 FP ops per
+// 3 MFMAs to build the folded A operand, which bounds it near 55 TF; it reaches 39 TF (ch0) / 33 TF (ch1).
+template <int NT, int WN, int FT, int KC>
+__global__ __launch_bounds__(64 * (FT / 16) * WN) void k_frontend(FrontendParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NTP = NT * 16;
-    constexpr int NTW = NT / WN;                 // mel tiles per wave (waves are 4 frame-groups x WN mel-groups)
-    constexpr int NTHR = 256 * WN;
+    constexpr int NTW = NT / WN;                 // mel tiles per wave
+    constexpr int FG = FT / 16;                  // frame groups
+    constexpr int NTHR = 64 * FG * WN;
     constexpr int GS = NTP + 16;                 // LDS row stride (doubles): k-rows land 32 banks apart for ds_read_b64
-    constexpr int GQ = (NT * 128 + NTHR - 1) / NTHR;   // double4 (32 B) per thread per chunk
-    const int seg_len = (FE_FT - 1) * p.hop + p.Lfft + 4;   // +4: the n'=0 mirror reads one past the frame (weight 0)
+    constexpr int GQ = (KC * (NTP / 4) + NTHR - 1) / NTHR;   // double4 (32 B) per thread per chunk
+    const int seg_len = (FT - 1) * p.hop + p.Lfft + 4;      // +4: the n'=0 mirror reads one past the frame (weight 0)
     float* seg = smem;
     float* win = smem + ((seg_len + 3) & ~3);                // [Kp] window at n'
     float* win2 = win + p.Kp;                                // [Kp] window at the mirror index (0 where there is none)
-    double* Gs = reinterpret_cast<double*>(win2 + p.Kp);     // Kp is a multiple of 32 -> 16-byte aligned
+    double* Gs = reinterpret_cast<double*>(win2 + p.Kp);     // Kp is a multiple of 16 -> 16-byte aligned
 
     const int b = blockIdx.y;
-    const int f0 = blockIdx.x * FE_FT;
+    const int f0 = blockIdx.x * FT;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = (tid >> 6) & 3, nh = tid >> 8;
+    const int lane = tid & 63, wave = (tid >> 6) % FG, nh = (tid >> 6) / FG;
     const int li = lane & 15, kq = lane >> 4;
 
     // ---- stage + normalise the clip segment ((x - min) / (range+eps) - 0.5) * 2, exactly the graph's op order
@@ -136,8 +144,8 @@ __global__ __launch_bounds__(256 * WN) void k_frontend(FrontendParams p) {
         const float2 mm = p.mm[b];
         const float* xc = p.x + (size_t)b * p.n_samples;
         const int s0 = f0 * p.hop;
-        // all of this thread's loads are issued before the first use: the rolled one-load-per-iteration loop exposed
-        // the global latency ~38 times per block, and with one block per CU nothing else covers it
+        // all of this thread's loads are issued before the first use (a rolled one-load-per-iteration loop exposes
+        // the global latency once per element)
         auto norm = [&](float x) { float t = x - mm.x; t = t / mm.y; t = t - p.norm_sub; return t * p.norm_mul; };
         const int lim = min(seg_len - 4, p.n_samples - s0);      // samples of this segment that exist
         if ((((size_t)xc & 15) | (s0 & 3)) == 0) {
@@ -173,24 +181,26 @@ __global__ __launch_bounds__(256 * WN) void k_frontend(FrontendParams p) {
         for (int i = tid; i < p.Kp; i += NTHR) { win[i] = p.window[i]; win2[i] = p.window[p.Kp + i]; }
     }
 
+    // G chunks travel global -> registers (two stages: the load for chunk c+3 is issued while chunk c computes, so it
+    // has two full iterations to arrive; one iteration is shorter than the L2 latency under load) -> LDS (2 buffers)
     const double4* G4 = reinterpret_cast<const double4*>(p.G);
-    double4 greg[GQ];
-    auto gload = [&](int chunk) {
+    double4 greg[2][GQ];
+    auto gload = [&](int chunk, double4 (&gr)[GQ]) {
 #pragma unroll
         for (int q = 0; q < GQ; q++) {
             int idx = tid + NTHR * q;
             double4 v = make_double4(0., 0., 0., 0.);
-            if (idx < FE_KC * (NTP / 4)) v = G4[(size_t)chunk * FE_KC * (NTP / 4) + idx];
-            greg[q] = v;
+            if (idx < KC * (NTP / 4)) v = G4[(size_t)chunk * KC * (NTP / 4) + idx];
+            gr[q] = v;
         }
     };
-    auto gstore = [&](int buf) {
+    auto gstore = [&](int buf, const double4 (&gr)[GQ]) {
 #pragma unroll
         for (int q = 0; q < GQ; q++) {
             int idx = tid + NTHR * q;
-            if (idx < FE_KC * (NTP / 4)) {
+            if (idx < KC * (NTP / 4)) {
                 int r = idx / (NTP / 4), c4 = idx % (NTP / 4);
-                *reinterpret_cast<double4*>(&Gs[buf * FE_KC * GS + r * GS + 4 * c4]) = greg[q];
+                *reinterpret_cast<double4*>(&Gs[buf * KC * GS + r * GS + 4 * c4]) = gr[q];
             }
         }
     };
@@ -199,20 +209,20 @@ __global__ __launch_bounds__(256 * WN) void k_frontend(FrontendParams p) {
 #pragma unroll
     for (int t = 0; t < NTW; t++) acc[t] = (f64x4){0., 0., 0., 0.};
 
-    // Register pipeline, one chunk deep: while the 8*NTW MFMAs of chunk ch run from registers, the operands of
+    // Register pipeline, one chunk deep: while the KS*NTW MFMAs of chunk ch run from registers, the operands of
     // chunk ch+1 are fetched from LDS (folded window products + G fragments) and G(ch+2) travels global -> regs ->
-    // LDS.  (ISA of the previous version: every k-step was ds_read -> s_waitcnt lgkmcnt(0) -> mfma, i.e. the LDS
-    // latency was exposed 8 times per chunk with only two waves per SIMD to cover it: 41 % of the f64 MFMA peak.)
-    constexpr int KS = FE_KC / 4;
-    const int nchunks = p.Kp / FE_KC;
+    // LDS.  (ISA of the first version: every k-step was ds_read -> s_waitcnt lgkmcnt(0) -> mfma, i.e. the LDS
+    // latency was exposed once per k-step with only two waves per SIMD to cover it.)
+    constexpr int KS = KC / 4;
+    const int nchunks = p.Kp / KC;
     const float* arow = seg + (16 * wave + li) * p.hop + kq;                 // x[f*hop + n']
     const float* mrow = seg + (16 * wave + li) * p.hop + p.Lfft - kq;        // x[f*hop + N - n']
     auto fetch = [&](int ch, double (&av)[KS], double (&bm)[KS][NTW]) {
-        const double* gb = Gs + (ch & 1) * FE_KC * GS + kq * GS + nh * NTW * 16 + li;
-        const float* ab = arow + ch * FE_KC;
-        const float* mb = mrow - ch * FE_KC;
-        const float* wb = win + ch * FE_KC + kq;
-        const float* wb2 = win2 + ch * FE_KC + kq;
+        const double* gb = Gs + (ch & 1) * KC * GS + kq * GS + nh * NTW * 16 + li;
+        const float* ab = arow + ch * KC;
+        const float* mb = mrow - ch * KC;
+        const float* wb = win + ch * KC + kq;
+        const float* wb2 = win2 + ch * KC + kq;
 #pragma unroll
         for (int kk = 0; kk < KS; kk++) {
             float xw = ab[kk * 4] * wb[kk * 4];          // fp32 products, rounded like the graph's window MUL
@@ -229,16 +239,19 @@ __global__ __launch_bounds__(256 * WN) void k_frontend(FrontendParams p) {
             for (int t = 0; t < NTW; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bm[kk][t], acc[t], 0, 0, 0);
     };
     double a0[KS], b0[KS][NTW], a1[KS], b1[KS][NTW];
-    gload(0);
-    gstore(0);
-    if (nchunks > 1) gload(1);
+    gload(0, greg[0]);
+    if (nchunks > 1) gload(1, greg[1]);
+    gstore(0, greg[0]);
+    if (nchunks > 2) gload(2, greg[0]);
     __syncthreads();
     fetch(0, a0, b0);
-    if (nchunks > 1) gstore(1);
+    if (nchunks > 1) gstore(1, greg[1]);
     __syncthreads();
-    // iteration invariant: (a0,b0) = chunk ch in registers, LDS buffer (ch+1)&1 = G(ch+1) visible to all
-    auto iter = [&](int ch, double (&ac)[KS], double (&bc)[KS][NTW], double (&an)[KS], double (&bn)[KS][NTW]) {
-        if (ch + 2 < nchunks) gload(ch + 2);
+    // iteration invariant: (ac,bc) = chunk ch in registers, LDS buffer (ch+1)&1 = G(ch+1) visible to all
+    // (ac,bc) = chunk ch in registers, LDS buffer (ch+1)&1 = G(ch+1) visible to all, gc = G(ch+2) in flight/registers
+    auto iter = [&](int ch, double (&ac)[KS], double (&bc)[KS][NTW], double (&an)[KS], double (&bn)[KS][NTW],
+                    double4 (&gc)[GQ], double4 (&gn)[GQ]) {
+        if (ch + 3 < nchunks) gload(ch + 3, gn);
         // unconditional (the last iteration re-reads its own chunk, unused) so that fetch and the MFMA burst share a
         // basic block; the group barriers then interleave them: each 64-cycle f64 MFMA leaves 15 issue slots
         fetch(min(ch + 1, nchunks - 1), an, bn);
@@ -249,12 +262,12 @@ __global__ __launch_bounds__(256 * WN) void k_frontend(FrontendParams p) {
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 LDS reads
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // 3 VALU
         }
-        if (ch + 2 < nchunks) gstore(ch & 1);       // buffer ch&1 was last read (chunk ch) before the previous barrier
+        if (ch + 2 < nchunks) gstore(ch & 1, gc);   // buffer ch&1 was last read (chunk ch) before the previous barrier
         __syncthreads();
     };
     for (int ch = 0; ch < nchunks; ch += 2) {
-        iter(ch, a0, b0, a1, b1);
-        if (ch + 1 < nchunks) iter(ch + 1, a1, b1, a0, b0);
+        iter(ch, a0, b0, a1, b1, greg[0], greg[1]);
+        if (ch + 1 < nchunks) iter(ch + 1, a1, b1, a0, b0, greg[1], greg[0]);
     }
 
     // ---- epilogue: f64 C/D layout D[row = kq + 4*r][col = li]  (row = frame, col = mel)
@@ -274,22 +287,47 @@ __global__ __launch_bounds__(256 * WN) void k_frontend(FrontendParams p) {
     }
 }
 
+static size_t fe_lds_bytes(int FT, int KC, int Lfft, int Kp, int hop, int NTP) {
+    int seg_len = (FT - 1) * hop + Lfft + 4;
+    return (size_t)(((seg_len + 3) & ~3) + 2 * Kp) * sizeof(float) + (size_t)2 * KC * (NTP + 16) * sizeof(double);
+}
+// two blocks of the 32-frame shape must fit in the CU's 160 KB, otherwise the 64-frame shape is used
+static bool fe_small_shape(int Lfft, int Kp, int hop, int NTP) {
+    return 2 * (fe_lds_bytes(32, 16, Lfft, Kp, hop, NTP) + 512) <= 160 * 1024;
+}
+int frontend_kc(int Lfft, int hop, int NTP) {
+    int Kp16 = (Lfft / 2 + 1 + 15) / 16 * 16;
+    return fe_small_shape(Lfft, Kp16, hop, NTP) ? 16 : 32;
+}
 size_t frontend_lds_bytes(int Lfft, int Kp, int hop, int NTP) {
-    int seg_len = (FE_FT - 1) * hop + Lfft + 4;
-    return (size_t)(((seg_len + 3) & ~3) + 2 * Kp) * sizeof(float) + (size_t)2 * FE_KC * (NTP + 16) * sizeof(double);
+    return fe_small_shape(Lfft, Kp, hop, NTP) ? fe_lds_bytes(32, 16, Lfft, Kp, hop, NTP) : fe_lds_bytes(64, Kp % 32 ? 16 : 32, Lfft, Kp, hop, NTP);
 }
 
-template <int NT, int WN>
-static void launch_frontend_nt(const FrontendParams& p, hipStream_t s) {
-    size_t lds = frontend_lds_bytes(p.Lfft, p.Kp, p.hop, p.NTP);
+template <int NT, int WN, int FT, int KC>
+static void launch_frontend_shape(const FrontendParams& p, hipStream_t s) {
+    size_t lds = fe_lds_bytes(FT, KC, p.Lfft, p.Kp, p.hop, p.NTP);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frontend<NT, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frontend<NT, WN, FT, KC>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
+        if (getenv("BNHIP_DEBUG")) {
+            int nb = -1;
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_frontend<NT, WN, FT, KC>),
+                                                         64 * (FT / 16) * WN, lds);
+            fprintf(stderr, "[bnhip] k_frontend<%d,%d,%d,%d>: lds %zu B, %d block(s)/CU\n", NT, WN, FT, KC, lds, nb);
+        }
     }
-    dim3 grid((p.F + FE_FT - 1) / FE_FT, p.n_clips);
-    hipLaunchKernelGGL((k_frontend<NT, WN>), grid, dim3(256 * WN), lds, s, p);
+    dim3 grid((p.F + FT - 1) / FT, p.n_clips);
+    hipLaunchKernelGGL((k_frontend<NT, WN, FT, KC>), grid, dim3(64 * (FT / 16) * WN), lds, s, p);
+}
+template <int NT, int WN>
+static void launch_frontend_nt(const FrontendParams& p, hipStream_t s) {
+    static const char* force = getenv("BNHIP_FE_SHAPE");       // experiment switch: "64" forces the large shape
+    bool small = fe_small_shape(p.Lfft, p.Kp, p.hop, p.NTP) && p.Kp % 16 == 0 && !(force && atoi(force) == 64);
+    if (small) launch_frontend_shape<NT, WN, 32, 16>(p, s);
+    else if (p.Kp % 32 == 0) launch_frontend_shape<NT, WN, 64, 32>(p, s);
+    else launch_frontend_shape<NT, WN, 64, 16>(p, s);
 }
 void launch_frontend(const FrontendParams& p, hipStream_t s) {
     // even tile counts run 8 waves (two mel halves): two waves per SIMD keep the f64 matrix pipe fed while the
