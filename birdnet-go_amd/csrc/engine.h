@@ -60,6 +60,11 @@ class Engine {
     bool autotune = true;               // time pw_gemm tile widths per layer at create time (a few ms)
     bool use_graphs = false;            // opt-in: replay the plan as a hipGraph once a (pointers, n) combination repeats (measured: no gain on ROCm 7.2)
     void drop_graphs();
+    static constexpr int kMaxLanes = 4;
+    int n_lanes = 2;                    // batches of >= dual_lane_min clips are split over this many streams (see run_eager)
+    int dual_lane_min = 32;
+    hipStream_t lane_stream[kMaxLanes - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxLanes - 1] = {nullptr, nullptr, nullptr};
     void autotune_pw();
     std::map<int, int> tensor_value;    // tflite tensor index -> value id (diagnostics)
     const float* value_ptr(int v) const { return reinterpret_cast<const float*>(act_arena + vals[v].offset); }
@@ -102,7 +107,7 @@ class Engine {
     size_t w_bytes = 0;
     std::vector<ProfEntry> prof;
     std::vector<hipEvent_t> ev_pool;
-    float* vptr(int v, const float* d_in, float* d_logits, float* d_emb) const;
+    float* vptr(int v, const float* d_in, float* d_logits, float* d_emb, int clip0 = 0) const;
     hipEvent_t get_event();
 };
 
