@@ -1245,15 +1245,38 @@ __global__ __launch_bounds__(1024) void k_se(SeParams p) {
     float* r = sm + p.C;         // [Cr]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float inv = 1.0f / (float)p.HW;
-    for (int c = tid; c < p.C; c += 1024) {
-        float sum = 0.f;
-        for (int sidx = 0; sidx < p.S; sidx++) sum += p.partial[((size_t)b * p.S + sidx) * p.C + c];
-        mean[c] = sum * inv;
+    // the per-slab sums: P threads per channel walk interleaved slab subsets (a 96-slab layer with 96 channels used to
+    // be 96 threads x 96 serial loads), then fold through LDS in a fixed order
+    int P = 1;
+    while (P * 2 * p.C <= 1024 && P * 2 <= p.S) P *= 2;
+    float* part = r + p.Cr;      // [P][C] scratch (P*C <= 1024)
+    if (P > 1) {
+        const int c = tid % p.C, q = tid / p.C;
+        if (q < P) {
+            float sum = 0.f;
+#pragma unroll 4
+            for (int sidx = q; sidx < p.S; sidx += P) sum += p.partial[((size_t)b * p.S + sidx) * p.C + c];
+            part[q * p.C + c] = sum;
+        }
+        __syncthreads();
+        for (int c2 = tid; c2 < p.C; c2 += 1024) {
+            float sum = 0.f;
+            for (int q2 = 0; q2 < P; q2++) sum += part[q2 * p.C + c2];
+            mean[c2] = sum * inv;
+        }
+    } else {
+        for (int c = tid; c < p.C; c += 1024) {
+            float sum = 0.f;
+#pragma unroll 4
+            for (int sidx = 0; sidx < p.S; sidx++) sum += p.partial[((size_t)b * p.S + sidx) * p.C + c];
+            mean[c] = sum * inv;
+        }
     }
     __syncthreads();
     for (int j = wave; j < p.Cr; j += 16) {
         float acc = 0.f;
         const float* wr = p.w1 + (size_t)j * p.C;
+#pragma unroll 4
         for (int c = lane; c < p.C; c += 64) acc = fmaf(wr[c], mean[c], acc);
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
         if (lane == 0) r[j] = apply_act(acc + (p.b1 ? p.b1[j] : 0.f), p.act1);
@@ -1261,12 +1284,13 @@ __global__ __launch_bounds__(1024) void k_se(SeParams p) {
     __syncthreads();
     for (int c = tid; c < p.C; c += 1024) {
         float acc = 0.f;
+#pragma unroll 8
         for (int j = 0; j < p.Cr; j++) acc = fmaf(p.w2[(size_t)j * p.C + c], r[j], acc);
         p.scale[(size_t)b * p.C + c] = apply_act(acc + (p.b2 ? p.b2[c] : 0.f), p.act2);
     }
 }
 void launch_se(const SeParams& p, hipStream_t s) {
-    size_t lds = (size_t)(p.C + p.Cr) * sizeof(float);
+    size_t lds = (size_t)(p.C + p.Cr + 1024) * sizeof(float);
     hipLaunchKernelGGL(k_se, dim3(p.B), dim3(1024), lds, s, p);
 }
 
