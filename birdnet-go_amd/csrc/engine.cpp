@@ -517,8 +517,9 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                         const TflTensor& wd = m.tensors[d.inputs[1]];
                         int kd = wd.shape.size() == 4 ? wd.shape[1] : 0;
                         int act_d = map_act(d.act);
+                        const int fpt = d.padding == 0 ? std::max((dHo - 1) * d.stride_h + kd - dH, 0) / 2 : 0;
                         if (kd == wd.shape[2] && wd.shape[3] == dC && act_d >= 0 && expdw_supported(kd, d.stride_h, C, Co) &&
-                            need_val(in_t) >= 0) {
+                            expdw_sum_slabs(kd, d.stride_h, dH, dHo, dWo, fpt) > 0 && need_val(in_t) >= 0) {
                             int dout = d.outputs[0];
                             if (act_d == ACT_NONE) dout = trailing_act(dout, &act_d);
                             P.absorbed[di] = 1;
@@ -645,7 +646,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                 mp.in0 = vin; mp.H = H; mp.W = W; mp.C = C;
                 if (!steps.empty() && steps.back().kind == S_EXPAND_DW && steps.back().out == vin) {
                     const Step& d = steps.back();
-                    int slabs = expdw_sum_slabs(d.kh, d.sh, d.Ho, d.Wo);
+                    int slabs = expdw_sum_slabs(d.kh, d.sh, d.H, d.Ho, d.Wo, d.pt);
                     if (slabs > 0) {
                         S = slabs;
                         fused_sum = true;

@@ -56,7 +56,7 @@ void launch_dwconv(const DwParams& p, float* partial, hipStream_t s);
 
 // fused MBConv front half: y = act_d(dwconv(act_e(x We^T + be)) + bd); partial (nullable) [B, slabs, Cmid]
 bool expdw_supported(int k, int s, int Cin, int Cmid);
-int expdw_sum_slabs(int k, int s, int Ho, int Wo);
+int expdw_sum_slabs(int k, int s, int H, int Ho, int Wo, int pt);   // 0 = no tile shape fits (do not fuse)
 // parameters are the planner's padded copies: we [expdw_cp(Cmid)][expdw_kw(Cin)], be/bd [Cp], wd [k*k][Cp] (zeros beyond)
 int expdw_kw(int Cin);
 int expdw_cp(int Cmid);

@@ -7,6 +7,7 @@
 // depthwise weights [kh][kw][C], stem weights re-laid to [kh][kw][Cin][Cout] at plan time.
 #include "kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -957,15 +958,19 @@ struct ExpDwParams {
 // unconditional: pixels outside the image read a clamped (valid) address and are masked when E is written, the
 // K tail multiplies finite activations by zero weights.  All small parameter loads (biases, taps) are issued at
 // the top so their latency overlaps phase 1 (ISA check: they used to sit behind s_waitcnt vmcnt(0) mid-kernel).
-template <int K, int S, int TOH, int TOW>
+// TRH = footprint rows held in LDS.  Only in-image rows are computed and stored (compacted), so a tile that spans the
+// whole image height has no vertical halo at all; phase 2 skips the taps that fall on padding rows (the row test is
+// wave-uniform: a wave owns one row group of the tile).
+template <int K, int S, int TOH, int TOW, int TRH>
 __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk) {
     constexpr int TIH = (TOH - 1) * S + K, TIW = (TOW - 1) * S + K;
-    constexpr int NPIX = TIH * TIW, NPIXP = (NPIX + 15) / 16 * 16;
+    static_assert(TRH <= TIH, "TRH is a cap on the footprint rows");
+    constexpr int NPIX = TRH * TIW, NPIXP = (NPIX + 15) / 16 * 16;
     constexpr int JT = NPIXP / 16, JTW = (JT + 3) / 4;
     constexpr int SH = TOH / 4, SW = TOW / 8;                 // outputs per thread in phase 2 (thread-tiles are 4 x 8)
     constexpr int RW = (SW - 1) * S + K;
     __shared__ __attribute__((aligned(16))) float lds[NPIX * ED_ES + 128 + K * K * 32];
-    float* E = lds;                                                      // [NPIX][36] expanded footprint
+    float* E = lds;                                                      // [<=TRH rows][TIW][36] expanded footprint
     float4* red = reinterpret_cast<float4*>(lds + NPIX * ED_ES);         // [4 waves][8] sum scratch
     float4* wds = reinterpret_cast<float4*>(lds + NPIX * ED_ES + 128);   // [K*K][8] depthwise taps of this chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -978,8 +983,9 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
     const int tile = rest / p.cchunks, cc = rest % p.cchunks;
     const int oh0 = (tile / p.tiles_w) * TOH, ow0 = (tile % p.tiles_w) * TOW;
     const int ih0 = oh0 * S - p.pt, iw0 = ow0 * S - p.pl;
-    // footprint rows are compacted to the in-image range [vr0, vr1); columns keep the compile-time width TIW
-    // (out-of-image columns are masked): GEMM row j <-> footprint pixel (vr0 + j / TIW, j % TIW), constant divisors
+    // footprint rows are compacted to the in-image range [vr0, vr1) (host guarantees vr1 - vr0 <= TRH); columns keep
+    // the compile-time width TIW (out-of-image columns are masked): GEMM row j <-> footprint pixel
+    // (vr0 + j / TIW, j % TIW), stored at E[j]
     const int vr0 = max(ih0, 0) - ih0, vr1 = min(ih0 + TIH, p.H) - ih0;
     const int nvalid = (vr1 - vr0) * TIW;
     const int jtv = (nvalid + 15) >> 4;
@@ -993,12 +999,6 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
     const float4 bq0 = *reinterpret_cast<const float4*>(p.be + n_base + 4 * kq);
     const float4 bq1 = *reinterpret_cast<const float4*>(p.be + n_base + 16 + 4 * kq);
     const float4 bv = *reinterpret_cast<const float4*>(p.bd + n_base + 4 * c4);
-
-    if (nvalid < NPIX) {      // rows outside the image are zero padding of the expanded tensor
-        for (int i = tid; i < vr0 * TIW * (ED_ES / 4); i += 256) reinterpret_cast<float4*>(E)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = vr1 * TIW * (ED_ES / 4) + tid; i < NPIX * (ED_ES / 4); i += 256)
-            reinterpret_cast<float4*>(E)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
 
     // this lane's pixel per owned tile (a): clamped global offset + validity
     int xoff[JTW];
@@ -1061,31 +1061,30 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
         }
     }
 
-    // ---- E <- act_e(acc + be) at footprint coordinates (masked columns are zero)
-    with_act(p.act_e, [&](auto f) {
-#pragma unroll
-        for (int a = 0; a < JTW; a++) {
-            f32x4& v0 = acc[a][0];
-            f32x4& v1 = acc[a][1];
-            v0[0] = f(v0[0] + bq0.x); v0[1] = f(v0[1] + bq0.y); v0[2] = f(v0[2] + bq0.z); v0[3] = f(v0[3] + bq0.w);
-            v1[0] = f(v1[0] + bq1.x); v1[1] = f(v1[1] + bq1.y); v1[2] = f(v1[2] + bq1.z); v1[3] = f(v1[3] + bq1.w);
-        }
-    });
+    // ---- E <- act_e(acc + be) at compacted footprint coordinates (masked columns are zero)
 #pragma unroll
     for (int a = 0; a < JTW; a++) {
-        int j = 16 * (wave + 4 * a) + li;
-        if (j < nvalid) {
-            int e = (vr0 * TIW + j) * ED_ES + 4 * kq;
-            const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(&E[e]) = xin[a] ? acc[a][0] : z;
-            *reinterpret_cast<f32x4*>(&E[e + 16]) = xin[a] ? acc[a][1] : z;
+        if (wave + 4 * a < jtv) {                         // wave-uniform: tiles beyond the valid rows cost nothing
+            with_act(p.act_e, [&](auto f) {
+                f32x4& v0 = acc[a][0];
+                f32x4& v1 = acc[a][1];
+                v0[0] = f(v0[0] + bq0.x); v0[1] = f(v0[1] + bq0.y); v0[2] = f(v0[2] + bq0.z); v0[3] = f(v0[3] + bq0.w);
+                v1[0] = f(v1[0] + bq1.x); v1[1] = f(v1[1] + bq1.y); v1[2] = f(v1[2] + bq1.z); v1[3] = f(v1[3] + bq1.w);
+            });
+            int j = 16 * (wave + 4 * a) + li;
+            if (j < nvalid) {
+                int e = j * ED_ES + 4 * kq;
+                const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(&E[e]) = xin[a] ? acc[a][0] : z;
+                *reinterpret_cast<f32x4*>(&E[e + 16]) = xin[a] ? acc[a][1] : z;
+            }
         }
     }
     if (tid < K * K * 8) wds[tid] = wdreg;
     __syncthreads();
 
     // ---- depthwise from LDS
-    const int ty = tt >> 3, tx = tt & 7;
+    const int ty = tt >> 3, tx = tt & 7;                 // ty == wave: row tests below are wave-uniform
     const int n = n_base + 4 * c4;
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n < p.Cmid) {
@@ -1094,7 +1093,7 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
         for (int a = 0; a < SH; a++)
 #pragma unroll
             for (int c = 0; c < SW; c++) acc2[a][c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* e0 = E + ((ty * SH * S) * TIW + tx * SW * S) * ED_ES + 4 * c4;
+        const float* e0 = E + (tx * SW * S) * ED_ES + 4 * c4;
 #pragma unroll 1
         for (int i = 0; i < K; i++) {                 // kernel row (kept rolled: bounds the live weight registers)
             float4 w[K];
@@ -1102,9 +1101,11 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
             for (int j = 0; j < K; j++) w[j] = wds[(i * K + j) * 8 + c4];
 #pragma unroll
             for (int a = 0; a < SH; a++) {
+                const int fr = (ty * SH + a) * S + i;                       // footprint row of this tap
+                if (fr < vr0 || fr >= vr1 || oh0 + ty * SH + a >= p.Ho) continue;   // padding row / no such output row
                 float4 xr[RW];
 #pragma unroll
-                for (int c = 0; c < RW; c++) xr[c] = *reinterpret_cast<const float4*>(e0 + ((a * S + i) * TIW + c) * ED_ES);
+                for (int c = 0; c < RW; c++) xr[c] = *reinterpret_cast<const float4*>(e0 + ((fr - vr0) * TIW + c) * ED_ES);
 #pragma unroll
                 for (int j = 0; j < K; j++) {
 #pragma unroll
@@ -1116,19 +1117,17 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
                 }
             }
         }
-        with_act(p.act_d, [&](auto f) {
 #pragma unroll
-            for (int a = 0; a < SH; a++)
+        for (int a = 0; a < SH; a++) {
+            int oh = oh0 + ty * SH + a;
+            if (oh >= p.Ho) continue;
+            with_act(p.act_d, [&](auto f) {
 #pragma unroll
                 for (int c = 0; c < SW; c++) {
                     float4& v = acc2[a][c];
                     v.x = f(v.x + bv.x); v.y = f(v.y + bv.y); v.z = f(v.z + bv.z); v.w = f(v.w + bv.w);
                 }
-        });
-#pragma unroll
-        for (int a = 0; a < SH; a++) {
-            int oh = oh0 + ty * SH + a;
-            if (oh >= p.Ho) continue;
+            });
 #pragma unroll
             for (int c = 0; c < SW; c++) {
                 int ow = ow0 + tx * SW + c;
@@ -1159,37 +1158,74 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
 
 int expdw_kw(int Cin) { return (Cin + 15) / 16 * 16; }
 int expdw_cp(int Cmid) { return (Cmid + 31) / 32 * 32; }
-static bool expdw_tile(int k, int s, int Ho, int* toh, int* tow) {
-    if (!((k == 3 || k == 5) && (s == 1 || s == 2))) return false;
-    if (s == 2) { *toh = 4; *tow = 8; return true; }
-    *toh = Ho > 4 ? 8 : 4;     // short images: one 8-row tile (only in-image footprint rows are computed)
-    *tow = 16;
-    return true;
+// Instantiated tile shapes.  The chooser takes, per layer, the shape that computes the fewest expanded pixels
+// (rows x TIW summed over the tiles of one image; halo recompute and masked padding columns both count) among those
+// whose in-image footprint rows fit TRH.
+struct ExpDwShape { int k, s, toh, tow, trh; };
+static const ExpDwShape kExpDwShapes[] = {
+    {3, 1, 8, 16, 10}, {3, 1, 4, 16, 6}, {3, 1, 8, 32, 6},
+    {5, 1, 8, 16, 12}, {5, 1, 4, 16, 8}, {5, 1, 8, 32, 6}, {5, 1, 12, 16, 12},
+    {3, 2, 4, 8, 9}, {3, 2, 8, 8, 12},
+    {5, 2, 4, 8, 11}, {5, 2, 4, 16, 6},
+};
+static long expdw_cost(const ExpDwShape& sh, int H, int Ho, int Wo, int pt, bool* fits) {
+    const int tih = (sh.toh - 1) * sh.s + sh.k, tiw = (sh.tow - 1) * sh.s + sh.k;
+    const int th = (Ho + sh.toh - 1) / sh.toh, tw = (Wo + sh.tow - 1) / sh.tow;
+    long rows = 0;
+    *fits = true;
+    for (int t = 0; t < th; t++) {
+        int ih0 = t * sh.toh * sh.s - pt;
+        int v = std::min(ih0 + tih, H) - std::max(ih0, 0);
+        if (v > sh.trh) *fits = false;
+        rows += std::max(v, 0);
+    }
+    return rows * tiw * tw;
 }
-int expdw_sum_slabs(int k, int s, int Ho, int Wo) {
-    int toh, tow;
-    if (!expdw_tile(k, s, Ho, &toh, &tow)) return 0;
-    return ((Ho + toh - 1) / toh) * ((Wo + tow - 1) / tow);
+static const ExpDwShape* expdw_pick(int k, int s, int H, int Ho, int Wo, int pt) {
+    static const char* force = getenv("BNHIP_EXPDW_OLD");      // experiment switch: the round-1 two-shape rule
+    const ExpDwShape* best = nullptr;
+    long best_cost = 0;
+    for (const ExpDwShape& sh : kExpDwShapes) {
+        if (sh.k != k || sh.s != s) continue;
+        if (force && atoi(force)) {
+            bool old = s == 2 ? (sh.toh == 4 && sh.tow == 8) : (sh.tow == 16 && sh.toh == (Ho > 4 ? 8 : 4));
+            if (!old) continue;
+        }
+        bool fits;
+        long c = expdw_cost(sh, H, Ho, Wo, pt, &fits);
+        if (!fits) continue;
+        if (!best || c < best_cost) { best = &sh; best_cost = c; }
+    }
+    return best;
+}
+int expdw_sum_slabs(int k, int s, int H, int Ho, int Wo, int pt) {
+    const ExpDwShape* sh = expdw_pick(k, s, H, Ho, Wo, pt);
+    if (!sh) return 0;
+    return ((Ho + sh->toh - 1) / sh->toh) * ((Wo + sh->tow - 1) / sh->tow);
 }
 bool expdw_supported(int k, int s, int Cin, int Cmid) {
-    int toh, tow;
     // measured on MI355X at batch 256: beyond ~128 input channels the unpipelined K loop of the fused kernel loses
     // to the separate pw_gemm + dwconv pair (b13-b16 of the B0 stack: 126 us vs 176 us), so those stay unfused
-    return expdw_tile(k, s, 8, &toh, &tow) && (Cin & 3) == 0 && (Cmid & 3) == 0 && Cin <= 128;
+    return (k == 3 || k == 5) && (s == 1 || s == 2) && (Cin & 3) == 0 && (Cmid & 3) == 0 && Cin <= 128;
 }
 void launch_expand_dw(const float* x, const float* we, const float* be, const float* wd, const float* bd, float* y,
                       float* partial, int B, int H, int W, int Cin, int Cmid, int Ho, int Wo, int k, int s, int pt,
                       int pl, int act_e, int act_d, hipStream_t st) {
-    int toh, tow;
-    expdw_tile(k, s, Ho, &toh, &tow);
+    const ExpDwShape* sh = expdw_pick(k, s, H, Ho, Wo, pt);
+    if (!sh) return;                                   // the planner only fuses shapes expdw_sum_slabs accepted
     ExpDwParams p{x, we, be, wd, bd, y, partial, B, H, W, Cin, Cmid, Ho, Wo, pt, pl, act_e, act_d,
-                  (Ho + toh - 1) / toh, (Wo + tow - 1) / tow, (Cmid + 31) / 32, expdw_kw(Cin), expdw_cp(Cmid)};
+                  (Ho + sh->toh - 1) / sh->toh, (Wo + sh->tow - 1) / sh->tow, (Cmid + 31) / 32, expdw_kw(Cin), expdw_cp(Cmid)};
     unsigned nblk = (unsigned)B * p.tiles_h * p.tiles_w * p.cchunks;
-#define ED_LAUNCH(K_, S_, TH_, TW_) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_>), dim3(nblk), dim3(256), 0, st, p, nblk)
-    if (s == 2) { if (k == 3) ED_LAUNCH(3, 2, 4, 8); else ED_LAUNCH(5, 2, 4, 8); }
-    else if (toh == 8) { if (k == 3) ED_LAUNCH(3, 1, 8, 16); else ED_LAUNCH(5, 1, 8, 16); }
-    else { if (k == 3) ED_LAUNCH(3, 1, 4, 16); else ED_LAUNCH(5, 1, 4, 16); }
-#undef ED_LAUNCH
+#define ED_CASE(K_, S_, TH_, TW_, TR_)                                                                        \
+    if (sh->k == K_ && sh->s == S_ && sh->toh == TH_ && sh->tow == TW_ && sh->trh == TR_) {                   \
+        hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_>), dim3(nblk), dim3(256), 0, st, p, nblk);      \
+        return;                                                                                               \
+    }
+    ED_CASE(3, 1, 8, 16, 10) ED_CASE(3, 1, 4, 16, 6) ED_CASE(3, 1, 8, 32, 6)
+    ED_CASE(5, 1, 8, 16, 12) ED_CASE(5, 1, 4, 16, 8) ED_CASE(5, 1, 8, 32, 6) ED_CASE(5, 1, 12, 16, 12)
+    ED_CASE(3, 2, 4, 8, 9) ED_CASE(3, 2, 8, 8, 12)
+    ED_CASE(5, 2, 4, 8, 11) ED_CASE(5, 2, 4, 16, 6)
+#undef ED_CASE
 }
 
 // ------------------------------------------------------------------------------------------ spatial mean
