@@ -7,6 +7,6 @@ container tooling (`tflite_schema.py`, `tflite_build.py`, `synth_model.py`) and 
 The directory name carries a hyphen (task contract); import it as `birdnet_go_amd` via the
 alias module at the repo root.
 """
-from . import tflite_schema, flatbuf_writer, tflite_build, synth_model, build, host, shard, wav  # noqa: F401
+from . import tflite_schema, flatbuf_writer, tflite_build, synth_model, build, host, shard, wav, results  # noqa: F401
 
-__all__ = ["tflite_schema", "flatbuf_writer", "tflite_build", "synth_model", "build", "host", "shard", "wav"]
+__all__ = ["tflite_schema", "flatbuf_writer", "tflite_build", "synth_model", "build", "host", "shard", "wav", "results"]

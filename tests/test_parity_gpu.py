@@ -185,6 +185,26 @@ def test_predict_topk_fused(full_clf):
         host.BirdNET(full_clf, ["a"] * 10)
 
 
+def test_results_handoff_batch(full_clf):
+    """one device call -> one Results message per clip, labels paired from the device top-K."""
+    from birdnet_go_amd import results as R
+    labels = [f"Species{i}_Common{i}" for i in range(6522)]
+    bn = host.BirdNET(full_clf, labels, sensitivity=1.0)
+    x = sm.synth_clips(5, 144000, 48000)
+    d = R.BatchDispatcher(bn, "BirdNET_GLOBAL_6K_V2.4", R.ResultsQueue(size=4))
+    sent = d.dispatch(x, start_times=[1.5 * i for i in range(5)], source="soundscape.wav")
+    assert sent == 4 and d.queue.drops() == {("soundscape.wav", "BirdNET_GLOBAL_6K_V2.4"): 1}   # bounded queue: 5th dropped
+    lg = full_clf.predict_batch(x.reshape(-1), 5)
+    for i in range(4):
+        m = d.queue.get()
+        assert m.start_time == 1.5 * i and len(m.results) == 10
+        assert m.results[0].species == labels[int(np.argmax(lg[i]))]
+        want = G.sigmoid_sensitivity(lg[i][np.argmax(lg[i])][None], 1.0)[0]
+        assert m.results[0].confidence == float(want)
+    snap = d.counters.peek_all()["BirdNET_GLOBAL_6K_V2.4"]
+    assert snap["invoke_count"] == 1 and snap["recent_p95_us"] > 0
+
+
 # ---- ultrasonic frame-CV (filter_test.go signals), GPU float64 vs the Go restatement
 SR, N = 256000, 144000
 
