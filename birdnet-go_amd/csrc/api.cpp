@@ -116,6 +116,8 @@ int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, 
     m->eng.autotune = json_int(opts_json, "autotune", 1) != 0;
     const char* lenv = getenv("BNHIP_LANES");            // experiment switch; the option wins when given
     m->eng.n_lanes = json_int(opts_json, "lanes", lenv ? atoi(lenv) : 2);
+    const char* fenv = getenv("BNHIP_FE_FFT");           // experiment switch; the option wins when given
+    m->eng.frontend_fft = json_int(opts_json, "frontend_fft", fenv ? atoi(fenv) : -1);
     const char* genv = getenv("BNHIP_GRAPHS");           // experiment switch; the option wins when given
     m->eng.use_graphs = json_int(opts_json, "graphs", genv ? atoi(genv) : 0) != 0;
     if (!m->eng.build(std::move(tm), device, max_batch, plan_only, &err, &code)) {

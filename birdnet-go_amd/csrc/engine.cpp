@@ -96,6 +96,7 @@ struct FrontendMatch {
     int mel_tensor = -1;     // const [n_mels, nbins]
     float p1 = 1.f, p2 = 1.f, eps = 0.f, norm_sub = 0.f, norm_mul = 1.f;
     bool reverse = false;
+    bool magnitude = false;  // COMPLEX_ABS instead of the real part
     int out_tensor = -1;     // [1, n_mels, F, 1]
 };
 
@@ -183,11 +184,8 @@ bool match_frontend(Planner& P, int ri, FrontendMatch* fm) {
     t = P.skip_down(R.outputs[0]);
     int ci = P.only_consumer(t);
     if (ci < 0) return P.fail("front-end: STFT output must have one consumer");
-    if (m.ops[ci].code == OP_COMPLEX_ABS) {
-        P.code = BNHIP_E_UNSUPPORTED;
-        return P.fail("front-end: magnitude STFT (COMPLEX_ABS) variant is not implemented; only the real-part (CAST) graph");
-    }
-    if (!(m.ops[ci].code == OP_CAST || m.ops[ci].code == OP_REAL)) return P.fail("front-end: expected CAST/REAL after RFFT2D");
+    if (m.ops[ci].code == OP_COMPLEX_ABS) fm->magnitude = true;
+    else if (!(m.ops[ci].code == OP_CAST || m.ops[ci].code == OP_REAL)) return P.fail("front-end: expected CAST/REAL/COMPLEX_ABS after RFFT2D");
     P.absorbed[ci] = 1;
     t = P.skip_down(m.ops[ci].outputs[0]);
     ci = P.only_consumer(t);
@@ -413,6 +411,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
         s.bytes = (double)n_samples * 4;
         add_step(s);
         int v_spec = new_val(spec_tensor, (size_t)fms[0].n_mels * fms[0].F * C_spec);
+        int v_xn = -1;                      // normalised clip (FFT front-end only)
         tv[spec_tensor] = v_spec;
         for (size_t i = 0; i < fms.size(); i++) {
             const FrontendMatch& fm = fms[i];
@@ -426,6 +425,64 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                 return false;
             }
             fs.p1 = fm.p1; fs.p2 = fm.p2; fs.eps = fm.eps; fs.norm_sub = fm.norm_sub; fs.norm_mul = fm.norm_mul;
+            // bins the mel matrix actually uses (DFT truncation)
+            std::vector<int> bins;
+            {
+                const int nbins = fm.Lfft / 2 + 1;
+                const float* melT = P.T(fm.mel_tensor).f32();
+                for (int k = 0; k < nbins; k++) {
+                    bool nz = false;
+                    for (int mm = 0; mm < fm.n_mels && !nz; mm++) nz = melT[(size_t)mm * nbins + k] != 0.0f;
+                    if (nz) bins.push_back(k);
+                }
+            }
+            const bool can_fft = stft_supported(fm.Lfft, (int)bins.size()) && !bins.empty();
+            if (fm.magnitude && !can_fft) {
+                *code = BNHIP_E_UNSUPPORTED;
+                *err = "front-end: magnitude STFT (COMPLEX_ABS) is only implemented for fft_length 512 / 1024 / 2048";
+                return false;
+            }
+            fs.fft = fm.magnitude || (frontend_fft == 1 && can_fft);
+            if (fs.fft) {
+                // normalise (once) -> STFT bins -> mel GEMM -> pow + NHWC store
+                if (v_xn < 0) {
+                    v_xn = new_val(-1, n_samples);
+                    Step nz; nz.kind = S_NORMALIZE; nz.name = "normalize"; nz.kclass = "frontend"; nz.in0 = v_input; nz.in1 = v_mm;
+                    nz.out = v_xn; nz.bytes = (double)n_samples * 8;
+                    add_step(nz);
+                }
+                fs.nb = (int)bins.size(); fs.nbp = (int)align_up(fs.nb, 4); fs.mode = fm.magnitude ? 1 : 0;
+                std::vector<float> wfull(fm.window.begin(), fm.window.end());
+                std::vector<float> binsf(bins.size());
+                memcpy(binsf.data(), bins.data(), bins.size() * sizeof(int));            // int32 image in the float arena
+                const int nbins = fm.Lfft / 2 + 1;
+                const float* melT = P.T(fm.mel_tensor).f32();
+                std::vector<float> melw((size_t)fm.n_mels * fs.nbp, 0.f);                // [n_mels][nbp], rows in output order
+                for (int mo = 0; mo < fm.n_mels; mo++) {
+                    int mm = fm.reverse ? fm.n_mels - 1 - mo : mo;
+                    for (int r = 0; r < fs.nb; r++) melw[(size_t)mo * fs.nbp + r] = melT[(size_t)mm * nbins + bins[r]];
+                }
+                size_t o_win = wpush(wfull.data(), wfull.size()), o_bins = wpush(binsf.data(), binsf.size());
+                size_t o_mel = wpush(melw.data(), melw.size());
+                specs.push_back(fs);
+                const int si = (int)specs.size() - 1;
+                int v_bins = new_val(-1, (size_t)fm.F * fs.nbp), v_T = new_val(-1, (size_t)fm.F * fm.n_mels);
+                Step st; st.kind = S_STFT; st.name = "stft" + std::to_string(i); st.kclass = "stft"; st.in0 = v_xn; st.out = v_bins;
+                st.spec = si;
+                st.flops = (double)fm.F * 2.5 * fm.Lfft * std::log2((double)fm.Lfft / 2);      // ~5 N/2 log2(N/2) per frame
+                st.bytes = (double)n_samples * 4 + (double)fm.F * fs.nbp * 4;
+                add_step(st, o_win, o_bins);
+                Step g; g.kind = S_PW; g.name = "mel" + std::to_string(i); g.kclass = "pw_gemm"; g.in0 = v_bins; g.out = v_T;
+                g.H = fm.F; g.W = 1; g.C = fs.nbp; g.Co = fm.n_mels; g.Ho = fm.F; g.Wo = 1; g.act = ACT_NONE;
+                g.flops = 2.0 * fm.F * fs.nbp * fm.n_mels;
+                g.bytes = 4.0 * ((double)fm.F * fs.nbp + (double)fm.F * fm.n_mels);
+                g.wbytes = 4.0 * fs.nbp * fm.n_mels;
+                add_step(g, o_mel);
+                Step mf; mf.kind = S_MELFIN; mf.name = "melspec" + std::to_string(i); mf.kclass = "frontend"; mf.in0 = v_T; mf.out = v_spec;
+                mf.spec = si; mf.bytes = 8.0 * fm.F * fm.n_mels;
+                add_step(mf);
+                continue;
+            }
             if (frontend_lds_bytes(fs.Lfft, fs.Kp, fs.hop, fs.NTP) > 160 * 1024) {
                 *err = "front-end: frame tile does not fit in LDS";
                 return false;
@@ -915,6 +972,10 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
             specs[steps[si].spec].G = reinterpret_cast<const double*>(steps[si].w0);
             specs[steps[si].spec].window = steps[si].w1;
         }
+        if (steps[si].kind == S_STFT) {
+            specs[steps[si].spec].window_full = steps[si].w0;
+            specs[steps[si].spec].bins = reinterpret_cast<const int*>(steps[si].w1);
+        }
     }
     HIPCHK(hipMalloc((void**)&d_stage_in, (size_t)max_batch * n_samples * 4));
     HIPCHK(hipMalloc((void**)&d_stage_logits, (size_t)max_batch * n_classes * 4));
@@ -1069,6 +1130,20 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
                 p.NTP = fs.NTP; p.C = C_spec; p.c = fs.c; p.norm_sub = fs.norm_sub; p.norm_mul = fs.norm_mul;
                 p.p1 = fs.p1; p.p2 = fs.p2; p.n_clips = n;
                 launch_frontend(p, stream);
+                break;
+            }
+            case S_NORMALIZE:
+                launch_normalize(in0, reinterpret_cast<const float2*>(in1), out, n, n_samples, specs[0].norm_sub, specs[0].norm_mul, stream);
+                break;
+            case S_STFT: {
+                const FrontSpec& fs = specs[s.spec];
+                StftParams p{in0, fs.window_full, fs.bins, out, n_samples, fs.Lfft, fs.L, fs.hop, fs.F, fs.nb, fs.nbp, fs.mode, n};
+                launch_stft_bins(p, stream);
+                break;
+            }
+            case S_MELFIN: {
+                const FrontSpec& fs = specs[s.spec];
+                launch_mel_finish(in0, out, n, fs.F, fs.n_mels, fs.n_mels, C_spec, fs.c, fs.p1, fs.p2, stream);
                 break;
             }
             case S_CONV_DIRECT: {

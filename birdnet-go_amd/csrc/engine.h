@@ -11,7 +11,7 @@
 
 namespace bnhip {
 
-enum StepKind { S_MINMAX, S_FRONTEND, S_CONV_DIRECT, S_PW, S_DW, S_EXPAND_DW, S_MEAN_PARTIAL, S_MEAN_FINISH, S_SE, S_UNARY, S_BINARY };
+enum StepKind { S_MINMAX, S_FRONTEND, S_NORMALIZE, S_STFT, S_MELFIN, S_CONV_DIRECT, S_PW, S_DW, S_EXPAND_DW, S_MEAN_PARTIAL, S_MEAN_FINISH, S_SE, S_UNARY, S_BINARY };
 
 struct Step {
     StepKind kind;
@@ -44,6 +44,11 @@ struct FrontSpec {
     float p1, p2, eps, norm_sub, norm_mul;
     const double* G = nullptr;   // device, fp64
     const float* window = nullptr;
+    // FFT path (stft.hip)
+    bool fft = false;
+    int nb = 0, nbp = 0, mode = 0;   // needed bins, padded to 4; 0 = real part, 1 = magnitude
+    const float* window_full = nullptr;
+    const int* bins = nullptr;
 };
 
 struct ProfEntry { hipEvent_t a, b; int step; int n; };
@@ -58,6 +63,7 @@ class Engine {
     int device = 0, max_batch = 256;
     bool no_reuse = false;              // diagnostics: every activation keeps its own buffer
     bool autotune = true;               // time pw_gemm tile widths per layer at create time (a few ms)
+    int frontend_fft = -1;              // -1 auto (magnitude graphs need it), 0 folded-GEMM kernel, 1 FFT path where supported
     bool use_graphs = false;            // opt-in: replay the plan as a hipGraph once a (pointers, n) combination repeats (measured: no gain on ROCm 7.2)
     void drop_graphs();
     static constexpr int kMaxLanes = 4;

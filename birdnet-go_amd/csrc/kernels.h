@@ -27,6 +27,23 @@ struct FrontendParams {
 };
 void launch_frontend(const FrontendParams& p, hipStream_t s);
 size_t frontend_lds_bytes(int Lfft, int Kp, int hop, int NTP);
+
+// FFT-based front-end (stft.hip): normalise once, STFT -> needed bins (fp32), then k_pw_gemm with the mel matrix and
+// k_mel_finish.  Serves both the real-part (CAST) and the magnitude (COMPLEX_ABS) graph.
+struct StftParams {
+    const float* xn;        // [B, n_samples] normalised clip
+    const float* window;    // [L]
+    const int* bins;        // [nb] ascending DFT bins the mel matrix uses
+    float* out;             // [B, F, nbp]; columns nb..nbp-1 are written as zeros
+    int n_samples, Lfft, L, hop, F, nb, nbp, mode /*0 real part, 1 magnitude*/, n_clips;
+    int nb_cap = 0, fpw = 0;    // set by the launcher
+};
+void launch_normalize(const float* x, const float2* mm, float* out, int n_clips, int n_samples, float norm_sub,
+                      float norm_mul, hipStream_t s);
+bool stft_supported(int Lfft, int nb);
+void launch_stft_bins(const StftParams& p, hipStream_t s);
+void launch_mel_finish(const float* T, float* out, int n_clips, int F, int n_mels, int ldt, int C, int c, float p1, float p2,
+                       hipStream_t s);
 int frontend_kc(int Lfft, int hop, int NTP);   // K-chunk of the front-end GEMM (G rows per LDS stage): 16 or 32; Kp is padded to it
 
 // ---- CNN

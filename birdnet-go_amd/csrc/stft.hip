@@ -1,0 +1,281 @@
+// FFT-based mel front-end for gfx950: normalise -> frame -> window -> real FFT (fp64, like TFLite's RFFT2D which runs
+// Ooura fft2d on doubles) -> needed bins as fp32 (real part for the CAST graph, magnitude for the COMPLEX_ABS graph)
+// -> [k_pw_gemm with the mel matrix] -> pow/pow -> NHWC store.
+//
+// Reference path being replaced: the in-graph front-end of the v2.4 .tflite the reference feeds its interpreter
+// (`internal/inference/tflite/classifier.go:95-119`); op semantics restated from TFLite 2.17.1 (rfft2d.cc, cast.cc,
+// complex_support.cc).  Unlike the folded-GEMM kernel (k_frontend) this path is not restricted to the real-part graph:
+// the magnitude is non-linear, so the DFT itself has to be produced.
+//
+// One wave transforms one frame at a time.  A length-N real frame is packed into N/2 complex points z[n] = x[2n] +
+// i x[2n+1]; the N/2-point complex FFT is a four-step decomposition N/2 = P x 64 (P = 16 / 8 / 4 for N = 2048 / 1024 / 512):
+//   1. lane n2 holds z[64 n1 + n2], n1 = 0..P-1: P-point FFT in registers             -> Y[k1][n2]
+//   2. twiddle W_{N/2}^{k1 n2} (LDS table), transpose through the wave's LDS slice
+//   3. 64-point FFTs over n2 for each k1, themselves P x Q (Q = 64/P): lane (k1, q) runs a P-point FFT in registers
+//      over n2 = Q j + q, twiddles W_64^{q j'}, exchanges through LDS, then Q-point FFTs in registers
+//   4. Z[k1 + P (j' + P q')] back to LDS, and the real-input split X[k] = E + W_N^k O on the bins the mel matrix uses.
+// All LDS traffic of a frame stays inside the wave's private 16 KB slice, so no block barriers are needed in the loop.
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+namespace bnhip {
+
+// ------------------------------------------------------------------------------------------ normalise
+// ((x - min) / (range + eps) - sub) * mul in the graph's op order, once per clip (the FFT kernel re-reads every sample
+// ~7 times through L2 because frames overlap; normalising on the fly would repeat the division each time)
+__global__ void k_normalize(const float* __restrict__ x, const float2* __restrict__ mm, float* __restrict__ out,
+                            int n_samples, float norm_sub, float norm_mul) {
+    const int b = blockIdx.y;
+    const float2 m = mm[b];
+    const float* xc = x + (size_t)b * n_samples;
+    float* oc = out + (size_t)b * n_samples;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_samples; i += gridDim.x * blockDim.x) {
+        float t = xc[i] - m.x;
+        t = t / m.y;
+        t = t - norm_sub;
+        oc[i] = t * norm_mul;
+    }
+}
+void launch_normalize(const float* x, const float2* mm, float* out, int n_clips, int n_samples, float norm_sub,
+                      float norm_mul, hipStream_t s) {
+    dim3 grid((n_samples + 256 * 8 - 1) / (256 * 8), n_clips);
+    hipLaunchKernelGGL(k_normalize, grid, dim3(256), 0, s, x, mm, out, n_samples, norm_sub, norm_mul);
+}
+
+// ------------------------------------------------------------------------------------------ register FFTs
+// In-place radix-2 DIT on P complex doubles held in registers; every index is a compile-time constant after unrolling.
+template <int P>
+__device__ __forceinline__ void fft_regs(double (&re)[P], double (&im)[P]) {
+    // cos / sin of 2 pi t / 16, t = 0..7 (P <= 16 uses a stride into this table)
+    constexpr double C16[8] = {1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173,
+                               0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128673848};
+    constexpr double S16[8] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128673848,
+                               1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173};
+    constexpr int LOG = P == 16 ? 4 : (P == 8 ? 3 : (P == 4 ? 2 : 1));
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        int j = 0;
+#pragma unroll
+        for (int bit = 0; bit < LOG; bit++) j |= ((i >> bit) & 1) << (LOG - 1 - bit);
+        if (i < j) { double t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; }
+    }
+#pragma unroll
+    for (int len = 2; len <= P; len <<= 1) {
+        const int half = len >> 1, step = 16 / len;
+#pragma unroll
+        for (int i = 0; i < P; i += len) {
+#pragma unroll
+            for (int k = 0; k < half; k++) {
+                const double wr = C16[k * step], wi = -S16[k * step];      // e^{-2 pi i k / len}
+                const double xr = re[i + k + half], xi = im[i + k + half];
+                const double vr = xr * wr - xi * wi, vi = xr * wi + xi * wr;
+                const double ur = re[i + k], ui = im[i + k];
+                re[i + k] = ur + vr; im[i + k] = ui + vi;
+                re[i + k + half] = ur - vr; im[i + k + half] = ui - vi;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ STFT -> needed bins
+#define STFT_WAVES 8
+template <int P>
+__global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_bins(StftParams p) {
+    constexpr int N2 = 64 * P;            // complex points
+    constexpr int N = 2 * N2;             // real frame length (= fft length)
+    constexpr int Q = 64 / P;
+    constexpr int RS = 65;                // padded row stride of the transposed Y[k1][n2]
+    constexpr int WSZ = P * RS;           // doubles per component in a wave's slice (>= N2)
+    constexpr int NPAIR = (P * P + 63) / 64;   // (k1, j') pairs per lane in the last stage (P = 4: only 16 lanes hold one)
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* twr = sm;                     // [P][64] Re W_{N2}^{k1 n2}
+    double* twi = twr + P * 64;
+    double* t2r = twi + P * 64;           // [Q][P]  W_64^{q j'}
+    double* t2i = t2r + Q * P;
+    double* trr = t2i + Q * P;            // [nb_cap] W_N^{k} for the needed bins
+    double* tri = trr + p.nb_cap;
+    double* work = tri + p.nb_cap;        // [STFT_WAVES][2][WSZ]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+
+    // ---- tables (once per block)
+    for (int i = tid; i < P * 64; i += blockDim.x) {
+        int k1 = i >> 6, n2 = i & 63;
+        double s, c;
+        sincos(-6.283185307179586476925286766559 * (double)((k1 * n2) % N2) / (double)N2, &s, &c);
+        twr[i] = c; twi[i] = s;
+    }
+    for (int i = tid; i < Q * P; i += blockDim.x) {
+        int q = i / P, j = i % P;
+        double s, c;
+        sincos(-6.283185307179586476925286766559 * (double)((q * j) % 64) / 64.0, &s, &c);
+        t2r[i] = c; t2i[i] = s;
+    }
+    for (int i = tid; i < p.nb; i += blockDim.x) {
+        double s, c;
+        sincos(-6.283185307179586476925286766559 * (double)p.bins[i] / (double)N, &s, &c);
+        trr[i] = c; tri[i] = s;
+    }
+    __syncthreads();
+
+    double* wre = work + (size_t)wave * 2 * WSZ;
+    double* wim = wre + WSZ;
+    const float* xc = p.xn + (size_t)b * p.n_samples;
+    // this lane's window taps: samples 128 n1 + 2 n2 (+1)
+    float w0[P], w1[P];
+#pragma unroll
+    for (int n1 = 0; n1 < P; n1++) {
+        int n = 128 * n1 + 2 * lane;
+        w0[n1] = n < p.L ? p.window[n] : 0.f;
+        w1[n1] = n + 1 < p.L ? p.window[n + 1] : 0.f;
+    }
+    const int k1b = lane % P, qb = lane / P;
+
+    const int f_begin = (blockIdx.x * STFT_WAVES + wave) * p.fpw;
+    const int f_end = min(f_begin + p.fpw, p.F);
+    for (int f = f_begin; f < f_end; f++) {
+        double re[P], im[P];
+        // ---- 1. load + window (fp32 product, as the graph's MUL) + P-point FFT over n1
+        const int s0 = f * p.hop + 2 * lane;
+#pragma unroll
+        for (int n1 = 0; n1 < P; n1++) {
+            int s = s0 + 128 * n1;
+            float2 v = make_float2(0.f, 0.f);
+            if (s + 1 < p.n_samples) v = *reinterpret_cast<const float2*>(xc + s);
+            else if (s < p.n_samples) v.x = xc[s];
+            re[n1] = (double)(v.x * w0[n1]);
+            im[n1] = (double)(v.y * w1[n1]);
+        }
+        fft_regs<P>(re, im);
+        // ---- 2. twiddle + transpose
+#pragma unroll
+        for (int k1 = 0; k1 < P; k1++) {
+            const double c = twr[k1 * 64 + lane], s = twi[k1 * 64 + lane];
+            const double r = re[k1] * c - im[k1] * s, i2 = re[k1] * s + im[k1] * c;
+            wre[k1 * RS + lane] = r; wim[k1 * RS + lane] = i2;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < P; j++) { re[j] = wre[k1b * RS + Q * j + qb]; im[j] = wim[k1b * RS + Q * j + qb]; }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // ---- 3. P-point FFT over j, twiddle W_64^{q j'}, exchange, Q-point FFTs
+        fft_regs<P>(re, im);
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            const double c = t2r[qb * P + j], s = t2i[qb * P + j];
+            const double r = re[j] * c - im[j] * s, i2 = re[j] * s + im[j] * c;
+            const int slot = j * P + k1b;
+            wre[slot * Q + qb] = r; wim[slot * Q + qb] = i2;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        double ar[NPAIR][Q], ai[NPAIR][Q];
+#pragma unroll
+        for (int t = 0; t < NPAIR; t++) {
+            const int slot = min(lane + 64 * t, P * P - 1);
+#pragma unroll
+            for (int q = 0; q < Q; q++) { ar[t][q] = wre[slot * Q + q]; ai[t][q] = wim[slot * Q + q]; }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < NPAIR; t++) {
+            fft_regs<Q>(ar[t], ai[t]);
+            const int slot = lane + 64 * t;              // = j' P + k1  ->  k = k1 + P j' + P^2 q'
+            const int kbase = (slot % P) + P * (slot / P);
+            if (slot < P * P) {
+#pragma unroll
+                for (int q = 0; q < Q; q++) { wre[kbase + P * P * q] = ar[t][q]; wim[kbase + P * P * q] = ai[t][q]; }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // ---- 4. real-input split on the needed bins
+        float* orow = p.out + ((size_t)b * p.F + f) * p.nbp;
+        for (int idx = lane; idx < p.nbp; idx += 64) {
+            float o = 0.f;
+            if (idx < p.nb) {
+                const int k = p.bins[idx];
+                const int ka = k % N2, kb = (N2 - k % N2) % N2;
+                const double zr = wre[ka], zi = wim[ka], mr = wre[kb], mi = -wim[kb];       // Z[k], conj(Z[N2-k])
+                const double er = 0.5 * (zr + mr), ei = 0.5 * (zi + mi);
+                const double dr = zr - mr, di = zi - mi;
+                const double or_ = 0.5 * di, oi = -0.5 * dr;                                 // -i/2 (Z[k] - conj(Z[N2-k]))
+                const double c = trr[idx], s = tri[idx];
+                const double xr = er + (or_ * c - oi * s), xi = ei + (or_ * s + oi * c);
+                if (p.mode == 0) o = (float)xr;
+                else o = hypotf((float)xr, (float)xi);       // COMPLEX_ABS on complex64
+            }
+            orow[idx] = o;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+size_t stft_lds_bytes(int P, int nb_cap) {
+    return (size_t)(2 * P * 64 + 2 * (64 / P) * P + 2 * nb_cap + STFT_WAVES * 2 * P * 65) * sizeof(double);
+}
+bool stft_supported(int Lfft, int nb) {
+    if (Lfft != 2048 && Lfft != 1024 && Lfft != 512) return false;
+    int P = Lfft / 128, cap = (nb + 63) / 64 * 64;
+    return stft_lds_bytes(P, cap) <= 160 * 1024;
+}
+void launch_stft_bins(const StftParams& p0, hipStream_t s) {
+    StftParams p = p0;
+    p.nb_cap = (p.nb + 63) / 64 * 64;
+    p.fpw = 8;
+    const int P = p.Lfft / 128;
+    size_t lds = stft_lds_bytes(P, p.nb_cap);
+    dim3 grid((p.F + STFT_WAVES * p.fpw - 1) / (STFT_WAVES * p.fpw), p.n_clips);
+    static bool attr16 = false, attr8 = false;
+    if (P == 4) {
+        hipLaunchKernelGGL((k_stft_bins<4>), grid, dim3(64 * STFT_WAVES), lds, s, p);      // < 64 KB of LDS
+    } else if (P == 16) {
+        if (!attr16) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr16 = true; }
+        hipLaunchKernelGGL((k_stft_bins<16>), grid, dim3(64 * STFT_WAVES), lds, s, p);
+    } else {
+        if (!attr8) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr8 = true; }
+        hipLaunchKernelGGL((k_stft_bins<8>), grid, dim3(64 * STFT_WAVES), lds, s, p);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ pow + NHWC store
+// T[b][f][m] (mel GEMM output) -> out[b][m][f][c] = pow(pow(v, p1), p2); a 32 x 32 LDS transpose keeps both sides
+// coalesced.
+__global__ __launch_bounds__(256) void k_mel_finish(const float* __restrict__ T, float* __restrict__ out, int F, int n_mels,
+                                                    int ldt, int C, int c, float p1, float p2) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, f0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        int f = f0 + r, m = m0 + tx;
+        float v = 0.f;
+        if (f < F && m < n_mels) {
+            v = T[((size_t)b * F + f) * ldt + m];
+            float y = (p1 == 2.0f) ? v * v : powf(v, p1);
+            if (p2 != 1.0f) y = powf(y, p2);
+            v = y;
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int m = m0 + r, f = f0 + tx;
+        if (f < F && m < n_mels) out[(((size_t)b * n_mels + m) * F + f) * C + c] = tile[tx][r];
+    }
+}
+void launch_mel_finish(const float* T, float* out, int n_clips, int F, int n_mels, int ldt, int C, int c, float p1, float p2,
+                       hipStream_t s) {
+    dim3 grid((F + 31) / 32, (n_mels + 31) / 32, n_clips);
+    hipLaunchKernelGGL(k_mel_finish, grid, dim3(256), 0, s, T, out, F, n_mels, ldt, C, c, p1, p2);
+}
+
+}  // namespace bnhip

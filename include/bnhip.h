@@ -48,7 +48,7 @@ void bnhip_shutdown(void);
 /* Build a classifier from in-memory TFLite model bytes — the same byte slice the reference hands to
  * NewTFLiteClassifier(modelData []byte, ...) (internal/inference/tflite/classifier.go:38).  The blob
  * is consumed during the call and may be freed afterwards (classifier.go:37).
- * opts_json (nullable): {"device":0,"max_batch":256,"plan_only":0,"debug_no_reuse":0,"autotune":1,"graphs":0,"lanes":2}; plan_only builds the
+ * opts_json (nullable): {"device":0,"max_batch":256,"plan_only":0,"debug_no_reuse":0,"autotune":1,"graphs":0,"lanes":2,"frontend_fft":-1}; plan_only builds the
  * kernel plan on the CPU without touching a device (info/describe work, predict is rejected).  */
 int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, bnhip_model** out);
 

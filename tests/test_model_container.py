@@ -140,12 +140,25 @@ def test_unsupported_graph_reports_op(built_lib):
     assert e.value.code == host.E_UNSUPPORTED
 
 
-def test_magnitude_frontend_is_reported_unsupported(built_lib):
-    blob = sm.build_model(sm.tiny_config(complex_mode="abs"))
-    with pytest.raises(host.HipError, match="COMPLEX_ABS") as e:
-        host.HipClassifier(blob, plan_only=True)
+def test_magnitude_frontend_plans_onto_the_fft_path(built_lib):
+    """COMPLEX_ABS graphs cannot use the folded-GEMM kernel (the magnitude is non-linear): the planner routes them through
+    normalize -> stft -> mel GEMM -> finish; an fft_length the FFT kernel does not cover is reported, not guessed."""
+    specs = (sm.SpecConfig(512, 94, 0.0, 3000.0), sm.SpecConfig(512, 94, 500.0, 15000.0))
+    blob = sm.build_model(sm.tiny_config(complex_mode="abs", specs=specs))
+    with pytest.raises(host.HipError, match="fft_length") as e:          # the default tiny geometry has a 256-point branch
+        host.HipClassifier(sm.build_model(sm.tiny_config(complex_mode="abs")), plan_only=True)
     assert e.value.code == host.E_UNSUPPORTED
-    # ...while the oracle executes it generically
+    d = host.HipClassifier(blob, plan_only=True).describe()
+    kinds = [s["kernel"] for s in d["steps"]]
+    assert kinds.count("stft") == 2 and "frontend" in kinds
+    names = [s["name"] for s in d["steps"]]
+    assert names[:2] == ["clip_minmax", "normalize"] and "mel0" in names and "melspec1" in names
+    # the real-part graph keeps the folded GEMM unless asked otherwise
+    d2 = host.HipClassifier(sm.build_model(sm.tiny_config(specs=specs)), plan_only=True).describe()
+    assert "stft" not in [s["kernel"] for s in d2["steps"]]
+    d3 = host.HipClassifier(sm.build_model(sm.tiny_config(specs=specs)), plan_only=True, frontend_fft=1).describe()
+    assert [s["kernel"] for s in d3["steps"]].count("stft") == 2
+    # the oracle executes the op generically
     assert np.isfinite(Interpreter(blob).invoke(sm.synth_clips(1, 12000))[0]).all()
 
 

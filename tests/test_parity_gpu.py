@@ -72,6 +72,55 @@ def test_full_vs_oracle_and_golden(full_clf, full_blob):
     assert (got[:2].argmax(1) == g["idx"][:, 0]).all()
 
 
+# ---- FFT front-end (stft.hip): serves the magnitude (COMPLEX_ABS) graph and, on request, the real-part graph
+FFT_TINY_SPECS = (sm.SpecConfig(512, 94, 0.0, 3000.0), sm.SpecConfig(512, 94, 500.0, 15000.0))
+
+
+@pytest.mark.parametrize("mode", ["abs", "real"])
+def test_fft_frontend_tiny_vs_oracle(built_lib, mode):
+    cfg = sm.tiny_config(complex_mode=mode, specs=FFT_TINY_SPECS)
+    blob = sm.build_model(cfg)
+    x = sm.synth_clips(3, cfg.n_samples, cfg.sample_rate)
+    x[2] = 0.0                                                  # digital silence: the bins that cancel to ~0
+    ref = Interpreter(blob).invoke(x)[0]
+    c = host.HipClassifier(blob, max_batch=4, frontend_fft=1)
+    try:
+        assert "stft" in [s["kernel"] for s in c.describe()["steps"]]
+        assert_parity(c.predict_batch(x.reshape(-1), 3), ref)
+    finally:
+        c.close()
+
+
+def test_fft_frontend_full_magnitude_graph_vs_oracle(built_lib):
+    blob = sm.build_model(sm.SynthConfig(complex_mode="abs"))
+    x = sm.synth_clips(3, 144000, 48000)
+    x[2] = 0.0
+    ref = Interpreter(blob).invoke(x)[0]
+    c = host.HipClassifier(blob, max_batch=8)                   # magnitude graphs select the FFT path themselves
+    try:
+        got = c.predict_batch(x.reshape(-1), 3)
+        assert_parity(got, ref)
+        # ragged batch through the lanes / chunking
+        x9 = sm.synth_clips(9, 144000, 48000)
+        g9 = c.predict_batch(x9.reshape(-1), 9)
+        assert np.abs(g9[:2] - got[:2]).max() == 0.0
+    finally:
+        c.close()
+
+
+def test_fft_frontend_matches_folded_gemm_on_the_real_part_graph(full_clf, full_blob):
+    x = sm.synth_clips(4, 144000, 48000)
+    x[3] = 0.0
+    a = full_clf.predict_batch(x.reshape(-1), 4)
+    c = host.HipClassifier(full_blob, max_batch=8, frontend_fft=1)
+    try:
+        b = c.predict_batch(x.reshape(-1), 4)
+    finally:
+        c.close()
+    assert (a.argmax(1) == b.argmax(1)).all()
+    assert np.abs(sig(a) - sig(b)).max() <= 1e-4
+
+
 def test_reference_benchmark_input_silence(full_clf, full_blob):
     """cmd/benchmark/benchmark.go:99-101 feeds 144000 zeros; the graph's min/max normalisation maps a
     constant clip to -1 everywhere (0/(0+1e-6) - 0.5)*2, which must not produce NaN/Inf."""
