@@ -412,6 +412,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
         add_step(s);
         int v_spec = new_val(spec_tensor, (size_t)fms[0].n_mels * fms[0].F * C_spec);
         int v_xn = -1;                      // normalised clip (FFT front-end only)
+        std::vector<std::pair<int, int>> fft_fin;   // (mel GEMM output value, spec index) awaiting pow + NHWC store
         tv[spec_tensor] = v_spec;
         for (size_t i = 0; i < fms.size(); i++) {
             const FrontendMatch& fm = fms[i];
@@ -478,9 +479,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                 g.bytes = 4.0 * ((double)fm.F * fs.nbp + (double)fm.F * fm.n_mels);
                 g.wbytes = 4.0 * fs.nbp * fm.n_mels;
                 add_step(g, o_mel);
-                Step mf; mf.kind = S_MELFIN; mf.name = "melspec" + std::to_string(i); mf.kclass = "frontend"; mf.in0 = v_T; mf.out = v_spec;
-                mf.spec = si; mf.bytes = 8.0 * fm.F * fm.n_mels;
-                add_step(mf);
+                fft_fin.push_back({v_T, si});
                 continue;
             }
             if (frontend_lds_bytes(fs.Lfft, fs.Kp, fs.hop, fs.NTP) > 160 * 1024) {
@@ -503,6 +502,19 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
             f.flops = 2.0 * fm.F * (fm.Lfft / 2 + 1) * fm.n_mels;
             f.bytes = (double)n_samples * 4 + (double)fm.F * fm.n_mels * 4;
             add_step(f, goff, woff);
+        }
+        // pow + NHWC store of the FFT-path channels: two adjacent channels go out as one float2 per pixel
+        for (size_t k = 0; k < fft_fin.size();) {
+            const FrontSpec& a = specs[fft_fin[k].second];
+            bool pair = k + 1 < fft_fin.size() && specs[fft_fin[k + 1].second].c == a.c + 1 && (a.c & 1) == 0 &&
+                        specs[fft_fin[k + 1].second].F == a.F && specs[fft_fin[k + 1].second].n_mels == a.n_mels;
+            Step mf; mf.kind = S_MELFIN; mf.name = "melspec" + std::to_string(a.c); mf.kclass = "frontend";
+            mf.in0 = fft_fin[k].first; mf.spec = fft_fin[k].second; mf.out = v_spec;
+            mf.S = pair ? 2 : 1;
+            if (pair) { mf.in1 = fft_fin[k + 1].first; mf.op = fft_fin[k + 1].second; mf.name += "+" + std::to_string(a.c + 1); }
+            mf.bytes = 8.0 * a.F * a.n_mels * mf.S;
+            add_step(mf);
+            k += mf.S;
         }
     }
 
@@ -1142,8 +1154,10 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
                 break;
             }
             case S_MELFIN: {
-                const FrontSpec& fs = specs[s.spec];
-                launch_mel_finish(in0, out, n, fs.F, fs.n_mels, fs.n_mels, C_spec, fs.c, fs.p1, fs.p2, stream);
+                const FrontSpec& fa = specs[s.spec];
+                const FrontSpec& fb = specs[s.S == 2 ? s.op : s.spec];
+                MelFinParams p{{in0, s.S == 2 ? in1 : in0}, {fa.p1, fb.p1}, {fa.p2, fb.p2}, out, fa.F, fa.n_mels, fa.n_mels, C_spec, fa.c};
+                launch_mel_finish(p, s.S, n, stream);
                 break;
             }
             case S_CONV_DIRECT: {

@@ -42,8 +42,13 @@ void launch_normalize(const float* x, const float2* mm, float* out, int n_clips,
                       float norm_mul, hipStream_t s);
 bool stft_supported(int Lfft, int nb);
 void launch_stft_bins(const StftParams& p, hipStream_t s);
-void launch_mel_finish(const float* T, float* out, int n_clips, int F, int n_mels, int ldt, int C, int c, float p1, float p2,
-                       hipStream_t s);
+struct MelFinParams {
+    const float* T[2];      // [B, F, ldt] per channel handled by this launch
+    float p1[2], p2[2];
+    float* out;             // [B, n_mels, F, Ctot]
+    int F, n_mels, ldt, Ctot, c0;   // c0 = first channel written (two channels are written as one float2 when c0 is even)
+};
+void launch_mel_finish(const MelFinParams& p, int nch, int n_clips, hipStream_t s);
 int frontend_kc(int Lfft, int hop, int NTP);   // K-chunk of the front-end GEMM (G rows per LDS stage): 16 or 32; Kp is padded to it
 
 // ---- CNN

@@ -73,10 +73,17 @@ __device__ __forceinline__ void fft_regs(double (&re)[P], double (&im)[P]) {
             for (int k = 0; k < half; k++) {
                 const double wr = C16[k * step], wi = -S16[k * step];      // e^{-2 pi i k / len}
                 const double xr = re[i + k + half], xi = im[i + k + half];
-                const double vr = xr * wr - xi * wi, vi = xr * wi + xi * wr;
                 const double ur = re[i + k], ui = im[i + k];
-                re[i + k] = ur + vr; im[i + k] = ui + vi;
-                re[i + k + half] = ur - vr; im[i + k + half] = ui - vi;
+                if (k == 0) {                                               // w = 1
+                    re[i + k] = ur + xr; im[i + k] = ui + xi; re[i + k + half] = ur - xr; im[i + k + half] = ui - xi;
+                } else if (2 * k == half) {                                 // w = -i
+                    re[i + k] = ur + xi; im[i + k] = ui - xr; re[i + k + half] = ur - xi; im[i + k + half] = ui + xr;
+                } else {                                                    // explicit FMAs (contraction is off file-wide)
+                    re[i + k] = fma(xr, wr, fma(-xi, wi, ur));
+                    im[i + k] = fma(xr, wi, fma(xi, wr, ui));
+                    re[i + k + half] = fma(-xr, wr, fma(xi, wi, ur));
+                    im[i + k + half] = fma(-xr, wi, fma(-xi, wr, ui));
+                }
             }
         }
     }
@@ -135,28 +142,53 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_bins(StftParams p) {
         w1[n1] = n + 1 < p.L ? p.window[n + 1] : 0.f;
     }
     const int k1b = lane % P, qb = lane / P;
+    // this lane's output bins (constant across frames): LDS indices of Z[k], Z[N2-k]
+    constexpr int NBL = 8;                               // bins per lane held in registers (nb <= 512)
+    int ka_[NBL], kb_[NBL];
+#pragma unroll
+    for (int t = 0; t < NBL; t++) {
+        int idx = lane + 64 * t;
+        int k = idx < p.nb ? p.bins[idx] : 0;
+        ka_[t] = k % N2; kb_[t] = (N2 - k % N2) % N2;
+    }
 
     const int f_begin = (blockIdx.x * STFT_WAVES + wave) * p.fpw;
     const int f_end = min(f_begin + p.fpw, p.F);
+    // the next frame's samples are requested before the current frame is transformed (a frame's 16 loads would
+    // otherwise be an exposed L2 round trip per frame with two waves per SIMD)
+    float2 nx[P];
+    auto fetch = [&](int f) {
+        const int s0 = f * p.hop + 2 * lane;
+        if (f * p.hop + N <= p.n_samples && ((f * p.hop) & 1) == 0) {        // whole frame in range, 8-byte aligned
+#pragma unroll
+            for (int n1 = 0; n1 < P; n1++) nx[n1] = *reinterpret_cast<const float2*>(xc + s0 + 128 * n1);
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < P; n1++) {
+                int s = s0 + 128 * n1;
+                float2 v = make_float2(0.f, 0.f);
+                if (s < p.n_samples) v.x = xc[s];
+                if (s + 1 < p.n_samples) v.y = xc[s + 1];
+                nx[n1] = v;
+            }
+        }
+    };
+    if (f_begin < f_end) fetch(f_begin);
     for (int f = f_begin; f < f_end; f++) {
         double re[P], im[P];
-        // ---- 1. load + window (fp32 product, as the graph's MUL) + P-point FFT over n1
-        const int s0 = f * p.hop + 2 * lane;
+        // ---- 1. window (fp32 product, as the graph's MUL) + P-point FFT over n1
 #pragma unroll
         for (int n1 = 0; n1 < P; n1++) {
-            int s = s0 + 128 * n1;
-            float2 v = make_float2(0.f, 0.f);
-            if (s + 1 < p.n_samples) v = *reinterpret_cast<const float2*>(xc + s);
-            else if (s < p.n_samples) v.x = xc[s];
-            re[n1] = (double)(v.x * w0[n1]);
-            im[n1] = (double)(v.y * w1[n1]);
+            re[n1] = (double)(nx[n1].x * w0[n1]);
+            im[n1] = (double)(nx[n1].y * w1[n1]);
         }
+        if (f + 1 < f_end) fetch(f + 1);
         fft_regs<P>(re, im);
         // ---- 2. twiddle + transpose
 #pragma unroll
         for (int k1 = 0; k1 < P; k1++) {
             const double c = twr[k1 * 64 + lane], s = twi[k1 * 64 + lane];
-            const double r = re[k1] * c - im[k1] * s, i2 = re[k1] * s + im[k1] * c;
+            const double r = fma(re[k1], c, -(im[k1] * s)), i2 = fma(re[k1], s, im[k1] * c);
             wre[k1 * RS + lane] = r; wim[k1 * RS + lane] = i2;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -170,7 +202,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_bins(StftParams p) {
 #pragma unroll
         for (int j = 0; j < P; j++) {
             const double c = t2r[qb * P + j], s = t2i[qb * P + j];
-            const double r = re[j] * c - im[j] * s, i2 = re[j] * s + im[j] * c;
+            const double r = fma(re[j], c, -(im[j] * s)), i2 = fma(re[j], s, im[j] * c);
             const int slot = j * P + k1b;
             wre[slot * Q + qb] = r; wim[slot * Q + qb] = i2;
         }
@@ -199,19 +231,24 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_bins(StftParams p) {
         __builtin_amdgcn_wave_barrier();
         // ---- 4. real-input split on the needed bins
         float* orow = p.out + ((size_t)b * p.F + f) * p.nbp;
-        for (int idx = lane; idx < p.nbp; idx += 64) {
+#pragma unroll
+        for (int t = 0; t < NBL; t++) {
+            const int idx = lane + 64 * t;
+            if (idx >= p.nbp) break;
             float o = 0.f;
             if (idx < p.nb) {
-                const int k = p.bins[idx];
-                const int ka = k % N2, kb = (N2 - k % N2) % N2;
+                const int ka = ka_[t], kb = kb_[t];
                 const double zr = wre[ka], zi = wim[ka], mr = wre[kb], mi = -wim[kb];       // Z[k], conj(Z[N2-k])
                 const double er = 0.5 * (zr + mr), ei = 0.5 * (zi + mi);
                 const double dr = zr - mr, di = zi - mi;
                 const double or_ = 0.5 * di, oi = -0.5 * dr;                                 // -i/2 (Z[k] - conj(Z[N2-k]))
                 const double c = trr[idx], s = tri[idx];
-                const double xr = er + (or_ * c - oi * s), xi = ei + (or_ * s + oi * c);
+                const double xr = er + fma(or_, c, -(oi * s));
                 if (p.mode == 0) o = (float)xr;
-                else o = hypotf((float)xr, (float)xi);       // COMPLEX_ABS on complex64
+                else {
+                    const double xi = ei + fma(or_, s, oi * c);
+                    o = hypotf((float)xr, (float)xi);        // COMPLEX_ABS on complex64
+                }
             }
             orow[idx] = o;
         }
@@ -226,7 +263,7 @@ size_t stft_lds_bytes(int P, int nb_cap) {
 bool stft_supported(int Lfft, int nb) {
     if (Lfft != 2048 && Lfft != 1024 && Lfft != 512) return false;
     int P = Lfft / 128, cap = (nb + 63) / 64 * 64;
-    return stft_lds_bytes(P, cap) <= 160 * 1024;
+    return nb <= 508 && stft_lds_bytes(P, cap) <= 160 * 1024;      // 8 bins per lane are held in registers
 }
 void launch_stft_bins(const StftParams& p0, hipStream_t s) {
     StftParams p = p0;
@@ -248,34 +285,42 @@ void launch_stft_bins(const StftParams& p0, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------ pow + NHWC store
-// T[b][f][m] (mel GEMM output) -> out[b][m][f][c] = pow(pow(v, p1), p2); a 32 x 32 LDS transpose keeps both sides
-// coalesced.
-__global__ __launch_bounds__(256) void k_mel_finish(const float* __restrict__ T, float* __restrict__ out, int F, int n_mels,
-                                                    int ldt, int C, int c, float p1, float p2) {
-    __shared__ float tile[32][33];
+// T_c[b][f][m] (mel GEMM outputs, one per channel) -> out[b][m][f][c] = pow(pow(v, p1), p2); a 32 x 32 LDS transpose keeps
+// both sides coalesced and all channels of a pixel are written together.  The second power runs on the hardware
+// log2/exp2 units (1 ulp each): with p1 = 2 the operand is a square, so there is no sign to carry.
+__device__ __forceinline__ float mel_pow(float v, float p1, float p2) {
+    float y = (p1 == 2.0f) ? v * v : powf(v, p1);
+    if (p2 == 1.0f) return y;
+    if (y >= 0.0f) return y == 0.0f ? 0.0f : __builtin_amdgcn_exp2f(p2 * __builtin_amdgcn_logf(y));
+    return powf(y, p2);
+}
+template <int C>
+__global__ __launch_bounds__(256) void k_mel_finish(MelFinParams p) {
+    __shared__ float tile[C][32][33];
     const int b = blockIdx.z, f0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int r = ty; r < 32; r += 8) {
-        int f = f0 + r, m = m0 + tx;
-        float v = 0.f;
-        if (f < F && m < n_mels) {
-            v = T[((size_t)b * F + f) * ldt + m];
-            float y = (p1 == 2.0f) ? v * v : powf(v, p1);
-            if (p2 != 1.0f) y = powf(y, p2);
-            v = y;
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        for (int r = ty; r < 32; r += 8) {
+            int f = f0 + r, m = m0 + tx;
+            float v = 0.f;
+            if (f < p.F && m < p.n_mels) v = mel_pow(p.T[c][((size_t)b * p.F + f) * p.ldt + m], p.p1[c], p.p2[c]);
+            tile[c][r][tx] = v;
         }
-        tile[r][tx] = v;
-    }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         int m = m0 + r, f = f0 + tx;
-        if (f < F && m < n_mels) out[(((size_t)b * n_mels + m) * F + f) * C + c] = tile[tx][r];
+        if (f < p.F && m < p.n_mels) {
+            float* o = p.out + (((size_t)b * p.n_mels + m) * p.F + f) * p.Ctot + p.c0;
+            if (C == 2) *reinterpret_cast<float2*>(o) = make_float2(tile[0][tx][r], tile[1][tx][r]);
+            else o[0] = tile[0][tx][r];
+        }
     }
 }
-void launch_mel_finish(const float* T, float* out, int n_clips, int F, int n_mels, int ldt, int C, int c, float p1, float p2,
-                       hipStream_t s) {
-    dim3 grid((F + 31) / 32, (n_mels + 31) / 32, n_clips);
-    hipLaunchKernelGGL(k_mel_finish, grid, dim3(256), 0, s, T, out, F, n_mels, ldt, C, c, p1, p2);
+void launch_mel_finish(const MelFinParams& p, int nch, int n_clips, hipStream_t s) {
+    dim3 grid((p.F + 31) / 32, (p.n_mels + 31) / 32, n_clips);
+    if (nch == 2) hipLaunchKernelGGL((k_mel_finish<2>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_mel_finish<1>), grid, dim3(256), 0, s, p);
 }
 
 }  // namespace bnhip
