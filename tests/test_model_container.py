@@ -87,7 +87,8 @@ def test_cpp_reader_and_planner_fuse_everything(built_lib, full_blob):
     assert (clf.n_samples, clf.num_species(), clf.emb_dim) == (144000, 6522, 0)
     d = clf.describe()
     kinds = [s["kernel"] for s in d["steps"]]
-    assert kinds.count("frontend") == 2 and kinds.count("clip_minmax") == 1
+    # front-end (FFT path): clip_minmax, normalize, 2 x (stft + mel GEMM), one fused finish
+    assert kinds.count("stft") == 2 and kinds.count("frontend") == 2 and kinds.count("clip_minmax") == 1
     assert "elementwise" not in kinds, "an op fell back to the unfused elementwise path"
     # 16 MBConv blocks: 11 with the fused expand+depthwise kernel (Cin <= 128), 5 plain depthwise (b1 + the 4 wide ones)
     assert kinds.count("expand_dw") == 11 and kinds.count("dwconv") == 5 and kinds.count("se") == 16
@@ -95,7 +96,10 @@ def test_cpp_reader_and_planner_fuse_everything(built_lib, full_blob):
     assert sum(s["fused_sum"] for s in d["steps"]) == 16 and kinds.count("mean") == 2
     pw = [s for s in d["steps"] if s["kernel"] == "pw_gemm"]
     assert sum(s["fused_scale"] for s in pw) == 16 and sum(s["fused_res"] for s in pw) == 9
-    assert len(d["steps"]) == 60
+    assert len(d["steps"]) == 64
+    # with the folded-GEMM front-end: clip_minmax + one k_frontend launch per channel
+    d0 = host.HipClassifier(full_blob, plan_only=True, frontend_fft=0).describe()
+    assert len(d0["steps"]) == 60 and [s["kernel"] for s in d0["steps"]].count("frontend") == 2
     assert d["specs"][0]["hop"] == 278 and d["specs"][1]["hop"] == 280 and d["specs"][0]["frames"] == 511
     assert abs(d["specs"][0]["p2"] - 1.0 / (1.0 + np.exp(1.23))) < 1e-6
     with pytest.raises(host.HipError, match="plan-only"):
@@ -154,10 +158,15 @@ def test_magnitude_frontend_plans_onto_the_fft_path(built_lib):
     names = [s["name"] for s in d["steps"]]
     assert names[:2] == ["clip_minmax", "normalize"] and "mel0" in names and "melspec0+1" in names
     # the real-part graph keeps the folded GEMM unless asked otherwise
-    d2 = host.HipClassifier(sm.build_model(sm.tiny_config(specs=specs)), plan_only=True).describe()
+    # the real-part graph can use either front-end: FFT by default where the frame length is covered, folded GEMM on request
+    d2 = host.HipClassifier(sm.build_model(sm.tiny_config(specs=specs)), plan_only=True, frontend_fft=0).describe()
     assert "stft" not in [s["kernel"] for s in d2["steps"]]
-    d3 = host.HipClassifier(sm.build_model(sm.tiny_config(specs=specs)), plan_only=True, frontend_fft=1).describe()
+    d3 = host.HipClassifier(sm.build_model(sm.tiny_config(specs=specs)), plan_only=True).describe()
     assert [s["kernel"] for s in d3["steps"]].count("stft") == 2
+    # mixed: the default tiny geometry has one 512-point and one 256-point branch
+    d4 = host.HipClassifier(sm.build_model(sm.tiny_config()), plan_only=True).describe()
+    k4 = [s["kernel"] for s in d4["steps"]]
+    assert k4.count("stft") == 1 and k4.count("frontend") >= 2
     # the oracle executes the op generically
     assert np.isfinite(Interpreter(blob).invoke(sm.synth_clips(1, 12000))[0]).all()
 

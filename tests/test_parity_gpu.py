@@ -111,8 +111,10 @@ def test_fft_frontend_full_magnitude_graph_vs_oracle(built_lib):
 def test_fft_frontend_matches_folded_gemm_on_the_real_part_graph(full_clf, full_blob):
     x = sm.synth_clips(4, 144000, 48000)
     x[3] = 0.0
-    a = full_clf.predict_batch(x.reshape(-1), 4)
-    c = host.HipClassifier(full_blob, max_batch=8, frontend_fft=1)
+    a = full_clf.predict_batch(x.reshape(-1), 4)                 # default: FFT front-end
+    assert "stft" in [s["kernel"] for s in full_clf.describe()["steps"]]
+    c = host.HipClassifier(full_blob, max_batch=8, frontend_fft=0)   # folded-GEMM front-end
+    assert "stft" not in [s["kernel"] for s in c.describe()["steps"]]
     try:
         b = c.predict_batch(x.reshape(-1), 4)
     finally:
