@@ -90,7 +90,7 @@ def cpu_baseline(blob, n_samples, sample_rate, n_clips_hint):
     cores = os.cpu_count() or 1
     workers = max(1, min(32, cores // 4))
     threads = max(1, cores // workers)
-    per_worker = max(2, (n_clips_hint or 8 * workers) // workers)
+    per_worker = max(2, (n_clips_hint or 24 * workers) // workers)     # ~15 s of host compute on the bench box
     tmp = tempfile.NamedTemporaryFile(suffix=".tflite", delete=False)
     tmp.write(blob)
     tmp.close()
