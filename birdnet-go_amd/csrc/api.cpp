@@ -116,6 +116,8 @@ int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, 
     m->eng.autotune = json_int(opts_json, "autotune", 1) != 0;
     const char* lenv = getenv("BNHIP_LANES");            // experiment switch; the option wins when given
     m->eng.n_lanes = json_int(opts_json, "lanes", lenv ? atoi(lenv) : 2);
+    const char* denv = getenv("BNHIP_DEPTH");            // experiment switch; the option wins when given
+    m->eng.depth = json_int(opts_json, "depth", denv ? atoi(denv) : 1);
     const char* fenv = getenv("BNHIP_FE_FFT");           // experiment switch; the option wins when given
     m->eng.frontend_fft = json_int(opts_json, "frontend_fft", fenv ? atoi(fenv) : -1);
     const char* genv = getenv("BNHIP_GRAPHS");           // experiment switch; the option wins when given
@@ -147,6 +149,7 @@ int bnhip_set_stream(bnhip_model* m, void* hip_stream) {
     Engine& e = m->eng;
     hipSetDevice(e.device);
     e.drop_graphs();                                    // captured on the old stream
+    e.sync_contexts();
     if (e.own_stream && e.stream) { hipStreamSynchronize(e.stream); hipStreamDestroy(e.stream); }
     e.stream = reinterpret_cast<hipStream_t>(hip_stream);
     e.own_stream = false;
@@ -156,6 +159,7 @@ int bnhip_set_stream(bnhip_model* m, void* hip_stream) {
 int bnhip_synchronize(bnhip_model* m) {
     if (!m || m->eng.device < 0) return set_err(BNHIP_E_INVALID, "model is NULL or plan-only");
     hipSetDevice(m->eng.device);
+    m->eng.sync_contexts();
     hipError_t e = hipStreamSynchronize(m->eng.stream);
     if (e != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
     return BNHIP_OK;
@@ -170,8 +174,8 @@ int bnhip_predict_device(bnhip_model* m, const float* d_samples, int n_clips, fl
     std::string err;
     for (int off = 0; off < n_clips; off += e.max_batch) {
         int n = std::min(e.max_batch, n_clips - off);
-        if (!e.run(d_samples + (size_t)off * e.n_samples, n, d_logits + (size_t)off * e.n_classes,
-                   d_emb ? d_emb + (size_t)off * e.emb_dim : nullptr, &err))
+        if (!e.run_pipelined(d_samples + (size_t)off * e.n_samples, n, d_logits + (size_t)off * e.n_classes,
+                             d_emb ? d_emb + (size_t)off * e.emb_dim : nullptr, &err))
             return set_err(BNHIP_E_RUNTIME, err);
     }
     return BNHIP_OK;

@@ -282,6 +282,12 @@ Engine::~Engine() {
                     (void*)d_stage_logits2, (void*)d_stage_emb2})
         if (p) hipFree(p);
     for (int i = 0; i < 2; i++) { if (ev_copied[i]) hipEventDestroy(ev_copied[i]); if (ev_done[i]) hipEventDestroy(ev_done[i]); }
+    for (int c = 0; c < kMaxDepth; c++) {
+        if (ctx_stream[c]) { hipStreamSynchronize(ctx_stream[c]); hipStreamDestroy(ctx_stream[c]); }
+        if (c > 0 && ctx_arena[c]) hipFree(ctx_arena[c]);
+        if (ev_ctx_done[c]) hipEventDestroy(ev_ctx_done[c]);
+    }
+    if (ev_ctx_fork) hipEventDestroy(ev_ctx_fork);
     if (copy_stream) hipStreamDestroy(copy_stream);
     for (int i = 0; i < kMaxLanes - 1; i++) {
         if (lane_stream[i]) { hipStreamSynchronize(lane_stream[i]); hipStreamDestroy(lane_stream[i]); }
@@ -976,6 +982,16 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
     HIPCHK(hipMalloc((void**)&w_arena, std::max<size_t>(w_bytes, 256)));
     HIPCHK(hipMemcpy(w_arena, wimg.data(), w_bytes, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&act_arena, std::max<size_t>(act_bytes, 256)));
+    depth = std::max(1, std::min(depth, kMaxDepth));
+    if (depth > 1) {
+        HIPCHK(hipEventCreateWithFlags(&ev_ctx_fork, hipEventDisableTiming));
+        for (int c = 0; c < depth; c++) {
+            HIPCHK(hipStreamCreateWithFlags(&ctx_stream[c], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&ev_ctx_done[c], hipEventDisableTiming));
+            if (c == 0) ctx_arena[c] = act_arena;
+            else HIPCHK(hipMalloc((void**)&ctx_arena[c], std::max<size_t>(act_bytes, 256)));
+        }
+    }
     for (size_t si = 0; si < steps.size(); si++) {
         const float** slots[4] = {&steps[si].w0, &steps[si].w1, &steps[si].w2, &steps[si].w3};
         for (int k = 0; k < 4; k++)
@@ -1004,29 +1020,34 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
 void Engine::autotune_pw() {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
-    const int n = (max_batch + n_lanes - 1) / n_lanes;      // the batch one lane launches with (measured: +1 % over tuning at max_batch)
-    for (auto& s : steps) {
-        if (s.kind != S_PW || (s.C & 3)) continue;
-        float* in0 = vptr(s.in0, d_stage_in, d_stage_logits, nullptr);
-        float* in1 = vptr(s.in1, d_stage_in, d_stage_logits, nullptr);
-        float* in2 = vptr(s.in2, d_stage_in, d_stage_logits, nullptr);
-        float* out = vptr(s.out, d_stage_in, d_stage_logits, nullptr);
-        float best = 1e30f; int best_nt = 0, best_wm = 0;
-        for (int wm = 2; wm >= 1; wm--) {
-            for (int nt = 1; nt <= 4; nt++) {
-                long cols = (long)((s.Co + nt * 16 - 1) / (nt * 16)) * nt * 16;
-                if (cols * 100 > (long)((s.Co + 15) / 16 * 16) * 130) continue;         // skip absurd padding
-                PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, nt, wm};
-                launch_pw_gemm(p, stream);                                             // warm-up
-                hipEventRecord(a, stream);
-                for (int r = 0; r < 3; r++) launch_pw_gemm(p, stream);
-                hipEventRecord(b, stream);
-                hipEventSynchronize(b);
-                float ms = 0; hipEventElapsedTime(&ms, a, b);
-                if (ms < best * 0.98f) { best = ms; best_nt = nt; best_wm = wm; }      // prefer the larger tile on ties
+    // two tunings: the batch one lane launches with (+1 % over tuning at max_batch), and max_batch for calls that run unsplit
+    const int n_lane = (max_batch + n_lanes - 1) / n_lanes;
+    for (int pass = 0; pass < 2; pass++) {
+        const int n = pass == 0 ? n_lane : max_batch;
+        if (pass == 1 && n == n_lane) { for (auto& s : steps) { s.nt_full = s.nt; s.wm_full = s.wm; } break; }
+        for (auto& s : steps) {
+            if (s.kind != S_PW || (s.C & 3)) continue;
+            float* in0 = vptr(s.in0, d_stage_in, d_stage_logits, nullptr);
+            float* in1 = vptr(s.in1, d_stage_in, d_stage_logits, nullptr);
+            float* in2 = vptr(s.in2, d_stage_in, d_stage_logits, nullptr);
+            float* out = vptr(s.out, d_stage_in, d_stage_logits, nullptr);
+            float best = 1e30f; int best_nt = 0, best_wm = 0;
+            for (int wm = 2; wm >= 1; wm--) {
+                for (int nt = 1; nt <= 4; nt++) {
+                    long cols = (long)((s.Co + nt * 16 - 1) / (nt * 16)) * nt * 16;
+                    if (cols * 100 > (long)((s.Co + 15) / 16 * 16) * 130) continue;         // skip absurd padding
+                    PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, nt, wm};
+                    launch_pw_gemm(p, stream);                                             // warm-up
+                    hipEventRecord(a, stream);
+                    for (int r = 0; r < 3; r++) launch_pw_gemm(p, stream);
+                    hipEventRecord(b, stream);
+                    hipEventSynchronize(b);
+                    float ms = 0; hipEventElapsedTime(&ms, a, b);
+                    if (ms < best * 0.98f) { best = ms; best_nt = nt; best_wm = wm; }      // prefer the larger tile on ties
+                }
             }
+            if (pass == 0) { s.nt = best_nt; s.wm = best_wm; } else { s.nt_full = best_nt; s.wm_full = best_wm; }
         }
-        s.nt = best_nt; s.wm = best_wm;
     }
     hipStreamSynchronize(stream);
     hipEventDestroy(a); hipEventDestroy(b);
@@ -1039,7 +1060,7 @@ float* Engine::vptr(int v, const float* d_in, float* d_logits, float* d_emb, int
     if (v == v_input) return const_cast<float*>(d_in);
     if (v == v_logits) return d_logits;
     (void)d_emb;
-    return reinterpret_cast<float*>(act_arena + vals[v].offset) + (size_t)clip0 * vals[v].elems;   // values are [clip][elems]
+    return reinterpret_cast<float*>((cur_arena ? cur_arena : act_arena) + vals[v].offset) + (size_t)clip0 * vals[v].elems;   // values are [clip][elems]
 }
 
 hipEvent_t Engine::get_event() {
@@ -1056,8 +1077,32 @@ void Engine::drop_graphs() {
 // is launch-bound, so once the same (input, output, n) combination shows up a second time it is captured into a
 // hipGraph and replayed from then on (the host-pointer entry points always use the same staging buffers).  Per-launch
 // profiling needs real launches and bypasses the graph.
+// Call i of a pipelined sequence: wait (on the GPU) for whatever the caller's stream has queued so far, then run the whole
+// plan on context i % depth.  Calls on different contexts overlap; calls on the same context are ordered by its stream.
+bool Engine::run_pipelined(const float* d_in, int n, float* d_logits, float* d_emb, std::string* err) {
+    if (n <= 0 || n > max_batch) { *err = "batch size out of range"; return false; }
+    if (depth <= 1 || (profiling && profile_filter.empty())) return run(d_in, n, d_logits, d_emb, err);
+    const int c = (int)(call_idx++ % (unsigned)depth);
+    hipEventRecord(ev_ctx_fork, stream);
+    hipStreamWaitEvent(ctx_stream[c], ev_ctx_fork, 0);
+    cur_arena = ctx_arena[c];
+    cur_stream = ctx_stream[c];
+    bool ok = run_eager(d_in, n, d_logits, d_emb, err);
+    cur_arena = nullptr;
+    cur_stream = nullptr;
+    return ok;
+}
+void Engine::sync_contexts() {
+    for (int c = 0; c < kMaxDepth; c++) if (ctx_stream[c]) hipStreamSynchronize(ctx_stream[c]);
+}
+
 bool Engine::run(const float* d_in, int n, float* d_logits, float* d_emb, std::string* err) {
     if (n <= 0 || n > max_batch) { *err = "batch size out of range"; return false; }
+    if (depth > 1 && call_idx) {
+        // an unsplit call after pipelined ones: order it (on the GPU) behind whatever the contexts still have queued -
+        // context 0 shares this call's arena
+        for (int c = 0; c < depth; c++) { hipEventRecord(ev_ctx_done[c], ctx_stream[c]); hipStreamWaitEvent(stream, ev_ctx_done[c], 0); }
+    }
     if (!use_graphs || profiling) return run_eager(d_in, n, d_logits, d_emb, err);
     GraphEntry* ge = nullptr;
     for (auto& g : graphs)
@@ -1103,17 +1148,18 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
     struct Lane { const float* d_in; int n; float* d_logits; float* d_emb; hipStream_t st; int clip0; };
     Lane lanes[kMaxLanes];
     int nl = 1;
+    hipStream_t main_stream = cur_stream ? cur_stream : stream;
     // (an unfiltered profile wants clean per-kernel times and stays single-lane; a class-filtered one measures the
     // kernels as they run in production, overlapped)
-    if (n_lanes > 1 && (!profiling || !profile_filter.empty()) && n_all >= dual_lane_min) nl = std::min(n_lanes, n_all);
+    if (n_lanes > 1 && !cur_stream && (!profiling || !profile_filter.empty()) && n_all >= dual_lane_min) nl = std::min(n_lanes, n_all);
     for (int li = 0, c0 = 0; li < nl; li++) {
         int cnt = n_all / nl + (li < n_all % nl ? 1 : 0);
         lanes[li] = Lane{d_in_all + (size_t)c0 * n_samples, cnt, d_logits_all + (size_t)c0 * n_classes,
-                         d_emb_all ? d_emb_all + (size_t)c0 * emb_dim : nullptr, li == 0 ? stream : lane_stream[li - 1], c0};
+                         d_emb_all ? d_emb_all + (size_t)c0 * emb_dim : nullptr, li == 0 ? main_stream : lane_stream[li - 1], c0};
         c0 += cnt;
     }
     if (nl > 1) {
-        hipEventRecord(ev_fork, stream);
+        hipEventRecord(ev_fork, main_stream);
         for (int li = 1; li < nl; li++) hipStreamWaitEvent(lanes[li].st, ev_fork, 0);
     }
     for (int si = 0; si < (int)steps.size(); si++) {
@@ -1166,7 +1212,8 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
                 break;
             }
             case S_PW: {
-                PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, s.nt, s.wm};
+                PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, nl > 1 ? s.nt : s.nt_full,
+                           nl > 1 ? s.wm : s.wm_full};
                 launch_pw_gemm(p, stream);
                 break;
             }
@@ -1211,7 +1258,7 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
     }
     for (int li = 1; li < nl; li++) {
         hipEventRecord(ev_join[li - 1], lanes[li].st);
-        hipStreamWaitEvent(stream, ev_join[li - 1], 0);
+        hipStreamWaitEvent(main_stream, ev_join[li - 1], 0);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { *err = std::string("kernel launch: ") + hipGetErrorString(e); return false; }
@@ -1241,7 +1288,7 @@ std::string Engine::describe() const {
         jesc(os, s.name);
         os << "\",\"H\":" << s.H << ",\"W\":" << s.W << ",\"C\":" << s.C << ",\"Co\":" << s.Co << ",\"k\":" << s.kh
            << ",\"stride\":" << s.sh << ",\"act\":" << s.act << ",\"fused_scale\":" << (s.kind == S_PW && s.in1 >= 0 ? 1 : 0)
-           << ",\"nt\":" << s.nt << ",\"wm\":" << s.wm << ",\"fused_res\":" << (s.kind == S_PW && s.in2 >= 0 ? 1 : 0) << ",\"fused_sum\":" << (s.out2 >= 0 ? 1 : 0) << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << ",\"wbytes\":" << s.wbytes << "}";
+           << ",\"nt\":" << s.nt << ",\"wm\":" << s.wm << ",\"nt_full\":" << s.nt_full << ",\"wm_full\":" << s.wm_full << ",\"fused_res\":" << (s.kind == S_PW && s.in2 >= 0 ? 1 : 0) << ",\"fused_sum\":" << (s.out2 >= 0 ? 1 : 0) << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << ",\"wbytes\":" << s.wbytes << "}";
     }
     os << "]}";
     return os.str();

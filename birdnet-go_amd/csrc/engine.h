@@ -24,7 +24,8 @@ struct Step {
     // geometry per clip
     int H = 0, W = 0, C = 0, Ho = 0, Wo = 0, Co = 0, kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0;
     int act = 0, act2 = 0, op = 0, mode = 0, S = 1, Cr = 0;
-    int nt = 0, wm = 0;      // pw_gemm tile shape chosen by the create-time autotuner (0 = heuristic)
+    int nt = 0, wm = 0;      // pw_gemm tile shape chosen by the create-time autotuner (0 = heuristic), for a lane's batch
+    int nt_full = 0, wm_full = 0;   // same, tuned at max_batch (calls that run unsplit: pipelined contexts, profiling)
     // front-end
     int spec = -1;
     // accounting per clip
@@ -66,6 +67,17 @@ class Engine {
     int frontend_fft = -1;              // -1 / 1: FFT path where the frame length is supported (512/1024/2048), 0: folded-GEMM kernel for real-part graphs
     bool use_graphs = false;            // opt-in: replay the plan as a hipGraph once a (pointers, n) combination repeats (measured: no gain on ROCm 7.2)
     void drop_graphs();
+    // Pipelining across calls ("depth" option, bnhip_predict_device only): call i runs on context i % depth (own stream,
+    // own activation arena), so the tail of one batch overlaps the head of the next.  Completion is then signalled by
+    // synchronize(), not by the caller's stream.
+    static constexpr int kMaxDepth = 3;
+    int depth = 1;
+    hipStream_t ctx_stream[kMaxDepth] = {nullptr, nullptr, nullptr};
+    char* ctx_arena[kMaxDepth] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_ctx_fork = nullptr, ev_ctx_done[kMaxDepth] = {nullptr, nullptr, nullptr};
+    unsigned call_idx = 0;
+    bool run_pipelined(const float* d_in, int n, float* d_logits, float* d_emb, std::string* err);
+    void sync_contexts();
     static constexpr int kMaxLanes = 4;
     int n_lanes = 2;                    // batches of >= dual_lane_min clips are split over this many streams (see run_eager)
     int dual_lane_min = 32;
@@ -108,6 +120,8 @@ class Engine {
     std::vector<GraphEntry> graphs;     // tiny cache: the host path always presents the same staging pointers
     bool run_eager(const float* d_in, int n, float* d_logits, float* d_emb, std::string* err);
     char* act_arena = nullptr;
+    char* cur_arena = nullptr;          // arena the launches of the current call address (act_arena or a context's)
+    hipStream_t cur_stream = nullptr;   // main stream of the current call (stream or a context's)
     size_t act_bytes = 0;
     char* w_arena = nullptr;
     size_t w_bytes = 0;

@@ -97,7 +97,7 @@ class HipClassifier:
     """inference.Classifier + EmbeddingExtractor over libbnhip.so.  NOT thread-safe (backend.go:7)."""
 
     def __init__(self, model_bytes: bytes, device=0, max_batch=256, plan_only=False, debug_no_reuse=False,
-                 graphs=None, frontend_fft=None):
+                 graphs=None, frontend_fft=None, depth=None, lanes=None):
         self._lib = load_library()
         self._h = C.c_void_p()
         o = {"device": device, "max_batch": max_batch, "plan_only": int(plan_only), "debug_no_reuse": int(debug_no_reuse)}
@@ -105,6 +105,10 @@ class HipClassifier:
             o["graphs"] = int(graphs)
         if frontend_fft is not None:
             o["frontend_fft"] = int(frontend_fft)
+        if depth is not None:
+            o["depth"] = int(depth)
+        if lanes is not None:
+            o["lanes"] = int(lanes)
         opts = json.dumps(o).encode()
         buf = (C.c_char * len(model_bytes)).from_buffer_copy(model_bytes)
         _check(self._lib, self._lib.bnhip_model_create(C.cast(buf, C.c_void_p), len(model_bytes), opts, C.byref(self._h)))

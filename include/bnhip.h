@@ -48,8 +48,12 @@ void bnhip_shutdown(void);
 /* Build a classifier from in-memory TFLite model bytes — the same byte slice the reference hands to
  * NewTFLiteClassifier(modelData []byte, ...) (internal/inference/tflite/classifier.go:38).  The blob
  * is consumed during the call and may be freed afterwards (classifier.go:37).
- * opts_json (nullable): {"device":0,"max_batch":256,"plan_only":0,"debug_no_reuse":0,"autotune":1,"graphs":0,"lanes":2,"frontend_fft":-1}; plan_only builds the
- * kernel plan on the CPU without touching a device (info/describe work, predict is rejected).  */
+ * opts_json (nullable): {"device":0,"max_batch":256,"plan_only":0,"debug_no_reuse":0,"autotune":1,"graphs":0,"lanes":2,"frontend_fft":-1,"depth":1}; plan_only builds the
+ * kernel plan on the CPU without touching a device (info/describe work, predict is rejected).
+ * "lanes": batches of >= 32 clips are split over this many concurrent streams inside one call (default 2).
+ * "depth": > 1 lets successive bnhip_predict_device calls overlap on alternating contexts (own stream and activation
+ *          arena each); their outputs are complete after bnhip_synchronize, not merely in the caller's stream order.
+ * "frontend_fft": 0 selects the folded-GEMM mel front-end for real-part graphs instead of the FFT path.  */
 int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, bnhip_model** out);
 
 /* n_samples: exact input length per clip (tflite/classifier.go:100-104); n_classes: size of the logits
@@ -70,7 +74,8 @@ int bnhip_predict_pcm16(bnhip_model* m, const int16_t* pcm, int n_clips, float* 
 
 /* Device-resident variant: all pointers are device memory on the model's device; work is enqueued on
  * the model's stream and NOT synchronised (call bnhip_synchronize). Used by the throughput harness so
- * timing starts with inputs already in HBM. */
+ * timing starts with inputs already in HBM.  With "depth" > 1 successive calls run on alternating contexts and may
+ * overlap; the caller must not reuse an output (or overwrite an input) of an in-flight call before bnhip_synchronize. */
 int bnhip_predict_device(bnhip_model* m, const float* d_samples, int n_clips, float* d_logits, float* d_emb);
 
 /* Post-processing on device for a batch of logits already on the host:

@@ -72,6 +72,60 @@ def test_full_vs_oracle_and_golden(full_clf, full_blob):
     assert (got[:2].argmax(1) == g["idx"][:, 0]).all()
 
 
+class _DevBuf:
+    """Device memory through the HIP runtime the library itself uses (torch bundles a second runtime; mixing the two in
+    one process after libbnhip has initialised the first one finds no GPU)."""
+    _hip = None
+
+    def __init__(self, nbytes):
+        import ctypes as C
+        if _DevBuf._hip is None:
+            _DevBuf._hip = C.CDLL("libamdhip64.so")
+        self.C, self.n = C, nbytes
+        self.ptr = C.c_void_p()
+        assert _DevBuf._hip.hipMalloc(C.byref(self.ptr), C.c_size_t(nbytes)) == 0
+
+    def upload(self, arr):
+        a = np.ascontiguousarray(arr)
+        assert _DevBuf._hip.hipMemcpy(self.ptr, a.ctypes.data_as(self.C.c_void_p), self.C.c_size_t(a.nbytes), 1) == 0
+
+    def download(self, shape, dtype=np.float32):
+        out = np.empty(shape, dtype)
+        assert _DevBuf._hip.hipMemcpy(out.ctypes.data_as(self.C.c_void_p), self.ptr, self.C.c_size_t(out.nbytes), 2) == 0
+        return out
+
+    def at(self, byte_off):
+        return self.ptr.value + byte_off
+
+    def free(self):
+        _DevBuf._hip.hipFree(self.ptr)
+
+
+def test_pipeline_depth_gives_identical_results(full_blob):
+    """"depth" > 1: successive device calls run on alternating contexts; every call's output must equal the serial one."""
+    xh = sm.synth_clips(12, 144000, 48000)
+    a = host.HipClassifier(full_blob, max_batch=4)
+    b = host.HipClassifier(full_blob, max_batch=4, depth=2, lanes=1)
+    x, ref, out = _DevBuf(xh.nbytes), _DevBuf(12 * 6522 * 4), _DevBuf(12 * 6522 * 4)
+    try:
+        x.upload(xh)
+        for i in range(3):
+            a.predict_device(x.at(4 * i * 144000 * 4), 4, ref.at(4 * i * 6522 * 4))
+        a.synchronize()
+        for i in range(3):                                        # three calls in flight over two contexts
+            b.predict_device(x.at(4 * i * 144000 * 4), 4, out.at(4 * i * 6522 * 4))
+        b.synchronize()
+        r, o = ref.download((12, 6522)), out.download((12, 6522))
+        assert np.array_equal(r, o)
+        # an unsplit (host-pointer) call right after pipelined ones is ordered behind them
+        b.predict_device(x.at(0), 4, out.at(0))
+        h = b.predict_batch(xh[:4].reshape(-1), 4)
+        assert np.array_equal(h, r[:4])
+    finally:
+        a.close(); b.close()
+        x.free(); ref.free(); out.free()
+
+
 # ---- FFT front-end (stft.hip): serves the magnitude (COMPLEX_ABS) graph and, on request, the real-part graph
 FFT_TINY_SPECS = (sm.SpecConfig(512, 94, 0.0, 3000.0), sm.SpecConfig(512, 94, 500.0, 15000.0))
 
