@@ -725,7 +725,8 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                     if (slabs > 0) {
                         S = slabs;
                         fused_sum = true;
-                        mp.out = new_val(-1, (size_t)S * C);
+                        // sized for the candidate shape with the most tiles: the autotuner may pick another one
+                        mp.out = new_val(-1, (size_t)expdw_max_slabs(d.kh, d.sh, d.H, d.Ho, d.Wo, d.pt) * C);
                         steps.back().out2 = mp.out;
                         steps.back().S = S;
                     }
@@ -1009,7 +1010,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
     HIPCHK(hipMalloc((void**)&d_stage_logits, (size_t)max_batch * n_classes * 4));
     HIPCHK(hipMalloc((void**)&d_post_conf, (size_t)max_batch * n_classes * 4));
     if (emb_dim) HIPCHK(hipMalloc((void**)&d_stage_emb, (size_t)max_batch * emb_dim * 4));
-    if (autotune) autotune_pw();
+    if (autotune) { autotune_pw(); autotune_expdw(); }
     *code = BNHIP_OK;
     return true;
 }
@@ -1017,6 +1018,45 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
 // Per-layer choice of the pw_gemm N-tile width: the best width depends on (M, N, K) through occupancy, grid size and
 // padding in ways no closed-form rule captured (late layers at batch 256 have as few as 288 blocks), so each
 // pointwise/FC step is timed once at create time on its real shapes and buffers (contents are irrelevant to timing).
+// Tile shape of every fused expand+depthwise layer: time each shape of the kernel's table that fits the layer (the
+// pixel-count cost model picks wrongly when a shape's LDS/register footprint costs more than its smaller halo saves).
+void Engine::autotune_expdw() {
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    const int n = (max_batch + n_lanes - 1) / n_lanes;
+    for (size_t si = 0; si < steps.size(); si++) {
+        Step& s = steps[si];
+        if (s.kind != S_EXPAND_DW) continue;
+        float* in0 = vptr(s.in0, d_stage_in, d_stage_logits, nullptr);
+        float* out = vptr(s.out, d_stage_in, d_stage_logits, nullptr);
+        float* out2 = vptr(s.out2, d_stage_in, d_stage_logits, nullptr);
+        float best = 1e30f; int best_idx = -1;
+        for (int idx = 0; idx < expdw_num_shapes(); idx++) {
+            if (!expdw_shape_fits(idx, s.kh, s.sh, s.H, s.Ho, s.Wo, s.pt)) continue;
+            auto go = [&]() {
+                launch_expand_dw(in0, s.w0, s.w1, s.w2, s.w3, out, out2, n, s.H, s.W, s.C, s.Co, s.Ho, s.Wo, s.kh, s.sh, s.pt, s.pl,
+                                 s.act, s.act2, idx, stream);
+            };
+            go();
+            hipEventRecord(a, stream);
+            for (int r = 0; r < 3; r++) go();
+            hipEventRecord(b, stream);
+            hipEventSynchronize(b);
+            float ms = 0; hipEventElapsedTime(&ms, a, b);
+            if (ms < best * 0.98f) { best = ms; best_idx = idx; }
+        }
+        if (best_idx < 0) continue;
+        s.shape = best_idx;
+        if (s.out2 >= 0) {                       // the consumers of the per-tile sums index them by tile count
+            s.S = expdw_shape_slabs(best_idx, s.Ho, s.Wo);
+            for (auto& c : steps) if (&c != &s && c.in0 == s.out2) c.S = s.S;
+        }
+    }
+    hipStreamSynchronize(stream);
+    hipEventDestroy(a); hipEventDestroy(b);
+    (void)hipGetLastError();
+}
+
 void Engine::autotune_pw() {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
@@ -1224,7 +1264,7 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
             }
             case S_EXPAND_DW:
                 launch_expand_dw(in0, s.w0, s.w1, s.w2, s.w3, out, out2, n, s.H, s.W, s.C, s.Co,
-                                 s.Ho, s.Wo, s.kh, s.sh, s.pt, s.pl, s.act, s.act2, stream);
+                                 s.Ho, s.Wo, s.kh, s.sh, s.pt, s.pl, s.act, s.act2, s.shape, stream);
                 break;
             case S_MEAN_PARTIAL:
                 launch_mean_partial(in0, out, n, s.H * s.W, s.C, s.S, stream);
@@ -1288,7 +1328,7 @@ std::string Engine::describe() const {
         jesc(os, s.name);
         os << "\",\"H\":" << s.H << ",\"W\":" << s.W << ",\"C\":" << s.C << ",\"Co\":" << s.Co << ",\"k\":" << s.kh
            << ",\"stride\":" << s.sh << ",\"act\":" << s.act << ",\"fused_scale\":" << (s.kind == S_PW && s.in1 >= 0 ? 1 : 0)
-           << ",\"nt\":" << s.nt << ",\"wm\":" << s.wm << ",\"nt_full\":" << s.nt_full << ",\"wm_full\":" << s.wm_full << ",\"fused_res\":" << (s.kind == S_PW && s.in2 >= 0 ? 1 : 0) << ",\"fused_sum\":" << (s.out2 >= 0 ? 1 : 0) << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << ",\"wbytes\":" << s.wbytes << "}";
+           << ",\"shape\":" << s.shape << ",\"nt\":" << s.nt << ",\"wm\":" << s.wm << ",\"nt_full\":" << s.nt_full << ",\"wm_full\":" << s.wm_full << ",\"fused_res\":" << (s.kind == S_PW && s.in2 >= 0 ? 1 : 0) << ",\"fused_sum\":" << (s.out2 >= 0 ? 1 : 0) << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << ",\"wbytes\":" << s.wbytes << "}";
     }
     os << "]}";
     return os.str();

@@ -25,6 +25,7 @@ struct Step {
     int H = 0, W = 0, C = 0, Ho = 0, Wo = 0, Co = 0, kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0;
     int act = 0, act2 = 0, op = 0, mode = 0, S = 1, Cr = 0;
     int nt = 0, wm = 0;      // pw_gemm tile shape chosen by the create-time autotuner (0 = heuristic), for a lane's batch
+    int shape = -1;          // expand_dw tile shape (index into the kernel's table) chosen by the autotuner; -1 = cost model
     int nt_full = 0, wm_full = 0;   // same, tuned at max_batch (calls that run unsplit: pipelined contexts, profiling)
     // front-end
     int spec = -1;
@@ -67,6 +68,7 @@ class Engine {
     int frontend_fft = -1;              // -1 / 1: FFT path where the frame length is supported (512/1024/2048), 0: folded-GEMM kernel for real-part graphs
     bool use_graphs = false;            // opt-in: replay the plan as a hipGraph once a (pointers, n) combination repeats (measured: no gain on ROCm 7.2)
     void drop_graphs();
+    void autotune_expdw();
     // Pipelining across calls ("depth" option, bnhip_predict_device only): call i runs on context i % depth (own stream,
     // own activation arena), so the tail of one batch overlaps the head of the next.  Completion is then signalled by
     // synchronize(), not by the caller's stream.

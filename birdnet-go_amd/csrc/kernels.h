@@ -78,13 +78,18 @@ void launch_dwconv(const DwParams& p, float* partial, hipStream_t s);
 
 // fused MBConv front half: y = act_d(dwconv(act_e(x We^T + be)) + bd); partial (nullable) [B, slabs, Cmid]
 bool expdw_supported(int k, int s, int Cin, int Cmid);
-int expdw_sum_slabs(int k, int s, int H, int Ho, int Wo, int pt);   // 0 = no tile shape fits (do not fuse)
+int expdw_sum_slabs(int k, int s, int H, int Ho, int Wo, int pt);   // slabs of the cost-model shape; 0 = no tile shape fits (do not fuse)
+int expdw_num_shapes();
+bool expdw_shape_fits(int idx, int k, int s, int H, int Ho, int Wo, int pt);
+int expdw_shape_slabs(int idx, int Ho, int Wo);
+int expdw_default_shape(int k, int s, int H, int Ho, int Wo, int pt);
+int expdw_max_slabs(int k, int s, int H, int Ho, int Wo, int pt);
 // parameters are the planner's padded copies: we [expdw_cp(Cmid)][expdw_kw(Cin)], be/bd [Cp], wd [k*k][Cp] (zeros beyond)
 int expdw_kw(int Cin);
 int expdw_cp(int Cmid);
 void launch_expand_dw(const float* x, const float* we, const float* be, const float* wd, const float* bd, float* y,
                       float* partial, int B, int H, int W, int Cin, int Cmid, int Ho, int Wo, int k, int s, int pt,
-                      int pl, int act_e, int act_d, hipStream_t st);
+                      int pl, int act_e, int act_d, int shape /* index into the shape table; -1 = cost model */, hipStream_t st);
 
 // mean over H*W: in [B,HW,C] -> partial [B,S,C] (sums), S = number of pixel splits
 int mean_splits(int HW);

@@ -1166,7 +1166,8 @@ static const ExpDwShape kExpDwShapes[] = {
     {3, 1, 8, 16, 10}, {3, 1, 4, 16, 6}, {3, 1, 8, 32, 6}, {3, 1, 8, 32, 10},
     {5, 1, 8, 16, 12}, {5, 1, 4, 16, 8}, {5, 1, 8, 32, 6}, {5, 1, 12, 16, 12},
     {3, 2, 4, 8, 9}, {3, 2, 8, 8, 12}, {3, 2, 8, 8, 17},
-    {5, 2, 4, 8, 11}, {5, 2, 4, 16, 6},     // (a {5,2,8,8,19} shape measured 27 % slower on b4: 52 KB of LDS, 6 MFMA tiles per wave)
+    {5, 2, 4, 8, 11}, {5, 2, 4, 16, 6}, {5, 2, 8, 8, 19},   // the last one computes fewer pixels on b4 but measured 27 % slower
+                                                             // there (52 KB of LDS, 6 MFMA tiles per wave): hence the autotuner
 };
 static long expdw_cost(const ExpDwShape& sh, int H, int Ho, int Wo, int pt, bool* fits) {
     const int tih = (sh.toh - 1) * sh.s + sh.k, tiw = (sh.tow - 1) * sh.s + sh.k;
@@ -1181,27 +1182,43 @@ static long expdw_cost(const ExpDwShape& sh, int H, int Ho, int Wo, int pt, bool
     }
     return rows * tiw * tw;
 }
-static const ExpDwShape* expdw_pick(int k, int s, int H, int Ho, int Wo, int pt) {
-    static const char* force = getenv("BNHIP_EXPDW_OLD");      // experiment switch: the round-1 two-shape rule
-    const ExpDwShape* best = nullptr;
+int expdw_num_shapes() { return (int)(sizeof(kExpDwShapes) / sizeof(kExpDwShapes[0])); }
+bool expdw_shape_fits(int idx, int k, int s, int H, int Ho, int Wo, int pt) {
+    if (idx < 0 || idx >= expdw_num_shapes()) return false;
+    const ExpDwShape& sh = kExpDwShapes[idx];
+    if (sh.k != k || sh.s != s) return false;
+    bool fits;
+    (void)expdw_cost(sh, H, Ho, Wo, pt, &fits);
+    return fits;
+}
+int expdw_shape_slabs(int idx, int Ho, int Wo) {
+    const ExpDwShape& sh = kExpDwShapes[idx];
+    return ((Ho + sh.toh - 1) / sh.toh) * ((Wo + sh.tow - 1) / sh.tow);
+}
+// cost-model choice (fewest expanded pixels); the engine's create-time autotuner may override it per layer
+int expdw_default_shape(int k, int s, int H, int Ho, int Wo, int pt) {
+    int best = -1;
     long best_cost = 0;
-    for (const ExpDwShape& sh : kExpDwShapes) {
-        if (sh.k != k || sh.s != s) continue;
-        if (force && atoi(force)) {
-            bool old = s == 2 ? (sh.toh == 4 && sh.tow == 8) : (sh.tow == 16 && sh.toh == (Ho > 4 ? 8 : 4));
-            if (!old) continue;
-        }
+    for (int i = 0; i < expdw_num_shapes(); i++) {
+        if (!expdw_shape_fits(i, k, s, H, Ho, Wo, pt)) continue;
         bool fits;
-        long c = expdw_cost(sh, H, Ho, Wo, pt, &fits);
-        if (!fits) continue;
-        if (!best || c < best_cost) { best = &sh; best_cost = c; }
+        long c = expdw_cost(kExpDwShapes[i], H, Ho, Wo, pt, &fits);
+        const ExpDwShape& sh = kExpDwShapes[i];
+        const long lds = (long)sh.trh * ((sh.tow - 1) * sh.s + sh.k) * ED_ES * 4;
+        if (lds > 51 * 1024) c += c / 3;                // fewer than three blocks per CU: measured to outweigh a smaller halo
+        if (best < 0 || c < best_cost) { best = i; best_cost = c; }
     }
     return best;
 }
 int expdw_sum_slabs(int k, int s, int H, int Ho, int Wo, int pt) {
-    const ExpDwShape* sh = expdw_pick(k, s, H, Ho, Wo, pt);
-    if (!sh) return 0;
-    return ((Ho + sh->toh - 1) / sh->toh) * ((Wo + sh->tow - 1) / sh->tow);
+    int idx = expdw_default_shape(k, s, H, Ho, Wo, pt);
+    return idx < 0 ? 0 : expdw_shape_slabs(idx, Ho, Wo);
+}
+int expdw_max_slabs(int k, int s, int H, int Ho, int Wo, int pt) {
+    int mx = 0;
+    for (int i = 0; i < expdw_num_shapes(); i++)
+        if (expdw_shape_fits(i, k, s, H, Ho, Wo, pt)) mx = std::max(mx, expdw_shape_slabs(i, Ho, Wo));
+    return mx;
 }
 bool expdw_supported(int k, int s, int Cin, int Cmid) {
     // measured on MI355X at batch 256: beyond ~128 input channels the unpipelined K loop of the fused kernel loses
@@ -1210,9 +1227,10 @@ bool expdw_supported(int k, int s, int Cin, int Cmid) {
 }
 void launch_expand_dw(const float* x, const float* we, const float* be, const float* wd, const float* bd, float* y,
                       float* partial, int B, int H, int W, int Cin, int Cmid, int Ho, int Wo, int k, int s, int pt,
-                      int pl, int act_e, int act_d, hipStream_t st) {
-    const ExpDwShape* sh = expdw_pick(k, s, H, Ho, Wo, pt);
-    if (!sh) return;                                   // the planner only fuses shapes expdw_sum_slabs accepted
+                      int pl, int act_e, int act_d, int shape, hipStream_t st) {
+    if (!expdw_shape_fits(shape, k, s, H, Ho, Wo, pt)) shape = expdw_default_shape(k, s, H, Ho, Wo, pt);
+    if (shape < 0) return;                             // the planner only fuses layers some shape accepts
+    const ExpDwShape* sh = &kExpDwShapes[shape];
     ExpDwParams p{x, we, be, wd, bd, y, partial, B, H, W, Cin, Cmid, Ho, Wo, pt, pl, act_e, act_d,
                   (Ho + sh->toh - 1) / sh->toh, (Wo + sh->tow - 1) / sh->tow, (Cmid + 31) / 32, expdw_kw(Cin), expdw_cp(Cmid)};
     unsigned nblk = (unsigned)B * p.tiles_h * p.tiles_w * p.cchunks;
@@ -1224,7 +1242,7 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
     ED_CASE(3, 1, 8, 16, 10) ED_CASE(3, 1, 4, 16, 6) ED_CASE(3, 1, 8, 32, 6) ED_CASE(3, 1, 8, 32, 10)
     ED_CASE(5, 1, 8, 16, 12) ED_CASE(5, 1, 4, 16, 8) ED_CASE(5, 1, 8, 32, 6) ED_CASE(5, 1, 12, 16, 12)
     ED_CASE(3, 2, 4, 8, 9) ED_CASE(3, 2, 8, 8, 12) ED_CASE(3, 2, 8, 8, 17)
-    ED_CASE(5, 2, 4, 8, 11) ED_CASE(5, 2, 4, 16, 6)
+    ED_CASE(5, 2, 4, 8, 11) ED_CASE(5, 2, 4, 16, 6) ED_CASE(5, 2, 8, 8, 19)
 #undef ED_CASE
 }
 
