@@ -1083,6 +1083,7 @@ void Engine::autotune_pw() {
                     hipEventRecord(b, stream);
                     hipEventSynchronize(b);
                     float ms = 0; hipEventElapsedTime(&ms, a, b);
+                    if (getenv("BNHIP_DEBUG")) fprintf(stderr, "[bnhip] tune %-16s n=%d M=%d N=%d K=%d nt=%d wm=%d: %.1f us (%.1f TF)\n", s.name.c_str(), n, n * s.H * s.W, s.Co, s.C, nt, wm, ms / 3 * 1e3, 2.0 * n * s.H * s.W * s.Co * s.C / (ms / 3 * 1e-3) / 1e12);
                     if (ms < best * 0.98f) { best = ms; best_nt = nt; best_wm = wm; }      // prefer the larger tile on ties
                 }
             }
