@@ -97,7 +97,7 @@ class HipClassifier:
     """inference.Classifier + EmbeddingExtractor over libbnhip.so.  NOT thread-safe (backend.go:7)."""
 
     def __init__(self, model_bytes: bytes, device=0, max_batch=256, plan_only=False, debug_no_reuse=False,
-                 graphs=None, frontend_fft=None, depth=None, lanes=None):
+                 graphs=None, frontend_fft=None, depth=None, lanes=None, autotune=None):
         self._lib = load_library()
         self._h = C.c_void_p()
         o = {"device": device, "max_batch": max_batch, "plan_only": int(plan_only), "debug_no_reuse": int(debug_no_reuse)}
@@ -109,6 +109,8 @@ class HipClassifier:
             o["depth"] = int(depth)
         if lanes is not None:
             o["lanes"] = int(lanes)
+        if autotune is not None:
+            o["autotune"] = int(autotune)
         opts = json.dumps(o).encode()
         buf = (C.c_char * len(model_bytes)).from_buffer_copy(model_bytes)
         _check(self._lib, self._lib.bnhip_model_create(C.cast(buf, C.c_void_p), len(model_bytes), opts, C.byref(self._h)))

@@ -132,6 +132,38 @@ def test_pipeline_depth_gives_identical_results(full_blob):
         x.free(); ref.free(); out.free()
 
 
+# ---- geometry sweep: spectrogram sizes, kernel sizes, strides and widths the v2.4 topology does not have, so that every
+# tile-shape / halo / padding-row / ragged-edge branch of the fused kernels meets the oracle at least once
+def _geo_cfg(i):
+    rng = np.random.default_rng(1000 + i)
+    n_mels = int(rng.choice([20, 24, 33, 40, 48]))
+    hop = int(rng.choice([94, 96, 120]))
+    frames = int(rng.choice([37, 50, 64, 91, 123]))
+    n_samples = 512 + hop * (frames - 1)
+    specs = (sm.SpecConfig(512, hop, 0.0, 3000.0), sm.SpecConfig(512, hop, 500.0, 15000.0))
+    blocks, c = [(1, 3, 1, int(rng.choice([8, 12])), 1)], None
+    for _ in range(int(rng.integers(3, 6))):
+        blocks.append((int(rng.choice([4, 6])), int(rng.choice([3, 5])), int(rng.choice([1, 1, 2])),
+                       int(rng.choice([12, 16, 20, 24, 36])), int(rng.integers(1, 3))))
+    return sm.tiny_config(n_samples=n_samples, n_mels=n_mels, specs=specs, blocks=tuple(blocks), stem=int(rng.choice([8, 16])),
+                          top=int(rng.choice([48, 64])), n_classes=int(rng.choice([17, 50, 101])), seed=77 + i)
+
+
+@pytest.mark.parametrize("i", range(8))
+def test_geometry_sweep_vs_oracle(built_lib, i):
+    cfg = _geo_cfg(i)
+    blob = sm.build_model(cfg)
+    x = sm.synth_clips(5, cfg.n_samples, cfg.sample_rate, first=10 * i)
+    ref = Interpreter(blob).invoke(x)[0]
+    for opts in (dict(), dict(lanes=1, autotune=False)):      # autotuned shapes, and the cost-model / heuristic defaults
+        c = host.HipClassifier(blob, max_batch=5 if "lanes" in opts else 64, **opts)
+        try:
+            got = c.predict_batch(x.reshape(-1), 5)
+        finally:
+            c.close()
+        assert_parity(got, ref)
+
+
 # ---- FFT front-end (stft.hip): serves the magnitude (COMPLEX_ABS) graph and, on request, the real-part graph
 FFT_TINY_SPECS = (sm.SpecConfig(512, 94, 0.0, 3000.0), sm.SpecConfig(512, 94, 500.0, 15000.0))
 
