@@ -198,8 +198,8 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_bins(StftParams p) {
         for (int j = 0; j < P; j++) {
             const double c = t2r[qb * P + j], s = t2i[qb * P + j];
             const double r = fma(re[j], c, -(im[j] * s)), i2 = fma(re[j], s, im[j] * c);
-            const int slot = j * P + k1b;
-            wre[slot * Q + qb] = r; wim[slot * Q + qb] = i2;
+            const int slot = j * P + k1b;                 // [q][slot] layout: both sides of the exchange are conflict-free
+            wre[qb * (P * P) + slot] = r; wim[qb * (P * P) + slot] = i2;   // ([slot][q] made the reads below 16-way bank conflicts)
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_bins(StftParams p) {
         for (int t = 0; t < NPAIR; t++) {
             const int slot = min(lane + 64 * t, P * P - 1);
 #pragma unroll
-            for (int q = 0; q < Q; q++) { ar[t][q] = wre[slot * Q + q]; ai[t][q] = wim[slot * Q + q]; }
+            for (int q = 0; q < Q; q++) { ar[t][q] = wre[q * (P * P) + slot]; ai[t][q] = wim[q * (P * P) + slot]; }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
