@@ -96,7 +96,8 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_bins(StftParams p) {
     constexpr int N2 = 64 * P;            // complex points
     constexpr int N = 2 * N2;             // real frame length (= fft length)
     constexpr int Q = 64 / P;
-    constexpr int RS = 65;                // padded row stride of the transposed Y[k1][n2]
+    constexpr int RS = P == 8 ? 66 : 65;  // padded row stride of the transposed Y[k1][n2]: the (k1, q) read pattern of
+                                          // stage 3 then spreads evenly over the bank pairs (65 left P = 8 at 2x the minimum)
     constexpr int WSZ = P * RS;           // doubles per component in a wave's slice (>= N2)
     constexpr int NPAIR = (P * P + 63) / 64;   // (k1, j') pairs per lane in the last stage (P = 4: only 16 lanes hold one)
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_bins(StftParams p) {
 
 size_t stft_lds_bytes(int P, int nb_cap) {
     (void)nb_cap;
-    return (size_t)(2 * P * 64 + 2 * (64 / P) * P + STFT_WAVES * 2 * P * 65) * sizeof(double);
+    return (size_t)(2 * P * 64 + 2 * (64 / P) * P + STFT_WAVES * 2 * P * (P == 8 ? 66 : 65)) * sizeof(double);
 }
 bool stft_supported(int Lfft, int nb) {
     if (Lfft != 2048 && Lfft != 1024 && Lfft != 512) return false;
