@@ -673,6 +673,21 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                     s.bytes = 4.0 * ((double)H * W * C + (double)Ho * Wo * Co);
                     s.out = new_val(outt, (size_t)Ho * Wo * Co);
                     tv[outt] = s.out;
+                    {
+                        // second image for the MFMA stem (used when stem_mfma_supported): [Cout][32], kk = i*8 + j*2 + ic
+                        ConvParams cp{nullptr, nullptr, nullptr, nullptr, 1, H, W, C, Ho, Wo, Co, kh, kw, s.sh, s.sw, s.pt, s.pl, act};
+                        if (stem_mfma_supported(cp) && !getenv("BNHIP_NO_STEM_MFMA")) {
+                            std::vector<float> wm((size_t)Co * 32, 0.f), bp(Co, 0.f);
+                            for (int oc = 0; oc < Co; oc++)
+                                for (int i = 0; i < 3; i++)
+                                    for (int j = 0; j < 3; j++)
+                                        for (int ic = 0; ic < 2; ic++)
+                                            wm[(size_t)oc * 32 + i * 8 + j * 2 + ic] = ws[(((size_t)oc * kh + i) * kw + j) * C + ic];
+                            if (o.inputs.size() > 2 && o.inputs[2] >= 0) memcpy(bp.data(), m.tensors[o.inputs[2]].f32(), (size_t)Co * sizeof(float));
+                            add_step(s, wpush(wt.data(), wt.size()), boff, wpush(wm.data(), wm.size()), wpush(bp.data(), bp.size()));
+                            break;
+                        }
+                    }
                     add_step(s, wpush(wt.data(), wt.size()), boff);
                 }
                 break;
@@ -1249,7 +1264,8 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
             }
             case S_CONV_DIRECT: {
                 ConvParams p{in0, s.w0, s.w1, out, n, s.H, s.W, s.C, s.Ho, s.Wo, s.Co, s.kh, s.kw, s.sh, s.sw, s.pt, s.pl, s.act};
-                launch_conv_direct(p, stream);
+                if (s.w2) launch_stem_mfma(p, s.w2, s.w3, stream);
+                else launch_conv_direct(p, stream);
                 break;
             }
             case S_PW: {

@@ -57,6 +57,9 @@ struct ConvParams {       // direct conv, small Cin (stem)
     int B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, pt, pl, act;
 };
 void launch_conv_direct(const ConvParams& p, hipStream_t s);
+// MFMA stem: wm = [Cout][32] weights in (row, 4 columns, channel) order with zero pads, bias_p = [Cout] (zeros if absent)
+bool stem_mfma_supported(const ConvParams& p);
+void launch_stem_mfma(const ConvParams& p, const float* wm, const float* bias_p, hipStream_t s);
 
 struct PwParams {         // pointwise conv / fully-connected as GEMM: out[M,N] = act(A[M,K] W[N,K]^T + b) (+res)
     const float* A; const float* W; const float* bias; const float* ascale; const float* res; float* out;

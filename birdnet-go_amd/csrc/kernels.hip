@@ -503,6 +503,90 @@ void launch_conv_direct(const ConvParams& p, hipStream_t s) {
     else hipLaunchKernelGGL(k_conv_direct, grid, dim3(256), 0, s, p);
 }
 
+// Stem as an implicit GEMM on the f32 MFMA (3x3 stride-2 conv, Cin = 2): out[pixel][n] = sum_kk A[pixel][kk] W[n][kk]
+// with kk = i*8 + jj*2 + ch over a 3 x 4 x 2 window (the fourth column is a zero-weight pad, so a k-group of 4 is two
+// adjacent input pixels x 2 channels = 4 contiguous floats).  K = 24 -> two 16-wide slabs in the fragment order of
+// k_expand_dw (lane kq of slab s holds k = 16 s + 4 kq .. +3).  The VALU version above spends 288 FMAs + addressing per
+// 4 pixels x 4 channels (58 % VALU-busy at 188 us); here the FMAs move to the matrix pipe.
+struct StemParams {
+    const float* in; const float* wm /*[Cout][32]*/; const float* bias /*[Cout], zeros if absent*/; float* out;
+    int B, H, W, Ho, Wo, Cout, pt, pl, act;
+    unsigned total_px, tiles_per_wave;
+};
+template <int NTILES>
+__global__ __launch_bounds__(256) void k_stem_mfma(StemParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    // weight fragments + bias of this lane (constant for the block)
+    f32x4 wf[2][NTILES];
+    float4 bq[NTILES];
+#pragma unroll
+    for (int t = 0; t < NTILES; t++) {
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++) {
+            float4 w = *reinterpret_cast<const float4*>(p.wm + (size_t)(16 * t + li) * 32 + 16 * sl + 4 * kq);
+            wf[sl][t] = (f32x4){w.x, w.y, w.z, w.w};
+        }
+        bq[t] = *reinterpret_cast<const float4*>(p.bias + 16 * t + 4 * kq);
+    }
+    // window position of this lane's k-groups: slab 0 -> row i = kq >> 1, slab 1 -> row 2 (kq >= 2: zero weights)
+    const int i0 = kq >> 1, j0 = (kq & 1) * 2;
+    const unsigned tile0 = (blockIdx.x * 4u + wave) * p.tiles_per_wave;
+    const unsigned hw = (unsigned)p.Ho * p.Wo;
+    for (unsigned tt = 0; tt < p.tiles_per_wave; tt++) {
+        const unsigned px = (tile0 + tt) * 16u + li;
+        if ((tile0 + tt) * 16u >= p.total_px) break;                    // wave-uniform
+        const unsigned pc = min(px, p.total_px - 1);
+        const unsigned b = pc / hw, rem = pc - b * hw;
+        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+        const float* xb = p.in + (size_t)b * p.H * p.W * 2;
+        f32x4 xf[2];
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++) {
+            const int row = oh * 2 - p.pt + (sl == 0 ? i0 : 2), col = ow * 2 - p.pl + j0;
+            const bool rv = row >= 0 && row < p.H;
+            const bool v0 = rv && col >= 0 && col < p.W, v1 = rv && col + 1 >= 0 && col + 1 < p.W;
+            const int rc = min(max(row, 0), p.H - 1);
+            const float2 a = *reinterpret_cast<const float2*>(xb + ((size_t)rc * p.W + min(max(col, 0), p.W - 1)) * 2);
+            const float2 c = *reinterpret_cast<const float2*>(xb + ((size_t)rc * p.W + min(max(col + 1, 0), p.W - 1)) * 2);
+            xf[sl] = (f32x4){v0 ? a.x : 0.f, v0 ? a.y : 0.f, v1 ? c.x : 0.f, v1 ? c.y : 0.f};
+        }
+        f32x4 acc[NTILES];
+#pragma unroll
+        for (int t = 0; t < NTILES; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++)
+#pragma unroll
+            for (int sidx = 0; sidx < 4; sidx++)
+#pragma unroll
+                for (int t = 0; t < NTILES; t++)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[sl][t][sidx], xf[sl][sidx], acc[t], 0, 0, 0);
+        with_act(p.act, [&](auto f) {
+#pragma unroll
+            for (int t = 0; t < NTILES; t++) {
+                acc[t][0] = f(acc[t][0] + bq[t].x); acc[t][1] = f(acc[t][1] + bq[t].y);
+                acc[t][2] = f(acc[t][2] + bq[t].z); acc[t][3] = f(acc[t][3] + bq[t].w);
+            }
+        });
+        if (px < p.total_px) {
+            float* o = p.out + (size_t)px * p.Cout + 4 * kq;
+#pragma unroll
+            for (int t = 0; t < NTILES; t++) *reinterpret_cast<f32x4*>(o + 16 * t) = acc[t];
+        }
+    }
+}
+bool stem_mfma_supported(const ConvParams& p) {
+    return p.kh == 3 && p.kw == 3 && p.sh == 2 && p.sw == 2 && p.Cin == 2 && (p.Cout == 32 || p.Cout == 64);
+}
+void launch_stem_mfma(const ConvParams& c, const float* wm, const float* bias_p, hipStream_t s) {
+    StemParams p{c.in, wm, bias_p, c.out, c.B, c.H, c.W, c.Ho, c.Wo, c.Cout, c.pt, c.pl, c.act,
+                 (unsigned)((size_t)c.B * c.Ho * c.Wo), 8u};
+    unsigned tiles = (p.total_px + 15) / 16;
+    unsigned blocks = (tiles + 4 * p.tiles_per_wave - 1) / (4 * p.tiles_per_wave);
+    if (c.Cout == 32) hipLaunchKernelGGL((k_stem_mfma<2>), dim3(blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_stem_mfma<4>), dim3(blocks), dim3(256), 0, s, p);
+}
+
 // ------------------------------------------------------------------------------------------ pointwise GEMM
 // out[M,N] = act(A[M,K] * W[N,K]^T + bias[N]) (+ res[M,N]); optional per-(batch,k) scale on A (squeeze-excite
 // MUL folded into the consumer's operand load).  f32 MFMA 16x16x4 with the roles swapped (W rows feed
