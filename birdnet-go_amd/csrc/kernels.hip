@@ -515,6 +515,8 @@ struct StemParams {
 };
 template <int NTILES>
 __global__ __launch_bounds__(256) void k_stem_mfma(StemParams p) {
+    constexpr int CS = NTILES * 16 + 4;                          // staging row stride (floats)
+    __shared__ __attribute__((aligned(16))) float stage[4 * 16 * CS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, kq = lane >> 4;
     // weight fragments + bias of this lane (constant for the block)
@@ -533,23 +535,45 @@ __global__ __launch_bounds__(256) void k_stem_mfma(StemParams p) {
     const int i0 = kq >> 1, j0 = (kq & 1) * 2;
     const unsigned tile0 = (blockIdx.x * 4u + wave) * p.tiles_per_wave;
     const unsigned hw = (unsigned)p.Ho * p.Wo;
-    for (unsigned tt = 0; tt < p.tiles_per_wave; tt++) {
-        const unsigned px = (tile0 + tt) * 16u + li;
-        if ((tile0 + tt) * 16u >= p.total_px) break;                    // wave-uniform
+    // pixel coordinates of this lane: decoded once, then advanced by 16 columns per tile (carry into row / clip)
+    unsigned px = tile0 * 16u + li;
+    int b, oh, ow;
+    {
         const unsigned pc = min(px, p.total_px - 1);
-        const unsigned b = pc / hw, rem = pc - b * hw;
-        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+        b = pc / hw;
+        const unsigned rem = pc - (unsigned)b * hw;
+        oh = rem / p.Wo; ow = rem - oh * p.Wo;
+    }
+    for (unsigned tt = 0; tt < p.tiles_per_wave; tt++, px += 16u) {
+        if ((tile0 + tt) * 16u >= p.total_px) break;                    // wave-uniform
+        if (tt) {
+            ow += 16;
+            while (ow >= p.Wo) { ow -= p.Wo; if (++oh == p.Ho) { oh = 0; b++; } }
+            if (b >= p.B) { b = p.B - 1; oh = p.Ho - 1; ow = p.Wo - 1; }  // lanes past the end: any valid pixel
+        }
         const float* xb = p.in + (size_t)b * p.H * p.W * 2;
         f32x4 xf[2];
+        const int r0 = oh * 2 - p.pt, c0 = ow * 2 - p.pl + j0;
+        // interior pixels (all but the image border) need neither clamps nor masks: one wave-uniform test
+        const bool inner = r0 >= 0 && r0 + 2 < p.H && c0 >= 0 && c0 + 1 < p.W;
+        if (__builtin_amdgcn_ballot_w64(!inner) == 0) {
 #pragma unroll
-        for (int sl = 0; sl < 2; sl++) {
-            const int row = oh * 2 - p.pt + (sl == 0 ? i0 : 2), col = ow * 2 - p.pl + j0;
-            const bool rv = row >= 0 && row < p.H;
-            const bool v0 = rv && col >= 0 && col < p.W, v1 = rv && col + 1 >= 0 && col + 1 < p.W;
-            const int rc = min(max(row, 0), p.H - 1);
-            const float2 a = *reinterpret_cast<const float2*>(xb + ((size_t)rc * p.W + min(max(col, 0), p.W - 1)) * 2);
-            const float2 c = *reinterpret_cast<const float2*>(xb + ((size_t)rc * p.W + min(max(col + 1, 0), p.W - 1)) * 2);
-            xf[sl] = (f32x4){v0 ? a.x : 0.f, v0 ? a.y : 0.f, v1 ? c.x : 0.f, v1 ? c.y : 0.f};
+            for (int sl = 0; sl < 2; sl++) {
+                const float* q = xb + ((size_t)(r0 + (sl == 0 ? i0 : 2)) * p.W + c0) * 2;
+                const float2 a = *reinterpret_cast<const float2*>(q), c = *reinterpret_cast<const float2*>(q + 2);
+                xf[sl] = (f32x4){a.x, a.y, c.x, c.y};
+            }
+        } else {
+#pragma unroll
+            for (int sl = 0; sl < 2; sl++) {
+                const int row = r0 + (sl == 0 ? i0 : 2), col = c0;
+                const bool rv = row >= 0 && row < p.H;
+                const bool v0 = rv && col >= 0 && col < p.W, v1 = rv && col + 1 >= 0 && col + 1 < p.W;
+                const int rc = min(max(row, 0), p.H - 1);
+                const float2 a = *reinterpret_cast<const float2*>(xb + ((size_t)rc * p.W + min(max(col, 0), p.W - 1)) * 2);
+                const float2 c = *reinterpret_cast<const float2*>(xb + ((size_t)rc * p.W + min(max(col + 1, 0), p.W - 1)) * 2);
+                xf[sl] = (f32x4){v0 ? a.x : 0.f, v0 ? a.y : 0.f, v1 ? c.x : 0.f, v1 ? c.y : 0.f};
+            }
         }
         f32x4 acc[NTILES];
 #pragma unroll
@@ -568,11 +592,22 @@ __global__ __launch_bounds__(256) void k_stem_mfma(StemParams p) {
                 acc[t][2] = f(acc[t][2] + bq[t].z); acc[t][3] = f(acc[t][3] + bq[t].w);
             }
         });
-        if (px < p.total_px) {
-            float* o = p.out + (size_t)px * p.Cout + 4 * kq;
+        // the lane holds 4 channels of one pixel per n-tile: stage the 16 x Cout tile through this wave's LDS slice and write
+        // it out as one contiguous run (16 pixels x Cout floats) instead of 64-byte pieces
+        float* stg = stage + wave * (16 * CS);
 #pragma unroll
-            for (int t = 0; t < NTILES; t++) *reinterpret_cast<f32x4*>(o + 16 * t) = acc[t];
+        for (int t = 0; t < NTILES; t++) *reinterpret_cast<f32x4*>(&stg[li * CS + 16 * t + 4 * kq]) = acc[t];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const unsigned px0 = (tile0 + tt) * 16u;
+#pragma unroll
+        for (int q = 0; q < (16 * NTILES * 4) / 64; q++) {
+            const int idx = lane + 64 * q;                       // float4 index inside the 16 x Cout tile
+            const int row = idx / (NTILES * 4), c4 = idx % (NTILES * 4);
+            if (px0 + row < p.total_px)
+                *reinterpret_cast<f32x4*>(p.out + (size_t)(px0 + row) * p.Cout + 4 * c4) = *reinterpret_cast<const f32x4*>(&stg[row * CS + 4 * c4]);
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 bool stem_mfma_supported(const ConvParams& p) {
@@ -580,7 +615,7 @@ bool stem_mfma_supported(const ConvParams& p) {
 }
 void launch_stem_mfma(const ConvParams& c, const float* wm, const float* bias_p, hipStream_t s) {
     StemParams p{c.in, wm, bias_p, c.out, c.B, c.H, c.W, c.Ho, c.Wo, c.Cout, c.pt, c.pl, c.act,
-                 (unsigned)((size_t)c.B * c.Ho * c.Wo), 8u};
+                 (unsigned)((size_t)c.B * c.Ho * c.Wo), (unsigned)(getenv("BNHIP_STEM_TPW") ? atoi(getenv("BNHIP_STEM_TPW")) : 8)};
     unsigned tiles = (p.total_px + 15) / 16;
     unsigned blocks = (tiles + 4 * p.tiles_per_wave - 1) / (4 * p.tiles_per_wave);
     if (c.Cout == 32) hipLaunchKernelGGL((k_stem_mfma<2>), dim3(blocks), dim3(256), 0, s, p);
