@@ -684,6 +684,49 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                                         for (int ic = 0; ic < 2; ic++)
                                             wm[(size_t)oc * 32 + i * 8 + j * 2 + ic] = ws[(((size_t)oc * kh + i) * kw + j) * C + ic];
                             if (o.inputs.size() > 2 && o.inputs[2] >= 0) memcpy(bp.data(), m.tensors[o.inputs[2]].f32(), (size_t)Co * sizeof(float));
+                            // ---- stem whose only consumer is a 3x3 stride-1 depthwise conv: one k_expand_dw<STEM> launch; the
+                            // stem output (the largest tensor of the network) never reaches HBM
+                            if (fuse_expdw && !getenv("BNHIP_NO_FUSE_STEM") && P.uses[outt] == 1 && P.consumers[outt].size() == 1 && (Co % 32) == 0) {
+                                int di = P.consumers[outt][0];
+                                const TflOp& d = m.ops[di];
+                                int dH, dW, dC, dHo, dWo, dCo;
+                                if (d.code == OP_DEPTHWISE_CONV_2D && !P.absorbed[di] && d.inputs[0] == outt && P.is_const(d.inputs[1]) &&
+                                    hwc(outt, &dH, &dW, &dC) && hwc(d.outputs[0], &dHo, &dWo, &dCo) && dCo == dC && d.depth_multiplier == 1 &&
+                                    d.dil_h == 1 && d.dil_w == 1 && d.stride_h == 1 && d.stride_w == 1) {
+                                    const TflTensor& wd = m.tensors[d.inputs[1]];
+                                    int kd = wd.shape.size() == 4 ? wd.shape[1] : 0;
+                                    int act_d = map_act(d.act);
+                                    const int fpt = d.padding == 0 ? std::max((dHo - 1) + kd - dH, 0) / 2 : 0;
+                                    const int fpl = d.padding == 0 ? std::max((dWo - 1) + kd - dW, 0) / 2 : 0;
+                                    if (kd == 3 && wd.shape[2] == 3 && wd.shape[3] == dC && act_d >= 0 && s.in0 >= 0 &&
+                                        expdw_sum_slabs(kd, 1, dH, dHo, dWo, fpt) > 0) {
+                                        int dout = d.outputs[0];
+                                        if (act_d == ACT_NONE) dout = trailing_act(dout, &act_d);
+                                        P.absorbed[di] = 1;
+                                        Step f; f.kind = S_EXPAND_DW; f.kclass = "expand_dw"; f.name = oname + "+dw"; f.mode = 1;
+                                        f.in0 = s.in0;
+                                        f.H = Ho; f.W = Wo; f.C = 32; f.Co = Co; f.Ho = dHo; f.Wo = dWo; f.kh = kd; f.kw = kd; f.sh = 1; f.sw = 1;
+                                        f.pt = fpt; f.pl = fpl; f.act = act; f.act2 = act_d;
+                                        f.H2 = H; f.W2 = W; f.pt2 = s.pt; f.pl2 = s.pl;
+                                        f.flops = 2.0 * Ho * Wo * Co * kh * kw * C + 2.0 * dHo * dWo * Co * kd * kd;
+                                        f.bytes = 4.0 * ((double)H * W * C + (double)dHo * dWo * Co);
+                                        f.wbytes = 4.0 * (Co * 32 + kd * kd * Co);
+                                        f.out = new_val(dout, (size_t)dHo * dWo * Co);
+                                        tv[dout] = f.out;
+                                        const int Cp = expdw_cp(Co);
+                                        std::vector<float> wep((size_t)Cp * 32, 0.f), bep(Cp, 0.f), wdp((size_t)kd * kd * Cp, 0.f), bdp(Cp, 0.f);
+                                        memcpy(wep.data(), wm.data(), wm.size() * sizeof(float));
+                                        memcpy(bep.data(), bp.data(), bp.size() * sizeof(float));
+                                        const float* dsrc = wd.f32();
+                                        for (int t = 0; t < kd * kd; t++) memcpy(&wdp[(size_t)t * Cp], dsrc + (size_t)t * Co, (size_t)Co * sizeof(float));
+                                        if (d.inputs.size() > 2 && d.inputs[2] >= 0) memcpy(bdp.data(), m.tensors[d.inputs[2]].f32(), (size_t)Co * sizeof(float));
+                                        size_t o_we = wpush(wep.data(), wep.size()), o_be = wpush(bep.data(), bep.size());
+                                        size_t o_wd = wpush(wdp.data(), wdp.size()), o_bd = wpush(bdp.data(), bdp.size());
+                                        add_step(f, o_we, o_be, o_wd, o_bd);
+                                        break;
+                                    }
+                                }
+                            }
                             add_step(s, wpush(wt.data(), wt.size()), boff, wpush(wm.data(), wm.size()), wpush(bp.data(), bp.size()));
                             break;
                         }
@@ -1049,8 +1092,9 @@ void Engine::autotune_expdw() {
         for (int idx = 0; idx < expdw_num_shapes(); idx++) {
             if (!expdw_shape_fits(idx, s.kh, s.sh, s.H, s.Ho, s.Wo, s.pt)) continue;
             auto go = [&]() {
+                StemGeom sg{s.H2, s.W2, s.pt2, s.pl2};
                 launch_expand_dw(in0, s.w0, s.w1, s.w2, s.w3, out, out2, n, s.H, s.W, s.C, s.Co, s.Ho, s.Wo, s.kh, s.sh, s.pt, s.pl,
-                                 s.act, s.act2, idx, stream);
+                                 s.act, s.act2, idx, s.mode == 1 ? &sg : nullptr, stream);
             };
             go();
             hipEventRecord(a, stream);
@@ -1280,8 +1324,11 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
                 break;
             }
             case S_EXPAND_DW:
-                launch_expand_dw(in0, s.w0, s.w1, s.w2, s.w3, out, out2, n, s.H, s.W, s.C, s.Co,
-                                 s.Ho, s.Wo, s.kh, s.sh, s.pt, s.pl, s.act, s.act2, s.shape, stream);
+                {
+                    StemGeom sg{s.H2, s.W2, s.pt2, s.pl2};
+                    launch_expand_dw(in0, s.w0, s.w1, s.w2, s.w3, out, out2, n, s.H, s.W, s.C, s.Co,
+                                     s.Ho, s.Wo, s.kh, s.sh, s.pt, s.pl, s.act, s.act2, s.shape, s.mode == 1 ? &sg : nullptr, stream);
+                }
                 break;
             case S_MEAN_PARTIAL:
                 launch_mean_partial(in0, out, n, s.H * s.W, s.C, s.S, stream);

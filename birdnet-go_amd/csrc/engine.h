@@ -25,6 +25,7 @@ struct Step {
     int H = 0, W = 0, C = 0, Ho = 0, Wo = 0, Co = 0, kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0;
     int act = 0, act2 = 0, op = 0, mode = 0, S = 1, Cr = 0;
     int nt = 0, wm = 0;      // pw_gemm tile shape chosen by the create-time autotuner (0 = heuristic), for a lane's batch
+    int H2 = 0, W2 = 0, pt2 = 0, pl2 = 0;   // fused stem + depthwise (mode == 1 on an S_EXPAND_DW step): raw image size, stem padding
     int shape = -1;          // expand_dw tile shape (index into the kernel's table) chosen by the autotuner; -1 = cost model
     int nt_full = 0, wm_full = 0;   // same, tuned at max_batch (calls that run unsplit: pipelined contexts, profiling)
     // front-end

@@ -87,12 +87,15 @@ bool expdw_shape_fits(int idx, int k, int s, int H, int Ho, int Wo, int pt);
 int expdw_shape_slabs(int idx, int Ho, int Wo);
 int expdw_default_shape(int k, int s, int H, int Ho, int Wo, int pt);
 int expdw_max_slabs(int k, int s, int H, int Ho, int Wo, int pt);
+struct StemGeom { int Hin, Win, pt, pl; };   // raw image size and the stem conv's top/left padding
 // parameters are the planner's padded copies: we [expdw_cp(Cmid)][expdw_kw(Cin)], be/bd [Cp], wd [k*k][Cp] (zeros beyond)
 int expdw_kw(int Cin);
 int expdw_cp(int Cmid);
 void launch_expand_dw(const float* x, const float* we, const float* be, const float* wd, const float* bd, float* y,
                       float* partial, int B, int H, int W, int Cin, int Cmid, int Ho, int Wo, int k, int s, int pt,
-                      int pl, int act_e, int act_d, int shape /* index into the shape table; -1 = cost model */, hipStream_t st);
+                      int pl, int act_e, int act_d, int shape /* index into the shape table; -1 = cost model */,
+                      const StemGeom* stem /* non-null: x is the raw image and the expand is the 3x3/2 stem (see kernels.hip) */,
+                      hipStream_t st);
 
 // mean over H*W: in [B,HW,C] -> partial [B,S,C] (sums), S = number of pixel splits
 int mean_splits(int HW);

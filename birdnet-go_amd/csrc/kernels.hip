@@ -1065,6 +1065,9 @@ struct ExpDwParams {
     const float* x; const float* we; const float* be; const float* wd; const float* bd;
     float* y; float* partial;
     int B, H, W, Cin, Cmid, Ho, Wo, pt, pl, act_e, act_d, tiles_h, tiles_w, cchunks, Kw, Cp;
+    // STEM variant: x is the raw [B, Hin, Win, 2] image and the "expand" is the 3x3 stride-2 stem conv seen as an implicit
+    // GEMM (K layout of k_stem_mfma); H, W above are then the stem's output size
+    int Hin = 0, Win = 0, pts = 0, pls = 0;
 };
 #define ED_ES 36     // E row stride (floats)
 // Phase 1 feeds the MFMA straight from global memory: every footprint pixel row belongs to exactly one wave
@@ -1080,7 +1083,7 @@ struct ExpDwParams {
 // TRH = footprint rows held in LDS.  Only in-image rows are computed and stored (compacted), so a tile that spans the
 // whole image height has no vertical halo at all; phase 2 skips the taps that fall on padding rows (the row test is
 // wave-uniform: a wave owns one row group of the tile).
-template <int K, int S, int TOH, int TOW, int TRH>
+template <int K, int S, int TOH, int TOW, int TRH, bool STEM = false>
 __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk) {
     constexpr int TIH = (TOH - 1) * S + K, TIW = (TOW - 1) * S + K;
     static_assert(TRH <= TIH, "TRH is a cap on the footprint rows");
@@ -1120,7 +1123,8 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
     const float4 bv = *reinterpret_cast<const float4*>(p.bd + n_base + 4 * c4);
 
     // this lane's pixel per owned tile (a): clamped global offset + validity
-    int xoff[JTW];
+    int xoff[JTW];               // STEM: top input row of the pixel's 3x4 window, and (scol) its left input column
+    int scol[JTW];
     bool xin[JTW];
 #pragma unroll
     for (int a = 0; a < JTW; a++) {
@@ -1129,8 +1133,10 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
         int iw = iw0 + c;
         xin[a] = j < nvalid && iw >= 0 && iw < p.W;
         int ihc = min(ih0 + vr0 + r, p.H - 1), iwc = min(max(iw, 0), p.W - 1);
-        xoff[a] = (((b * p.H + ihc) * p.W) + iwc) * Cin + 4 * kq;
+        if (STEM) { xoff[a] = ihc * 2 - p.pts; scol[a] = iwc * 2 - p.pls + (kq & 1) * 2; }
+        else { xoff[a] = (((b * p.H + ihc) * p.W) + iwc) * Cin + 4 * kq; scol[a] = 0; }
     }
+    const float* xb = STEM ? p.x + (size_t)b * p.Hin * p.Win * 2 : p.x;
     const float* wrow0 = p.we + (size_t)(n_base + li) * Kw + 4 * kq;
     const float* wrow1 = wrow0 + (size_t)16 * Kw;
 
@@ -1141,6 +1147,21 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
     auto fload = [&](int k0, f32x4& wf0, f32x4& wf1, f32x4 (&xf)[JTW]) {
         float4 t0 = *reinterpret_cast<const float4*>(wrow0 + k0), t1 = *reinterpret_cast<const float4*>(wrow1 + k0);
         wf0 = (f32x4){t0.x, t0.y, t0.z, t0.w}; wf1 = (f32x4){t1.x, t1.y, t1.z, t1.w};
+        if (STEM) {
+            // k-group of this lane: window row i (slab 0: kq >> 1, slab 1: 2), columns j0, j0 + 1 (in scol), both channels
+            const int i = k0 == 0 ? (kq >> 1) : 2;
+#pragma unroll
+            for (int a = 0; a < JTW; a++) {
+                const int row = xoff[a] + i, col = scol[a];
+                const bool rv = row >= 0 && row < p.Hin;
+                const bool v0 = rv && col >= 0 && col < p.Win, v1 = rv && col + 1 >= 0 && col + 1 < p.Win;
+                const size_t ro = (size_t)min(max(row, 0), p.Hin - 1) * p.Win;
+                const float2 u = *reinterpret_cast<const float2*>(xb + (ro + min(max(col, 0), p.Win - 1)) * 2);
+                const float2 w = *reinterpret_cast<const float2*>(xb + (ro + min(max(col + 1, 0), p.Win - 1)) * 2);
+                xf[a] = (f32x4){v0 ? u.x : 0.f, v0 ? u.y : 0.f, v1 ? w.x : 0.f, v1 ? w.y : 0.f};
+            }
+            return;
+        }
         const int kx = (k0 + 4 * kq < Cin) ? k0 : -4 * kq;     // K tail: any in-bounds address (its weights are zero)
 #pragma unroll
         for (int a = 0; a < JTW; a++) {
@@ -1346,13 +1367,24 @@ bool expdw_supported(int k, int s, int Cin, int Cmid) {
 }
 void launch_expand_dw(const float* x, const float* we, const float* be, const float* wd, const float* bd, float* y,
                       float* partial, int B, int H, int W, int Cin, int Cmid, int Ho, int Wo, int k, int s, int pt,
-                      int pl, int act_e, int act_d, int shape, hipStream_t st) {
+                      int pl, int act_e, int act_d, int shape, const StemGeom* stem, hipStream_t st) {
     if (!expdw_shape_fits(shape, k, s, H, Ho, Wo, pt)) shape = expdw_default_shape(k, s, H, Ho, Wo, pt);
     if (shape < 0) return;                             // the planner only fuses layers some shape accepts
     const ExpDwShape* sh = &kExpDwShapes[shape];
     ExpDwParams p{x, we, be, wd, bd, y, partial, B, H, W, Cin, Cmid, Ho, Wo, pt, pl, act_e, act_d,
                   (Ho + sh->toh - 1) / sh->toh, (Wo + sh->tow - 1) / sh->tow, (Cmid + 31) / 32, expdw_kw(Cin), expdw_cp(Cmid)};
     unsigned nblk = (unsigned)B * p.tiles_h * p.tiles_w * p.cchunks;
+    if (stem) {
+        p.Hin = stem->Hin; p.Win = stem->Win; p.pts = stem->pt; p.pls = stem->pl; p.Kw = 32;
+#define ED_STEM(TH_, TW_, TR_)                                                                                \
+    if (sh->k == 3 && sh->s == 1 && sh->toh == TH_ && sh->tow == TW_ && sh->trh == TR_) {                     \
+        hipLaunchKernelGGL((k_expand_dw<3, 1, TH_, TW_, TR_, true>), dim3(nblk), dim3(256), 0, st, p, nblk);  \
+        return;                                                                                               \
+    }
+        ED_STEM(8, 16, 10) ED_STEM(4, 16, 6) ED_STEM(8, 32, 6) ED_STEM(8, 32, 10)
+#undef ED_STEM
+        return;
+    }
 #define ED_CASE(K_, S_, TH_, TW_, TR_)                                                                        \
     if (sh->k == K_ && sh->s == S_ && sh->toh == TH_ && sh->tow == TW_ && sh->trh == TR_) {                   \
         hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_>), dim3(nblk), dim3(256), 0, st, p, nblk);      \

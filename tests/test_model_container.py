@@ -90,16 +90,18 @@ def test_cpp_reader_and_planner_fuse_everything(built_lib, full_blob):
     # front-end (FFT path): clip_minmax, normalize, 2 x (stft + mel GEMM), one fused finish
     assert kinds.count("stft") == 2 and kinds.count("frontend") == 2 and kinds.count("clip_minmax") == 1
     assert "elementwise" not in kinds, "an op fell back to the unfused elementwise path"
-    # 16 MBConv blocks: 11 with the fused expand+depthwise kernel (Cin <= 128), 5 plain depthwise (b1 + the 4 wide ones)
-    assert kinds.count("expand_dw") == 11 and kinds.count("dwconv") == 5 and kinds.count("se") == 16
+    # 16 MBConv blocks: 11 with the fused expand+depthwise kernel (Cin <= 128) + the stem fused with b1's depthwise in the same
+    # kernel family; 4 plain depthwise (the wide blocks)
+    assert kinds.count("expand_dw") == 12 and kinds.count("dwconv") == 4 and kinds.count("se") == 16
+    assert kinds.count("conv_direct") == 0
     # every squeeze-excite mean comes from sums emitted by the producing depthwise kernel; only the GAP uses the mean pass
     assert sum(s["fused_sum"] for s in d["steps"]) == 16 and kinds.count("mean") == 2
     pw = [s for s in d["steps"] if s["kernel"] == "pw_gemm"]
     assert sum(s["fused_scale"] for s in pw) == 16 and sum(s["fused_res"] for s in pw) == 9
-    assert len(d["steps"]) == 64
+    assert len(d["steps"]) == 63
     # with the folded-GEMM front-end: clip_minmax + one k_frontend launch per channel
     d0 = host.HipClassifier(full_blob, plan_only=True, frontend_fft=0).describe()
-    assert len(d0["steps"]) == 60 and [s["kernel"] for s in d0["steps"]].count("frontend") == 2
+    assert len(d0["steps"]) == 59 and [s["kernel"] for s in d0["steps"]].count("frontend") == 2
     assert d["specs"][0]["hop"] == 278 and d["specs"][1]["hop"] == 280 and d["specs"][0]["frames"] == 511
     assert abs(d["specs"][0]["p2"] - 1.0 / (1.0 + np.exp(1.23))) < 1e-6
     with pytest.raises(host.HipError, match="plan-only"):
