@@ -145,7 +145,7 @@ def _geo_cfg(i):
     for _ in range(int(rng.integers(3, 6))):
         blocks.append((int(rng.choice([4, 6])), int(rng.choice([3, 5])), int(rng.choice([1, 1, 2])),
                        int(rng.choice([12, 16, 20, 24, 36])), int(rng.integers(1, 3))))
-    return sm.tiny_config(n_samples=n_samples, n_mels=n_mels, specs=specs, blocks=tuple(blocks), stem=int(rng.choice([8, 16])),
+    return sm.tiny_config(n_samples=n_samples, n_mels=n_mels, specs=specs, blocks=tuple(blocks), stem=int(rng.choice([8, 16, 32, 32])),
                           top=int(rng.choice([48, 64])), n_classes=int(rng.choice([17, 50, 101])), seed=77 + i)
 
 
