@@ -1089,13 +1089,8 @@ void Engine::autotune_expdw() {
         float* out = vptr(s.out, d_stage_in, d_stage_logits, nullptr);
         float* out2 = vptr(s.out2, d_stage_in, d_stage_logits, nullptr);
         float best = 1e30f; int best_idx = -1;
-        for (int cand = 0; cand < 2 * expdw_num_shapes(); cand++) {
-            int idx = cand % expdw_num_shapes();
+        for (int idx = 0; idx < expdw_num_shapes(); idx++) {
             if (!expdw_shape_fits(idx, s.kh, s.sh, s.H, s.Ho, s.Wo, s.pt)) continue;
-            if (cand >= expdw_num_shapes()) {            // second round: the same shape as a column strip
-                if (!expdw_strip_capable(idx) || getenv("BNHIP_NO_STRIP")) continue;
-                idx |= kExpDwStripBit;
-            }
             auto go = [&]() {
                 StemGeom sg{s.H2, s.W2, s.pt2, s.pl2};
                 launch_expand_dw(in0, s.w0, s.w1, s.w2, s.w3, out, out2, n, s.H, s.W, s.C, s.Co, s.Ho, s.Wo, s.kh, s.sh, s.pt, s.pl,
@@ -1107,13 +1102,12 @@ void Engine::autotune_expdw() {
             hipEventRecord(b, stream);
             hipEventSynchronize(b);
             float ms = 0; hipEventElapsedTime(&ms, a, b);
-            if (getenv("BNHIP_DEBUG")) fprintf(stderr, "[bnhip] tune %-16s shape %2d%s: %.1f us\n", s.name.c_str(), idx & ~kExpDwStripBit, (idx & kExpDwStripBit) ? " strip" : "", ms / 3 * 1e3);
             if (ms < best * 0.98f) { best = ms; best_idx = idx; }
         }
         if (best_idx < 0) continue;
         s.shape = best_idx;
         if (s.out2 >= 0) {                       // the consumers of the per-tile sums index them by tile count
-            s.S = expdw_shape_slabs(best_idx & ~kExpDwStripBit, s.Ho, s.Wo);
+            s.S = expdw_shape_slabs(best_idx, s.Ho, s.Wo);
             for (auto& c : steps) if (&c != &s && c.in0 == s.out2) c.S = s.S;
         }
     }

@@ -87,8 +87,6 @@ bool expdw_shape_fits(int idx, int k, int s, int H, int Ho, int Wo, int pt);
 int expdw_shape_slabs(int idx, int Ho, int Wo);
 int expdw_default_shape(int k, int s, int H, int Ho, int Wo, int pt);
 int expdw_max_slabs(int k, int s, int H, int Ho, int Wo, int pt);
-bool expdw_strip_capable(int idx);
-constexpr int kExpDwStripBit = 64;    // or-ed into a shape index: walk a whole column of tiles per block (ring buffer, no vertical halo)
 struct StemGeom { int Hin, Win, pt, pl; };   // raw image size and the stem conv's top/left padding
 // parameters are the planner's padded copies: we [expdw_cp(Cmid)][expdw_kw(Cin)], be/bd [Cp], wd [k*k][Cp] (zeros beyond)
 int expdw_kw(int Cin);

@@ -1083,231 +1083,215 @@ struct ExpDwParams {
 // TRH = footprint rows held in LDS.  Only in-image rows are computed and stored (compacted), so a tile that spans the
 // whole image height has no vertical halo at all; phase 2 skips the taps that fall on padding rows (the row test is
 // wave-uniform: a wave owns one row group of the tile).
-template <int K, int S, int TOH, int TOW, int TRH, bool STEM = false, bool STRIP = false>
+template <int K, int S, int TOH, int TOW, int TRH, bool STEM = false>
 __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk) {
     constexpr int TIH = (TOH - 1) * S + K, TIW = (TOW - 1) * S + K;
     static_assert(TRH <= TIH, "TRH is a cap on the footprint rows");
-    static_assert(!STRIP || TRH == TIH, "a strip needs the full footprint height as ring capacity");
     constexpr int NPIX = TRH * TIW, NPIXP = (NPIX + 15) / 16 * 16;
     constexpr int JT = NPIXP / 16, JTW = (JT + 3) / 4;
     constexpr int SH = TOH / 4, SW = TOW / 8;                 // outputs per thread in phase 2 (thread-tiles are 4 x 8)
     constexpr int RW = (SW - 1) * S + K;
     __shared__ __attribute__((aligned(16))) float lds[NPIX * ED_ES + 128 + K * K * 32];
-    float* E = lds;                                                      // [TRH row slots][TIW][36] expanded footprint
+    float* E = lds;                                                      // [<=TRH rows][TIW][36] expanded footprint
     float4* red = reinterpret_cast<float4*>(lds + NPIX * ED_ES);         // [4 waves][8] sum scratch
     float4* wds = reinterpret_cast<float4*>(lds + NPIX * ED_ES + 128);   // [K*K][8] depthwise taps of this chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
 
-    // STRIP: the block walks down a column of tiles and keeps the expanded rows in a ring of TRH row slots, so rows shared
-    // by vertically adjacent tiles are expanded (and activated) once instead of twice: no vertical halo at all.
     const unsigned L = xcd_remap(blockIdx.x, nblk);
     const int tiles = p.tiles_h * p.tiles_w;
-    const int bpc = (STRIP ? p.tiles_w : tiles) * p.cchunks;
+    const int bpc = tiles * p.cchunks;
     const int b = L / bpc, rest = L % bpc;
-    const int tsel = rest / p.cchunks, cc = rest % p.cchunks;
-    const int tw_i = STRIP ? tsel : tsel % p.tiles_w;
-    const int th_first = STRIP ? 0 : tsel / p.tiles_w, th_last = STRIP ? p.tiles_h - 1 : th_first;
-    const int ow0 = tw_i * TOW, iw0 = ow0 * S - p.pl;
+    const int tile = rest / p.cchunks, cc = rest % p.cchunks;
+    const int oh0 = (tile / p.tiles_w) * TOH, ow0 = (tile % p.tiles_w) * TOW;
+    const int ih0 = oh0 * S - p.pt, iw0 = ow0 * S - p.pl;
+    // footprint rows are compacted to the in-image range [vr0, vr1) (host guarantees vr1 - vr0 <= TRH); columns keep
+    // the compile-time width TIW (out-of-image columns are masked): GEMM row j <-> footprint pixel
+    // (vr0 + j / TIW, j % TIW), stored at E[j]
+    const int vr0 = max(ih0, 0) - ih0, vr1 = min(ih0 + TIH, p.H) - ih0;
+    const int nvalid = (vr1 - vr0) * TIW;
+    const int jtv = (nvalid + 15) >> 4;
     const int Cin = p.Cin, Kw = p.Kw;
     const int n_base = cc * 32;
 
-    // ---- small parameters first (registers; the taps go to LDS after the first phase 1)
+    // ---- small parameters first (registers; the taps go to LDS after phase 1)
     const int c4 = tid & 7, tt = tid >> 3;
     float4 wdreg = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < K * K * 8) wdreg = *reinterpret_cast<const float4*>(p.wd + (size_t)(tid >> 3) * p.Cp + n_base + 4 * (tid & 7));
     const float4 bq0 = *reinterpret_cast<const float4*>(p.be + n_base + 4 * kq);
     const float4 bq1 = *reinterpret_cast<const float4*>(p.be + n_base + 16 + 4 * kq);
     const float4 bv = *reinterpret_cast<const float4*>(p.bd + n_base + 4 * c4);
+
+    // this lane's pixel per owned tile (a): clamped global offset + validity
+    int xoff[JTW];               // STEM: top input row of the pixel's 3x4 window, and (scol) its left input column
+    int scol[JTW];
+    bool xin[JTW];
+#pragma unroll
+    for (int a = 0; a < JTW; a++) {
+        int j = 16 * (wave + 4 * a) + li;
+        int r = j / TIW, c = j - r * TIW;
+        int iw = iw0 + c;
+        xin[a] = j < nvalid && iw >= 0 && iw < p.W;
+        int ihc = min(ih0 + vr0 + r, p.H - 1), iwc = min(max(iw, 0), p.W - 1);
+        if (STEM) { xoff[a] = ihc * 2 - p.pts; scol[a] = iwc * 2 - p.pls + (kq & 1) * 2; }
+        else { xoff[a] = (((b * p.H + ihc) * p.W) + iwc) * Cin + 4 * kq; scol[a] = 0; }
+    }
     const float* xb = STEM ? p.x + (size_t)b * p.Hin * p.Win * 2 : p.x;
     const float* wrow0 = p.we + (size_t)(n_base + li) * Kw + 4 * kq;
     const float* wrow1 = wrow0 + (size_t)16 * Kw;
-    const int ty = tt >> 3, tx = tt & 7;                 // ty == wave: row tests in phase 2 are wave-uniform
-    const int n = n_base + 4 * c4;
 
-    const int base = max(th_first * TOH * S - p.pt, 0);  // image row held by ring slot 0
-    int done = base;                                     // image rows below this are already in the ring
-    for (int th = th_first; th <= th_last; th++) {
-        const int oh0 = th * TOH;
-        const int ih0 = oh0 * S - p.pt;
-        // in-image footprint rows [lo, hi) of this tile; the ones not yet in the ring, [nlo, hi), are computed now:
-        // GEMM row j <-> image pixel (nlo + j / TIW, iw0 + j % TIW), stored at ring slot (row - base) % TRH
-        const int lo = max(ih0, 0), hi = min(ih0 + TIH, p.H);
-        const int nlo = max(lo, done);
-        const int nvalid = (hi - nlo) * TIW;
-        const int jtv = (nvalid + 15) >> 4;
-        done = hi;
+    f32x4 acc[JTW][2];
+#pragma unroll
+    for (int a = 0; a < JTW; a++) { acc[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-        // this lane's pixel per owned MFMA tile (a): clamped global offset + validity
-        int xoff[JTW];               // STEM: top input row of the pixel's 3x4 window, and (scol) its left input column
-        int scol[JTW];
-        int eoff[JTW];
-        bool xin[JTW];
+    auto fload = [&](int k0, f32x4& wf0, f32x4& wf1, f32x4 (&xf)[JTW]) {
+        float4 t0 = *reinterpret_cast<const float4*>(wrow0 + k0), t1 = *reinterpret_cast<const float4*>(wrow1 + k0);
+        wf0 = (f32x4){t0.x, t0.y, t0.z, t0.w}; wf1 = (f32x4){t1.x, t1.y, t1.z, t1.w};
+        if (STEM) {
+            // k-group of this lane: window row i (slab 0: kq >> 1, slab 1: 2), columns j0, j0 + 1 (in scol), both channels
+            const int i = k0 == 0 ? (kq >> 1) : 2;
+#pragma unroll
+            for (int a = 0; a < JTW; a++) {
+                const int row = xoff[a] + i, col = scol[a];
+                const bool rv = row >= 0 && row < p.Hin;
+                const bool v0 = rv && col >= 0 && col < p.Win, v1 = rv && col + 1 >= 0 && col + 1 < p.Win;
+                const size_t ro = (size_t)min(max(row, 0), p.Hin - 1) * p.Win;
+                const float2 u = *reinterpret_cast<const float2*>(xb + (ro + min(max(col, 0), p.Win - 1)) * 2);
+                const float2 w = *reinterpret_cast<const float2*>(xb + (ro + min(max(col + 1, 0), p.Win - 1)) * 2);
+                xf[a] = (f32x4){v0 ? u.x : 0.f, v0 ? u.y : 0.f, v1 ? w.x : 0.f, v1 ? w.y : 0.f};
+            }
+            return;
+        }
+        const int kx = (k0 + 4 * kq < Cin) ? k0 : -4 * kq;     // K tail: any in-bounds address (its weights are zero)
 #pragma unroll
         for (int a = 0; a < JTW; a++) {
+            float4 t = *reinterpret_cast<const float4*>(p.x + (size_t)xoff[a] + kx);
+            xf[a] = (f32x4){t.x, t.y, t.z, t.w};
+        }
+    };
+    auto fmma = [&](const f32x4& wf0, const f32x4& wf1, const f32x4 (&xf)[JTW]) {
+#pragma unroll
+        for (int a = 0; a < JTW; a++) {
+            if (wave + 4 * a < jtv) {
+#pragma unroll
+                for (int sidx = 0; sidx < 4; sidx++) {
+                    acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf0[sidx], xf[a][sidx], acc[a][0], 0, 0, 0);
+                    acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf1[sidx], xf[a][sidx], acc[a][1], 0, 0, 0);
+                }
+            }
+        }
+    };
+    if (Kw <= 16) {
+        f32x4 wA0, wA1, xA[JTW];
+        fload(0, wA0, wA1, xA);
+        fmma(wA0, wA1, xA);
+    } else if (Kw <= 32) {
+        // early blocks (Cin 17..32): both K slabs requested back-to-back -> one memory latency instead of two
+        f32x4 wA0, wA1, xA[JTW], wB0, wB1, xB[JTW];
+        fload(0, wA0, wA1, xA);
+        fload(16, wB0, wB1, xB);
+        fmma(wA0, wA1, xA);
+        fmma(wB0, wB1, xB);
+    } else {
+        // (a rolling two-slab register prefetch was measured here: the extra VGPRs cost more occupancy than it buys)
+        for (int k0 = 0; k0 < Kw; k0 += 16) {
+            f32x4 wf0, wf1, xf[JTW];
+            fload(k0, wf0, wf1, xf);
+            fmma(wf0, wf1, xf);
+        }
+    }
+
+    // ---- E <- act_e(acc + be) at compacted footprint coordinates (masked columns are zero)
+#pragma unroll
+    for (int a = 0; a < JTW; a++) {
+        if (wave + 4 * a < jtv) {                         // wave-uniform: tiles beyond the valid rows cost nothing
+            with_act(p.act_e, [&](auto f) {
+                f32x4& v0 = acc[a][0];
+                f32x4& v1 = acc[a][1];
+                v0[0] = f(v0[0] + bq0.x); v0[1] = f(v0[1] + bq0.y); v0[2] = f(v0[2] + bq0.z); v0[3] = f(v0[3] + bq0.w);
+                v1[0] = f(v1[0] + bq1.x); v1[1] = f(v1[1] + bq1.y); v1[2] = f(v1[2] + bq1.z); v1[3] = f(v1[3] + bq1.w);
+            });
             int j = 16 * (wave + 4 * a) + li;
-            int r = j / TIW, c = j - r * TIW;
-            int iw = iw0 + c;
-            xin[a] = j < nvalid && iw >= 0 && iw < p.W;
-            int ihc = min(nlo + r, p.H - 1), iwc = min(max(iw, 0), p.W - 1);
-            eoff[a] = (((ihc - base) % TRH) * TIW + c) * ED_ES + 4 * kq;
-            if (STEM) { xoff[a] = ihc * 2 - p.pts; scol[a] = iwc * 2 - p.pls + (kq & 1) * 2; }
-            else { xoff[a] = (((b * p.H + ihc) * p.W) + iwc) * Cin + 4 * kq; scol[a] = 0; }
-        }
-
-        f32x4 acc[JTW][2];
-#pragma unroll
-        for (int a = 0; a < JTW; a++) { acc[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-
-        auto fload = [&](int k0, f32x4& wf0, f32x4& wf1, f32x4 (&xf)[JTW]) {
-            float4 t0 = *reinterpret_cast<const float4*>(wrow0 + k0), t1 = *reinterpret_cast<const float4*>(wrow1 + k0);
-            wf0 = (f32x4){t0.x, t0.y, t0.z, t0.w}; wf1 = (f32x4){t1.x, t1.y, t1.z, t1.w};
-            if (STEM) {
-                // k-group of this lane: window row i (slab 0: kq >> 1, slab 1: 2), columns j0, j0 + 1 (in scol), both channels
-                const int i = k0 == 0 ? (kq >> 1) : 2;
-#pragma unroll
-                for (int a = 0; a < JTW; a++) {
-                    const int row = xoff[a] + i, col = scol[a];
-                    const bool rv = row >= 0 && row < p.Hin;
-                    const bool v0 = rv && col >= 0 && col < p.Win, v1 = rv && col + 1 >= 0 && col + 1 < p.Win;
-                    const size_t ro = (size_t)min(max(row, 0), p.Hin - 1) * p.Win;
-                    const float2 u = *reinterpret_cast<const float2*>(xb + (ro + min(max(col, 0), p.Win - 1)) * 2);
-                    const float2 w = *reinterpret_cast<const float2*>(xb + (ro + min(max(col + 1, 0), p.Win - 1)) * 2);
-                    xf[a] = (f32x4){v0 ? u.x : 0.f, v0 ? u.y : 0.f, v1 ? w.x : 0.f, v1 ? w.y : 0.f};
-                }
-                return;
-            }
-            const int kx = (k0 + 4 * kq < Cin) ? k0 : -4 * kq;     // K tail: any in-bounds address (its weights are zero)
-#pragma unroll
-            for (int a = 0; a < JTW; a++) {
-                float4 t = *reinterpret_cast<const float4*>(p.x + (size_t)xoff[a] + kx);
-                xf[a] = (f32x4){t.x, t.y, t.z, t.w};
-            }
-        };
-        auto fmma = [&](const f32x4& wf0, const f32x4& wf1, const f32x4 (&xf)[JTW]) {
-#pragma unroll
-            for (int a = 0; a < JTW; a++) {
-                if (wave + 4 * a < jtv) {
-#pragma unroll
-                    for (int sidx = 0; sidx < 4; sidx++) {
-                        acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf0[sidx], xf[a][sidx], acc[a][0], 0, 0, 0);
-                        acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf1[sidx], xf[a][sidx], acc[a][1], 0, 0, 0);
-                    }
-                }
-            }
-        };
-        if (Kw <= 16) {
-            f32x4 wA0, wA1, xA[JTW];
-            fload(0, wA0, wA1, xA);
-            fmma(wA0, wA1, xA);
-        } else if (Kw <= 32) {
-            // early blocks (Cin 17..32): both K slabs requested back-to-back -> one memory latency instead of two
-            f32x4 wA0, wA1, xA[JTW], wB0, wB1, xB[JTW];
-            fload(0, wA0, wA1, xA);
-            fload(16, wB0, wB1, xB);
-            fmma(wA0, wA1, xA);
-            fmma(wB0, wB1, xB);
-        } else {
-            // (a rolling two-slab register prefetch was measured here: the extra VGPRs cost more occupancy than it buys)
-            for (int k0 = 0; k0 < Kw; k0 += 16) {
-                f32x4 wf0, wf1, xf[JTW];
-                fload(k0, wf0, wf1, xf);
-                fmma(wf0, wf1, xf);
+            if (j < nvalid) {
+                int e = j * ED_ES + 4 * kq;
+                const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(&E[e]) = xin[a] ? acc[a][0] : z;
+                *reinterpret_cast<f32x4*>(&E[e + 16]) = xin[a] ? acc[a][1] : z;
             }
         }
+    }
+    if (tid < K * K * 8) wds[tid] = wdreg;
+    __syncthreads();
 
-        // ---- E <- act_e(acc + be) at ring coordinates (masked columns are zero)
+    // ---- depthwise from LDS
+    const int ty = tt >> 3, tx = tt & 7;                 // ty == wave: row tests below are wave-uniform
+    const int n = n_base + 4 * c4;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < p.Cmid) {
+        float4 acc2[SH][SW];
 #pragma unroll
-        for (int a = 0; a < JTW; a++) {
-            if (wave + 4 * a < jtv) {                         // wave-uniform: tiles beyond the new rows cost nothing
-                with_act(p.act_e, [&](auto f) {
-                    f32x4& v0 = acc[a][0];
-                    f32x4& v1 = acc[a][1];
-                    v0[0] = f(v0[0] + bq0.x); v0[1] = f(v0[1] + bq0.y); v0[2] = f(v0[2] + bq0.z); v0[3] = f(v0[3] + bq0.w);
-                    v1[0] = f(v1[0] + bq1.x); v1[1] = f(v1[1] + bq1.y); v1[2] = f(v1[2] + bq1.z); v1[3] = f(v1[3] + bq1.w);
-                });
-                int j = 16 * (wave + 4 * a) + li;
-                if (j < nvalid) {
-                    const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    *reinterpret_cast<f32x4*>(&E[eoff[a]]) = xin[a] ? acc[a][0] : z;
-                    *reinterpret_cast<f32x4*>(&E[eoff[a] + 16]) = xin[a] ? acc[a][1] : z;
-                }
-            }
-        }
-        if (th == th_first && tid < K * K * 8) wds[tid] = wdreg;
-        __syncthreads();
-
-        // ---- depthwise from LDS
-        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < p.Cmid) {
-            float4 acc2[SH][SW];
+        for (int a = 0; a < SH; a++)
 #pragma unroll
-            for (int a = 0; a < SH; a++)
-#pragma unroll
-                for (int c = 0; c < SW; c++) acc2[a][c] = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float* e0 = E + (tx * SW * S) * ED_ES + 4 * c4;
+            for (int c = 0; c < SW; c++) acc2[a][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* e0 = E + (tx * SW * S) * ED_ES + 4 * c4;
 #pragma unroll 1
-            for (int i = 0; i < K; i++) {                 // kernel row (kept rolled: bounds the live weight registers)
-                float4 w[K];
+        for (int i = 0; i < K; i++) {                 // kernel row (kept rolled: bounds the live weight registers)
+            float4 w[K];
 #pragma unroll
-                for (int j = 0; j < K; j++) w[j] = wds[(i * K + j) * 8 + c4];
-#pragma unroll
-                for (int a = 0; a < SH; a++) {
-                    const int ih = ih0 + (ty * SH + a) * S + i;                 // image row of this tap
-                    if (ih < lo || ih >= hi || oh0 + ty * SH + a >= p.Ho) continue;   // padding row / no such output row
-                    const float* er = e0 + (((ih - base) % TRH) * TIW) * ED_ES;
-                    float4 xr[RW];
-#pragma unroll
-                    for (int c = 0; c < RW; c++) xr[c] = *reinterpret_cast<const float4*>(er + c * ED_ES);
-#pragma unroll
-                    for (int j = 0; j < K; j++) {
-#pragma unroll
-                        for (int c = 0; c < SW; c++) {
-                            const float4 xv = xr[c * S + j];
-                            acc2[a][c].x = fmaf(xv.x, w[j].x, acc2[a][c].x); acc2[a][c].y = fmaf(xv.y, w[j].y, acc2[a][c].y);
-                            acc2[a][c].z = fmaf(xv.z, w[j].z, acc2[a][c].z); acc2[a][c].w = fmaf(xv.w, w[j].w, acc2[a][c].w);
-                        }
-                    }
-                }
-            }
+            for (int j = 0; j < K; j++) w[j] = wds[(i * K + j) * 8 + c4];
 #pragma unroll
             for (int a = 0; a < SH; a++) {
-                int oh = oh0 + ty * SH + a;
-                if (oh >= p.Ho) continue;
-                with_act(p.act_d, [&](auto f) {
+                const int fr = (ty * SH + a) * S + i;                       // footprint row of this tap
+                if (fr < vr0 || fr >= vr1 || oh0 + ty * SH + a >= p.Ho) continue;   // padding row / no such output row
+                float4 xr[RW];
+#pragma unroll
+                for (int c = 0; c < RW; c++) xr[c] = *reinterpret_cast<const float4*>(e0 + ((fr - vr0) * TIW + c) * ED_ES);
+#pragma unroll
+                for (int j = 0; j < K; j++) {
 #pragma unroll
                     for (int c = 0; c < SW; c++) {
-                        float4& v = acc2[a][c];
-                        v.x = f(v.x + bv.x); v.y = f(v.y + bv.y); v.z = f(v.z + bv.z); v.w = f(v.w + bv.w);
+                        const float4 xv = xr[c * S + j];
+                        acc2[a][c].x = fmaf(xv.x, w[j].x, acc2[a][c].x); acc2[a][c].y = fmaf(xv.y, w[j].y, acc2[a][c].y);
+                        acc2[a][c].z = fmaf(xv.z, w[j].z, acc2[a][c].z); acc2[a][c].w = fmaf(xv.w, w[j].w, acc2[a][c].w);
                     }
-                });
-#pragma unroll
-                for (int c = 0; c < SW; c++) {
-                    int ow = ow0 + tx * SW + c;
-                    if (ow >= p.Wo) continue;
-                    float4 v = acc2[a][c];
-                    *reinterpret_cast<float4*>(p.y + (((size_t)b * p.Ho + oh) * p.Wo + ow) * p.Cmid + n) = v;
-                    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
                 }
             }
         }
-        if (p.partial) {
-            // lanes with equal (lane & 7) hold the same channel quad: butterfly over the other lane bits, then 4 waves
 #pragma unroll
-            for (int o = 8; o < 64; o <<= 1) {
-                sum.x += __shfl_xor(sum.x, o, 64); sum.y += __shfl_xor(sum.y, o, 64);
-                sum.z += __shfl_xor(sum.z, o, 64); sum.w += __shfl_xor(sum.w, o, 64);
-            }
-            if (lane < 8) red[wave * 8 + lane] = sum;
-            __syncthreads();
-            if (tid < 8 && n_base + 4 * tid < p.Cmid) {
-                float4 t = red[tid];
+        for (int a = 0; a < SH; a++) {
+            int oh = oh0 + ty * SH + a;
+            if (oh >= p.Ho) continue;
+            with_act(p.act_d, [&](auto f) {
 #pragma unroll
-                for (int w = 1; w < 4; w++) { float4 v = red[w * 8 + tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
-                *reinterpret_cast<float4*>(p.partial + ((size_t)b * tiles + th * p.tiles_w + tw_i) * p.Cmid + n_base + 4 * tid) = t;
+                for (int c = 0; c < SW; c++) {
+                    float4& v = acc2[a][c];
+                    v.x = f(v.x + bv.x); v.y = f(v.y + bv.y); v.z = f(v.z + bv.z); v.w = f(v.w + bv.w);
+                }
+            });
+#pragma unroll
+            for (int c = 0; c < SW; c++) {
+                int ow = ow0 + tx * SW + c;
+                if (ow >= p.Wo) continue;
+                float4 v = acc2[a][c];
+                *reinterpret_cast<float4*>(p.y + (((size_t)b * p.Ho + oh) * p.Wo + ow) * p.Cmid + n) = v;
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
             }
-        } else if (STRIP) {
-            __syncthreads();                               // everyone is done reading the ring before it is refilled
+        }
+    }
+    if (p.partial) {
+        // lanes with equal (lane & 7) hold the same channel quad: butterfly over the other lane bits, then 4 waves
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+            sum.x += __shfl_xor(sum.x, o, 64); sum.y += __shfl_xor(sum.y, o, 64);
+            sum.z += __shfl_xor(sum.z, o, 64); sum.w += __shfl_xor(sum.w, o, 64);
+        }
+        if (lane < 8) red[wave * 8 + lane] = sum;
+        __syncthreads();
+        if (tid < 8 && n_base + 4 * tid < p.Cmid) {
+            float4 t = red[tid];
+#pragma unroll
+            for (int w = 1; w < 4; w++) { float4 v = red[w * 8 + tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            *reinterpret_cast<float4*>(p.partial + ((size_t)b * tiles + tile) * p.Cmid + n_base + 4 * tid) = t;
         }
     }
 }
@@ -1317,12 +1301,12 @@ int expdw_cp(int Cmid) { return (Cmid + 31) / 32 * 32; }
 // Instantiated tile shapes.  The chooser takes, per layer, the shape that computes the fewest expanded pixels
 // (rows x TIW summed over the tiles of one image; halo recompute and masked padding columns both count) among those
 // whose in-image footprint rows fit TRH.
-struct ExpDwShape { int k, s, toh, tow, trh; bool strip; };   // strip: a column-strip (ring buffer) variant is instantiated
+struct ExpDwShape { int k, s, toh, tow, trh; };
 static const ExpDwShape kExpDwShapes[] = {
-    {3, 1, 8, 16, 10, true}, {3, 1, 4, 16, 6, false}, {3, 1, 8, 32, 6, false}, {3, 1, 8, 32, 10, true},
-    {5, 1, 8, 16, 12, true}, {5, 1, 4, 16, 8, false}, {5, 1, 8, 32, 6, false}, {5, 1, 12, 16, 12, false},
-    {3, 2, 4, 8, 9, true}, {3, 2, 8, 8, 12, false}, {3, 2, 8, 8, 17, true},
-    {5, 2, 4, 8, 11, true}, {5, 2, 4, 16, 6, false}, {5, 2, 8, 8, 19, true},   // the last one computes fewer pixels on b4 but measured 27 % slower
+    {3, 1, 8, 16, 10}, {3, 1, 4, 16, 6}, {3, 1, 8, 32, 6}, {3, 1, 8, 32, 10},
+    {5, 1, 8, 16, 12}, {5, 1, 4, 16, 8}, {5, 1, 8, 32, 6}, {5, 1, 12, 16, 12},
+    {3, 2, 4, 8, 9}, {3, 2, 8, 8, 12}, {3, 2, 8, 8, 17},
+    {5, 2, 4, 8, 11}, {5, 2, 4, 16, 6}, {5, 2, 8, 8, 19},   // the last one computes fewer pixels on b4 but measured 27 % slower
                                                              // there (52 KB of LDS, 6 MFMA tiles per wave): hence the autotuner
 };
 static long expdw_cost(const ExpDwShape& sh, int H, int Ho, int Wo, int pt, bool* fits) {
@@ -1370,12 +1354,6 @@ int expdw_sum_slabs(int k, int s, int H, int Ho, int Wo, int pt) {
     int idx = expdw_default_shape(k, s, H, Ho, Wo, pt);
     return idx < 0 ? 0 : expdw_shape_slabs(idx, Ho, Wo);
 }
-// a strip keeps TIH rows in its ring: only shapes whose TRH is the full footprint height can run as one
-bool expdw_strip_capable(int idx) {
-    if (idx < 0 || idx >= expdw_num_shapes()) return false;
-    const ExpDwShape& sh = kExpDwShapes[idx];
-    return sh.strip && sh.trh == (sh.toh - 1) * sh.s + sh.k;
-}
 int expdw_max_slabs(int k, int s, int H, int Ho, int Wo, int pt) {
     int mx = 0;
     for (int i = 0; i < expdw_num_shapes(); i++)
@@ -1387,41 +1365,36 @@ bool expdw_supported(int k, int s, int Cin, int Cmid) {
     // to the separate pw_gemm + dwconv pair (b13-b16 of the B0 stack: 126 us vs 176 us), so those stay unfused
     return (k == 3 || k == 5) && (s == 1 || s == 2) && (Cin & 3) == 0 && (Cmid & 3) == 0 && Cin <= 128;
 }
-// `shape`: index into kExpDwShapes, + kExpDwStripBit when the block should walk a whole column of tiles (ring buffer)
 void launch_expand_dw(const float* x, const float* we, const float* be, const float* wd, const float* bd, float* y,
                       float* partial, int B, int H, int W, int Cin, int Cmid, int Ho, int Wo, int k, int s, int pt,
                       int pl, int act_e, int act_d, int shape, const StemGeom* stem, hipStream_t st) {
-    bool strip = shape >= 0 && (shape & kExpDwStripBit);
-    if (shape >= 0) shape &= ~kExpDwStripBit;
-    if (!expdw_shape_fits(shape, k, s, H, Ho, Wo, pt)) { shape = expdw_default_shape(k, s, H, Ho, Wo, pt); strip = false; }
+    if (!expdw_shape_fits(shape, k, s, H, Ho, Wo, pt)) shape = expdw_default_shape(k, s, H, Ho, Wo, pt);
     if (shape < 0) return;                             // the planner only fuses layers some shape accepts
     const ExpDwShape* sh = &kExpDwShapes[shape];
     ExpDwParams p{x, we, be, wd, bd, y, partial, B, H, W, Cin, Cmid, Ho, Wo, pt, pl, act_e, act_d,
                   (Ho + sh->toh - 1) / sh->toh, (Wo + sh->tow - 1) / sh->tow, (Cmid + 31) / 32, expdw_kw(Cin), expdw_cp(Cmid)};
-    strip = strip && expdw_strip_capable(shape) && p.tiles_h > 1;
-    unsigned nblk = (unsigned)B * (strip ? 1 : p.tiles_h) * p.tiles_w * p.cchunks;
-#define ED_GO(K_, S_, TH_, TW_, TR_, STEM_, STRIP_) \
-    hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, STEM_, STRIP_>), dim3(nblk), dim3(256), 0, st, p, nblk)
-#define ED_IS(K_, S_, TH_, TW_, TR_) (sh->k == K_ && sh->s == S_ && sh->toh == TH_ && sh->tow == TW_ && sh->trh == TR_)
+    unsigned nblk = (unsigned)B * p.tiles_h * p.tiles_w * p.cchunks;
     if (stem) {
         p.Hin = stem->Hin; p.Win = stem->Win; p.pts = stem->pt; p.pls = stem->pl; p.Kw = 32;
-        if (ED_IS(3, 1, 8, 16, 10)) { if (strip) ED_GO(3, 1, 8, 16, 10, true, true); else ED_GO(3, 1, 8, 16, 10, true, false); }
-        else if (ED_IS(3, 1, 8, 32, 10)) { if (strip) ED_GO(3, 1, 8, 32, 10, true, true); else ED_GO(3, 1, 8, 32, 10, true, false); }
-        else if (ED_IS(3, 1, 4, 16, 6)) ED_GO(3, 1, 4, 16, 6, true, false);
-        else if (ED_IS(3, 1, 8, 32, 6)) ED_GO(3, 1, 8, 32, 6, true, false);
+#define ED_STEM(TH_, TW_, TR_)                                                                                \
+    if (sh->k == 3 && sh->s == 1 && sh->toh == TH_ && sh->tow == TW_ && sh->trh == TR_) {                     \
+        hipLaunchKernelGGL((k_expand_dw<3, 1, TH_, TW_, TR_, true>), dim3(nblk), dim3(256), 0, st, p, nblk);  \
+        return;                                                                                               \
+    }
+        ED_STEM(8, 16, 10) ED_STEM(4, 16, 6) ED_STEM(8, 32, 6) ED_STEM(8, 32, 10)
+#undef ED_STEM
         return;
     }
-#define ED_CASE(K_, S_, TH_, TW_, TR_) if (ED_IS(K_, S_, TH_, TW_, TR_)) { ED_GO(K_, S_, TH_, TW_, TR_, false, false); return; }
-#define ED_CASE_S(K_, S_, TH_, TW_, TR_) \
-    if (ED_IS(K_, S_, TH_, TW_, TR_)) { if (strip) ED_GO(K_, S_, TH_, TW_, TR_, false, true); else ED_GO(K_, S_, TH_, TW_, TR_, false, false); return; }
-    ED_CASE_S(3, 1, 8, 16, 10) ED_CASE(3, 1, 4, 16, 6) ED_CASE(3, 1, 8, 32, 6) ED_CASE_S(3, 1, 8, 32, 10)
-    ED_CASE_S(5, 1, 8, 16, 12) ED_CASE(5, 1, 4, 16, 8) ED_CASE(5, 1, 8, 32, 6) ED_CASE(5, 1, 12, 16, 12)
-    ED_CASE_S(3, 2, 4, 8, 9) ED_CASE(3, 2, 8, 8, 12) ED_CASE_S(3, 2, 8, 8, 17)
-    ED_CASE_S(5, 2, 4, 8, 11) ED_CASE(5, 2, 4, 16, 6) ED_CASE_S(5, 2, 8, 8, 19)
+#define ED_CASE(K_, S_, TH_, TW_, TR_)                                                                        \
+    if (sh->k == K_ && sh->s == S_ && sh->toh == TH_ && sh->tow == TW_ && sh->trh == TR_) {                   \
+        hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_>), dim3(nblk), dim3(256), 0, st, p, nblk);      \
+        return;                                                                                               \
+    }
+    ED_CASE(3, 1, 8, 16, 10) ED_CASE(3, 1, 4, 16, 6) ED_CASE(3, 1, 8, 32, 6) ED_CASE(3, 1, 8, 32, 10)
+    ED_CASE(5, 1, 8, 16, 12) ED_CASE(5, 1, 4, 16, 8) ED_CASE(5, 1, 8, 32, 6) ED_CASE(5, 1, 12, 16, 12)
+    ED_CASE(3, 2, 4, 8, 9) ED_CASE(3, 2, 8, 8, 12) ED_CASE(3, 2, 8, 8, 17)
+    ED_CASE(5, 2, 4, 8, 11) ED_CASE(5, 2, 4, 16, 6) ED_CASE(5, 2, 8, 8, 19)
 #undef ED_CASE
-#undef ED_CASE_S
-#undef ED_IS
-#undef ED_GO
 }
 
 // ------------------------------------------------------------------------------------------ spatial mean
