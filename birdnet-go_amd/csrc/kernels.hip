@@ -42,6 +42,21 @@ __device__ __forceinline__ void with_act(int act, Body&& body) {
     else body([act](float v) { return apply_act(v, act); });
 }
 
+// Four-wide swish with the non-transcendental steps on packed-f32 instructions (v_pk_mul_f32 / v_pk_add_f32): the scalar
+// form compiles to 5 VALU instructions per element (ISA check), this one to 4 - the two transcendentals stay scalar.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 swish2(f32x2 v) {
+    const f32x2 t = v * (f32x2){-1.4426950408889634f, -1.4426950408889634f};
+    f32x2 e = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    e = e + (f32x2){1.0f, 1.0f};
+    const f32x2 r = (f32x2){__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+    return v * r;
+}
+__device__ __forceinline__ f32x4 swish4(f32x4 v) {
+    f32x2 lo = swish2((f32x2){v[0], v[1]}), hi = swish2((f32x2){v[2], v[3]});
+    return (f32x4){lo[0], lo[1], hi[0], hi[1]};
+}
+
 // XCD-aware logical block id: the dispatcher places block b on XCD b % 8; remapping so that each XCD walks a
 // contiguous range of logical blocks keeps halo rows / shared operand panels in ONE XCD's L2 (bijective form).
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
@@ -766,14 +781,21 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
             for (int mt = 0; mt < WM; mt++) acc[t][mt] += bq;
         }
     }
-    with_act(p.act, [&](auto f) {
+    if (p.act == ACT_SWISH) {
 #pragma unroll
         for (int t = 0; t < NT; t++)
 #pragma unroll
-            for (int mt = 0; mt < WM; mt++)
+            for (int mt = 0; mt < WM; mt++) acc[t][mt] = swish4(acc[t][mt]);
+    } else {
+        with_act(p.act, [&](auto f) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) acc[t][mt][r] = f(acc[t][mt][r]);
-    });
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int mt = 0; mt < WM; mt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[t][mt][r] = f(acc[t][mt][r]);
+        });
+    }
 #pragma unroll
     for (int mt = 0; mt < WM; mt++) {
 #pragma unroll
@@ -930,15 +952,26 @@ __global__ __launch_bounds__(256) void k_dwconv_t(DwParams p, int CX, int PY, in
     if (live) {
         float4 bv = p.bias ? reinterpret_cast<const float4*>(p.bias)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
         float4* out4 = reinterpret_cast<float4*>(p.out) + (size_t)b * p.Ho * p.Wo * C4 + c4;
-        with_act(p.act, [&](auto f) {
+        if (p.act == ACT_SWISH) {
 #pragma unroll
             for (int a = 0; a < TH; a++)
 #pragma unroll
                 for (int c = 0; c < TW; c++) {
                     float4& v = acc[a][c];
-                    v.x = f(v.x + bv.x); v.y = f(v.y + bv.y); v.z = f(v.z + bv.z); v.w = f(v.w + bv.w);
+                    const f32x4 r = swish4((f32x4){v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w});
+                    v = make_float4(r[0], r[1], r[2], r[3]);
                 }
-        });
+        } else {
+            with_act(p.act, [&](auto f) {
+#pragma unroll
+                for (int a = 0; a < TH; a++)
+#pragma unroll
+                    for (int c = 0; c < TW; c++) {
+                        float4& v = acc[a][c];
+                        v.x = f(v.x + bv.x); v.y = f(v.y + bv.y); v.z = f(v.z + bv.z); v.w = f(v.w + bv.w);
+                    }
+            });
+        }
 #pragma unroll
         for (int a = 0; a < TH; a++) {
             int ho = th0 + a;
@@ -1205,12 +1238,17 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
 #pragma unroll
     for (int a = 0; a < JTW; a++) {
         if (wave + 4 * a < jtv) {                         // wave-uniform: tiles beyond the valid rows cost nothing
-            with_act(p.act_e, [&](auto f) {
-                f32x4& v0 = acc[a][0];
-                f32x4& v1 = acc[a][1];
-                v0[0] = f(v0[0] + bq0.x); v0[1] = f(v0[1] + bq0.y); v0[2] = f(v0[2] + bq0.z); v0[3] = f(v0[3] + bq0.w);
-                v1[0] = f(v1[0] + bq1.x); v1[1] = f(v1[1] + bq1.y); v1[2] = f(v1[2] + bq1.z); v1[3] = f(v1[3] + bq1.w);
-            });
+            if (p.act_e == ACT_SWISH) {
+                acc[a][0] = swish4(acc[a][0] + (f32x4){bq0.x, bq0.y, bq0.z, bq0.w});
+                acc[a][1] = swish4(acc[a][1] + (f32x4){bq1.x, bq1.y, bq1.z, bq1.w});
+            } else {
+                with_act(p.act_e, [&](auto f) {
+                    f32x4& v0 = acc[a][0];
+                    f32x4& v1 = acc[a][1];
+                    v0[0] = f(v0[0] + bq0.x); v0[1] = f(v0[1] + bq0.y); v0[2] = f(v0[2] + bq0.z); v0[3] = f(v0[3] + bq0.w);
+                    v1[0] = f(v1[0] + bq1.x); v1[1] = f(v1[1] + bq1.y); v1[2] = f(v1[2] + bq1.z); v1[3] = f(v1[3] + bq1.w);
+                });
+            }
             int j = 16 * (wave + 4 * a) + li;
             if (j < nvalid) {
                 int e = j * ED_ES + 4 * kq;
@@ -1261,13 +1299,22 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
         for (int a = 0; a < SH; a++) {
             int oh = oh0 + ty * SH + a;
             if (oh >= p.Ho) continue;
-            with_act(p.act_d, [&](auto f) {
+            if (p.act_d == ACT_SWISH) {
 #pragma unroll
                 for (int c = 0; c < SW; c++) {
                     float4& v = acc2[a][c];
-                    v.x = f(v.x + bv.x); v.y = f(v.y + bv.y); v.z = f(v.z + bv.z); v.w = f(v.w + bv.w);
+                    const f32x4 r = swish4((f32x4){v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w});
+                    v = make_float4(r[0], r[1], r[2], r[3]);
                 }
-            });
+            } else {
+                with_act(p.act_d, [&](auto f) {
+#pragma unroll
+                    for (int c = 0; c < SW; c++) {
+                        float4& v = acc2[a][c];
+                        v.x = f(v.x + bv.x); v.y = f(v.y + bv.y); v.z = f(v.z + bv.z); v.w = f(v.w + bv.w);
+                    }
+                });
+            }
 #pragma unroll
             for (int c = 0; c < SW; c++) {
                 int ow = ow0 + tx * SW + c;
