@@ -19,6 +19,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -265,8 +266,12 @@ bool stft_supported(int Lfft, int nb) {
 void launch_stft_bins(const StftParams& p0, hipStream_t s) {
     StftParams p = p0;
     p.nb_cap = (p.nb + 63) / 64 * 64;
-    static int fpw_env = getenv("BNHIP_STFT_FPW") ? atoi(getenv("BNHIP_STFT_FPW")) : 16;
-    p.fpw = fpw_env;
+    // frames per wave: 16 amortises the per-block table build at batch size; small batches trade that for parallelism
+    // (one clip with 16 frames per wave would occupy 4 of the 256 CUs)
+    static int fpw_env = getenv("BNHIP_STFT_FPW") ? atoi(getenv("BNHIP_STFT_FPW")) : 0;
+    long waves_wanted = 2048;
+    long fpw = fpw_env > 0 ? fpw_env : ((long)p.F * p.n_clips + waves_wanted - 1) / waves_wanted;
+    p.fpw = (int)std::min<long>(std::max<long>(fpw, 1), 16);
     const int P = p.Lfft / 128;
     size_t lds = stft_lds_bytes(P, p.nb_cap);
     dim3 grid((p.F + STFT_WAVES * p.fpw - 1) / (STFT_WAVES * p.fpw), p.n_clips);
