@@ -874,10 +874,17 @@ void launch_pw_gemm(const PwParams& p, hipStream_t s) {
         return;
     }
     int nt = (p.nt >= 1 && p.nt <= 8) ? p.nt : pick_nt(p.M, p.N);
-    const int wm = p.wm == 1 ? 1 : 2;
-    const int bm = 64 * wm;
+    int wm = p.wm == 1 ? 1 : 2;
+    int bm = 64 * wm;
     int nblk_n = (p.N + nt * 16 - 1) / (nt * 16);
     unsigned nblk = (unsigned)((p.M + bm - 1) / bm) * nblk_n;
+    // the tile was tuned at batch size; a call with a handful of clips would leave most CUs idle with it (one clip:
+    // 1-5 workgroups each walking the whole K loop): fall back to the smallest tile to get workgroups
+    if (nblk < 64 && (nt > 1 || wm > 1)) {
+        nt = 1; wm = 1; bm = 64;
+        nblk_n = (p.N + 15) / 16;
+        nblk = (unsigned)((p.M + bm - 1) / bm) * nblk_n;
+    }
     dim3 grid(nblk);
     const bool sc = p.ascale != nullptr;
 #define PW_LAUNCH(NT_, SC_, WM_) hipLaunchKernelGGL((k_pw_gemm<NT_, SC_, WM_>), grid, dim3(256), 0, s, p, nblk_n, nblk)
