@@ -1509,7 +1509,7 @@ void launch_mean_finish(const float* partial, float* out, int B, int HW, int C, 
 // time so thread c reads it coalesced.  (Splitting a clip over 4 blocks that each redo mean+FC1 measured 2x slower:
 // the pass over the per-slab sums dominates.)
 __global__ __launch_bounds__(1024) void k_se(SeParams p) {
-    extern __shared__ float sm[];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     float* mean = sm;            // [C]
     float* r = sm + p.C;         // [Cr]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1518,7 +1518,7 @@ __global__ __launch_bounds__(1024) void k_se(SeParams p) {
     // be 96 threads x 96 serial loads), then fold through LDS in a fixed order
     int P = 1;
     while (P * 2 * p.C <= 1024 && P * 2 <= p.S) P *= 2;
-    float* part = r + p.Cr;      // [P][C] scratch (P*C <= 1024)
+    float* part = sm + ((p.C + p.Cr + 3) & ~3);      // [P][C] / float4 [G][C/4] scratch, 16-byte aligned
     if (P > 1) {
         const int c = tid % p.C, q = tid / p.C;
         if (q < P) {
@@ -1542,24 +1542,73 @@ __global__ __launch_bounds__(1024) void k_se(SeParams p) {
         }
     }
     __syncthreads();
+    const bool v4 = (p.C & 3) == 0;
+    // FC1: one wave per output, 16-byte loads (the scalar form was ~54 dependent 4-byte loads per thread per FC)
     for (int j = wave; j < p.Cr; j += 16) {
         float acc = 0.f;
         const float* wr = p.w1 + (size_t)j * p.C;
+        if (v4) {
+            const float4* w4 = reinterpret_cast<const float4*>(wr);
+            const float4* m4 = reinterpret_cast<const float4*>(mean);
+#pragma unroll 5
+            for (int c = lane; c < p.C / 4; c += 64) {
+                float4 w = w4[c], mv = m4[c];
+                acc = fmaf(w.x, mv.x, acc); acc = fmaf(w.y, mv.y, acc); acc = fmaf(w.z, mv.z, acc); acc = fmaf(w.w, mv.w, acc);
+            }
+        } else {
 #pragma unroll 4
-        for (int c = lane; c < p.C; c += 64) acc = fmaf(wr[c], mean[c], acc);
+            for (int c = lane; c < p.C; c += 64) acc = fmaf(wr[c], mean[c], acc);
+        }
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
         if (lane == 0) r[j] = apply_act(acc + (p.b1 ? p.b1[j] : 0.f), p.act1);
     }
     __syncthreads();
-    for (int c = tid; c < p.C; c += 1024) {
-        float acc = 0.f;
+    // FC2: a thread owns 4 channels; G thread groups split the Cr range and fold through LDS in a fixed order
+    if (v4) {
+        const int C4 = p.C / 4;
+        int G = 1;
+        while (G * 2 * C4 <= 1024 && G * 2 <= p.Cr) G *= 2;
+        float4* part4 = reinterpret_cast<float4*>(part);           // [G][C4] (G * C <= 4096 floats <= scratch? see launch)
+        const int c4 = tid % C4, g = tid / C4;
+        if (g < G) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4* w4 = reinterpret_cast<const float4*>(p.w2) + c4;
 #pragma unroll 8
-        for (int j = 0; j < p.Cr; j++) acc = fmaf(p.w2[(size_t)j * p.C + c], r[j], acc);
-        p.scale[(size_t)b * p.C + c] = apply_act(acc + (p.b2 ? p.b2[c] : 0.f), p.act2);
+            for (int j = g; j < p.Cr; j += G) {
+                float4 w = w4[(size_t)j * C4];
+                float rj = r[j];
+                acc.x = fmaf(w.x, rj, acc.x); acc.y = fmaf(w.y, rj, acc.y); acc.z = fmaf(w.z, rj, acc.z); acc.w = fmaf(w.w, rj, acc.w);
+            }
+            if (G > 1) part4[g * C4 + c4] = acc;
+            else {
+                float4 bb = p.b2 ? reinterpret_cast<const float4*>(p.b2)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 o = make_float4(apply_act(acc.x + bb.x, p.act2), apply_act(acc.y + bb.y, p.act2),
+                                       apply_act(acc.z + bb.z, p.act2), apply_act(acc.w + bb.w, p.act2));
+                reinterpret_cast<float4*>(p.scale + (size_t)b * p.C)[c4] = o;
+            }
+        }
+        if (G > 1) {
+            __syncthreads();
+            for (int c = tid; c < C4; c += 1024) {
+                float4 acc = part4[c];
+                for (int g2 = 1; g2 < G; g2++) { float4 v = part4[g2 * C4 + c]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+                float4 bb = p.b2 ? reinterpret_cast<const float4*>(p.b2)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 o = make_float4(apply_act(acc.x + bb.x, p.act2), apply_act(acc.y + bb.y, p.act2),
+                                       apply_act(acc.z + bb.z, p.act2), apply_act(acc.w + bb.w, p.act2));
+                reinterpret_cast<float4*>(p.scale + (size_t)b * p.C)[c] = o;
+            }
+        }
+    } else {
+        for (int c = tid; c < p.C; c += 1024) {
+            float acc = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < p.Cr; j++) acc = fmaf(p.w2[(size_t)j * p.C + c], r[j], acc);
+            p.scale[(size_t)b * p.C + c] = apply_act(acc + (p.b2 ? p.b2[c] : 0.f), p.act2);
+        }
     }
 }
 void launch_se(const SeParams& p, hipStream_t s) {
-    size_t lds = (size_t)(p.C + p.Cr + 1024) * sizeof(float);
+    size_t lds = (size_t)(p.C + p.Cr + 4096 + 16) * sizeof(float);   // mean, r, [P][C] / [G][C] scratch (<= 1024 float4)
     hipLaunchKernelGGL(k_se, dim3(p.B), dim3(1024), lds, s, p);
 }
 
