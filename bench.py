@@ -216,6 +216,14 @@ def main():
         dt = float(t.item())
 
     ok = bool(torch.isfinite(logits).all().item())
+    # cheap end-to-end consistency check outside the timed region: the first rows of the full batch must match what a
+    # small call (single lane, single context, other tile shapes) computes for the same clips
+    clf.synchronize()
+    small = torch.empty((8, clf.num_species()), dtype=torch.float32, device=dev)
+    clf.predict_device(x.data_ptr(), 8, small.data_ptr())
+    clf.synchronize()
+    torch.cuda.synchronize(dev)
+    consist = float((logits[:8] - small).abs().max().item())
     if rank == 0:
         total_clips = B * world * args.steps
         out = {
@@ -229,7 +237,7 @@ def main():
                        "batch_per_gpu": B, "n_samples": cfg.n_samples, "n_classes": clf.num_species(),
                        "sharding": f"clips index-contiguous over {world} rank(s); weights broadcast once",
                        "pipeline_depth": depth},
-            "finite_outputs": ok,
+            "finite_outputs": ok, "max_abs_logit_diff_vs_small_batch": consist,
         }
         if prof:
             prof = sorted(prof, key=lambda r: -r["ms"])

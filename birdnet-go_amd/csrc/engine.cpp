@@ -975,10 +975,15 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
         }
     }
     if (v_emb >= 0) vals[v_emb].last = (int)steps.size();      // keep until copy-out
-    {
+    // The plan is laid out twice: for max_batch clips (unsplit calls) and for one lane's share.  Lanes drift apart in
+    // time, and values that reuse each other's memory have different per-clip sizes, so addressing lanes as clip offsets
+    // into ONE liveness-reused layout lets lane 0's step-k output overwrite lane 1's still-live step-j input: each lane
+    // gets its own copy of the (smaller) lane layout instead.
+    auto plan_arena = [&](size_t cap, bool lane_plan) -> size_t {
         struct Block { size_t off, size; };
         std::vector<Block> free_list;
         size_t top = 0;
+        auto off_of = [&](int v) -> size_t& { return lane_plan ? vals[v].offset_lane : vals[v].offset; };
         std::vector<std::vector<int>> born(steps.size() + 1), dies(steps.size() + 2);
         for (int v = 0; v < (int)vals.size(); v++) {
             if (vals[v].external || vals[v].first < 0) continue;
@@ -987,7 +992,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
         }
         for (size_t si = 0; si <= steps.size(); si++) {
             for (int v : dies[si]) {
-                free_list.push_back(Block{vals[v].offset, align_up(vals[v].elems * 4 * (size_t)max_batch, 256)});
+                free_list.push_back(Block{off_of(v), align_up(vals[v].elems * 4 * cap, 256)});
                 // coalesce
                 std::sort(free_list.begin(), free_list.end(), [](const Block& a, const Block& b) { return a.off < b.off; });
                 std::vector<Block> merged;
@@ -999,29 +1004,34 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
             }
             if (si == steps.size()) break;
             for (int v : born[si]) {
-                size_t need = align_up(vals[v].elems * 4 * (size_t)max_batch, 256);
+                size_t need = align_up(vals[v].elems * 4 * cap, 256);
                 int best = -1;
                 if (no_reuse) free_list.clear();
                 for (int i = 0; i < (int)free_list.size(); i++)
                     if (free_list[i].size >= need && (best < 0 || free_list[i].size < free_list[best].size)) best = i;
                 if (best >= 0) {
-                    vals[v].offset = free_list[best].off;
+                    off_of(v) = free_list[best].off;
                     free_list[best].off += need; free_list[best].size -= need;
                     if (free_list[best].size == 0) free_list.erase(free_list.begin() + best);
                 } else {
                     // extend the arena top (absorb a trailing free block if adjacent)
                     if (!free_list.empty() && free_list.back().off + free_list.back().size == top) {
-                        vals[v].offset = free_list.back().off;
-                        top = vals[v].offset + need;
+                        off_of(v) = free_list.back().off;
+                        top = off_of(v) + need;
                         free_list.pop_back();
                     } else {
-                        vals[v].offset = top; top += need;
+                        off_of(v) = top; top += need;
                     }
                 }
             }
         }
-        act_bytes = top;
-    }
+        return top;
+    };
+    n_lanes = std::max(1, std::min(n_lanes, kMaxLanes));
+    lane_cap = (max_batch + n_lanes - 1) / n_lanes;
+    act_bytes = plan_arena((size_t)max_batch, false);
+    lane_bytes = n_lanes > 1 ? align_up(plan_arena((size_t)lane_cap, true), 256) : 0;
+    act_bytes = std::max(act_bytes, lane_bytes * (size_t)n_lanes);
 
     // ---------------------------------------------------------------- device allocation
     w_bytes = wimg.size() * sizeof(float);
@@ -1155,12 +1165,15 @@ void Engine::autotune_pw() {
 }
 
 // ================================================================================================ run
-float* Engine::vptr(int v, const float* d_in, float* d_logits, float* d_emb, int clip0) const {
+float* Engine::vptr(int v, const float* d_in, float* d_logits, float* d_emb, int lane) const {
     if (v < 0) return nullptr;
     if (v == v_input) return const_cast<float*>(d_in);
     if (v == v_logits) return d_logits;
     (void)d_emb;
-    return reinterpret_cast<float*>((cur_arena ? cur_arena : act_arena) + vals[v].offset) + (size_t)clip0 * vals[v].elems;   // values are [clip][elems]
+    char* base = cur_arena ? cur_arena : act_arena;
+    // lane >= 0: that lane's own copy of the lane layout (values are [clip][elems] from the lane's first clip)
+    if (lane >= 0) return reinterpret_cast<float*>(base + (size_t)lane * lane_bytes + vals[v].offset_lane);
+    return reinterpret_cast<float*>(base + vals[v].offset);
 }
 
 hipEvent_t Engine::get_event() {
@@ -1266,7 +1279,7 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
       for (int li = 0; li < nl; li++) {
         const Step& s = steps[si];
         const float* d_in = lanes[li].d_in; float* d_logits = lanes[li].d_logits; float* d_emb = lanes[li].d_emb;
-        const int n = lanes[li].n, clip0 = lanes[li].clip0;
+        const int n = lanes[li].n, clip0 = nl > 1 ? li : -1;      // arena addressing: lane index, or -1 for the unsplit layout
         hipStream_t stream = lanes[li].st;
         float* in0 = vptr(s.in0, d_in, d_logits, d_emb, clip0);
         float* in1 = vptr(s.in1, d_in, d_logits, d_emb, clip0);
@@ -1355,7 +1368,7 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
     for (int li = 0; li < nl; li++) {
         const Lane& L = lanes[li];
         if (L.d_emb && v_emb >= 0) {
-            hipError_t e = hipMemcpyAsync(L.d_emb, vptr(v_emb, L.d_in, L.d_logits, L.d_emb, L.clip0), (size_t)L.n * emb_dim * 4,
+            hipError_t e = hipMemcpyAsync(L.d_emb, vptr(v_emb, L.d_in, L.d_logits, L.d_emb, nl > 1 ? li : -1), (size_t)L.n * emb_dim * 4,
                                           hipMemcpyDeviceToDevice, L.st);
             if (e != hipSuccess) { *err = std::string("emb copy: ") + hipGetErrorString(e); return false; }
         }

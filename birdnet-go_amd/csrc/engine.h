@@ -38,6 +38,7 @@ struct Value {               // an activation tensor (per clip geometry)
     int tfl = -1;            // tflite tensor id (or -1 for internal scratch)
     size_t elems = 0;        // floats per clip
     size_t offset = 0;       // byte offset in the activation arena (for max_batch)
+    size_t offset_lane = 0;  // byte offset inside one lane's region (layout for lane_cap clips)
     int first = -1, last = -1;   // step liveness
     bool external = false;   // bound at run time (graph input / outputs)
 };
@@ -130,7 +131,9 @@ class Engine {
     size_t w_bytes = 0;
     std::vector<ProfEntry> prof;
     std::vector<hipEvent_t> ev_pool;
-    float* vptr(int v, const float* d_in, float* d_logits, float* d_emb, int clip0 = 0) const;
+    float* vptr(int v, const float* d_in, float* d_logits, float* d_emb, int lane = -1) const;
+    int lane_cap = 0;                   // clips one lane can hold (ceil(max_batch / n_lanes))
+    size_t lane_bytes = 0;              // size of one lane's arena region
     hipEvent_t get_event();
 };
 

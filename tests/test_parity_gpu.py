@@ -241,6 +241,47 @@ def test_chunking_over_max_batch_and_ragged_tail(tiny_clf, tiny_blob, tiny_cfg):
     assert np.array_equal(tiny_clf.predict_batch(x[perm].reshape(-1), n), got[perm])   # order independence, bit-exact
 
 
+def test_host_batch_split_and_ragged_sizes(built_lib):
+    """Host-pointer calls of >= 128 clips are split in two (copy/compute overlap), larger ones chunked by max_batch: every
+    size must give the rows a small call gives, embeddings included."""
+    cfg = sm.tiny_config(emit_embeddings=True)
+    blob = sm.build_model(cfg)
+    x = sm.synth_clips(300, cfg.n_samples, cfg.sample_rate)
+    c = host.HipClassifier(blob, max_batch=256)
+    try:
+        ref_l, ref_e = c.predict_with_embeddings(x[:7].reshape(-1), 7) if False else (None, None)
+        small = np.concatenate([c.predict_batch(x[i:i + 20].reshape(-1), 20) for i in range(0, 300, 20)])
+        for n in (127, 128, 131, 256, 259, 300):
+            got = c.predict_batch(x[:n].reshape(-1), n)
+            assert got.shape == (n, cfg.n_classes)
+            assert np.abs(got - small[:n]).max() < 1e-5, n       # other batch sizes may pick other tiles: fp32 reorder only
+            assert (got.argmax(1) == small[:n].argmax(1)).all()
+        pcm = np.clip(np.round(x[:131] * 32767.0), -32768, 32767).astype(np.int16)
+        a = c.predict_pcm16(pcm.reshape(-1), 131)
+        b = c.predict_batch((pcm.astype(np.float32) / 32768.0).reshape(-1), 131)
+        assert np.abs(a - b).max() < 1e-5
+    finally:
+        c.close()
+
+
+def test_lanes_full_model_equal_small_batches(full_blob):
+    """Batches of >= 32 clips run as two concurrent lanes (each with its own arena region): every row must match what a
+    small, single-lane call computes.  (Lanes once shared one liveness-reused layout: out-of-phase lanes overwrote each
+    other's live tensors - only caught by comparing against small batches, the outputs stayed finite.)"""
+    x = sm.synth_clips(70, 144000, 48000)
+    c = host.HipClassifier(full_blob, max_batch=128)
+    try:
+        small = np.concatenate([c.predict_batch(x[i:i + 10].reshape(-1), 10) for i in range(0, 70, 10)])
+        for n in (33, 64, 70):
+            for rep in range(2):
+                got = c.predict_batch(x[:n].reshape(-1), n)
+                assert (got.argmax(1) == small[:n].argmax(1)).all(), (n, rep)
+                assert np.abs(sig(got) - sig(small[:n])).max() <= 1e-4, (n, rep)
+                assert np.abs(got - small[:n]).max() < 1e-3, (n, rep)
+    finally:
+        c.close()
+
+
 def test_determinism(full_clf):
     x = sm.synth_clips(3, 144000, 48000, first=100)
     a = full_clf.predict_batch(x.reshape(-1), 3)
