@@ -256,6 +256,16 @@ def test_host_batch_split_and_ragged_sizes(built_lib):
             assert got.shape == (n, cfg.n_classes)
             assert np.abs(got - small[:n]).max() < 1e-5, n       # other batch sizes may pick other tiles: fp32 reorder only
             assert (got.argmax(1) == small[:n].argmax(1)).all()
+        # embeddings through the lane / split paths (the embedding tensor lives in a lane's own arena region)
+        se = np.concatenate([c.predict_batch(x[i:i + 20].reshape(-1), 20, want_embeddings=True)[1] for i in range(0, 140, 20)])
+        for n in (40, 131):
+            lg, em = c.predict_batch(x[:n].reshape(-1), n, want_embeddings=True)
+            assert em.shape == (n, c.emb_dim) and np.abs(em - se[:n]).max() < 1e-5, n
+            assert np.abs(lg - small[:n]).max() < 1e-5, n
+        # device top-k on a lane-sized batch
+        conf, idx = c.predict_topk(x[:50].reshape(-1), 50, 5, 0, 1.0)
+        c2, i2 = c.postprocess_topk(small[:50], k=5)
+        assert np.array_equal(idx, i2) and np.abs(conf - c2).max() < 1e-6
         pcm = np.clip(np.round(x[:131] * 32767.0), -32768, 32767).astype(np.int16)
         a = c.predict_pcm16(pcm.reshape(-1), 131)
         b = c.predict_batch((pcm.astype(np.float32) / 32768.0).reshape(-1), 131)
