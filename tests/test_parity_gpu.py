@@ -292,6 +292,22 @@ def test_lanes_full_model_equal_small_batches(full_blob):
         c.close()
 
 
+def test_opt_in_graph_replay_matches_eager(tiny_blob, tiny_cfg):
+    """"graphs":1 replays the plan as a hipGraph from the third identical call on; results must not change (single lane and
+    two lanes)."""
+    x = sm.synth_clips(40, tiny_cfg.n_samples, tiny_cfg.sample_rate)
+    e = host.HipClassifier(tiny_blob, max_batch=64)
+    g = host.HipClassifier(tiny_blob, max_batch=64, graphs=True)
+    try:
+        for n in (3, 40):
+            ref = e.predict_batch(x[:n].reshape(-1), n)
+            for rep in range(4):
+                got = g.predict_batch(x[:n].reshape(-1), n)
+                assert np.abs(got - ref).max() < 1e-5, (n, rep)
+    finally:
+        e.close(); g.close()
+
+
 def test_determinism(full_clf):
     x = sm.synth_clips(3, 144000, 48000, first=100)
     a = full_clf.predict_batch(x.reshape(-1), 3)
