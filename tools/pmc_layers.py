@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Per-(kernel, grid) counter table from rocprofv3 PMC databases, normalised per wave when SQ_WAVES was collected.
-Usage: python tools/pmc_layers.py <kernel-substring> <db> [<db> ...]"""
+Usage: [LASTN=n] python tools/pmc_layers.py <kernel-substring> <db> [<db> ...]
+LASTN keeps only the last n matching dispatches (e.g. one step's worth: skips the create-time autotune launches)."""
 import collections
+import os
 import re
 import sqlite3
 import sys
@@ -32,9 +34,11 @@ def main():
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         cnt = collections.Counter()
         dur = collections.Counter()
-        for eid, (name, blocks, d) in disp.items():
-            if pat not in name:
-                continue
+        items = [(eid, v) for eid, v in sorted(disp.items()) if pat in v[0]]
+        lastn = int(os.environ.get("LASTN", "0"))
+        if lastn:
+            items = items[-lastn:]
+        for eid, (name, blocks, d) in items:
             key = (re.sub(r"\(.*", "", name).replace("void bnhip::", ""), blocks)
             cnt[key] += 1
             dur[key] += d
