@@ -12,6 +12,7 @@ LIB = os.path.join(LIBDIR, "libbnhip.so")
 SOURCES = ["kernels.hip", "resample.hip", "stft.hip", "engine.cpp", "tflite_model.cpp", "api.cpp"]
 HEADERS = ["kernels.h", "engine.h", "tflite_model.h", os.path.join("..", "..", "include", "bnhip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+NO_VGPR_FORM = set()     # sources to compile without the VGPR-form MFMA rewrite (none at present)
 
 
 def _digest():
@@ -30,14 +31,21 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
+    objs, cmds = [], []
     for src in SOURCES:
         obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc, "-x", "hip"] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        flags = [f for f in FLAGS if src not in NO_VGPR_FORM or f not in ("-mllvm", "-amdgpu-mfma-vgpr-form")]
+        cmds.append([hipcc, "-x", "hip"] + flags + ["-c", os.path.join(CSRC, src), "-o", obj])
+        objs.append(obj)
+    # the translation units are independent: compile them side by side
+    procs = []
+    for cmd in cmds:
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
-        objs.append(obj)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.check_call(cmd)
     with open(stamp, "w") as fh:
