@@ -639,8 +639,9 @@ bool stem_mfma_supported(const ConvParams& p) {
     return p.kh == 3 && p.kw == 3 && p.sh == 2 && p.sw == 2 && p.Cin == 2 && (p.Cout == 32 || p.Cout == 64);
 }
 void launch_stem_mfma(const ConvParams& c, const float* wm, const float* bias_p, hipStream_t s) {
+    static const int stem_tpw = getenv("BNHIP_STEM_TPW") ? std::max(atoi(getenv("BNHIP_STEM_TPW")), 1) : 8;   // tiles per wave
     StemParams p{c.in, wm, bias_p, c.out, c.B, c.H, c.W, c.Ho, c.Wo, c.Cout, c.pt, c.pl, c.act,
-                 (unsigned)((size_t)c.B * c.Ho * c.Wo), (unsigned)(getenv("BNHIP_STEM_TPW") ? atoi(getenv("BNHIP_STEM_TPW")) : 8)};
+                 (unsigned)((size_t)c.B * c.Ho * c.Wo), (unsigned)stem_tpw};
     unsigned tiles = (p.total_px + 15) / 16;
     unsigned blocks = (tiles + 4 * p.tiles_per_wave - 1) / (4 * p.tiles_per_wave);
     if (c.Cout == 32) hipLaunchKernelGGL((k_stem_mfma<2>), dim3(blocks), dim3(256), 0, s, p);
@@ -870,8 +871,8 @@ static int pick_nt(int M, int N) {
         long cols = (long)((N + nt * 16 - 1) / (nt * 16)) * nt * 16;
         if (cols * 100 <= best_cols * 115) best = nt;
     }
-    const char* ov = getenv("BNHIP_PW_NT");
-    if (ov && atoi(ov) >= 1 && atoi(ov) <= 8) best = atoi(ov);
+    static const int ov = getenv("BNHIP_PW_NT") ? atoi(getenv("BNHIP_PW_NT")) : 0;      // experiment switch
+    if (ov >= 1 && ov <= 8) best = ov;
     return best;
 }
 

@@ -1,6 +1,9 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 rocpd sqlite database (--kernel-trace [--pmc ...]) as per-kernel stats.
-Usage: python tools/prof_summary.py <results.db> [--csv out.csv]"""
+Usage: python tools/prof_summary.py <results.db> [--csv out.csv] [--window SKIP_TAIL:COUNT]
+--window restricts the kernel table to COUNT consecutive bnhip dispatches ending SKIP_TAIL dispatches before the last one
+(e.g. 63:1260 = the 20 timed steps of `bench.py --steps 20`: the create-time autotune launches come before them, the
+8-clip consistency check (63 launches) after them), so the per-kernel averages are those of the timed region."""
 import re
 import sqlite3
 import sys
@@ -19,10 +22,19 @@ def main():
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
     kd = [t for t in tabs if "kernel_dispatch" in t][0]
     ks = [t for t in tabs if "kernel_symbol" in t][0]
+    where = ""
+    if "--window" in sys.argv:
+        skip, count = (int(v) for v in sys.argv[sys.argv.index("--window") + 1].split(":"))
+        ids = [r[0] for r in cur.execute(f"select d.id from {kd} d join {ks} s on d.kernel_id = s.id "
+                                         f"where s.display_name like '%bnhip%' order by d.start")]
+        ids = ids[len(ids) - skip - count:len(ids) - skip]
+        cur.execute("create temp table win (id integer primary key)")
+        cur.executemany("insert into win values (?)", [(i,) for i in ids])
+        where = "where d.id in (select id from win) "
     rows = cur.execute(
         f"select s.display_name, count(*), sum(d.end-d.start), min(d.end-d.start), max(d.end-d.start), "
         f"max(s.arch_vgpr_count), max(s.accum_vgpr_count), max(s.sgpr_count), max(d.group_segment_size) "
-        f"from {kd} d join {ks} s on d.kernel_id = s.id group by s.display_name order by 3 desc").fetchall()
+        f"from {kd} d join {ks} s on d.kernel_id = s.id {where}group by s.display_name order by 3 desc").fetchall()
     total = sum(r[2] for r in rows) or 1
     lines = ["kernel,calls,total_ms,avg_us,min_us,max_us,pct,vgpr,agpr,sgpr,lds_bytes"]
     for n, c, t, mn, mx, vg, ag, sg, lds in rows:
