@@ -471,6 +471,8 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                 }
                 size_t o_win = wpush(wfull.data(), wfull.size()), o_bins = wpush(binsf.data(), binsf.size());
                 size_t o_mel = wpush(melw.data(), melw.size());
+                std::vector<double> twt = stft_build_tables(fm.Lfft, bins.data(), fs.nb);
+                size_t o_tw = wpush(reinterpret_cast<const float*>(twt.data()), twt.size() * 2);   // fp64 image, 256-B aligned
                 specs.push_back(fs);
                 const int si = (int)specs.size() - 1;
                 int v_bins = new_val(-1, (size_t)fm.F * fs.nbp), v_T = new_val(-1, (size_t)fm.F * fm.n_mels);
@@ -478,7 +480,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                 st.spec = si;
                 st.flops = (double)fm.F * 2.5 * fm.Lfft * std::log2((double)fm.Lfft / 2);      // ~5 N/2 log2(N/2) per frame
                 st.bytes = (double)n_samples * 4 + (double)fm.F * fs.nbp * 4;
-                add_step(st, o_win, o_bins);
+                add_step(st, o_win, o_bins, o_tw);
                 Step g; g.kind = S_PW; g.name = "mel" + std::to_string(i); g.kclass = "pw_gemm"; g.in0 = v_bins; g.out = v_T;
                 g.H = fm.F; g.W = 1; g.C = fs.nbp; g.Co = fm.n_mels; g.Ho = fm.F; g.Wo = 1; g.act = ACT_NONE;
                 g.flops = 2.0 * fm.F * fs.nbp * fm.n_mels;
@@ -1072,6 +1074,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
         if (steps[si].kind == S_STFT) {
             specs[steps[si].spec].window_full = steps[si].w0;
             specs[steps[si].spec].bins = reinterpret_cast<const int*>(steps[si].w1);
+            specs[steps[si].spec].stft_tw = reinterpret_cast<const double*>(steps[si].w2);
         }
     }
     HIPCHK(hipMalloc((void**)&d_stage_in, (size_t)max_batch * n_samples * 4));
@@ -1308,7 +1311,7 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
                 break;
             case S_STFT: {
                 const FrontSpec& fs = specs[s.spec];
-                StftParams p{in0, fs.window_full, fs.bins, out, n_samples, fs.Lfft, fs.L, fs.hop, fs.F, fs.nb, fs.nbp, fs.mode, n};
+                StftParams p{in0, fs.window_full, fs.bins, out, n_samples, fs.Lfft, fs.L, fs.hop, fs.F, fs.nb, fs.nbp, fs.mode, n, fs.stft_tw};
                 launch_stft_bins(p, stream);
                 break;
             }

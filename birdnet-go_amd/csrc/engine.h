@@ -52,6 +52,7 @@ struct FrontSpec {
     bool fft = false;
     int nb = 0, nbp = 0, mode = 0;   // needed bins, padded to 4; 0 = real part, 1 = magnitude
     const float* window_full = nullptr;
+    const double* stft_tw = nullptr;   // twiddle image of the STFT step (stft_build_tables)
     const int* bins = nullptr;
 };
 

@@ -1,6 +1,8 @@
 // Launch wrappers for the gfx950 kernels in kernels.hip.  All tensors are fp32, activations NHWC.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <vector>
 #include <cstdint>
 
 namespace bnhip {
@@ -36,8 +38,10 @@ struct StftParams {
     const int* bins;        // [nb] ascending DFT bins the mel matrix uses
     float* out;             // [B, F, nbp]; columns nb..nbp-1 are written as zeros
     int n_samples, Lfft, L, hop, F, nb, nbp, mode /*0 real part, 1 magnitude*/, n_clips;
+    const double* tw = nullptr;   // plan-time twiddle image (stft_build_tables)
     int nb_cap = 0, fpw = 0;    // set by the launcher
 };
+std::vector<double> stft_build_tables(int Lfft, const int* bins, int nb);
 void launch_normalize(const float* x, const float2* mm, float* out, int n_clips, int n_samples, float norm_sub,
                       float norm_mul, hipStream_t s);
 bool stft_supported(int Lfft, int nb);

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <vector>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -110,19 +111,10 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_bins(StftParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
 
-    // ---- tables (once per block)
-    for (int i = tid; i < P * 64; i += blockDim.x) {
-        int k1 = i >> 6, n2 = i & 63;
-        double s, c;
-        sincos(-6.283185307179586476925286766559 * (double)((k1 * n2) % N2) / (double)N2, &s, &c);
-        twr[i] = c; twi[i] = s;
-    }
-    for (int i = tid; i < Q * P; i += blockDim.x) {
-        int q = i / P, j = i % P;
-        double s, c;
-        sincos(-6.283185307179586476925286766559 * (double)((q * j) % 64) / 64.0, &s, &c);
-        t2r[i] = c; t2i[i] = s;
-    }
+    // ---- tables (once per block): copied from the plan-time image (stft_build_tables); computing them here cost ten
+    // fp64 sincos per thread and block - a sixth of the kernel at 16 frames per wave
+    constexpr int NTAB = 2 * P * 64 + 2 * Q * P;
+    for (int i = tid; i < NTAB; i += blockDim.x) sm[i] = p.tw[i];
     __syncthreads();
 
     double* wre = work + (size_t)wave * 2 * WSZ;
@@ -146,7 +138,9 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_bins(StftParams p) {
         int idx = lane + 64 * t;
         int k = idx < p.nb ? p.bins[idx] : 0;
         ka_[t] = k % N2; kb_[t] = (N2 - k % N2) % N2;
-        sincos(-6.283185307179586476925286766559 * (double)k / (double)N, &tri[t], &trr[t]);
+        const bool in = idx < p.nb_cap;
+        trr[t] = in ? p.tw[NTAB + idx] : 1.0;
+        tri[t] = in ? p.tw[NTAB + p.nb_cap + idx] : 0.0;
     }
 
     const int f_begin = (blockIdx.x * STFT_WAVES + wave) * p.fpw;
@@ -254,6 +248,33 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_bins(StftParams p) {
     }
 }
 
+// Plan-time twiddle image of one STFT step: [Re W_{N/2}^{k1 n2} (P x 64)][Im ..][Re W_64^{q j} (Q x P)][Im ..]
+// [Re W_N^k of the needed bins, padded to a multiple of 64 with W^0][Im ..] - the kernel's LDS table layout followed by the
+// per-lane bin twiddles.
+std::vector<double> stft_build_tables(int Lfft, const int* bins, int nb) {
+    const int P = Lfft / 128, Q = 64 / P, N2 = 64 * P, cap = (nb + 63) / 64 * 64;
+    const double tau = -6.283185307179586476925286766559;
+    std::vector<double> t((size_t)2 * P * 64 + 2 * Q * P + 2 * cap);
+    double* twr = t.data();
+    double* twi = twr + P * 64;
+    double* t2r = twi + P * 64;
+    double* t2i = t2r + Q * P;
+    double* trr = t2i + Q * P;
+    double* tri = trr + cap;
+    for (int i = 0; i < P * 64; i++) {
+        const double a = tau * (double)(((i >> 6) * (i & 63)) % N2) / (double)N2;
+        twr[i] = std::cos(a); twi[i] = std::sin(a);
+    }
+    for (int i = 0; i < Q * P; i++) {
+        const double a = tau * (double)(((i / P) * (i % P)) % 64) / 64.0;
+        t2r[i] = std::cos(a); t2i[i] = std::sin(a);
+    }
+    for (int i = 0; i < cap; i++) {
+        const double a = tau * (double)(i < nb ? bins[i] : 0) / (double)Lfft;
+        trr[i] = std::cos(a); tri[i] = std::sin(a);
+    }
+    return t;
+}
 size_t stft_lds_bytes(int P, int nb_cap) {
     (void)nb_cap;
     return (size_t)(2 * P * 64 + 2 * (64 / P) * P + STFT_WAVES * 2 * P * (P == 8 ? 66 : 65)) * sizeof(double);
