@@ -92,9 +92,10 @@ __device__ __forceinline__ void fft_regs(double (&re)[P], double (&im)[P]) {
 }
 
 // ------------------------------------------------------------------------------------------ STFT -> needed bins
-#define STFT_WAVES 8
-template <int P>
-__global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_bins(StftParams p) {
+// W = waves per block.  The 2048-point kernel (P = 16: 214 VGPRs, 16.6 KB of LDS per wave) holds two waves per SIMD
+// either way; the 1024-point one (146 VGPRs, 8.4 KB) fits three when the blocks are 4 waves (three blocks per CU).
+template <int P, int W>
+__global__ __launch_bounds__(64 * W) void k_stft_bins(StftParams p) {
     constexpr int N2 = 64 * P;            // complex points
     constexpr int N = 2 * N2;             // real frame length (= fft length)
     constexpr int Q = 64 / P;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_bins(StftParams p) {
     double* twi = twr + P * 64;
     double* t2r = twi + P * 64;           // [Q][P]  W_64^{q j'}
     double* t2i = t2r + Q * P;
-    double* work = t2i + Q * P;           // [STFT_WAVES][2][WSZ]
+    double* work = t2i + Q * P;           // [W][2][WSZ]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
 
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(64 * STFT_WAVES) void k_stft_bins(StftParams p) {
         tri[t] = in ? p.tw[NTAB + p.nb_cap + idx] : 0.0;
     }
 
-    const int f_begin = (blockIdx.x * STFT_WAVES + wave) * p.fpw;
+    const int f_begin = (blockIdx.x * W + wave) * p.fpw;
     const int f_end = min(f_begin + p.fpw, p.F);
     // the next frame's samples are requested before the current frame is transformed (a frame's 16 loads would
     // otherwise be an exposed L2 round trip per frame with two waves per SIMD)
@@ -275,9 +276,10 @@ std::vector<double> stft_build_tables(int Lfft, const int* bins, int nb) {
     }
     return t;
 }
+static int stft_waves(int P) { return P == 8 ? 4 : 8; }
 size_t stft_lds_bytes(int P, int nb_cap) {
     (void)nb_cap;
-    return (size_t)(2 * P * 64 + 2 * (64 / P) * P + STFT_WAVES * 2 * P * (P == 8 ? 66 : 65)) * sizeof(double);
+    return (size_t)(2 * P * 64 + 2 * (64 / P) * P + stft_waves(P) * 2 * P * (P == 8 ? 66 : 65)) * sizeof(double);
 }
 bool stft_supported(int Lfft, int nb) {
     if (Lfft != 2048 && Lfft != 1024 && Lfft != 512) return false;
@@ -287,24 +289,23 @@ bool stft_supported(int Lfft, int nb) {
 void launch_stft_bins(const StftParams& p0, hipStream_t s) {
     StftParams p = p0;
     p.nb_cap = (p.nb + 63) / 64 * 64;
-    // frames per wave: 16 amortises the per-block table build at batch size; small batches trade that for parallelism
+    // frames per wave: 16 amortises the per-block table copy at batch size; small batches trade that for parallelism
     // (one clip with 16 frames per wave would occupy 4 of the 256 CUs)
     static int fpw_env = getenv("BNHIP_STFT_FPW") ? atoi(getenv("BNHIP_STFT_FPW")) : 0;
     long waves_wanted = 2048;
     long fpw = fpw_env > 0 ? fpw_env : ((long)p.F * p.n_clips + waves_wanted - 1) / waves_wanted;
     p.fpw = (int)std::min<long>(std::max<long>(fpw, 1), 16);
-    const int P = p.Lfft / 128;
+    const int P = p.Lfft / 128, W = stft_waves(P);
     size_t lds = stft_lds_bytes(P, p.nb_cap);
-    dim3 grid((p.F + STFT_WAVES * p.fpw - 1) / (STFT_WAVES * p.fpw), p.n_clips);
-    static bool attr16 = false, attr8 = false;
+    dim3 grid((p.F + W * p.fpw - 1) / (W * p.fpw), p.n_clips);
+    static bool attr16 = false;
     if (P == 4) {
-        hipLaunchKernelGGL((k_stft_bins<4>), grid, dim3(64 * STFT_WAVES), lds, s, p);      // < 64 KB of LDS
+        hipLaunchKernelGGL((k_stft_bins<4, 8>), grid, dim3(64 * W), lds, s, p);      // < 64 KB of LDS
     } else if (P == 16) {
-        if (!attr16) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr16 = true; }
-        hipLaunchKernelGGL((k_stft_bins<16>), grid, dim3(64 * STFT_WAVES), lds, s, p);
+        if (!attr16) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<16, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr16 = true; }
+        hipLaunchKernelGGL((k_stft_bins<16, 8>), grid, dim3(64 * W), lds, s, p);
     } else {
-        if (!attr8) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr8 = true; }
-        hipLaunchKernelGGL((k_stft_bins<8>), grid, dim3(64 * STFT_WAVES), lds, s, p);
+        hipLaunchKernelGGL((k_stft_bins<8, 4>), grid, dim3(64 * W), lds, s, p);      // 42 KB of LDS
     }
 }
 
