@@ -181,7 +181,8 @@ int bnhip_predict_device(bnhip_model* m, const float* d_samples, int n_clips, fl
     return BNHIP_OK;
 }
 
-static int predict_host(bnhip_model* m, const void* src, bool pcm16, int n_clips, float* logits, float* emb) {
+// pcm_bits: 0 = float32 samples, 16 / 24 / 32 = little-endian PCM converted on the device
+static int predict_host(bnhip_model* m, const void* src, int pcm_bits, int n_clips, float* logits, float* emb) {
     if (!m || !src || !logits) return set_err(BNHIP_E_INVALID, "NULL argument");
     if (n_clips <= 0) return set_err(BNHIP_E_INVALID, "n_clips must be positive");
     Engine& e = m->eng;
@@ -189,9 +190,13 @@ static int predict_host(bnhip_model* m, const void* src, bool pcm16, int n_clips
     if (emb && !e.emb_dim) return set_err(BNHIP_E_INVALID, "model has no embedding output");
     if (hipSetDevice(e.device) != hipSuccess) return set_err(BNHIP_E_RUNTIME, "hipSetDevice failed");
     std::string err;
-    if (pcm16 && !e.d_stage_pcm) {
-        if (hipMalloc((void**)&e.d_stage_pcm, (size_t)e.max_batch * e.n_samples * 2) != hipSuccess)
+    const bool pcm = pcm_bits != 0;
+    const size_t bps = (size_t)pcm_bits / 8;
+    if (pcm && e.stage_pcm_bytes < (size_t)e.max_batch * e.n_samples * bps) {
+        if (e.d_stage_pcm) { hipStreamSynchronize(e.stream); hipFree(e.d_stage_pcm); e.d_stage_pcm = nullptr; e.stage_pcm_bytes = 0; }
+        if (hipMalloc((void**)&e.d_stage_pcm, (size_t)e.max_batch * e.n_samples * bps) != hipSuccess)
             return set_err(BNHIP_E_NOMEM, "device allocation failed (pcm staging)");
+        e.stage_pcm_bytes = (size_t)e.max_batch * e.n_samples * bps;
     }
     // chunk = max_batch for calls larger than it; a single large batch (>= 128 clips) is split too, so that the pageable
     // H2D copy of its second part overlaps the compute of the first (PCIe-inclusive rate of a 256-clip call: +25 %)
@@ -199,7 +204,7 @@ static int predict_host(bnhip_model* m, const void* src, bool pcm16, int n_clips
     int ck = e.max_batch;
     if (n_clips <= e.max_batch && n_clips >= 128 && split_env > 1) ck = (n_clips + split_env - 1) / split_env;
     const int nchunks = (n_clips + ck - 1) / ck;
-    const bool pipelined = nchunks > 1 && !pcm16;
+    const bool pipelined = nchunks > 1 && !pcm;
     if (pipelined && !e.d_stage_in2) {       // second staging set, created on first use
         hipError_t he = hipMalloc((void**)&e.d_stage_in2, (size_t)e.max_batch * e.n_samples * 4);
         if (he == hipSuccess) he = hipMalloc((void**)&e.d_stage_logits2, (size_t)e.max_batch * e.n_classes * 4);
@@ -216,10 +221,10 @@ static int predict_host(bnhip_model* m, const void* src, bool pcm16, int n_clips
             int n = std::min(e.max_batch, n_clips - off);
             size_t cnt = (size_t)n * e.n_samples;
             hipError_t he;
-            if (pcm16) {
-                he = hipMemcpyAsync(e.d_stage_pcm, (const int16_t*)src + (size_t)off * e.n_samples, cnt * 2,
+            if (pcm) {
+                he = hipMemcpyAsync(e.d_stage_pcm, (const char*)src + (size_t)off * e.n_samples * bps, cnt * bps,
                                     hipMemcpyHostToDevice, e.stream);
-                if (he == hipSuccess) launch_pcm16_to_f32(e.d_stage_pcm, e.d_stage_in, cnt, e.stream);
+                if (he == hipSuccess) launch_pcm_to_f32(e.d_stage_pcm, pcm_bits, e.d_stage_in, cnt, e.stream);
             } else {
                 he = hipMemcpyAsync(e.d_stage_in, (const float*)src + (size_t)off * e.n_samples, cnt * 4,
                                     hipMemcpyHostToDevice, e.stream);
@@ -276,11 +281,17 @@ static int predict_host(bnhip_model* m, const void* src, bool pcm16, int n_clips
 }
 
 int bnhip_predict(bnhip_model* m, const float* samples, int n_clips, float* logits, float* emb) {
-    return predict_host(m, samples, false, n_clips, logits, emb);
+    return predict_host(m, samples, 0, n_clips, logits, emb);
 }
 
 int bnhip_predict_pcm16(bnhip_model* m, const int16_t* pcm, int n_clips, float* logits, float* emb) {
-    return predict_host(m, pcm, true, n_clips, logits, emb);
+    return predict_host(m, pcm, 16, n_clips, logits, emb);
+}
+
+int bnhip_predict_pcm(bnhip_model* m, const void* pcm, int bits_per_sample, int n_clips, float* logits, float* emb) {
+    if (bits_per_sample != 16 && bits_per_sample != 24 && bits_per_sample != 32)
+        return set_err(BNHIP_E_INVALID, "unsupported bit depth (supported: 16, 24, 32)");
+    return predict_host(m, pcm, bits_per_sample, n_clips, logits, emb);
 }
 
 static int ensure_topk(Engine& e, int k) {

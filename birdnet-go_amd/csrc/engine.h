@@ -111,7 +111,8 @@ class Engine {
     float* d_stage_in2 = nullptr; float* d_stage_logits2 = nullptr; float* d_stage_emb2 = nullptr;
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
-    int16_t* d_stage_pcm = nullptr;
+    int16_t* d_stage_pcm = nullptr;      // PCM staging of the bnhip_predict_pcm* entries (16/24/32-bit: sized in bytes)
+    size_t stage_pcm_bytes = 0;
     float* d_post_conf = nullptr;     // [max_batch, n_classes]
     float* d_topk_conf = nullptr;
     int32_t* d_topk_idx = nullptr;

@@ -10,7 +10,7 @@ namespace bnhip {
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 3, ACT_SWISH = 100, ACT_SIGMOID = 101, ACT_HARD_SWISH = 102 };
 
 // ---- ingest
-void launch_pcm16_to_f32(const int16_t* pcm, float* out, size_t n, hipStream_t s);
+void launch_pcm_to_f32(const void* pcm, int bits /*16, 24, 32*/, float* out, size_t n, hipStream_t s);
 
 // ---- front-end
 // per-clip (min, max(x-min)+eps) as TFLite's REDUCE_MIN/SUB/REDUCE_MAX/ADD chain produces them

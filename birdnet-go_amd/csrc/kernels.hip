@@ -71,11 +71,29 @@ __global__ void k_pcm16_to_f32(const int16_t* __restrict__ pcm, float* __restric
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) out[i] = (float)pcm[i] / 32768.0f;
 }
-void launch_pcm16_to_f32(const int16_t* pcm, float* out, size_t n, hipStream_t s) {
+// internal/audiocore/convert/pcm.go:242-268: 24-bit little-endian with two's-complement sign extension / 8388608,
+// 32-bit / 2147483648 (float32(int32) rounds to nearest even in Go and here; the divisors are powers of two)
+__global__ void k_pcm24_to_f32(const uint8_t* __restrict__ pcm, float* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        int32_t v = (int32_t)pcm[3 * i] | ((int32_t)pcm[3 * i + 1] << 8) | ((int32_t)pcm[3 * i + 2] << 16);
+        if (v & 0x00800000) v |= ~0x00FFFFFF;
+        out[i] = (float)v / 8388608.0f;
+    }
+}
+__global__ void k_pcm32_to_f32(const int32_t* __restrict__ pcm, float* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = (float)pcm[i] / 2147483648.0f;
+}
+void launch_pcm_to_f32(const void* pcm, int bits, float* out, size_t n, hipStream_t s) {
     int blocks = (int)((n + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_pcm16_to_f32, dim3(blocks), dim3(256), 0, s, pcm, out, n);
+    if (bits == 16) hipLaunchKernelGGL(k_pcm16_to_f32, dim3(blocks), dim3(256), 0, s, static_cast<const int16_t*>(pcm), out, n);
+    else if (bits == 24) hipLaunchKernelGGL(k_pcm24_to_f32, dim3(blocks), dim3(256), 0, s, static_cast<const uint8_t*>(pcm), out, n);
+    else hipLaunchKernelGGL(k_pcm32_to_f32, dim3(blocks), dim3(256), 0, s, static_cast<const int32_t*>(pcm), out, n);
 }
 
 // ------------------------------------------------------------------------------------------ front-end

@@ -24,7 +24,7 @@ LIB_PATH = os.environ.get("BNHIP_LIB") or os.path.join(_HERE, "lib", "libbnhip.s
 BNHIP_OK, E_INVALID, E_NO_DEVICE, E_MODEL, E_UNSUPPORTED, E_RUNTIME, E_NOMEM = 0, -1, -2, -3, -4, -5, -6
 
 SYMBOLS = ["bnhip_init", "bnhip_shutdown", "bnhip_model_create", "bnhip_model_info", "bnhip_predict",
-           "bnhip_predict_pcm16", "bnhip_predict_device", "bnhip_postprocess_topk", "bnhip_predict_topk",
+           "bnhip_predict_pcm16", "bnhip_predict_pcm", "bnhip_predict_device", "bnhip_postprocess_topk", "bnhip_predict_topk",
            "bnhip_us_frame_cv", "bnhip_set_stream", "bnhip_synchronize", "bnhip_profile_enable",
            "bnhip_profile_read", "bnhip_model_describe", "bnhip_model_destroy", "bnhip_last_error",
            "bnhip_version", "bnhip_debug_fetch", "bnhip_profile_filter", "bnhip_resample_length",
@@ -59,6 +59,7 @@ def load_library(path=None):
     lib.bnhip_model_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.bnhip_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.bnhip_predict_pcm16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.bnhip_predict_pcm.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.bnhip_predict_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.bnhip_postprocess_topk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
                                            C.c_void_p, C.c_void_p]
@@ -164,6 +165,20 @@ class HipClassifier:
             raise HipError(E_INVALID, f"input size mismatch: expected {batch_size * self.n_samples} samples, got {x.size}")
         logits = np.empty((batch_size, self._n_classes), np.float32)
         _check(self._lib, self._lib.bnhip_predict_pcm16(self._h, x.ctypes.data, batch_size, logits.ctypes.data, None))
+        return logits
+
+    def predict_pcm(self, raw: bytes, bit_depth: int, batch_size: int):
+        """Little-endian PCM bytes of the three depths ConvertToFloat32 accepts (convert/pcm.go:206-268), converted on the
+        device.  An unsupported depth is a validation error, as in the reference (pcm.go:215-222)."""
+        self._alive()
+        if bit_depth not in (16, 24, 32):
+            raise HipError(E_INVALID, f"unsupported bit depth: {bit_depth} (supported: 16, 24, 32)")
+        x = np.frombuffer(raw, np.uint8)
+        if x.size != batch_size * self.n_samples * (bit_depth // 8):
+            raise HipError(E_INVALID, f"input size mismatch: expected {batch_size * self.n_samples} samples of "
+                                      f"{bit_depth // 8} bytes, got {x.size} bytes")
+        logits = np.empty((batch_size, self._n_classes), np.float32)
+        _check(self._lib, self._lib.bnhip_predict_pcm(self._h, x.ctypes.data, bit_depth, batch_size, logits.ctypes.data, None))
         return logits
 
     def predict_device(self, d_samples_ptr, n_clips, d_logits_ptr, d_emb_ptr=None):

@@ -72,6 +72,11 @@ int bnhip_predict(bnhip_model* m, const float* samples, int n_clips, float* logi
  * (internal/analysis/process.go:479-497, audiocore/convert/pcm.go:226-237). */
 int bnhip_predict_pcm16(bnhip_model* m, const int16_t* pcm, int n_clips, float* logits, float* emb);
 
+/* Same for the three bit depths of ConvertToFloat32 (internal/audiocore/convert/pcm.go:206-268): 16-bit /32768,
+ * 24-bit packed little-endian with sign extension /8388608, 32-bit /2147483648.  pcm: n_clips * n_samples samples of
+ * bits_per_sample / 8 bytes each.  Any other depth is BNHIP_E_INVALID (pcm.go:215-222 "supported_bit_depths 16,24,32"). */
+int bnhip_predict_pcm(bnhip_model* m, const void* pcm, int bits_per_sample, int n_clips, float* logits, float* emb);
+
 /* Device-resident variant: all pointers are device memory on the model's device; work is enqueued on
  * the model's stream and NOT synchronised (call bnhip_synchronize). Used by the throughput harness so
  * timing starts with inputs already in HBM.  With "depth" > 1 successive calls run on alternating contexts and may

@@ -340,6 +340,25 @@ def test_pcm16_path_matches_float_path(full_clf):
     assert np.array_equal(got, want)
 
 
+def test_pcm24_pcm32_paths_match_float_path(full_clf):
+    """a1: the 24- and 32-bit branches of ConvertToFloat32 (convert/pcm.go:242-268) on the device, bit-exact against the
+    oracle's restatement fed through the float entry; an unsupported depth is rejected like the reference does."""
+    x = sm.synth_clips(2, 144000, 48000)
+    i24 = np.clip(np.round(x.astype(np.float64) * 8388607), -8388608, 8388607).astype(np.int32)
+    i24[0, :4] = [-8388608, 8388607, -1, 0]                               # sign-extension edges
+    b = i24.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :3].tobytes()   # packed 3-byte little-endian
+    got = full_clf.predict_pcm(b, 24, 2)
+    want = full_clf.predict_batch(G.pcm_to_f32(b, 24), 2)
+    assert np.array_equal(got, want)
+    i32 = np.clip(np.round(x.astype(np.float64) * 2147483647), -2147483648, 2147483647).astype("<i4")
+    i32[1, :3] = [-2147483648, 2147483647, 16777217]                      # float32(int32) rounding edge
+    got = full_clf.predict_pcm(i32.tobytes(), 32, 2)
+    want = full_clf.predict_batch(G.pcm_to_f32(i32.tobytes(), 32), 2)
+    assert np.array_equal(got, want)
+    with pytest.raises(host.HipError):
+        full_clf.predict_pcm(bytes(2 * 144000), 8, 2)
+
+
 def test_embeddings_output(built_lib):
     cfg = sm.tiny_config(emit_embeddings=True)
     blob = sm.build_model(cfg)
