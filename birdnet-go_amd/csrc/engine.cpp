@@ -418,7 +418,8 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
         add_step(s);
         int v_spec = new_val(spec_tensor, (size_t)fms[0].n_mels * fms[0].F * C_spec);
         int v_xn = -1;                      // normalised clip (FFT front-end only)
-        std::vector<std::pair<int, int>> fft_fin;   // (mel GEMM output value, spec index) awaiting pow + NHWC store
+        struct FftFin { int v_bins, spec; size_t o_mel, o_span; bool banded; };
+        std::vector<FftFin> fft_fin;                 // FFT-path channels awaiting mel + pow + NHWC store
         tv[spec_tensor] = v_spec;
         for (size_t i = 0; i < fms.size(); i++) {
             const FrontendMatch& fm = fms[i];
@@ -475,19 +476,29 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                 size_t o_tw = wpush(reinterpret_cast<const float*>(twt.data()), twt.size() * 2);   // fp64 image, 256-B aligned
                 specs.push_back(fs);
                 const int si = (int)specs.size() - 1;
-                int v_bins = new_val(-1, (size_t)fm.F * fs.nbp), v_T = new_val(-1, (size_t)fm.F * fm.n_mels);
+                // band structure of the mel rows: [lo, hi) of the nonzero columns.  A filterbank (2 nonzeros per bin) takes the
+                // banded kernel; anything denser than a quarter of the matrix stays a GEMM.
+                std::vector<int> span((size_t)2 * fm.n_mels, 0);
+                long span_sum = 0;
+                for (int mo = 0; mo < fm.n_mels; mo++) {
+                    int lo = fs.nb, hi = 0;
+                    for (int r = 0; r < fs.nb; r++)
+                        if (melw[(size_t)mo * fs.nbp + r] != 0.0f) { lo = std::min(lo, r); hi = r + 1; }
+                    if (hi == 0) lo = 0;
+                    span[2 * mo] = lo; span[2 * mo + 1] = hi;
+                    span_sum += hi - lo;
+                }
+                std::vector<float> spanf(span.size());
+                memcpy(spanf.data(), span.data(), span.size() * sizeof(int));            // int32 image in the float arena
+                size_t o_span = wpush(spanf.data(), spanf.size());
+                const bool banded = !getenv("BNHIP_NO_MEL_BANDED") && span_sum * 4 <= (long)fm.n_mels * fs.nb;
+                int v_bins = new_val(-1, (size_t)fm.F * fs.nbp);
                 Step st; st.kind = S_STFT; st.name = "stft" + std::to_string(i); st.kclass = "stft"; st.in0 = v_xn; st.out = v_bins;
                 st.spec = si;
                 st.flops = (double)fm.F * 2.5 * fm.Lfft * std::log2((double)fm.Lfft / 2);      // ~5 N/2 log2(N/2) per frame
                 st.bytes = (double)n_samples * 4 + (double)fm.F * fs.nbp * 4;
                 add_step(st, o_win, o_bins, o_tw);
-                Step g; g.kind = S_PW; g.name = "mel" + std::to_string(i); g.kclass = "pw_gemm"; g.in0 = v_bins; g.out = v_T;
-                g.H = fm.F; g.W = 1; g.C = fs.nbp; g.Co = fm.n_mels; g.Ho = fm.F; g.Wo = 1; g.act = ACT_NONE;
-                g.flops = 2.0 * fm.F * fs.nbp * fm.n_mels;
-                g.bytes = 4.0 * ((double)fm.F * fs.nbp + (double)fm.F * fm.n_mels);
-                g.wbytes = 4.0 * fs.nbp * fm.n_mels;
-                add_step(g, o_mel);
-                fft_fin.push_back({v_T, si});
+                fft_fin.push_back({v_bins, si, o_mel, o_span, banded});
                 continue;
             }
             if (frontend_lds_bytes(fs.Lfft, fs.Kp, fs.hop, fs.NTP) > 160 * 1024) {
@@ -511,15 +522,44 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
             f.bytes = (double)n_samples * 4 + (double)fm.F * fm.n_mels * 4;
             add_step(f, goff, woff);
         }
-        // pow + NHWC store of the FFT-path channels: two adjacent channels go out as one float2 per pixel
+        // mel + pow + NHWC store of the FFT-path channels: two adjacent channels go out as one float2 per pixel.  Banded mel
+        // matrices take one fused kernel; otherwise the mel projection is a k_pw_gemm per channel followed by k_mel_finish.
         for (size_t k = 0; k < fft_fin.size();) {
-            const FrontSpec& a = specs[fft_fin[k].second];
-            bool pair = k + 1 < fft_fin.size() && specs[fft_fin[k + 1].second].c == a.c + 1 && (a.c & 1) == 0 &&
-                        specs[fft_fin[k + 1].second].F == a.F && specs[fft_fin[k + 1].second].n_mels == a.n_mels;
+            const FrontSpec& a = specs[fft_fin[k].spec];
+            bool pair = k + 1 < fft_fin.size() && specs[fft_fin[k + 1].spec].c == a.c + 1 && (a.c & 1) == 0 &&
+                        specs[fft_fin[k + 1].spec].F == a.F && specs[fft_fin[k + 1].spec].n_mels == a.n_mels;
+            const int nch = pair ? 2 : 1;
+            bool banded = fft_fin[k].banded && (!pair || fft_fin[k + 1].banded) &&
+                          mel_banded_supported(a.n_mels, a.nbp, pair ? specs[fft_fin[k + 1].spec].nbp : 0);
+            if (banded) {
+                Step mb; mb.kind = S_MELBAND; mb.name = "melband" + std::to_string(a.c); mb.kclass = "frontend";
+                mb.in0 = fft_fin[k].v_bins; mb.spec = fft_fin[k].spec; mb.out = v_spec; mb.S = nch;
+                double bytes = 4.0 * a.F * (a.nbp + a.n_mels), flops = 0;
+                if (pair) {
+                    mb.in1 = fft_fin[k + 1].v_bins; mb.op = fft_fin[k + 1].spec; mb.name += "+" + std::to_string(a.c + 1);
+                    bytes += 4.0 * a.F * (specs[mb.op].nbp + a.n_mels);
+                }
+                for (int c = 0; c < nch; c++) flops += 4.0 * a.F * specs[fft_fin[k + c].spec].nb;     // ~2 nonzeros per bin
+                mb.bytes = bytes; mb.flops = flops;
+                add_step(mb, fft_fin[k].o_mel, fft_fin[k].o_span, pair ? fft_fin[k + 1].o_mel : SIZE_MAX, pair ? fft_fin[k + 1].o_span : SIZE_MAX);
+                k += nch;
+                continue;
+            }
+            int v_T[2] = {-1, -1};
+            for (int c = 0; c < nch; c++) {
+                const FrontSpec& fc = specs[fft_fin[k + c].spec];
+                v_T[c] = new_val(-1, (size_t)fc.F * fc.n_mels);
+                Step g; g.kind = S_PW; g.name = "mel" + std::to_string(fc.c); g.kclass = "pw_gemm"; g.in0 = fft_fin[k + c].v_bins; g.out = v_T[c];
+                g.H = fc.F; g.W = 1; g.C = fc.nbp; g.Co = fc.n_mels; g.Ho = fc.F; g.Wo = 1; g.act = ACT_NONE;
+                g.flops = 2.0 * fc.F * fc.nbp * fc.n_mels;
+                g.bytes = 4.0 * ((double)fc.F * fc.nbp + (double)fc.F * fc.n_mels);
+                g.wbytes = 4.0 * fc.nbp * fc.n_mels;
+                add_step(g, fft_fin[k + c].o_mel);
+            }
             Step mf; mf.kind = S_MELFIN; mf.name = "melspec" + std::to_string(a.c); mf.kclass = "frontend";
-            mf.in0 = fft_fin[k].first; mf.spec = fft_fin[k].second; mf.out = v_spec;
-            mf.S = pair ? 2 : 1;
-            if (pair) { mf.in1 = fft_fin[k + 1].first; mf.op = fft_fin[k + 1].second; mf.name += "+" + std::to_string(a.c + 1); }
+            mf.in0 = v_T[0]; mf.spec = fft_fin[k].spec; mf.out = v_spec;
+            mf.S = nch;
+            if (pair) { mf.in1 = v_T[1]; mf.op = fft_fin[k + 1].spec; mf.name += "+" + std::to_string(a.c + 1); }
             mf.bytes = 8.0 * a.F * a.n_mels * mf.S;
             add_step(mf);
             k += mf.S;
@@ -1313,6 +1353,15 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
                 const FrontSpec& fs = specs[s.spec];
                 StftParams p{in0, fs.window_full, fs.bins, out, n_samples, fs.Lfft, fs.L, fs.hop, fs.F, fs.nb, fs.nbp, fs.mode, n, fs.stft_tw};
                 launch_stft_bins(p, stream);
+                break;
+            }
+            case S_MELBAND: {
+                const FrontSpec& fa = specs[s.spec];
+                const FrontSpec& fb = specs[s.S == 2 ? s.op : s.spec];
+                MelBandParams p{{in0, s.S == 2 ? in1 : in0}, {s.w0, s.S == 2 ? s.w2 : s.w0},
+                                {reinterpret_cast<const int*>(s.w1), reinterpret_cast<const int*>(s.S == 2 ? s.w3 : s.w1)},
+                                {fa.nbp, fb.nbp}, {fa.p1, fb.p1}, {fa.p2, fb.p2}, out, fa.F, fa.n_mels, C_spec, fa.c};
+                launch_mel_banded(p, s.S, n, stream);
                 break;
             }
             case S_MELFIN: {

@@ -11,7 +11,7 @@
 
 namespace bnhip {
 
-enum StepKind { S_MINMAX, S_FRONTEND, S_NORMALIZE, S_STFT, S_MELFIN, S_CONV_DIRECT, S_PW, S_DW, S_EXPAND_DW, S_MEAN_PARTIAL, S_MEAN_FINISH, S_SE, S_UNARY, S_BINARY };
+enum StepKind { S_MINMAX, S_FRONTEND, S_NORMALIZE, S_STFT, S_MELFIN, S_MELBAND, S_CONV_DIRECT, S_PW, S_DW, S_EXPAND_DW, S_MEAN_PARTIAL, S_MEAN_FINISH, S_SE, S_UNARY, S_BINARY };
 
 struct Step {
     StepKind kind;

@@ -53,6 +53,17 @@ struct MelFinParams {
     int F, n_mels, ldt, Ctot, c0;   // c0 = first channel written (two channels are written as one float2 when c0 is even)
 };
 void launch_mel_finish(const MelFinParams& p, int nch, int n_clips, hipStream_t s);
+struct MelBandParams {      // banded mel filterbank + pow + NHWC store, one or two channels per launch
+    const float* bins[2];   // [B, F, nbp_c] STFT values on the needed bins
+    const float* w[2];      // [n_mels, nbp_c] mel rows in output order (zero outside each row's band)
+    const int* span[2];     // [n_mels][2]: first / one-past-last nonzero column of each row
+    int nbp[2];
+    float p1[2], p2[2];
+    float* out;             // [B, n_mels, F, Ctot]
+    int F, n_mels, Ctot, c0;
+};
+bool mel_banded_supported(int n_mels, int nbp0, int nbp1);
+void launch_mel_banded(const MelBandParams& p, int nch, int n_clips, hipStream_t s);
 int frontend_kc(int Lfft, int hop, int NTP);   // K-chunk of the front-end GEMM (G rows per LDS stage): 16 or 32; Kp is padded to it
 
 // ---- CNN

@@ -342,6 +342,98 @@ __global__ __launch_bounds__(256) void k_mel_finish(MelFinParams p) {
         }
     }
 }
+// ------------------------------------------------------------------------------------------ banded mel + pow + NHWC store
+// The mel matrix is a bank of triangular filters: every band touches a short contiguous run of DFT bins (2 K nonzeros in
+// total, not K x n_mels).  As a dense GEMM it was 0.13 ms of MFMA time per batch for 98 % zero products; as a banded sum
+// it is a bandwidth-class kernel, and with both channels in one launch the mel values never go to HBM either:
+//   out[b][m][f][c] = pow(pow(sum_{k in [lo_m, hi_m)} bins_c[b][f][k] * w_c[m][k], p1_c), p2_c).
+// Block = 16 consecutive frames of one clip (their bin rows are one contiguous chunk, staged in LDS), 192 threads = 96 bands
+// x 2 frame groups of 8.  A thread walks its band in aligned groups of four columns: one float4 of the (dense, zero
+// outside the band) weight row from L1/L2 and one ds_read_b128 per frame - LDS instruction issue is what bounds the
+// kernel (PMC/A-B: scalar reads with the weights in LDS were 10 % slower than with the weights in global memory), so
+// the wide read is the lever.  Products are added in ascending k with fmaf (the GEMM summed them in its slab order).
+// Bands are dealt to waves in order (wave w: bands 32 w ..), so the wide top bands do not set the trip count of every wave.
+#define MSP_F 16
+template <int C>
+__global__ __launch_bounds__(192) void k_mel_banded(MelBandParams p) {
+    extern __shared__ __attribute__((aligned(16))) float msm[];
+    float* rows[2];
+    rows[0] = msm;
+    rows[1] = msm + (size_t)MSP_F * p.nbp[0];
+    float* tile = rows[C - 1] + (size_t)MSP_F * p.nbp[C - 1];          // [C][MSP_F][n_mels + 1]
+    const int TS = p.n_mels + 1;
+    const int b = blockIdx.y, f0 = blockIdx.x * MSP_F, nf = min(MSP_F, p.F - f0), tid = threadIdx.x;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const float4* src = reinterpret_cast<const float4*>(p.bins[c] + ((size_t)b * p.F + f0) * p.nbp[c]);
+        float4* dst = reinterpret_cast<float4*>(rows[c]);
+        const int n4 = nf * p.nbp[c] / 4, n4all = MSP_F * p.nbp[c] / 4;  // nbp is a multiple of 4
+        for (int base = 0; base < n4all; base += 4 * 192) {              // four loads in flight per thread
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int i = base + tid + 192 * j;
+                v[j] = i < n4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int i = base + tid + 192 * j;
+                if (i < n4all) dst[i] = v[j];
+            }
+        }
+    }
+    __syncthreads();
+    const int m = tid >> 1, g = tid & 1;
+    if (m < p.n_mels) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int lo = p.span[c][2 * m], hi = p.span[c][2 * m + 1], ld = p.nbp[c];
+            const float4* wr = reinterpret_cast<const float4*>(p.w[c] + (size_t)m * ld);
+            const float* L = rows[c] + (size_t)(g * (MSP_F / 2)) * ld;
+            float acc[MSP_F / 2];
+#pragma unroll
+            for (int i = 0; i < MSP_F / 2; i++) acc[i] = 0.f;
+            const int k4e = (hi + 3) >> 2, k4max = ld / 4 - 1;
+            for (int k4 = lo >> 2; k4 < k4e; k4 += 4) {                  // four weight quads requested at once
+                float4 w4[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) w4[j] = wr[min(k4 + j, k4max)];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (k4 + j < k4e) {
+#pragma unroll
+                        for (int i = 0; i < MSP_F / 2; i++) {
+                            const float4 x4 = *reinterpret_cast<const float4*>(L + (size_t)i * ld + 4 * (k4 + j));
+                            acc[i] = fmaf(x4.w, w4[j].w, fmaf(x4.z, w4[j].z, fmaf(x4.y, w4[j].y, fmaf(x4.x, w4[j].x, acc[i]))));
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MSP_F / 2; i++) tile[(c * MSP_F + g * (MSP_F / 2) + i) * TS + m] = mel_pow(acc[i], p.p1[c], p.p2[c]);
+        }
+    }
+    __syncthreads();
+    for (int it = tid; it < p.n_mels * MSP_F; it += 192) {
+        const int mm = it / MSP_F, f = it % MSP_F;
+        if (f < nf) {
+            float* o = p.out + (((size_t)b * p.n_mels + mm) * p.F + f0 + f) * p.Ctot + p.c0;
+            if (C == 2) *reinterpret_cast<float2*>(o) = make_float2(tile[f * TS + mm], tile[(MSP_F + f) * TS + mm]);
+            else o[0] = tile[f * TS + mm];
+        }
+    }
+}
+bool mel_banded_supported(int n_mels, int nbp0, int nbp1) {
+    size_t lds = (size_t)MSP_F * (nbp0 + nbp1) * 4 + (size_t)2 * MSP_F * (n_mels + 1) * 4;
+    return n_mels <= 96 && (nbp0 & 3) == 0 && (nbp1 & 3) == 0 && lds <= 64 * 1024;
+}
+void launch_mel_banded(const MelBandParams& p, int nch, int n_clips, hipStream_t s) {
+    size_t lds = (size_t)MSP_F * (p.nbp[0] + (nch == 2 ? p.nbp[1] : 0)) * 4 + (size_t)nch * MSP_F * (p.n_mels + 1) * 4;
+    dim3 grid((p.F + MSP_F - 1) / MSP_F, n_clips);
+    if (nch == 2) hipLaunchKernelGGL((k_mel_banded<2>), grid, dim3(192), lds, s, p);
+    else hipLaunchKernelGGL((k_mel_banded<1>), grid, dim3(192), lds, s, p);
+}
+
 void launch_mel_finish(const MelFinParams& p, int nch, int n_clips, hipStream_t s) {
     dim3 grid((p.F + 31) / 32, (p.n_mels + 31) / 32, n_clips);
     if (nch == 2) hipLaunchKernelGGL((k_mel_finish<2>), grid, dim3(256), 0, s, p);

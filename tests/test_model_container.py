@@ -98,7 +98,9 @@ def test_cpp_reader_and_planner_fuse_everything(built_lib, full_blob):
     assert sum(s["fused_sum"] for s in d["steps"]) == 16 and kinds.count("mean") == 2
     pw = [s for s in d["steps"] if s["kernel"] == "pw_gemm"]
     assert sum(s["fused_scale"] for s in pw) == 16 and sum(s["fused_res"] for s in pw) == 9
-    assert len(d["steps"]) == 63
+    # FFT front-end: clip_minmax, normalize, 2 x stft, one banded mel + pow + store launch for both channels
+    names = [s["name"] for s in d["steps"]]
+    assert len(d["steps"]) == 61 and "melband0+1" in names and "mel0" not in names
     # with the folded-GEMM front-end: clip_minmax + one k_frontend launch per channel
     d0 = host.HipClassifier(full_blob, plan_only=True, frontend_fft=0).describe()
     assert len(d0["steps"]) == 59 and [s["kernel"] for s in d0["steps"]].count("frontend") == 2
@@ -158,7 +160,14 @@ def test_magnitude_frontend_plans_onto_the_fft_path(built_lib):
     kinds = [s["kernel"] for s in d["steps"]]
     assert kinds.count("stft") == 2 and "frontend" in kinds
     names = [s["name"] for s in d["steps"]]
-    assert names[:2] == ["clip_minmax", "normalize"] and "mel0" in names and "melspec0+1" in names
+    assert names[:2] == ["clip_minmax", "normalize"] and "melband0+1" in names
+    # a dense mel matrix (or BNHIP_NO_MEL_BANDED) keeps the GEMM + finish pair
+    os.environ["BNHIP_NO_MEL_BANDED"] = "1"
+    try:
+        n2 = [s["name"] for s in host.HipClassifier(blob, plan_only=True).describe()["steps"]]
+    finally:
+        del os.environ["BNHIP_NO_MEL_BANDED"]
+    assert "mel0" in n2 and "mel1" in n2 and "melspec0+1" in n2
     # the real-part graph keeps the folded GEMM unless asked otherwise
     # the real-part graph can use either front-end: FFT by default where the frame length is covered, folded GEMM on request
     d2 = host.HipClassifier(sm.build_model(sm.tiny_config(specs=specs)), plan_only=True, frontend_fft=0).describe()

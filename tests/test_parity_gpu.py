@@ -359,6 +359,25 @@ def test_pcm24_pcm32_paths_match_float_path(full_clf):
         full_clf.predict_pcm(bytes(2 * 144000), 8, 2)
 
 
+def test_banded_mel_matches_gemm_mel(built_lib, full_blob):
+    """The fused banded mel + pow + store kernel against the dense mel GEMM + finish pair it replaces (same products, other
+    summation order), and both against the oracle."""
+    x = sm.synth_clips(3, 144000, 48000)
+    x[2] = 0.0                                                            # digital silence: the near-empty-bin case
+    a = host.HipClassifier(full_blob, max_batch=4)
+    os.environ["BNHIP_NO_MEL_BANDED"] = "1"
+    try:
+        b = host.HipClassifier(full_blob, max_batch=4)
+    finally:
+        del os.environ["BNHIP_NO_MEL_BANDED"]
+    assert "melband0+1" in [s["name"] for s in a.describe()["steps"]]
+    assert "melband0+1" not in [s["name"] for s in b.describe()["steps"]]
+    ya, yb = a.predict_batch(x.reshape(-1), 3), b.predict_batch(x.reshape(-1), 3)
+    a.close(); b.close()
+    assert_parity(ya, yb, tol=2e-5)
+    assert_parity(ya, Interpreter(full_blob).invoke(x)[0])
+
+
 def test_embeddings_output(built_lib):
     cfg = sm.tiny_config(emit_embeddings=True)
     blob = sm.build_model(cfg)
