@@ -3,7 +3,7 @@
 Usage: python tools/prof_summary.py <results.db> [--csv out.csv] [--window SKIP_TAIL:COUNT]
 --window restricts the kernel table to COUNT consecutive bnhip dispatches ending SKIP_TAIL dispatches before the last one
 (e.g. 63:1260 = the 20 timed steps of `bench.py --steps 20`: the create-time autotune launches come before them, the
-8-clip consistency check (63 launches) after them), so the per-kernel averages are those of the timed region."""
+8-clip consistency check (61 launches) after them), so the per-kernel averages are those of the timed region."""
 import re
 import sqlite3
 import sys
