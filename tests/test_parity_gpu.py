@@ -378,6 +378,28 @@ def test_banded_mel_matches_gemm_mel(built_lib, full_blob):
     assert_parity(ya, Interpreter(full_blob).invoke(x)[0])
 
 
+@pytest.mark.parametrize("dense_mel", [False, True])
+def test_three_channel_front_end_vs_oracle(built_lib, dense_mel):
+    """An odd channel count: channels 0+1 leave the mel stage as float2 pixels, channel 2 alone (the single-channel
+    instantiations of k_mel_banded / k_mel_finish, stride-3 NHWC stores), and the stem sees Cin = 3 (k_conv_direct)."""
+    specs = (sm.SpecConfig(512, 94, 0.0, 3000.0), sm.SpecConfig(512, 94, 500.0, 15000.0), sm.SpecConfig(512, 94, 200.0, 8000.0))
+    cfg = sm.tiny_config(specs=specs)
+    blob = sm.build_model(cfg)
+    if dense_mel:
+        os.environ["BNHIP_NO_MEL_BANDED"] = "1"
+    try:
+        c = host.HipClassifier(blob, max_batch=4)
+    finally:
+        os.environ.pop("BNHIP_NO_MEL_BANDED", None)
+    names = [s["name"] for s in c.describe()["steps"]]
+    assert ("melband2" in names) != dense_mel and ("melspec2" in names) == dense_mel
+    x = sm.synth_clips(3, cfg.n_samples, cfg.sample_rate)
+    x[1] = 0.0
+    got = c.predict_batch(x.reshape(-1), 3)
+    c.close()
+    assert_parity(got, Interpreter(blob).invoke(x)[0])
+
+
 def test_embeddings_output(built_lib):
     cfg = sm.tiny_config(emit_embeddings=True)
     blob = sm.build_model(cfg)
