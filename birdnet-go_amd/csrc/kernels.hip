@@ -676,17 +676,20 @@ void launch_stem_mfma(const ConvParams& c, const float* wm, const float* bias_p,
 // 16-lane service group.  K is consumed in permuted order inside each 16-wide slab (lane kq holds
 // k = 4kq..4kq+3, MFMA step s pairs element s of both operands) - a fixed reordering of the fp32 sum.
 #define PW_BM 128      // largest row tile (WM = 2); WM = 1 gives 64-row tiles for small grids
-#define PW_BK 32
-#define PW_LS 40
+#ifndef PW_BK
+#define PW_BK 32     // K slab; PW_LS = PW_BK + 8 keeps the (row, k-quad) slots conflict-free for 32 and 64
+#endif
+#define PW_LS (PW_BK + 8)
+#define PW_C4 (PW_BK / 4)
 template <int NT, bool SC, int WM>
 __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigned nblk) {
     constexpr int BM = 64 * WM;                  // rows per block: 4 waves x (16*WM) rows
-    constexpr int XQ = BM / 32;                  // float4 per thread for the activation tile
+    constexpr int XQ = BM * PW_C4 / 256;         // float4 per thread for the activation tile
     // operand tiles (the epilogue re-uses the array as per-wave output staging).  SC: squeeze-excite scale on A.
     constexpr bool DB = false;   // double-buffering measured neutral on this chip for these shapes; kept for experiments
     constexpr int TILE = (BM + NT * 16) * PW_LS;
     __shared__ __attribute__((aligned(16))) float lds[(DB ? 2 : 1) * TILE];
-    constexpr int WQ = (NT + 1) / 2;             // float4 per thread for the W tile
+    constexpr int WQ = (NT * 16 * PW_C4 + 255) / 256;   // float4 per thread for the W tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     // XCD-aware order: N-blocks fastest so the blocks that share an activation tile sit on one XCD's L2
@@ -700,7 +703,7 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
     if (SC) {
 #pragma unroll
         for (int q = 0; q < XQ; q++) {
-            int m = m0 + ((tid + 256 * q) >> 3);
+            int m = m0 + ((tid + 256 * q) / PW_C4);
             srow[SC ? q : 0] = (m < p.M ? m : 0) / p.HW;
         }
     }
@@ -709,7 +712,7 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
 #pragma unroll
         for (int q = 0; q < XQ; q++) {
             int idx = tid + 256 * q;
-            int row = idx >> 3, c4 = idx & 7;
+            int row = idx / PW_C4, c4 = idx % PW_C4;
             int m = m0 + row, k = k0 + 4 * c4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < p.M && k < K) {
@@ -722,7 +725,7 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
 #pragma unroll
         for (int q = 0; q < WQ; q++) {
             int idx = tid + 256 * q;
-            int row = idx >> 3, c4 = idx & 7;
+            int row = idx / PW_C4, c4 = idx % PW_C4;
             int n = n0 + row, k = k0 + 4 * c4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < NT * 16 && n < p.N && k < K) v = *reinterpret_cast<const float4*>(p.W + (size_t)n * K + k);
@@ -737,12 +740,12 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
             int idx = tid + 256 * q;
             float4 v = xreg[q];
             if (SC) { float4 sc = sreg[SC ? q : 0]; v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
-            *reinterpret_cast<float4*>(&Xs[(idx >> 3) * PW_LS + 4 * (idx & 7)]) = v;
+            *reinterpret_cast<float4*>(&Xs[(idx / PW_C4) * PW_LS + 4 * (idx % PW_C4)]) = v;
         }
 #pragma unroll
         for (int q = 0; q < WQ; q++) {
             int idx = tid + 256 * q;
-            if ((idx >> 3) < NT * 16) *reinterpret_cast<float4*>(&Ws[(idx >> 3) * PW_LS + 4 * (idx & 7)]) = wreg[q];
+            if ((idx / PW_C4) < NT * 16) *reinterpret_cast<float4*>(&Ws[(idx / PW_C4) * PW_LS + 4 * (idx % PW_C4)]) = wreg[q];
         }
     };
 
@@ -763,7 +766,7 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
         const float* Xs = lds + (DB ? (sl & 1) : 0) * TILE;
         const float* Ws = Xs + BM * PW_LS;
 #pragma unroll
-        for (int t16 = 0; t16 < 2; t16++) {
+        for (int t16 = 0; t16 < PW_BK / 16; t16++) {
             f32x4 xf[WM], wf[NT];
 #pragma unroll
             for (int mt = 0; mt < WM; mt++)
