@@ -192,19 +192,21 @@ static int predict_host(bnhip_model* m, const void* src, int pcm_bits, int n_cli
     std::string err;
     const bool pcm = pcm_bits != 0;
     const size_t bps = (size_t)pcm_bits / 8;
-    if (pcm && e.stage_pcm_bytes < (size_t)e.max_batch * e.n_samples * bps) {
-        if (e.d_stage_pcm) { hipStreamSynchronize(e.stream); hipFree(e.d_stage_pcm); e.d_stage_pcm = nullptr; e.stage_pcm_bytes = 0; }
-        if (hipMalloc((void**)&e.d_stage_pcm, (size_t)e.max_batch * e.n_samples * bps) != hipSuccess)
-            return set_err(BNHIP_E_NOMEM, "device allocation failed (pcm staging)");
-        e.stage_pcm_bytes = (size_t)e.max_batch * e.n_samples * bps;
-    }
     // chunk = max_batch for calls larger than it; a single large batch (>= 128 clips) is split too, so that the pageable
     // H2D copy of its second part overlaps the compute of the first (PCIe-inclusive rate of a 256-clip call: +25 %)
     static const int split_env = getenv("BNHIP_HOST_SPLIT") ? atoi(getenv("BNHIP_HOST_SPLIT")) : 2;
     int ck = e.max_batch;
     if (n_clips <= e.max_batch && n_clips >= 128 && split_env > 1) ck = (n_clips + split_env - 1) / split_env;
     const int nchunks = (n_clips + ck - 1) / ck;
-    const bool pipelined = nchunks > 1 && !pcm;
+    const bool pipelined = nchunks > 1;
+    // PCM staging: one buffer, or two (one per in-flight chunk) when the call is pipelined
+    const size_t pcm_half = (size_t)e.max_batch * e.n_samples * bps, pcm_need = pcm_half * (pipelined ? 2 : 1);
+    if (pcm && e.stage_pcm_bytes < pcm_need) {
+        if (e.d_stage_pcm) { hipStreamSynchronize(e.stream); hipFree(e.d_stage_pcm); e.d_stage_pcm = nullptr; e.stage_pcm_bytes = 0; }
+        if (hipMalloc((void**)&e.d_stage_pcm, pcm_need) != hipSuccess)
+            return set_err(BNHIP_E_NOMEM, "device allocation failed (pcm staging)");
+        e.stage_pcm_bytes = pcm_need;
+    }
     if (pipelined && !e.d_stage_in2) {       // second staging set, created on first use
         hipError_t he = hipMalloc((void**)&e.d_stage_in2, (size_t)e.max_batch * e.n_samples * 4);
         if (he == hipSuccess) he = hipMalloc((void**)&e.d_stage_logits2, (size_t)e.max_batch * e.n_classes * 4);
@@ -264,8 +266,16 @@ static int predict_host(bnhip_model* m, const void* src, int pcm_bits, int n_cli
     };
     for (int c = 0; c < nchunks; c++) {
         int off = c * ck, n = std::min(ck, n_clips - off), b = c & 1;
-        hipError_t he = hipMemcpyAsync(din[b], (const float*)src + (size_t)off * e.n_samples, (size_t)n * e.n_samples * 4,
-                                       hipMemcpyHostToDevice, e.copy_stream);
+        hipError_t he;
+        if (pcm) {      // raw PCM over PCIe (a half or a quarter of the float bytes), converted on the copy stream
+            char* dp = reinterpret_cast<char*>(e.d_stage_pcm) + (size_t)b * pcm_half;
+            he = hipMemcpyAsync(dp, (const char*)src + (size_t)off * e.n_samples * bps, (size_t)n * e.n_samples * bps,
+                                hipMemcpyHostToDevice, e.copy_stream);
+            if (he == hipSuccess) launch_pcm_to_f32(dp, pcm_bits, din[b], (size_t)n * e.n_samples, e.copy_stream);
+        } else {
+            he = hipMemcpyAsync(din[b], (const float*)src + (size_t)off * e.n_samples, (size_t)n * e.n_samples * 4,
+                                hipMemcpyHostToDevice, e.copy_stream);
+        }
         if (he == hipSuccess) he = hipEventRecord(e.ev_copied[b], e.copy_stream);
         if (he == hipSuccess) he = hipStreamWaitEvent(e.stream, e.ev_copied[b], 0);
         if (he != hipSuccess) return fail("H2D copy", he);

@@ -18,6 +18,9 @@ for n, reps in ((1, 300), (8, 200), (256, 20)):
 pcm = (np.clip(x, -1, 1) * 32767).astype(np.int16)
 dt = t(lambda: clf.predict_pcm16(pcm.reshape(-1), 256), 20)
 print(f"pcm16 n=256: {dt*1e3:.3f} ms  {256/dt:.0f} clips/s")
+bigp = np.tile(pcm, (8, 1))
+dt = t(lambda: clf.predict_pcm16(bigp.reshape(-1), 2048), 5)
+print(f"pcm16 n=2048 (8 chunks): {dt*1e3:.3f} ms  {2048/dt:.0f} clips/s")
 big = np.tile(x, (8, 1))
 dt = t(lambda: clf.predict_batch(big.reshape(-1), 2048), 5)
 print(f"fp32 n=2048 (8 chunks): {dt*1e3:.3f} ms  {2048/dt:.0f} clips/s")
