@@ -1184,10 +1184,12 @@ void Engine::autotune_pw() {
             float* in2 = vptr(s.in2, d_stage_in, d_stage_logits, nullptr);
             float* out = vptr(s.out, d_stage_in, d_stage_logits, nullptr);
             float best = 1e30f; int best_nt = 0, best_wm = 0;
-            for (int wm = 2; wm >= 1; wm--) {
+            // wm 2, 1: k_pw_gemm with 128- / 64-row tiles; 4, 3: the same tiles on the software-pipelined k_pw_pipe
+            for (int wm = 4; wm >= 1; wm--) {
                 for (int nt = 1; nt <= 4; nt++) {
                     long cols = (long)((s.Co + nt * 16 - 1) / (nt * 16)) * nt * 16;
                     if (cols * 100 > (long)((s.Co + 15) / 16 * 16) * 130) continue;         // skip absurd padding
+                    if (wm > 2 && !pw_pipe_ok(nt, wm - 2, s.C)) continue;
                     PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, nt, wm};
                     launch_pw_gemm(p, stream);                                             // warm-up
                     hipEventRecord(a, stream);

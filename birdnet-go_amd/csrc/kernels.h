@@ -80,9 +80,10 @@ struct PwParams {         // pointwise conv / fully-connected as GEMM: out[M,N] 
     const float* A; const float* W; const float* bias; const float* ascale; const float* res; float* out;
     int M, N, K, HW, act;
     int nt = 0;           // N-tile width in 16-column units (1..8); 0 = built-in heuristic
-    int wm = 0;           // row tile: 1 = 64 rows per block, otherwise 128
+    int wm = 0;           // row tile: 1 = 64 rows per block, otherwise 128; 3 / 4 = the same tiles on k_pw_pipe
 };
 void launch_pw_gemm(const PwParams& p, hipStream_t s);
+bool pw_pipe_ok(int nt, int wm, int K);   // PwParams::wm = 2 + wm selects the software-pipelined kernel (k_pw_pipe)
 int pw_default_nt(int M, int N);
 
 struct DwParams {

@@ -8,6 +8,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -681,6 +682,87 @@ void launch_stem_mfma(const ConvParams& c, const float* wm, const float* bias_p,
 #endif
 #define PW_LS (PW_BK + 8)
 #define PW_C4 (PW_BK / 4)
+// Epilogue shared by the k_pw_gemm variants.  D[i = n 4*kq + r][j = m li]: the lane holds 4 consecutive channels of one
+// row.  Bias and activation are applied in registers, the 16 x (16*NT) sub-tile is staged through this wave's private LDS
+// slice, and written out row-contiguously (full 64*NT-byte runs per row instead of 64-byte pieces); the residual is read
+// with the same coalesced pattern.  `lds` must hold 4 x 16 x (16 NT + 4) floats and be free of operand data.
+template <int NT, int WM>
+__device__ __forceinline__ void pw_epilogue(const PwParams& p, f32x4 (&acc)[NT][WM], float* lds, int m0, int n0) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    constexpr int BN = NT * 16;
+    constexpr int CS = BN + 4;                    // staging row stride (floats), keeps 16-byte alignment
+    float* stage = lds + wave * (16 * CS);        // 4 waves x 16 x CS floats fits in one operand tile
+    const bool vec_ok = (p.N & 3) == 0;
+    if (p.bias) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            int n = n0 + 16 * t + 4 * kq;
+            f32x4 bq = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (vec_ok && n + 3 < p.N) { float4 t4 = *reinterpret_cast<const float4*>(p.bias + n); bq = (f32x4){t4.x, t4.y, t4.z, t4.w}; }
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) if (n + r < p.N) bq[r] = p.bias[n + r];
+            }
+#pragma unroll
+            for (int mt = 0; mt < WM; mt++) acc[t][mt] += bq;
+        }
+    }
+    if (p.act == ACT_SWISH) {
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int mt = 0; mt < WM; mt++) acc[t][mt] = swish4(acc[t][mt]);
+    } else {
+        with_act(p.act, [&](auto f) {
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int mt = 0; mt < WM; mt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[t][mt][r] = f(acc[t][mt][r]);
+        });
+    }
+#pragma unroll
+    for (int mt = 0; mt < WM; mt++) {
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+            *reinterpret_cast<f32x4*>(&stage[li * CS + 16 * t + 4 * kq]) = acc[t][mt];
+        // wave-private region: the wave's own LDS writes are visible to it once the LDS counter drains
+        __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        const int mbase = m0 + 16 * WM * wave + 16 * mt;
+#pragma unroll
+        for (int q = 0; q < (16 * (BN / 4) + 63) / 64; q++) {
+            int idx = lane + 64 * q;
+            int row = idx / (BN / 4), c4 = idx % (BN / 4);
+            int m = mbase + row, n = n0 + 4 * c4;
+            if (row < 16 && m < p.M && n < p.N) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * CS + 4 * c4]);
+                float* op = p.out + (size_t)m * p.N + n;
+                if (vec_ok) {
+                    if (p.res) { float4 rv = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.N + n); v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
+                    *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (n + r < p.N) op[r] = v[r] + (p.res ? p.res[(size_t)m * p.N + n + r] : 0.f);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// PW_TRACE (tools/ubench/pw_trace.hip only): lane 0 of every wave of the first 64 logical blocks stamps the shader clock at
+// the phase boundaries of each K slab, to see where a wave's time goes.  Compiled out of the library.
+#ifdef PW_TRACE
+__device__ long long* g_pw_trace = nullptr;      // [64 blocks][4 waves][PW_TRACE_SLOTS]
+#define PW_TRACE_SLOTS 128
+#define PW_T(i) do { if (lane == 0 && L < 64u && (i) < PW_TRACE_SLOTS && !((i) >= 60 && (i) < 64)) g_pw_trace[((size_t)L * 4 + wave) * PW_TRACE_SLOTS + (i)] = clock64(); } while (0)
+#else
+#define PW_T(i) do { } while (0)
+#endif
 template <int NT, bool SC, int WM>
 __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigned nblk) {
     constexpr int BM = 64 * WM;                  // rows per block: 4 waves x (16*WM) rows
@@ -758,11 +840,14 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
     // software pipeline: slab s computes from LDS buffer s&1 while slab s+1 moves registers -> the other
     // buffer and slab s+2's global loads are in flight; one barrier per slab.
     const int nslab = (K + PW_BK - 1) / PW_BK;
+    PW_T(0);
     gload(0);
     lstore(0);
     if (nslab > 1) gload(PW_BK);
     __syncthreads();
+    PW_T(1);
     for (int sl = 0; sl < nslab; sl++) {
+        PW_T(4 + 4 * sl);
         const float* Xs = lds + (DB ? (sl & 1) : 0) * TILE;
         const float* Ws = Xs + BM * PW_LS;
 #pragma unroll
@@ -783,80 +868,153 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
                         acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][sidx], xf[mt][sidx], acc[t][mt], 0, 0, 0);
             }
         }
+        PW_T(5 + 4 * sl);                      // MFMAs issued
         if (sl + 1 < nslab) {
             if (!DB) __syncthreads();          // single buffer: everyone must be done reading it
+            PW_T(6 + 4 * sl);                  // all waves done with the slab
+#ifdef PW_TRACE
+            __builtin_amdgcn_s_waitcnt(0x0f70);    // vmcnt(0): the next slab's global loads have landed
+            PW_T(64 + 2 * sl);
+#endif
             lstore(DB ? ((sl + 1) & 1) : 0);
+#ifdef PW_TRACE
+            __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): LDS stores done
+            PW_T(65 + 2 * sl);
+#endif
             if (sl + 2 < nslab) gload((sl + 2) * PW_BK);
+            PW_T(7 + 4 * sl);                  // next slab stored (its global loads had landed), slab + 2 requested
         }
         __syncthreads();
     }
+    PW_T(2);
 
-    // ---- epilogue.  D[i = n 4*kq + r][j = m li]: the lane holds 4 consecutive channels of one row.  Bias and
-    // activation are applied in registers, the 16 x (16*NT) sub-tile is staged through this wave's private LDS
-    // slice, and written out row-contiguously (full 64*NT-byte runs per row instead of 64-byte pieces); the
-    // residual is read with the same coalesced pattern.
-    constexpr int BN = NT * 16;
-    constexpr int CS = BN + 4;                    // staging row stride (floats), keeps 16-byte alignment
-    float* stage = lds + wave * (16 * CS);        // 4 waves x 16 x CS floats fits in one operand tile
-    const bool vec_ok = (p.N & 3) == 0;
-    if (p.bias) {
+    pw_epilogue<NT, WM>(p, acc, lds, m0, n0);
+    PW_T(3);
+}
+
+// Software-pipelined variant for K % PW_BK == 0.  The phase trace of k_pw_gemm (tools/ubench/pw_trace.hip) shows a wave
+// spending only ~1/3 of a slab period issuing MFMAs: the rest is two barrier waits and the refill of the single operand
+// buffer, whose address VALU, LDS stores and global-load issue crawl because they compete with the other waves' MFMAs
+// for issue slots.  Here the refill rides in the wave's OWN MFMA shadow instead: two LDS operand buffers, the stores of
+// slab s+1 are interleaved with the MFMAs of the first half of slab s and the global loads of slab s+2 with those of the
+// second half (sched_group_barrier), one barrier per slab.  All per-slab address arithmetic is gone: loads use per-thread
+// offsets computed once (rows clamped into range: out-of-range rows produce values the epilogue never stores) plus k0.
+template <int NT, bool SC, int WM>
+__global__ __launch_bounds__(256) void k_pw_pipe(PwParams p, int nblk_n, unsigned nblk) {
+    constexpr int BM = 64 * WM;
+    constexpr int XQ = BM * PW_C4 / 256, WQ = (NT * 16 * PW_C4 + 255) / 256;
+    constexpr int TILE = (BM + NT * 16) * PW_LS;
+    __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const unsigned L = xcd_remap(blockIdx.x, nblk);
+    const int m0 = (int)(L / nblk_n) * BM;
+    const int n0 = (int)(L % nblk_n) * (NT * 16);
+    const int K = p.K;
+
+    unsigned xoff[XQ], soff[SC ? XQ : 1], woff[WQ];
+    // LDS store slots: thread idx = tid + 256 q -> row idx / PW_C4, k-quad idx % PW_C4 (256 / PW_C4 rows further per q)
+    const int lbase = (tid / PW_C4) * PW_LS + 4 * (tid % PW_C4);
+    constexpr int LQ = (256 / PW_C4) * PW_LS;
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            int n = n0 + 16 * t + 4 * kq;
-            f32x4 bq = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (vec_ok && n + 3 < p.N) { float4 t4 = *reinterpret_cast<const float4*>(p.bias + n); bq = (f32x4){t4.x, t4.y, t4.z, t4.w}; }
-            else {
-#pragma unroll
-                for (int r = 0; r < 4; r++) if (n + r < p.N) bq[r] = p.bias[n + r];
-            }
-#pragma unroll
-            for (int mt = 0; mt < WM; mt++) acc[t][mt] += bq;
-        }
+    for (int q = 0; q < XQ; q++) {
+        const int idx = tid + 256 * q, row = idx / PW_C4, c4 = idx % PW_C4;
+        const int m = min(m0 + row, p.M - 1);
+        xoff[q] = (unsigned)m * (unsigned)K + 4 * c4;
+        if (SC) soff[SC ? q : 0] = (unsigned)(m / p.HW) * (unsigned)K + 4 * c4;
     }
-    if (p.act == ACT_SWISH) {
 #pragma unroll
-        for (int t = 0; t < NT; t++)
+    for (int q = 0; q < WQ; q++) {
+        const int idx = tid + 256 * q, row = min(idx / PW_C4, NT * 16 - 1), c4 = idx % PW_C4;
+        woff[q] = (unsigned)min(n0 + row, p.N - 1) * (unsigned)K + 4 * c4;
+    }
+    float4 xreg[XQ], wreg[WQ], sreg[SC ? XQ : 1];
+    auto gload = [&](int k0) {
+        const float* Ak = p.A + k0;
+        const float* Wk = p.W + k0;
 #pragma unroll
-            for (int mt = 0; mt < WM; mt++) acc[t][mt] = swish4(acc[t][mt]);
-    } else {
-        with_act(p.act, [&](auto f) {
+        for (int q = 0; q < XQ; q++) {
+            xreg[q] = *reinterpret_cast<const float4*>(Ak + xoff[q]);
+            if (SC) sreg[SC ? q : 0] = *reinterpret_cast<const float4*>(p.ascale + k0 + soff[SC ? q : 0]);
+        }
+#pragma unroll
+        for (int q = 0; q < WQ; q++) wreg[q] = *reinterpret_cast<const float4*>(Wk + woff[q]);
+    };
+    auto lstore = [&](float* buf) {
+#pragma unroll
+        for (int q = 0; q < XQ; q++) {
+            float4 v = xreg[q];
+            if (SC) { const float4 sc = sreg[SC ? q : 0]; v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+            *reinterpret_cast<float4*>(&buf[lbase + q * LQ]) = v;
+        }
+#pragma unroll
+        for (int q = 0; q < WQ; q++)
+            if ((NT * 16 * PW_C4) % 256 == 0 || (tid + 256 * q) / PW_C4 < NT * 16)
+                *reinterpret_cast<float4*>(&buf[BM * PW_LS + lbase + q * LQ]) = wreg[q];
+    };
+
+    f32x4 acc[NT][WM];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int mt = 0; mt < WM; mt++) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nslab = K / PW_BK;
+    gload(0);
+    lstore(lds);
+    if (nslab > 1) gload(PW_BK);
+    __syncthreads();
+    // one slab: DS = also store slab sl + 1 (held in registers) into the other buffer, DL = also request slab sl + 2
+    auto slab = [&](int sl, auto DS, auto DL) {
+        const float* Xs = lds + (sl & 1) * TILE;
+        const float* Ws = Xs + BM * PW_LS;
+        float* nxt = lds + ((sl + 1) & 1) * TILE;
+#pragma unroll
+        for (int t16 = 0; t16 < PW_BK / 16; t16++) {
+            f32x4 xf[WM], wf[NT];
+#pragma unroll
+            for (int mt = 0; mt < WM; mt++)
+                xf[mt] = *reinterpret_cast<const f32x4*>(&Xs[(16 * WM * wave + 16 * mt + li) * PW_LS + 16 * t16 + 4 * kq]);
 #pragma unroll
             for (int t = 0; t < NT; t++)
+                wf[t] = *reinterpret_cast<const f32x4*>(&Ws[(16 * t + li) * PW_LS + 16 * t16 + 4 * kq]);
+            if (t16 == 0 && decltype(DS)::value) lstore(nxt);
+            if (t16 == PW_BK / 16 - 1 && decltype(DL)::value) gload((sl + 2) * PW_BK);
 #pragma unroll
-                for (int mt = 0; mt < WM; mt++)
+            for (int sidx = 0; sidx < 4; sidx++) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) acc[t][mt][r] = f(acc[t][mt][r]);
-        });
-    }
+                for (int t = 0; t < NT; t++)
 #pragma unroll
-    for (int mt = 0; mt < WM; mt++) {
+                    for (int mt = 0; mt < WM; mt++)
+                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][sidx], xf[mt][sidx], acc[t][mt], 0, 0, 0);
+            }
+            // interleave: fragment reads first, then the refill instructions spread between the MFMAs
+            constexpr int NMF = 4 * NT * WM, NREF = XQ + WQ, STEP = NMF / (NREF + 1) > 0 ? NMF / (NREF + 1) : 1;
+            __builtin_amdgcn_sched_group_barrier(0x100, WM + NT, 0);
+            if (t16 == 0 && decltype(DS)::value) {
 #pragma unroll
-        for (int t = 0; t < NT; t++)
-            *reinterpret_cast<f32x4*>(&stage[li * CS + 16 * t + 4 * kq]) = acc[t][mt];
-        // wave-private region: the wave's own LDS writes are visible to it once the LDS counter drains
-        __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0)
-        __builtin_amdgcn_wave_barrier();
-        const int mbase = m0 + 16 * WM * wave + 16 * mt;
+                for (int r = 0; r < NREF; r++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, STEP, 0);
+                    if (SC) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+            }
+            if (t16 == PW_BK / 16 - 1 && decltype(DL)::value) {
 #pragma unroll
-        for (int q = 0; q < (16 * (BN / 4) + 63) / 64; q++) {
-            int idx = lane + 64 * q;
-            int row = idx / (BN / 4), c4 = idx % (BN / 4);
-            int m = mbase + row, n = n0 + 4 * c4;
-            if (row < 16 && m < p.M && n < p.N) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * CS + 4 * c4]);
-                float* op = p.out + (size_t)m * p.N + n;
-                if (vec_ok) {
-                    if (p.res) { float4 rv = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.N + n); v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
-                    *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        if (n + r < p.N) op[r] = v[r] + (p.res ? p.res[(size_t)m * p.N + n + r] : 0.f);
+                for (int r = 0; r < NREF + (SC ? XQ : 0); r++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, SC ? 1 : STEP, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
-    }
+        __syncthreads();
+    };
+    int sl = 0;
+    for (; sl + 2 < nslab; sl++) slab(sl, std::true_type{}, std::true_type{});
+    if (nslab >= 2) { slab(sl, std::true_type{}, std::false_type{}); sl++; }
+    slab(sl, std::false_type{}, std::false_type{});
+
+    pw_epilogue<NT, WM>(p, acc, lds, m0, n0);
 }
 
 // scalar fallback for K not a multiple of 4 (never hit by EfficientNet-style graphs; kept for drop-in safety)
@@ -880,6 +1038,8 @@ __global__ void k_pw_naive(PwParams p) {
 // Tile-width choice.  Measured on MI355X (tests/micro sweep, late-layer shapes at batch 256): NT <= 4 keeps
 // the kernel at <= 112 VGPRs (4 waves/SIMD) and beats the wider tiles (134-158 VGPRs, 2 waves/SIMD) by
 // 10-45 % even where they pad less, so: widest NT in 1..4 whose padded width is within 15 % of the best.
+// k_pw_pipe needs whole K slabs and both operand buffers inside the 64 KB of static LDS
+bool pw_pipe_ok(int nt, int wm, int K) { return K % PW_BK == 0 && nt >= 1 && nt <= 4 && 2 * (64 * wm + 16 * nt) * PW_LS * 4 <= 64 * 1024; }
 static int pick_nt(int M, int N) {
     (void)M;
     long best_cols = -1;
@@ -906,14 +1066,18 @@ void launch_pw_gemm(const PwParams& p, hipStream_t s) {
         return;
     }
     int nt = (p.nt >= 1 && p.nt <= 8) ? p.nt : pick_nt(p.M, p.N);
-    int wm = p.wm == 1 ? 1 : 2;
+    // wm 3 / 4 = the software-pipelined kernel with 64 / 128-row tiles (needs whole K slabs and nt <= 4)
+    static const int wm_env = getenv("BNHIP_PW_WM") ? atoi(getenv("BNHIP_PW_WM")) : 0;      // test switch: force the row tile / kernel
+    const int wm_req = wm_env >= 1 && wm_env <= 4 ? wm_env : p.wm;
+    bool pipe = (wm_req == 3 || wm_req == 4) && pw_pipe_ok(nt, wm_req - 2, p.K);
+    int wm = (wm_req == 1 || wm_req == 3) ? 1 : 2;
     int bm = 64 * wm;
     int nblk_n = (p.N + nt * 16 - 1) / (nt * 16);
     unsigned nblk = (unsigned)((p.M + bm - 1) / bm) * nblk_n;
     // the tile was tuned at batch size; a call with a handful of clips would leave most CUs idle with it (one clip:
     // 1-5 workgroups each walking the whole K loop): fall back to the smallest tile to get workgroups
     if (nblk < 64 && (nt > 1 || wm > 1)) {
-        nt = 1; wm = 1; bm = 64;
+        nt = 1; wm = 1; bm = 64; pipe = false;
         nblk_n = (p.N + 15) / 16;
         nblk = (unsigned)((p.M + bm - 1) / bm) * nblk_n;
     }
@@ -922,6 +1086,15 @@ void launch_pw_gemm(const PwParams& p, hipStream_t s) {
 #define PW_LAUNCH(NT_, SC_, WM_) hipLaunchKernelGGL((k_pw_gemm<NT_, SC_, WM_>), grid, dim3(256), 0, s, p, nblk_n, nblk)
 #define PW_CASE(NT_) case NT_: if (sc) { if (wm == 1) PW_LAUNCH(NT_, true, 1); else PW_LAUNCH(NT_, true, 2); } \
                      else { if (wm == 1) PW_LAUNCH(NT_, false, 1); else PW_LAUNCH(NT_, false, 2); } break;
+#define PP_LAUNCH(NT_, SC_, WM_) hipLaunchKernelGGL((k_pw_pipe<NT_, SC_, WM_>), grid, dim3(256), 0, s, p, nblk_n, nblk)
+#define PP_CASE(NT_) case NT_: if (sc) { if (wm == 1) PP_LAUNCH(NT_, true, 1); else PP_LAUNCH(NT_, true, 2); } \
+                     else { if (wm == 1) PP_LAUNCH(NT_, false, 1); else PP_LAUNCH(NT_, false, 2); } break;
+    if (pipe) {
+        switch (nt) { PP_CASE(1) PP_CASE(2) PP_CASE(3) default: PP_CASE(4) }
+        return;
+    }
+#undef PP_LAUNCH
+#undef PP_CASE
     switch (nt) { PW_CASE(1) PW_CASE(2) PW_CASE(3) PW_CASE(4) PW_CASE(5) PW_CASE(6) PW_CASE(7) default: PW_CASE(8) }
 #undef PW_LAUNCH
 #undef PW_CASE
