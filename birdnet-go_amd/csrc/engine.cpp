@@ -1130,7 +1130,8 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
 // padding in ways no closed-form rule captured (late layers at batch 256 have as few as 288 blocks), so each
 // pointwise/FC step is timed once at create time on its real shapes and buffers (contents are irrelevant to timing).
 // Tile shape of every fused expand+depthwise layer: time each shape of the kernel's table that fits the layer (the
-// pixel-count cost model picks wrongly when a shape's LDS/register footprint costs more than its smaller halo saves).
+// pixel-count cost model picks wrongly when a shape's LDS/register footprint costs more than its smaller halo saves -
+// also for a pipelined engine: choosing by fewest expanded pixels there measured -1.5 %, unlike k_pw_gemm's tiles).
 void Engine::autotune_expdw() {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
@@ -1184,12 +1185,22 @@ void Engine::autotune_pw() {
             float* in2 = vptr(s.in2, d_stage_in, d_stage_logits, nullptr);
             float* out = vptr(s.out, d_stage_in, d_stage_logits, nullptr);
             float best = 1e30f; int best_nt = 0, best_wm = 0;
-            // wm 2, 1: k_pw_gemm with 128- / 64-row tiles; 4, 3: the same tiles on the software-pipelined k_pw_pipe
+            double best_work = 1e300;
+            // wm 2, 1: k_pw_gemm with 128- / 64-row tiles; 4, 3: the same tiles on the software-pipelined k_pw_pipe.
+            // Selection: a serial engine takes the fastest candidate.  A pipelined one (depth > 1) is issue-bound - the other
+            // context fills every stall - so there the candidate with the least padded MFMA work wins and time only breaks
+            // ties: N = 80 / 112 take exact 80- / 112-column tiles although 48- / 64-column ones are 10-45 % faster alone
+            // (measured: +1.2 % on the pipelined bench).
+            const bool by_work = depth > 1 && !getenv("BNHIP_TUNE_BY_TIME");
             for (int wm = 4; wm >= 1; wm--) {
-                for (int nt = 1; nt <= 4; nt++) {
+                for (int nt = 1; nt <= 8; nt++) {
+                    const long M_ = (long)n * s.H * s.W, bm = (wm == 1 || wm == 3) ? 64 : 128;
                     long cols = (long)((s.Co + nt * 16 - 1) / (nt * 16)) * nt * 16;
                     if (cols * 100 > (long)((s.Co + 15) / 16 * 16) * 130) continue;         // skip absurd padding
                     if (wm > 2 && !pw_pipe_ok(nt, wm - 2, s.C)) continue;
+                    if (nt > 4 && !by_work) continue;                                       // wide tiles never win alone (2 waves/SIMD)
+                    const double work = (double)((M_ + bm - 1) / bm * bm) * (double)cols;
+                    if (by_work && work > best_work * 1.01) continue;                       // cannot win: skip the timing
                     PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, nt, wm};
                     launch_pw_gemm(p, stream);                                             // warm-up
                     hipEventRecord(a, stream);
@@ -1198,7 +1209,8 @@ void Engine::autotune_pw() {
                     hipEventSynchronize(b);
                     float ms = 0; hipEventElapsedTime(&ms, a, b);
                     if (getenv("BNHIP_DEBUG")) fprintf(stderr, "[bnhip] tune %-16s n=%d M=%d N=%d K=%d nt=%d wm=%d: %.1f us (%.1f TF)\n", s.name.c_str(), n, n * s.H * s.W, s.Co, s.C, nt, wm, ms / 3 * 1e3, 2.0 * n * s.H * s.W * s.Co * s.C / (ms / 3 * 1e-3) / 1e12);
-                    if (ms < best * 0.98f) { best = ms; best_nt = nt; best_wm = wm; }      // prefer the larger tile on ties
+                    const bool less_work = by_work && work < best_work * 0.99;
+                    if (less_work || ms < best * 0.98f) { best = ms; best_nt = nt; best_wm = wm; best_work = std::min(best_work, work); }
                 }
             }
             if (pass == 0) { s.nt = best_nt; s.wm = best_wm; } else { s.nt_full = best_nt; s.wm_full = best_wm; }
