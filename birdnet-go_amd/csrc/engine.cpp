@@ -756,8 +756,10 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                                         f.out = new_val(dout, (size_t)dHo * dWo * Co);
                                         tv[dout] = f.out;
                                         const int Cp = expdw_cp(Co);
-                                        std::vector<float> wep((size_t)Cp * 32, 0.f), bep(Cp, 0.f), wdp((size_t)kd * kd * Cp, 0.f), bdp(Cp, 0.f);
-                                        memcpy(wep.data(), wm.data(), wm.size() * sizeof(float));
+                                        // expand-side weights: the first 24 of the 32 columns of the MFMA stem image (row 2 is the
+                                        // 8-wide half slab of the fused kernel; columns 24..31 are the zero padding of k_stem_mfma)
+                                        std::vector<float> wep((size_t)Cp * 24, 0.f), bep(Cp, 0.f), wdp((size_t)kd * kd * Cp, 0.f), bdp(Cp, 0.f);
+                                        for (int n = 0; n < Co; n++) memcpy(&wep[(size_t)n * 24], &wm[(size_t)n * 32], 24 * sizeof(float));
                                         memcpy(bep.data(), bp.data(), bp.size() * sizeof(float));
                                         const float* dsrc = wd.f32();
                                         for (int t = 0; t < kd * kd; t++) memcpy(&wdp[(size_t)t * Cp], dsrc + (size_t)t * Co, (size_t)Co * sizeof(float));

@@ -1320,7 +1320,7 @@ struct ExpDwParams {
 // (the guide's "operand streamed once per block and not shared -> load straight to VGPRs" case).  Each lane
 // loads its own fragment: pixel li of tile jt, input channels 16*t16 + 4*kq .. +3 (one float4); the K order
 // inside a 16-wide slab is permuted exactly as in k_pw_gemm.  The 32 x K weight panel is tiny and L1/L2 resident.
-// The planner hands over padded parameters (expand weights [Cp][Kw], Kw = Cin rounded up to 16 with zero
+// The planner hands over padded parameters (expand weights [Cp][Kw], Kw = Cin rounded up to 8 with zero
 // columns, Cp = Cmid rounded up to 32; biases and taps padded to Cp) so that every load in the kernel is
 // unconditional: pixels outside the image read a clamped (valid) address and are masked when E is written, the
 // K tail multiplies finite activations by zero weights.  All small parameter loads (biases, taps) are issued at
@@ -1338,7 +1338,7 @@ __device__ const unsigned char kExpDwPerm2[64] = {0, 1, 2, 3, 8, 9, 10, 11, 12, 
 __device__ const unsigned char kExpDwInv2[64] = {0, 1, 2, 3, 12, 13, 14, 15, 4, 5, 6, 7, 8, 9, 10, 11, 32, 33, 34, 35, 44, 45, 46, 47, 36, 37, 38, 39, 40, 41, 42, 43, 20, 21, 22, 23, 24, 25, 26, 27, 16, 17, 18, 19, 28, 29, 30, 31, 52, 53, 54, 55, 56, 57, 58, 59, 48, 49, 50, 51, 60, 61, 62, 63};
 __device__ const unsigned char kExpDwPerm4[64] = {0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 15, 4, 5, 6, 7, 24, 25, 26, 27, 16, 17, 18, 19, 20, 21, 22, 23, 28, 29, 30, 31, 32, 33, 34, 35, 40, 41, 42, 43, 44, 45, 46, 47, 36, 37, 38, 39, 56, 57, 58, 59, 48, 49, 50, 51, 52, 53, 54, 55, 60, 61, 62, 63};
 __device__ const unsigned char kExpDwInv4[64] = {0, 1, 2, 3, 12, 13, 14, 15, 4, 5, 6, 7, 8, 9, 10, 11, 20, 21, 22, 23, 24, 25, 26, 27, 16, 17, 18, 19, 28, 29, 30, 31, 32, 33, 34, 35, 44, 45, 46, 47, 36, 37, 38, 39, 40, 41, 42, 43, 52, 53, 54, 55, 56, 57, 58, 59, 48, 49, 50, 51, 60, 61, 62, 63};
-template <int K, int S, int TOH, int TOW, int TRH, bool STEM = false>
+template <int K, int S, int TOH, int TOW, int TRH, bool STEM = false, bool H8 = STEM>
 __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk) {
     constexpr int TIH = (TOH - 1) * S + K, TIW = (TOW - 1) * S + K;
     static_assert(TRH <= TIH, "TRH is a cap on the footprint rows");
@@ -1440,24 +1440,80 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
             }
         }
     };
-    if (Kw <= 16) {
+    // 8-wide half slab (Kw = 8 mod 16): lane kq holds k = k0 + 2 kq, + 1 - one float2 per operand, two MFMA steps
+    auto fload8 = [&](int k0, f32x2& wh0, f32x2& wh1, f32x2 (&xh)[JTW]) {
+        const float2 t0 = *reinterpret_cast<const float2*>(wrow0 - 2 * kq + k0), t1 = *reinterpret_cast<const float2*>(wrow1 - 2 * kq + k0);
+        wh0 = (f32x2){t0.x, t0.y}; wh1 = (f32x2){t1.x, t1.y};
+        if (STEM) {
+            // window row 2, column kq, both channels
+#pragma unroll
+            for (int a = 0; a < JTW; a++) {
+                const int row = xoff[a] + 2, col = scol[a] - (kq & 1) * 2 + kq;
+                const bool v = row >= 0 && row < p.Hin && col >= 0 && col < p.Win;
+                const float2 u = *reinterpret_cast<const float2*>(xb + ((size_t)min(max(row, 0), p.Hin - 1) * p.Win + min(max(col, 0), p.Win - 1)) * 2);
+                xh[a] = (f32x2){v ? u.x : 0.f, v ? u.y : 0.f};
+            }
+            return;
+        }
+        const int kx = (k0 + 2 * kq + 1 < Cin) ? k0 - 2 * kq : -4 * kq;     // K tail: any in-bounds address (its weights are zero)
+#pragma unroll
+        for (int a = 0; a < JTW; a++) {
+            const float2 t = *reinterpret_cast<const float2*>(p.x + (size_t)xoff[a] + kx);
+            xh[a] = (f32x2){t.x, t.y};
+        }
+    };
+    auto fmma8 = [&](const f32x2& wh0, const f32x2& wh1, const f32x2 (&xh)[JTW]) {
+#pragma unroll
+        for (int a = 0; a < JTW; a++) {
+            if (wave + 4 * a < jtv) {
+#pragma unroll
+                for (int sidx = 0; sidx < 2; sidx++) {
+                    acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh0[sidx], xh[a][sidx], acc[a][0], 0, 0, 0);
+                    acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh1[sidx], xh[a][sidx], acc[a][1], 0, 0, 0);
+                }
+            }
+        }
+    };
+    // H8 (compile time: the half slab costs ~10 VGPRs when it is a run-time option, which drops every shape at 120
+    // VGPRs from four waves per SIMD to three) = Kw is 8 mod 16
+    const int Kfull = Kw & ~15;
+    if (!H8) {
+        if (Kw <= 16) {
+            f32x4 wA0, wA1, xA[JTW];
+            fload(0, wA0, wA1, xA);
+            fmma(wA0, wA1, xA);
+        } else if (Kw <= 32) {
+            // early blocks (Cin 17..32): both K slabs requested back-to-back -> one memory latency instead of two
+            f32x4 wA0, wA1, xA[JTW], wB0, wB1, xB[JTW];
+            fload(0, wA0, wA1, xA);
+            fload(16, wB0, wB1, xB);
+            fmma(wA0, wA1, xA);
+            fmma(wB0, wB1, xB);
+        } else {
+            // (a rolling two-slab register prefetch was measured here: the extra VGPRs cost more occupancy than it buys)
+            for (int k0 = 0; k0 < Kw; k0 += 16) {
+                f32x4 wf0, wf1, xf[JTW];
+                fload(k0, wf0, wf1, xf);
+                fmma(wf0, wf1, xf);
+            }
+        }
+    } else if (Kfull == 16) {
+        // Cin 17..24 (and the stem's 3 x 4 x 2 window): slab + half slab requested back-to-back
         f32x4 wA0, wA1, xA[JTW];
+        f32x2 hA0, hA1, hx[JTW];
         fload(0, wA0, wA1, xA);
+        fload8(16, hA0, hA1, hx);
         fmma(wA0, wA1, xA);
-    } else if (Kw <= 32) {
-        // early blocks (Cin 17..32): both K slabs requested back-to-back -> one memory latency instead of two
-        f32x4 wA0, wA1, xA[JTW], wB0, wB1, xB[JTW];
-        fload(0, wA0, wA1, xA);
-        fload(16, wB0, wB1, xB);
-        fmma(wA0, wA1, xA);
-        fmma(wB0, wB1, xB);
+        fmma8(hA0, hA1, hx);
     } else {
-        // (a rolling two-slab register prefetch was measured here: the extra VGPRs cost more occupancy than it buys)
-        for (int k0 = 0; k0 < Kw; k0 += 16) {
+        for (int k0 = 0; k0 < Kfull; k0 += 16) {
             f32x4 wf0, wf1, xf[JTW];
             fload(k0, wf0, wf1, xf);
             fmma(wf0, wf1, xf);
         }
+        f32x2 hA0, hA1, hx[JTW];
+        fload8(Kfull, hA0, hA1, hx);
+        fmma8(hA0, hA1, hx);
     }
 
     // ---- E <- act_e(acc + be) at compacted footprint coordinates (masked columns are zero)
@@ -1570,7 +1626,9 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
     }
 }
 
-int expdw_kw(int Cin) { return (Cin + 15) / 16 * 16; }
+// K of the expand GEMM as the kernel walks it: 16-wide slabs plus, when Cin <= 8 mod 16, one 8-wide half slab (two MFMA
+// steps instead of four: Cin = 24 / 40 would otherwise spend 25 % / 17 % of their MFMAs on zero columns)
+int expdw_kw(int Cin) { return (Cin & 1) ? (Cin + 15) / 16 * 16 : (Cin + 7) / 8 * 8; }
 int expdw_cp(int Cmid) { return (Cmid + 31) / 32 * 32; }
 // Instantiated tile shapes.  The chooser takes, per layer, the shape that computes the fewest expanded pixels
 // (rows x TIW summed over the tiles of one image; halo recompute and masked padding columns both count) among those
@@ -1649,7 +1707,7 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
                   (Ho + sh->toh - 1) / sh->toh, (Wo + sh->tow - 1) / sh->tow, (Cmid + 31) / 32, expdw_kw(Cin), expdw_cp(Cmid)};
     unsigned nblk = (unsigned)B * p.tiles_h * p.tiles_w * p.cchunks;
     if (stem) {
-        p.Hin = stem->Hin; p.Win = stem->Win; p.pts = stem->pt; p.pls = stem->pl; p.Kw = 32;
+        p.Hin = stem->Hin; p.Win = stem->Win; p.pts = stem->pt; p.pls = stem->pl; p.Kw = 24;    // 3 rows x 4 columns x 2 channels
 #define ED_STEM(TH_, TW_, TR_)                                                                                \
     if (sh->k == 3 && sh->s == 1 && sh->toh == TH_ && sh->tow == TW_ && sh->trh == TR_) {                     \
         hipLaunchKernelGGL((k_expand_dw<3, 1, TH_, TW_, TR_, true>), dim3(nblk), dim3(256), 0, st, p, nblk);  \
@@ -1661,7 +1719,8 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
     }
 #define ED_CASE(K_, S_, TH_, TW_, TR_)                                                                        \
     if (sh->k == K_ && sh->s == S_ && sh->toh == TH_ && sh->tow == TW_ && sh->trh == TR_) {                   \
-        hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_>), dim3(nblk), dim3(256), 0, st, p, nblk);      \
+        if (p.Kw & 8) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        else hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_>), dim3(nblk), dim3(256), 0, st, p, nblk);  \
         return;                                                                                               \
     }
     ED_CASE(3, 1, 8, 16, 10) ED_CASE(3, 1, 4, 16, 6) ED_CASE(3, 1, 8, 32, 6) ED_CASE(3, 1, 8, 32, 10)
