@@ -65,6 +65,17 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// Division of a block-uniform index by a launch constant without the float-reciprocal sequence the compiler emits for
+// "uniform / uniform" (a dozen VALU instructions plus a readfirstlane each - measured as ~35 of the 540-1240 VALU
+// instructions of a k_expand_dw wave): q = (n * M) >> 40 with M = floor(2^40 / d) + 1, exact for n * d < 2^40, evaluated
+// as three scalar multiplies/adds.  n < 2^22.
+struct FDiv { unsigned lo, hi, d; };
+static FDiv make_fdiv(unsigned d) {
+    const unsigned long long M = (1ull << 40) / d + 1;
+    return FDiv{(unsigned)(M & 0xffffffffull), (unsigned)(M >> 32), d};
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FDiv& f) { return (__umulhi(n, f.lo) + n * f.hi) >> 8; }
+
 // ------------------------------------------------------------------------------------------ ingest
 // internal/analysis/process.go:491-495: float32(int16)/32768
 __global__ void k_pcm16_to_f32(const int16_t* __restrict__ pcm, float* __restrict__ out, size_t n) {
@@ -1313,6 +1324,7 @@ struct ExpDwParams {
     // STEM variant: x is the raw [B, Hin, Win, 2] image and the "expand" is the 3x3 stride-2 stem conv seen as an implicit
     // GEMM (K layout of k_stem_mfma); H, W above are then the stem's output size
     int Hin = 0, Win = 0, pts = 0, pls = 0;
+    FDiv d_bpc{}, d_cch{}, d_tw{};      // blocks per clip, channel chunks, tiles per row (set by the launcher)
 };
 #define ED_ES 36     // E row stride (floats)
 // Phase 1 feeds the MFMA straight from global memory: every footprint pixel row belongs to exactly one wave
@@ -1356,9 +1368,10 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
     const unsigned L = xcd_remap(blockIdx.x, nblk);
     const int tiles = p.tiles_h * p.tiles_w;
     const int bpc = tiles * p.cchunks;
-    const int b = L / bpc, rest = L % bpc;
-    const int tile = rest / p.cchunks, cc = rest % p.cchunks;
-    const int oh0 = (tile / p.tiles_w) * TOH, ow0 = (tile % p.tiles_w) * TOW;
+    const int b = (int)fdiv(L, p.d_bpc), rest = (int)L - b * bpc;
+    const int tile = (int)fdiv((unsigned)rest, p.d_cch), cc = rest - tile * p.cchunks;
+    const int trow = (int)fdiv((unsigned)tile, p.d_tw);
+    const int oh0 = trow * TOH, ow0 = (tile - trow * p.tiles_w) * TOW;
     const int ih0 = oh0 * S - p.pt, iw0 = ow0 * S - p.pl;
     // footprint rows are compacted to the in-image range [vr0, vr1) (host guarantees vr1 - vr0 <= TRH); columns keep
     // the compile-time width TIW (out-of-image columns are masked): GEMM row j <-> footprint pixel
@@ -1706,6 +1719,9 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
     ExpDwParams p{x, we, be, wd, bd, y, partial, B, H, W, Cin, Cmid, Ho, Wo, pt, pl, act_e, act_d,
                   (Ho + sh->toh - 1) / sh->toh, (Wo + sh->tow - 1) / sh->tow, (Cmid + 31) / 32, expdw_kw(Cin), expdw_cp(Cmid)};
     unsigned nblk = (unsigned)B * p.tiles_h * p.tiles_w * p.cchunks;
+    p.d_bpc = make_fdiv((unsigned)(p.tiles_h * p.tiles_w * p.cchunks));
+    p.d_cch = make_fdiv((unsigned)p.cchunks);
+    p.d_tw = make_fdiv((unsigned)p.tiles_w);
     if (stem) {
         p.Hin = stem->Hin; p.Win = stem->Win; p.pts = stem->pt; p.pls = stem->pl; p.Kw = 24;    // 3 rows x 4 columns x 2 channels
 #define ED_STEM(TH_, TW_, TR_)                                                                                \
