@@ -775,7 +775,7 @@ __device__ long long* g_pw_trace = nullptr;      // [64 blocks][4 waves][PW_TRAC
 #define PW_T(i) do { } while (0)
 #endif
 template <int NT, bool SC, int WM>
-__global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigned nblk) {
+__global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigned nblk, FDiv dn, FDiv dhw) {
     constexpr int BM = 64 * WM;                  // rows per block: 4 waves x (16*WM) rows
     constexpr int XQ = BM * PW_C4 / 256;         // float4 per thread for the activation tile
     // operand tiles (the epilogue re-uses the array as per-wave output staging).  SC: squeeze-excite scale on A.
@@ -787,8 +787,9 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
     const int li = lane & 15, kq = lane >> 4;
     // XCD-aware order: N-blocks fastest so the blocks that share an activation tile sit on one XCD's L2
     const unsigned L = xcd_remap(blockIdx.x, nblk);
-    const int m0 = (int)(L / nblk_n) * BM;
-    const int n0 = (int)(L % nblk_n) * (NT * 16);
+    const int mblk = (int)fdiv(L, dn);
+    const int m0 = mblk * BM;
+    const int n0 = ((int)L - mblk * nblk_n) * (NT * 16);
     const int K = p.K;
 
     float4 xreg[XQ], wreg[WQ], sreg[SC ? XQ : 1];
@@ -797,7 +798,7 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
 #pragma unroll
         for (int q = 0; q < XQ; q++) {
             int m = m0 + ((tid + 256 * q) / PW_C4);
-            srow[SC ? q : 0] = (m < p.M ? m : 0) / p.HW;
+            srow[SC ? q : 0] = (int)fdiv((unsigned)(m < p.M ? m : 0), dhw);
         }
     }
     // all global loads of a slab are issued back-to-back (scale included); the multiply happens at LDS-store time
@@ -911,7 +912,7 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
 // second half (sched_group_barrier), one barrier per slab.  All per-slab address arithmetic is gone: loads use per-thread
 // offsets computed once (rows clamped into range: out-of-range rows produce values the epilogue never stores) plus k0.
 template <int NT, bool SC, int WM>
-__global__ __launch_bounds__(256) void k_pw_pipe(PwParams p, int nblk_n, unsigned nblk) {
+__global__ __launch_bounds__(256) void k_pw_pipe(PwParams p, int nblk_n, unsigned nblk, FDiv dn, FDiv dhw) {
     constexpr int BM = 64 * WM;
     constexpr int XQ = BM * PW_C4 / 256, WQ = (NT * 16 * PW_C4 + 255) / 256;
     constexpr int TILE = (BM + NT * 16) * PW_LS;
@@ -919,8 +920,9 @@ __global__ __launch_bounds__(256) void k_pw_pipe(PwParams p, int nblk_n, unsigne
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const unsigned L = xcd_remap(blockIdx.x, nblk);
-    const int m0 = (int)(L / nblk_n) * BM;
-    const int n0 = (int)(L % nblk_n) * (NT * 16);
+    const int mblk = (int)fdiv(L, dn);
+    const int m0 = mblk * BM;
+    const int n0 = ((int)L - mblk * nblk_n) * (NT * 16);
     const int K = p.K;
 
     unsigned xoff[XQ], soff[SC ? XQ : 1], woff[WQ];
@@ -932,7 +934,7 @@ __global__ __launch_bounds__(256) void k_pw_pipe(PwParams p, int nblk_n, unsigne
         const int idx = tid + 256 * q, row = idx / PW_C4, c4 = idx % PW_C4;
         const int m = min(m0 + row, p.M - 1);
         xoff[q] = (unsigned)m * (unsigned)K + 4 * c4;
-        if (SC) soff[SC ? q : 0] = (unsigned)(m / p.HW) * (unsigned)K + 4 * c4;
+        if (SC) soff[SC ? q : 0] = fdiv((unsigned)m, dhw) * (unsigned)K + 4 * c4;
     }
 #pragma unroll
     for (int q = 0; q < WQ; q++) {
@@ -1093,11 +1095,12 @@ void launch_pw_gemm(const PwParams& p, hipStream_t s) {
         nblk = (unsigned)((p.M + bm - 1) / bm) * nblk_n;
     }
     dim3 grid(nblk);
+    const FDiv dn = make_fdiv((unsigned)nblk_n), dhw = make_fdiv((unsigned)std::max(p.HW, 1));
     const bool sc = p.ascale != nullptr;
-#define PW_LAUNCH(NT_, SC_, WM_) hipLaunchKernelGGL((k_pw_gemm<NT_, SC_, WM_>), grid, dim3(256), 0, s, p, nblk_n, nblk)
+#define PW_LAUNCH(NT_, SC_, WM_) hipLaunchKernelGGL((k_pw_gemm<NT_, SC_, WM_>), grid, dim3(256), 0, s, p, nblk_n, nblk, dn, dhw)
 #define PW_CASE(NT_) case NT_: if (sc) { if (wm == 1) PW_LAUNCH(NT_, true, 1); else PW_LAUNCH(NT_, true, 2); } \
                      else { if (wm == 1) PW_LAUNCH(NT_, false, 1); else PW_LAUNCH(NT_, false, 2); } break;
-#define PP_LAUNCH(NT_, SC_, WM_) hipLaunchKernelGGL((k_pw_pipe<NT_, SC_, WM_>), grid, dim3(256), 0, s, p, nblk_n, nblk)
+#define PP_LAUNCH(NT_, SC_, WM_) hipLaunchKernelGGL((k_pw_pipe<NT_, SC_, WM_>), grid, dim3(256), 0, s, p, nblk_n, nblk, dn, dhw)
 #define PP_CASE(NT_) case NT_: if (sc) { if (wm == 1) PP_LAUNCH(NT_, true, 1); else PP_LAUNCH(NT_, true, 2); } \
                      else { if (wm == 1) PP_LAUNCH(NT_, false, 1); else PP_LAUNCH(NT_, false, 2); } break;
     if (pipe) {
