@@ -1348,11 +1348,17 @@ struct ExpDwParams {
 // lanes cover 16 distinct 16-byte slots of a 256-byte row.  With the E row stride of 36 floats the slot of a lane is
 // (a * tx + c4) mod 16, a = SW * S (2 or 4 for every instantiated shape); the natural lane = tx * 8 + c4 order put three
 // lanes of a group on one slot (PMC: up to 25 % of CU cycles in LDS bank conflicts).  These permutations give each group
-// two tx values whose slot ranges are disjoint; kExpDwInv* are the inverse maps (for the cross-lane sum).
-__device__ const unsigned char kExpDwPerm2[64] = {0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 15, 4, 5, 6, 7, 40, 41, 42, 43, 32, 33, 34, 35, 36, 37, 38, 39, 44, 45, 46, 47, 16, 17, 18, 19, 24, 25, 26, 27, 28, 29, 30, 31, 20, 21, 22, 23, 56, 57, 58, 59, 48, 49, 50, 51, 52, 53, 54, 55, 60, 61, 62, 63};
-__device__ const unsigned char kExpDwInv2[64] = {0, 1, 2, 3, 12, 13, 14, 15, 4, 5, 6, 7, 8, 9, 10, 11, 32, 33, 34, 35, 44, 45, 46, 47, 36, 37, 38, 39, 40, 41, 42, 43, 20, 21, 22, 23, 24, 25, 26, 27, 16, 17, 18, 19, 28, 29, 30, 31, 52, 53, 54, 55, 56, 57, 58, 59, 48, 49, 50, 51, 60, 61, 62, 63};
-__device__ const unsigned char kExpDwPerm4[64] = {0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 15, 4, 5, 6, 7, 24, 25, 26, 27, 16, 17, 18, 19, 20, 21, 22, 23, 28, 29, 30, 31, 32, 33, 34, 35, 40, 41, 42, 43, 44, 45, 46, 47, 36, 37, 38, 39, 56, 57, 58, 59, 48, 49, 50, 51, 52, 53, 54, 55, 60, 61, 62, 63};
-__device__ const unsigned char kExpDwInv4[64] = {0, 1, 2, 3, 12, 13, 14, 15, 4, 5, 6, 7, 8, 9, 10, 11, 20, 21, 22, 23, 24, 25, 26, 27, 16, 17, 18, 19, 28, 29, 30, 31, 32, 33, 34, 35, 44, 45, 46, 47, 36, 37, 38, 39, 40, 41, 42, 43, 52, 53, 54, 55, 56, 57, 58, 59, 48, 49, 50, 51, 60, 61, 62, 63};
+// two tx values whose slot ranges are disjoint; ED_INV* are the inverse maps (for the cross-lane sum).
+// Every group of four lanes moves as a unit, so a permutation is 16 nibbles (lane group -> lane group) in one 64-bit
+// constant, decoded with a shift and a mask - a table in memory cost every block a dependent global load right before its
+// first operand loads.
+#define ED_PERM2 0xfdce5764b98a1320ull
+#define ED_INV2 0xfced7465a9b82130ull
+#define ED_PERM4 0xfdce9ba875461320ull
+#define ED_INV4 0xfceda9b874652130ull
+__device__ __forceinline__ int ed_perm(unsigned long long magic, int lane) {
+    return (int)((magic >> ((lane >> 2) * 4)) & 15ull) * 4 + (lane & 3);
+}
 template <int K, int S, int TOH, int TOW, int TRH, bool STEM = false, bool H8 = STEM>
 __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk) {
     constexpr int TIH = (TOH - 1) * S + K, TIW = (TOW - 1) * S + K;
@@ -1387,9 +1393,8 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
 
     // ---- small parameters first (registers; the taps go to LDS after phase 1)
     static_assert(SW * S == 2 || SW * S == 4, "lane permutation tables cover SW*S in {2, 4}");
-    const unsigned char* perm = SW * S == 2 ? kExpDwPerm2 : kExpDwPerm4;
-    const unsigned char* iperm = SW * S == 2 ? kExpDwInv2 : kExpDwInv4;
-    const int pl = perm[lane];                           // logical lane: tx * 8 + c4
+    constexpr unsigned long long PERM = SW * S == 2 ? ED_PERM2 : ED_PERM4, IPERM = SW * S == 2 ? ED_INV2 : ED_INV4;
+    const int pl = ed_perm(PERM, lane);                  // logical lane: tx * 8 + c4
     const int c4 = pl & 7, tt = (wave << 3) | (pl >> 3);
     float4 wdreg = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < K * K * 8) wdreg = *reinterpret_cast<const float4*>(p.wd + (size_t)(tid >> 3) * p.Cp + n_base + 4 * (tid & 7));
@@ -1627,7 +1632,7 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
         // lanes with equal (lane & 7) hold the same channel quad: butterfly over the other lane bits, then 4 waves
 #pragma unroll
         for (int o = 8; o < 64; o <<= 1) {
-            const int src = iperm[pl ^ o];               // physical lane of the logical partner
+            const int src = ed_perm(IPERM, pl ^ o);      // physical lane of the logical partner
             sum.x += __shfl(sum.x, src, 64); sum.y += __shfl(sum.y, src, 64);
             sum.z += __shfl(sum.z, src, 64); sum.w += __shfl(sum.w, src, 64);
         }
