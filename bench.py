@@ -224,6 +224,10 @@ def main():
     clf.synchronize()
     torch.cuda.synchronize(dev)
     consist = float((logits[:8] - small).abs().max().item())
+    # different tiles only reorder fp32 sums (1e-5 on logits of magnitude ~10); anything larger is a wrong kernel, and a
+    # throughput measured with a wrong kernel is not a result (this check caught an LDS staging overflow in round 1)
+    if not (consist <= 1e-3):
+        print(f"[bench] CONSISTENCY CHECK FAILED: full-batch logits differ from the small-batch path by {consist}", file=sys.stderr)
     if rank == 0:
         total_clips = B * world * args.steps
         out = {
@@ -237,7 +241,7 @@ def main():
                        "batch_per_gpu": B, "n_samples": cfg.n_samples, "n_classes": clf.num_species(),
                        "sharding": f"clips index-contiguous over {world} rank(s); weights broadcast once",
                        "pipeline_depth": depth},
-            "finite_outputs": ok, "max_abs_logit_diff_vs_small_batch": consist,
+            "finite_outputs": ok, "max_abs_logit_diff_vs_small_batch": consist, "consistent": bool(consist <= 1e-3),
         }
         if prof:
             prof = sorted(prof, key=lambda r: -r["ms"])

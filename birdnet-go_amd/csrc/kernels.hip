@@ -781,7 +781,12 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
     // operand tiles (the epilogue re-uses the array as per-wave output staging).  SC: squeeze-excite scale on A.
     constexpr bool DB = false;   // double-buffering measured neutral on this chip for these shapes; kept for experiments
     constexpr int TILE = (BM + NT * 16) * PW_LS;
-    __shared__ __attribute__((aligned(16))) float lds[(DB ? 2 : 1) * TILE];
+    // the epilogue stages 4 waves x 16 rows x (16 NT + 4) floats through the same array: with 64-row tiles and NT >= 7
+    // that is MORE than the operand tile (found by bench.py's batch-vs-small-batch check when the work-based tuner first
+    // picked <7, *, 1>: rows of neighbouring waves overwrote each other)
+    constexpr int STG = 4 * 16 * (NT * 16 + 4);
+    constexpr int LDSN = (DB ? 2 : 1) * TILE > STG ? (DB ? 2 : 1) * TILE : STG;
+    __shared__ __attribute__((aligned(16))) float lds[LDSN];
     constexpr int WQ = (NT * 16 * PW_C4 + 255) / 256;   // float4 per thread for the W tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
@@ -1089,7 +1094,8 @@ void launch_pw_gemm(const PwParams& p, hipStream_t s) {
     unsigned nblk = (unsigned)((p.M + bm - 1) / bm) * nblk_n;
     // the tile was tuned at batch size; a call with a handful of clips would leave most CUs idle with it (one clip:
     // 1-5 workgroups each walking the whole K loop): fall back to the smallest tile to get workgroups
-    if (nblk < 64 && (nt > 1 || wm > 1)) {
+    static const bool forced = getenv("BNHIP_PW_NT") != nullptr || getenv("BNHIP_PW_WM") != nullptr;   // tests pin the tile
+    if (nblk < 64 && (nt > 1 || wm > 1) && !forced) {
         nt = 1; wm = 1; bm = 64; pipe = false;
         nblk_n = (p.N + 15) / 16;
         nblk = (unsigned)((p.M + bm - 1) / bm) * nblk_n;
