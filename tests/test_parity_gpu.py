@@ -132,6 +132,28 @@ def test_pipeline_depth_gives_identical_results(full_blob):
         x.free(); ref.free(); out.free()
 
 
+def test_pipelined_engine_tiles_at_batch_size(full_blob):
+    """A depth-2 engine tunes its pointwise tiles by least padded work (exact 80- / 112-column tiles ...), a choice no
+    serial engine makes and one that only materialises at a batch large enough to fill the GPU: 64 clips through such an
+    engine must match a serial engine's logits (other tiles = another summation order) and the oracle.  (Which tiles win
+    depends on the box; test_pw_gemm_kernel_variants_agree pins each of them explicitly.)"""
+    xh = sm.synth_clips(64, 144000, 48000)
+    a = host.HipClassifier(full_blob, max_batch=64)
+    b = host.HipClassifier(full_blob, max_batch=64, depth=2, lanes=1)
+    x, out = _DevBuf(xh.nbytes), _DevBuf(64 * 6522 * 4)
+    try:
+        x.upload(xh)
+        a.predict_device(x.at(0), 64, out.at(0)); a.synchronize()
+        ra = out.download((64, 6522)).copy()
+        b.predict_device(x.at(0), 64, out.at(0)); b.synchronize()
+        rb = out.download((64, 6522)).copy()
+        assert np.isfinite(rb).all() and np.abs(ra - rb).max() < 1e-4
+        assert_parity(rb[:3], Interpreter(full_blob).invoke(xh[:3])[0])
+    finally:
+        a.close(); b.close()
+        x.free(); out.free()
+
+
 # ---- geometry sweep: spectrogram sizes, kernel sizes, strides and widths the v2.4 topology does not have, so that every
 # tile-shape / halo / padding-row / ragged-edge branch of the fused kernels meets the oracle at least once
 def _geo_cfg(i):
