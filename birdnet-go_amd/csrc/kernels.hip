@@ -67,14 +67,17 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
 
 // Division of a block-uniform index by a launch constant without the float-reciprocal sequence the compiler emits for
 // "uniform / uniform" (a dozen VALU instructions plus a readfirstlane each - measured as ~35 of the 540-1240 VALU
-// instructions of a k_expand_dw wave): q = (n * M) >> 40 with M = floor(2^40 / d) + 1, exact for n * d < 2^40, evaluated
-// as three scalar multiplies/adds.  n < 2^22.
+// instructions of a k_expand_dw wave): q = (n * M) >> 40 with M = floor(2^40 / d) + 1, exact for n * d < 2^40 (block and
+// row indices times tile / pixel counts: < 2^38 at batch 2048), evaluated as a few scalar multiplies/adds on the 41-bit M
+// split into lo (32 bits) and hi (<= 256).
 struct FDiv { unsigned lo, hi, d; };
 static FDiv make_fdiv(unsigned d) {
     const unsigned long long M = (1ull << 40) / d + 1;
     return FDiv{(unsigned)(M & 0xffffffffull), (unsigned)(M >> 32), d};
 }
-__device__ __forceinline__ unsigned fdiv(unsigned n, const FDiv& f) { return (__umulhi(n, f.lo) + n * f.hi) >> 8; }
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FDiv& f) {
+    return (unsigned)(((unsigned long long)n * f.hi + __umulhi(n, f.lo)) >> 8);      // 64-bit sum: any 32-bit n
+}
 
 // ------------------------------------------------------------------------------------------ ingest
 // internal/analysis/process.go:491-495: float32(int16)/32768
