@@ -1023,6 +1023,15 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
     // time, and values that reuse each other's memory have different per-clip sizes, so addressing lanes as clip offsets
     // into ONE liveness-reused layout lets lane 0's step-k output overwrite lane 1's still-live step-j input: each lane
     // gets its own copy of the (smaller) lane layout instead.
+    // the kernels index activations with 32-bit element offsets (batch x per-clip elements): refuse a max_batch that a
+    // tensor of this model would overflow rather than compute with wrapped addresses
+    for (const Value& v : vals)
+        if (v.elems * (size_t)max_batch >= ((size_t)1 << 31)) {
+            *err = "max_batch too large for this model: a " + std::to_string(v.elems) + "-element activation times " +
+                   std::to_string(max_batch) + " clips exceeds 32-bit indexing";
+            *code = BNHIP_E_INVALID;
+            return false;
+        }
     auto plan_arena = [&](size_t cap, bool lane_plan) -> size_t {
         struct Block { size_t off, size; };
         std::vector<Block> free_list;
