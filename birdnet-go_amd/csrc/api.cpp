@@ -1,23 +1,30 @@
 // C ABI of libbnhip.so (see include/bnhip.h for the reference interfaces each entry point replaces).
+//
+// Every extern "C" entry point is exception-tight: the engine is C++ (std::vector / std::map / std::string), and an
+// exception unwinding through a cgo frame aborts the host process, which would break the reference's rule for native
+// backends - "never panic; any failure => fall back" (internal/classifier/model_openvino.go:227-230).  BN_GUARD turns
+// std::bad_alloc into BNHIP_E_NOMEM and anything else into BNHIP_E_RUNTIME.
 #include "../../include/bnhip.h"
 
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
-#include <vector>
+#include <thread>
 #include <utility>
+#include <vector>
 
 #include "engine.h"
+#include "model_onnx.h"
 #include "tflite_model.h"
 
 using namespace bnhip;
-
-struct bnhip_model {
-    Engine eng;
-};
 
 namespace {
 
@@ -25,10 +32,17 @@ thread_local std::string g_err;
 std::mutex g_init_mu;
 int g_devices = -1;     // -1 = not initialised
 
-int set_err(int code, const std::string& msg) {
-    g_err = msg;
+int set_err(int code, const std::string& msg) noexcept {
+    try { g_err = msg; } catch (...) { g_err.clear(); }
     return code;
 }
+
+#define BN_GUARD_BEGIN try {
+#define BN_GUARD_END(fallback_stmt)                                                                   \
+    }                                                                                                 \
+    catch (const std::bad_alloc&) { fallback_stmt; return set_err(BNHIP_E_NOMEM, "out of host memory"); }                 \
+    catch (const std::exception& ex_) { fallback_stmt; return set_err(BNHIP_E_RUNTIME, std::string("internal error: ") + ex_.what()); } \
+    catch (...) { fallback_stmt; return set_err(BNHIP_E_RUNTIME, "internal error: unknown exception"); }
 
 // tiny extractor for {"key": <int>} options; absent -> def
 long json_int(const char* js, const char* key, long def) {
@@ -42,6 +56,39 @@ long json_int(const char* js, const char* key, long def) {
     long v = strtol(p, &end, 10);
     return end == p ? def : v;
 }
+// {"key": [i, j, ...]} -> values; absent or malformed -> empty
+std::vector<int> json_int_array(const char* js, const char* key) {
+    std::vector<int> v;
+    if (!js) return v;
+    std::string pat = std::string("\"") + key + "\"";
+    const char* p = strstr(js, pat.c_str());
+    if (!p) return v;
+    p += pat.size();
+    while (*p == ' ' || *p == ':' || *p == '\t') p++;
+    if (*p != '[') return v;
+    p++;
+    while (*p && *p != ']') {
+        char* end = nullptr;
+        long x = strtol(p, &end, 10);
+        if (end == p) { v.clear(); return v; }
+        v.push_back((int)x);
+        p = end;
+        while (*p == ' ' || *p == ',' || *p == '\t') p++;
+    }
+    return v;
+}
+// {"key": "text"} -> text; absent -> def
+std::string json_str(const char* js, const char* key, const char* def) {
+    if (!js) return def;
+    std::string pat = std::string("\"") + key + "\"";
+    const char* p = strstr(js, pat.c_str());
+    if (!p) return def;
+    p += pat.size();
+    while (*p == ' ' || *p == ':' || *p == '\t') p++;
+    if (*p != '"') return def;
+    const char* q = strchr(p + 1, '"');
+    return q ? std::string(p + 1, q) : std::string(def);
+}
 
 bool is_gfx950(int dev) {
     hipDeviceProp_t prop;
@@ -49,147 +96,190 @@ bool is_gfx950(int dev) {
     return strncmp(prop.gcnArchName, "gfx950", 6) == 0;
 }
 
+// One worker thread per engine of a multi-device handle: the thread owns its device's HIP context binding
+// (hipSetDevice is thread-local), runs one job at a time, never lets an exception escape.
+struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int(std::string&)> job;
+    bool pending = false, stop = false;
+    int rc = 0;
+    std::string err;
+
+    void start(int device) {
+        th = std::thread([this, device] {
+            hipSetDevice(device);
+            std::unique_lock<std::mutex> lk(mu);
+            for (;;) {
+                cv.wait(lk, [this] { return pending || stop; });
+                if (stop) return;
+                std::function<int(std::string&)> j = std::move(job);
+                lk.unlock();
+                int r; std::string e;
+                try { r = j(e); }
+                catch (const std::bad_alloc&) { r = BNHIP_E_NOMEM; e = "out of host memory"; }
+                catch (const std::exception& ex) { r = BNHIP_E_RUNTIME; try { e = std::string("internal error: ") + ex.what(); } catch (...) {} }
+                catch (...) { r = BNHIP_E_RUNTIME; }
+                lk.lock();
+                rc = r; err.swap(e); pending = false;
+                cv.notify_all();
+            }
+        });
+    }
+    void submit(std::function<int(std::string&)> j) {
+        std::lock_guard<std::mutex> lk(mu);
+        job = std::move(j); pending = true; rc = 0; err.clear();
+        cv.notify_all();
+    }
+    int wait(std::string* e) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return !pending; });
+        if (rc && e && e->empty()) *e = err;
+        return rc;
+    }
+    ~Worker() {
+        if (th.joinable()) {
+            { std::lock_guard<std::mutex> lk(mu); stop = true; cv.notify_all(); }
+            th.join();
+        }
+    }
+};
+
 }  // namespace
+
+// A handle owns one engine per device of its "devices" list (one for the plain "device" form).  Clips of a call are
+// sharded index-contiguously over the engines (independent clips, no exchange step).
+struct bnhip_model {
+    std::vector<std::unique_ptr<Engine>> engs;
+    std::vector<std::unique_ptr<Worker>> workers;      // parallel to engs when engs.size() > 1
+    std::string replication = "host-upload";           // how engines 1.. got their weights: "rccl-broadcast" | "peer-copy"
+    Engine& eng() { return *engs[0]; }
+    const Engine& eng() const { return *engs[0]; }
+};
 
 namespace bnhip {
 void resample_design(int L, int M, double beta, int half_factor, std::vector<float>* table, int* T_out, int* half_out);
-int launch_resample(const void* d_in, void* d_out, const float* d_table, bool pcm16, int n_clips, int n_in, int n_out, int L,
-                    int M, int T, int half, hipStream_t s);
+int launch_resample(const void* d_in, void* d_out, const float* d_table, int in_pcm16, int out_pcm16, int n_clips, int n_in,
+                    int n_out, int L, int M, int T, int half, long long i_base, long long n_base, hipStream_t s);
 }
 
-extern "C" {
+namespace {
 
-const char* bnhip_version(void) { return "bnhip 0.1 (gfx950)"; }
-const char* bnhip_last_error(void) { return g_err.c_str(); }
-
-int bnhip_init(int* n_devices) {
-    std::lock_guard<std::mutex> lk(g_init_mu);
-    if (g_devices < 0) {
-        int n = 0;
-        hipError_t e = hipGetDeviceCount(&n);
-        if (e != hipSuccess || n <= 0) {
-            (void)hipGetLastError();
-            if (n_devices) *n_devices = 0;
-            return set_err(BNHIP_E_NO_DEVICE, std::string("no HIP device available: ") + hipGetErrorString(e));
+// ---------------------------------------------------------------------------------------------- RCCL (optional, dlopen'd)
+// Weights of a multi-device handle are uploaded to the first device only and replicated device-to-device: RCCL
+// ncclBroadcast over xGMI when librccl is loadable and the devices are distinct, hipMemcpyPeer otherwise.  The library is
+// resolved at run time so libbnhip.so itself links against nothing but the HIP runtime.
+struct Rccl {
+    void* h = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool load() {
+        if (h) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
         }
-        int usable = 0;
-        for (int d = 0; d < n; d++) if (is_gfx950(d)) usable++;
-        if (!usable) {
-            if (n_devices) *n_devices = 0;
-            return set_err(BNHIP_E_NO_DEVICE, "no gfx950 (MI355X) device found; this library ships gfx950 code objects only");
+        if (!h) return false;
+        *(void**)&CommInitAll = dlsym(h, "ncclCommInitAll");
+        *(void**)&CommDestroy = dlsym(h, "ncclCommDestroy");
+        *(void**)&GroupStart = dlsym(h, "ncclGroupStart");
+        *(void**)&GroupEnd = dlsym(h, "ncclGroupEnd");
+        *(void**)&Broadcast = dlsym(h, "ncclBroadcast");
+        *(void**)&GetErrorString = dlsym(h, "ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Broadcast) { dlclose(h); h = nullptr; return false; }
+        return true;
+    }
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+
+// returns "" on success (and sets *how), else an error text
+std::string replicate_weights(bnhip_model* m, const std::string& mode, std::string* how) {
+    const int n = (int)m->engs.size();
+    Engine& root = *m->engs[0];
+    const size_t bytes = root.weights_bytes();
+    bool distinct = true;
+    for (int i = 0; i < n; i++)
+        for (int j = i + 1; j < n; j++) if (m->engs[i]->device == m->engs[j]->device) distinct = false;
+    bool want_rccl = mode == "rccl" || (mode == "auto" && distinct && n > 1);
+    if (want_rccl && !distinct) return "replicate=rccl needs distinct devices";
+    if (want_rccl) {
+        std::lock_guard<std::mutex> lk(g_rccl_mu);
+        if (!g_rccl.load()) {
+            if (mode == "rccl") return "replicate=rccl requested but librccl could not be loaded";
+            want_rccl = false;
+        } else {
+            std::vector<int> devs(n);
+            for (int i = 0; i < n; i++) devs[i] = m->engs[i]->device;
+            std::vector<void*> comms(n, nullptr);
+            int rc = g_rccl.CommInitAll(comms.data(), n, devs.data());
+            if (rc == 0) {
+                rc = g_rccl.GroupStart();
+                for (int i = 0; i < n && rc == 0; i++) {
+                    hipSetDevice(devs[i]);
+                    // count in 4-byte words (ncclFloat32 == 7); root sends in place
+                    rc = g_rccl.Broadcast(root.weights_ptr(), m->engs[i]->weights_ptr(), (bytes + 3) / 4, 7, 0, comms[i],
+                                          m->engs[i]->stream);
+                }
+                int rc2 = g_rccl.GroupEnd();
+                if (rc == 0) rc = rc2;
+                for (int i = 0; i < n; i++) { hipSetDevice(devs[i]); hipStreamSynchronize(m->engs[i]->stream); }
+                for (int i = 0; i < n; i++) if (comms[i]) g_rccl.CommDestroy(comms[i]);
+            }
+            hipSetDevice(devs[0]);
+            if (rc == 0) { *how = "rccl-broadcast"; return ""; }
+            if (mode == "rccl")
+                return std::string("RCCL broadcast failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+            want_rccl = false;          // auto: fall through to peer copies
         }
-        g_devices = n;
     }
-    if (n_devices) *n_devices = g_devices;
-    return BNHIP_OK;
+    for (int i = 1; i < n; i++) {
+        Engine& e = *m->engs[i];
+        hipError_t he;
+        if (e.device == root.device) he = hipMemcpy(e.weights_ptr(), root.weights_ptr(), bytes, hipMemcpyDeviceToDevice);
+        else he = hipMemcpyPeer(e.weights_ptr(), e.device, root.weights_ptr(), root.device, bytes);
+        if (he != hipSuccess) return std::string("weight peer copy failed: ") + hipGetErrorString(he);
+    }
+    hipSetDevice(root.device);
+    *how = n > 1 ? "peer-copy" : "host-upload";
+    return "";
 }
 
-void bnhip_shutdown(void) {
-    std::lock_guard<std::mutex> lk(g_init_mu);
-    g_devices = -1;
-}
-
-int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, bnhip_model** out) {
-    if (!out) return set_err(BNHIP_E_INVALID, "out is NULL");
-    *out = nullptr;
-    if (!blob || n_bytes == 0) return set_err(BNHIP_E_INVALID, "empty model blob");
-    // "plan_only": parse + plan on the CPU, no device touched (diagnostics / CPU-side tests); such a
-    // model answers info/describe and rejects predict calls.
-    const bool plan_only = json_int(opts_json, "plan_only", 0) != 0;
-    int device = (int)json_int(opts_json, "device", 0);
-    int max_batch = (int)json_int(opts_json, "max_batch", 256);
-    if (max_batch < 1 || max_batch > 4096) return set_err(BNHIP_E_INVALID, "max_batch must be in [1, 4096]");
-    if (!plan_only) {
-        int rc = bnhip_init(nullptr);
-        if (rc != BNHIP_OK) return rc;
-        if (device < 0 || device >= g_devices) return set_err(BNHIP_E_INVALID, "device ordinal out of range");
-        if (!is_gfx950(device)) return set_err(BNHIP_E_NO_DEVICE, "selected device is not gfx950");
-    }
-
-    TflModel tm;
+// runs f(engine, first_clip, clip_count, err) -> rc for every shard of [0, n_clips); multi-device handles run the shards
+// concurrently on their worker threads
+template <class F>
+int shard_run(bnhip_model* m, int n_clips, F f) {
+    const int n = (int)m->engs.size();
     std::string err;
-    if (!parse_tflite(blob, n_bytes, &tm, &err)) return set_err(BNHIP_E_MODEL, err);
-    bnhip_model* m = new (std::nothrow) bnhip_model();
-    if (!m) return set_err(BNHIP_E_NOMEM, "out of host memory");
-    int code = BNHIP_E_UNSUPPORTED;
-    m->eng.no_reuse = json_int(opts_json, "debug_no_reuse", 0) != 0;
-    m->eng.autotune = json_int(opts_json, "autotune", 1) != 0;
-    const char* lenv = getenv("BNHIP_LANES");            // experiment switch; the option wins when given
-    m->eng.n_lanes = json_int(opts_json, "lanes", lenv ? atoi(lenv) : 2);
-    const char* denv = getenv("BNHIP_DEPTH");            // experiment switch; the option wins when given
-    m->eng.depth = json_int(opts_json, "depth", denv ? atoi(denv) : 1);
-    const char* fenv = getenv("BNHIP_FE_FFT");           // experiment switch; the option wins when given
-    m->eng.frontend_fft = json_int(opts_json, "frontend_fft", fenv ? atoi(fenv) : -1);
-    const char* genv = getenv("BNHIP_GRAPHS");           // experiment switch; the option wins when given
-    m->eng.use_graphs = json_int(opts_json, "graphs", genv ? atoi(genv) : 0) != 0;
-    if (!m->eng.build(std::move(tm), device, max_batch, plan_only, &err, &code)) {
-        delete m;
-        return set_err(code == BNHIP_OK ? BNHIP_E_UNSUPPORTED : code, err);
+    if (n == 1) {
+        int rc = f(*m->engs[0], 0, n_clips, err);
+        return rc ? set_err(rc, err) : BNHIP_OK;
     }
-    *out = m;
-    return BNHIP_OK;
-}
-
-int bnhip_model_info(const bnhip_model* m, int* n_samples, int* n_classes, int* emb_dim) {
-    if (!m) return set_err(BNHIP_E_INVALID, "model is NULL");
-    if (n_samples) *n_samples = m->eng.n_samples;
-    if (n_classes) *n_classes = m->eng.n_classes;
-    if (emb_dim) *emb_dim = m->eng.emb_dim;
-    return BNHIP_OK;
-}
-
-void bnhip_model_destroy(bnhip_model* m) {
-    if (!m) return;
-    if (m->eng.device >= 0) hipSetDevice(m->eng.device);
-    delete m;
-}
-
-int bnhip_set_stream(bnhip_model* m, void* hip_stream) {
-    if (!m || m->eng.device < 0) return set_err(BNHIP_E_INVALID, "model is NULL or plan-only");
-    Engine& e = m->eng;
-    hipSetDevice(e.device);
-    e.drop_graphs();                                    // captured on the old stream
-    e.sync_contexts();
-    if (e.own_stream && e.stream) { hipStreamSynchronize(e.stream); hipStreamDestroy(e.stream); }
-    e.stream = reinterpret_cast<hipStream_t>(hip_stream);
-    e.own_stream = false;
-    return BNHIP_OK;
-}
-
-int bnhip_synchronize(bnhip_model* m) {
-    if (!m || m->eng.device < 0) return set_err(BNHIP_E_INVALID, "model is NULL or plan-only");
-    hipSetDevice(m->eng.device);
-    m->eng.sync_contexts();
-    hipError_t e = hipStreamSynchronize(m->eng.stream);
-    if (e != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
-    return BNHIP_OK;
-}
-
-int bnhip_predict_device(bnhip_model* m, const float* d_samples, int n_clips, float* d_logits, float* d_emb) {
-    if (!m || !d_samples || !d_logits) return set_err(BNHIP_E_INVALID, "NULL argument");
-    if (n_clips <= 0) return set_err(BNHIP_E_INVALID, "n_clips must be positive");
-    Engine& e = m->eng;
-    if (e.device < 0) return set_err(BNHIP_E_INVALID, "plan-only model cannot run");
-    if (hipSetDevice(e.device) != hipSuccess) return set_err(BNHIP_E_RUNTIME, "hipSetDevice failed");
-    std::string err;
-    for (int off = 0; off < n_clips; off += e.max_batch) {
-        int n = std::min(e.max_batch, n_clips - off);
-        if (!e.run_pipelined(d_samples + (size_t)off * e.n_samples, n, d_logits + (size_t)off * e.n_classes,
-                             d_emb ? d_emb + (size_t)off * e.emb_dim : nullptr, &err))
-            return set_err(BNHIP_E_RUNTIME, err);
+    std::vector<int> used;
+    for (int g = 0, off = 0; g < n; g++) {
+        int cnt = n_clips / n + (g < n_clips % n ? 1 : 0);
+        if (cnt > 0) {
+            Engine* e = m->engs[g].get();
+            const int o = off;
+            m->workers[g]->submit([f, e, o, cnt](std::string& er) { return f(*e, o, cnt, er); });
+            used.push_back(g);
+        }
+        off += cnt;
     }
-    return BNHIP_OK;
+    int rc = 0;
+    for (int g : used) { int r = m->workers[g]->wait(&err); if (r && !rc) rc = r; }
+    return rc ? set_err(rc, err) : BNHIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- one engine, one shard
 // pcm_bits: 0 = float32 samples, 16 / 24 / 32 = little-endian PCM converted on the device
-static int predict_host(bnhip_model* m, const void* src, int pcm_bits, int n_clips, float* logits, float* emb) {
-    if (!m || !src || !logits) return set_err(BNHIP_E_INVALID, "NULL argument");
-    if (n_clips <= 0) return set_err(BNHIP_E_INVALID, "n_clips must be positive");
-    Engine& e = m->eng;
-    if (e.device < 0) return set_err(BNHIP_E_INVALID, "plan-only model cannot run");
-    if (emb && !e.emb_dim) return set_err(BNHIP_E_INVALID, "model has no embedding output");
-    if (hipSetDevice(e.device) != hipSuccess) return set_err(BNHIP_E_RUNTIME, "hipSetDevice failed");
-    std::string err;
+int predict_host_one(Engine& e, const void* src, int pcm_bits, int n_clips, float* logits, float* emb, std::string& err) {
+    if (hipSetDevice(e.device) != hipSuccess) { err = "hipSetDevice failed"; return BNHIP_E_RUNTIME; }
     const bool pcm = pcm_bits != 0;
     const size_t bps = (size_t)pcm_bits / 8;
     // chunk = max_batch for calls larger than it; a single large batch (>= 128 clips) is split too, so that the pageable
@@ -203,20 +293,34 @@ static int predict_host(bnhip_model* m, const void* src, int pcm_bits, int n_cli
     const size_t pcm_half = (size_t)e.max_batch * e.n_samples * bps, pcm_need = pcm_half * (pipelined ? 2 : 1);
     if (pcm && e.stage_pcm_bytes < pcm_need) {
         if (e.d_stage_pcm) { hipStreamSynchronize(e.stream); hipFree(e.d_stage_pcm); e.d_stage_pcm = nullptr; e.stage_pcm_bytes = 0; }
-        if (hipMalloc((void**)&e.d_stage_pcm, pcm_need) != hipSuccess)
-            return set_err(BNHIP_E_NOMEM, "device allocation failed (pcm staging)");
+        if (hipMalloc((void**)&e.d_stage_pcm, pcm_need) != hipSuccess) { err = "device allocation failed (pcm staging)"; return BNHIP_E_NOMEM; }
         e.stage_pcm_bytes = pcm_need;
     }
-    if (pipelined && !e.d_stage_in2) {       // second staging set, created on first use
-        hipError_t he = hipMalloc((void**)&e.d_stage_in2, (size_t)e.max_batch * e.n_samples * 4);
-        if (he == hipSuccess) he = hipMalloc((void**)&e.d_stage_logits2, (size_t)e.max_batch * e.n_classes * 4);
-        if (he == hipSuccess && e.emb_dim) he = hipMalloc((void**)&e.d_stage_emb2, (size_t)e.max_batch * e.emb_dim * 4);
-        if (he == hipSuccess) he = hipStreamCreateWithFlags(&e.copy_stream, hipStreamNonBlocking);
+    if (pipelined && !e.staging2_ready) {       // second staging set, created on first use; committed only when complete
+        float *in2 = nullptr, *lg2 = nullptr, *em2 = nullptr;
+        hipStream_t cs = nullptr;
+        hipEvent_t evc[2] = {nullptr, nullptr}, evd[2] = {nullptr, nullptr};
+        hipError_t he = hipMalloc((void**)&in2, (size_t)e.max_batch * e.n_samples * 4);
+        if (he == hipSuccess) he = hipMalloc((void**)&lg2, (size_t)e.max_batch * e.n_classes * 4);
+        if (he == hipSuccess && e.emb_dim) he = hipMalloc((void**)&em2, (size_t)e.max_batch * e.emb_dim * 4);
+        if (he == hipSuccess) he = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
         for (int i = 0; i < 2 && he == hipSuccess; i++) {
-            he = hipEventCreateWithFlags(&e.ev_copied[i], hipEventDisableTiming);
-            if (he == hipSuccess) he = hipEventCreateWithFlags(&e.ev_done[i], hipEventDisableTiming);
+            he = hipEventCreateWithFlags(&evc[i], hipEventDisableTiming);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&evd[i], hipEventDisableTiming);
         }
-        if (he != hipSuccess) return set_err(BNHIP_E_NOMEM, std::string("staging allocation failed: ") + hipGetErrorString(he));
+        if (he != hipSuccess) {
+            if (in2) hipFree(in2);
+            if (lg2) hipFree(lg2);
+            if (em2) hipFree(em2);
+            if (cs) hipStreamDestroy(cs);
+            for (int i = 0; i < 2; i++) { if (evc[i]) hipEventDestroy(evc[i]); if (evd[i]) hipEventDestroy(evd[i]); }
+            (void)hipGetLastError();
+            err = std::string("staging allocation failed: ") + hipGetErrorString(he);
+            return BNHIP_E_NOMEM;
+        }
+        e.d_stage_in2 = in2; e.d_stage_logits2 = lg2; e.d_stage_emb2 = em2; e.copy_stream = cs;
+        for (int i = 0; i < 2; i++) { e.ev_copied[i] = evc[i]; e.ev_done[i] = evd[i]; }
+        e.staging2_ready = true;
     }
     if (!pipelined) {
         for (int off = 0; off < n_clips; off += e.max_batch) {
@@ -231,16 +335,15 @@ static int predict_host(bnhip_model* m, const void* src, int pcm_bits, int n_cli
                 he = hipMemcpyAsync(e.d_stage_in, (const float*)src + (size_t)off * e.n_samples, cnt * 4,
                                     hipMemcpyHostToDevice, e.stream);
             }
-            if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("H2D copy: ") + hipGetErrorString(he));
-            if (!e.run(e.d_stage_in, n, e.d_stage_logits, emb ? e.d_stage_emb : nullptr, &err))
-                return set_err(BNHIP_E_RUNTIME, err);
+            if (he != hipSuccess) { err = std::string("H2D copy: ") + hipGetErrorString(he); return BNHIP_E_RUNTIME; }
+            if (!e.run(e.d_stage_in, n, e.d_stage_logits, emb ? e.d_stage_emb : nullptr, &err)) return BNHIP_E_RUNTIME;
             he = hipMemcpyAsync(logits + (size_t)off * e.n_classes, e.d_stage_logits, (size_t)n * e.n_classes * 4,
                                 hipMemcpyDeviceToHost, e.stream);
             if (he == hipSuccess && emb)
                 he = hipMemcpyAsync(emb + (size_t)off * e.emb_dim, e.d_stage_emb, (size_t)n * e.emb_dim * 4,
                                     hipMemcpyDeviceToHost, e.stream);
             if (he == hipSuccess) he = hipStreamSynchronize(e.stream);
-            if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("D2H copy/sync: ") + hipGetErrorString(he));
+            if (he != hipSuccess) { err = std::string("D2H copy/sync: ") + hipGetErrorString(he); return BNHIP_E_RUNTIME; }
         }
         return BNHIP_OK;
     }
@@ -251,7 +354,8 @@ static int predict_host(bnhip_model* m, const void* src, int pcm_bits, int n_cli
     float* demb[2] = {e.d_stage_emb, e.d_stage_emb2};
     auto fail = [&](const std::string& what, hipError_t he) {
         hipStreamSynchronize(e.stream); hipStreamSynchronize(e.copy_stream);
-        return set_err(BNHIP_E_RUNTIME, what + ": " + hipGetErrorString(he));
+        err = what + ": " + hipGetErrorString(he);
+        return BNHIP_E_RUNTIME;
     };
     auto drain = [&](int c) -> hipError_t {      // copy chunk c's results to the caller (waits for its compute)
         int off = c * ck, n = std::min(ck, n_clips - off), b = c & 1;
@@ -279,7 +383,7 @@ static int predict_host(bnhip_model* m, const void* src, int pcm_bits, int n_cli
         if (he == hipSuccess) he = hipEventRecord(e.ev_copied[b], e.copy_stream);
         if (he == hipSuccess) he = hipStreamWaitEvent(e.stream, e.ev_copied[b], 0);
         if (he != hipSuccess) return fail("H2D copy", he);
-        if (!e.run(din[b], n, dlog[b], emb ? demb[b] : nullptr, &err)) { hipStreamSynchronize(e.stream); return set_err(BNHIP_E_RUNTIME, err); }
+        if (!e.run(din[b], n, dlog[b], emb ? demb[b] : nullptr, &err)) { hipStreamSynchronize(e.stream); return BNHIP_E_RUNTIME; }
         he = hipEventRecord(e.ev_done[b], e.stream);
         if (he != hipSuccess) return fail("event record", he);
         if (c >= 1) { he = drain(c - 1); if (he != hipSuccess) return fail("D2H copy", he); }
@@ -290,92 +394,365 @@ static int predict_host(bnhip_model* m, const void* src, int pcm_bits, int n_cli
     return BNHIP_OK;
 }
 
-int bnhip_predict(bnhip_model* m, const float* samples, int n_clips, float* logits, float* emb) {
-    return predict_host(m, samples, 0, n_clips, logits, emb);
+int predict_host(bnhip_model* m, const void* src, int pcm_bits, int n_clips, float* logits, float* emb) {
+    if (!m || !src || !logits) return set_err(BNHIP_E_INVALID, "NULL argument");
+    if (n_clips <= 0) return set_err(BNHIP_E_INVALID, "n_clips must be positive");
+    Engine& e0 = m->eng();
+    if (e0.device < 0) return set_err(BNHIP_E_INVALID, "plan-only model cannot run");
+    if (emb && !e0.emb_dim) return set_err(BNHIP_E_INVALID, "model has no embedding output");
+    const size_t in_stride = (size_t)e0.n_samples * (pcm_bits ? (size_t)pcm_bits / 8 : 4);
+    const int nc = e0.n_classes, ed = e0.emb_dim;
+    return shard_run(m, n_clips, [=](Engine& e, int off, int cnt, std::string& err) {
+        return predict_host_one(e, (const char*)src + (size_t)off * in_stride, pcm_bits, cnt, logits + (size_t)off * nc,
+                                emb ? emb + (size_t)off * ed : nullptr, err);
+    });
 }
 
-int bnhip_predict_pcm16(bnhip_model* m, const int16_t* pcm, int n_clips, float* logits, float* emb) {
-    return predict_host(m, pcm, 16, n_clips, logits, emb);
-}
-
-int bnhip_predict_pcm(bnhip_model* m, const void* pcm, int bits_per_sample, int n_clips, float* logits, float* emb) {
-    if (bits_per_sample != 16 && bits_per_sample != 24 && bits_per_sample != 32)
-        return set_err(BNHIP_E_INVALID, "unsupported bit depth (supported: 16, 24, 32)");
-    return predict_host(m, pcm, bits_per_sample, n_clips, logits, emb);
-}
-
-static int ensure_topk(Engine& e, int k) {
+int ensure_topk(Engine& e, int k, std::string& err) {
     if (k <= e.topk_cap) return BNHIP_OK;
     if (e.d_topk_conf) hipFree(e.d_topk_conf);
     if (e.d_topk_idx) hipFree(e.d_topk_idx);
     e.d_topk_conf = nullptr; e.d_topk_idx = nullptr; e.topk_cap = 0;
     if (hipMalloc((void**)&e.d_topk_conf, (size_t)e.max_batch * k * 4) != hipSuccess ||
-        hipMalloc((void**)&e.d_topk_idx, (size_t)e.max_batch * k * 4) != hipSuccess)
-        return set_err(BNHIP_E_NOMEM, "device allocation failed (top-k)");
+        hipMalloc((void**)&e.d_topk_idx, (size_t)e.max_batch * k * 4) != hipSuccess) {
+        if (e.d_topk_conf) { hipFree(e.d_topk_conf); e.d_topk_conf = nullptr; }
+        err = "device allocation failed (top-k)";
+        return BNHIP_E_NOMEM;
+    }
     e.topk_cap = k;
     return BNHIP_OK;
 }
 
-int bnhip_postprocess_topk(bnhip_model* m, const float* logits, int n_clips, int n_classes, int activation,
-                           double sensitivity, int k, float* out_conf, int32_t* out_idx) {
-    if (!m || !logits || !out_conf || !out_idx) return set_err(BNHIP_E_INVALID, "NULL argument");
-    Engine& e = m->eng;
-    if (n_clips <= 0 || k <= 0) return set_err(BNHIP_E_INVALID, "n_clips and k must be positive");
-    if (e.device < 0) return set_err(BNHIP_E_INVALID, "plan-only model cannot run");
-    if (n_classes != e.n_classes) return set_err(BNHIP_E_INVALID, "n_classes does not match the model");
-    if (activation < 0 || activation > 2) return set_err(BNHIP_E_INVALID, "unknown activation");
-    if (n_classes * 4 > 150 * 1024) return set_err(BNHIP_E_UNSUPPORTED, "too many classes for the LDS top-k");
-    hipSetDevice(e.device);
+// samples != nullptr: predict first; else `logits` (host) are the input
+int topk_one(Engine& e, const float* samples, const float* logits, int n_clips, int activation, double sensitivity, int k,
+             float* out_conf, int32_t* out_idx, std::string& err) {
+    if (hipSetDevice(e.device) != hipSuccess) { err = "hipSetDevice failed"; return BNHIP_E_RUNTIME; }
+    const int n_classes = e.n_classes;
     int kk = std::min(k, n_classes);
-    int rc = ensure_topk(e, kk);
+    int rc = ensure_topk(e, kk, err);
     if (rc) return rc;
     for (int off = 0; off < n_clips; off += e.max_batch) {
         int n = std::min(e.max_batch, n_clips - off);
-        hipError_t he = hipMemcpyAsync(e.d_stage_logits, logits + (size_t)off * n_classes, (size_t)n * n_classes * 4,
-                                       hipMemcpyHostToDevice, e.stream);
-        if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("H2D copy: ") + hipGetErrorString(he));
+        hipError_t he;
+        if (samples) {
+            he = hipMemcpyAsync(e.d_stage_in, samples + (size_t)off * e.n_samples, (size_t)n * e.n_samples * 4,
+                                hipMemcpyHostToDevice, e.stream);
+            if (he != hipSuccess) { err = std::string("H2D copy: ") + hipGetErrorString(he); return BNHIP_E_RUNTIME; }
+            if (!e.run(e.d_stage_in, n, e.d_stage_logits, nullptr, &err)) return BNHIP_E_RUNTIME;
+        } else {
+            he = hipMemcpyAsync(e.d_stage_logits, logits + (size_t)off * n_classes, (size_t)n * n_classes * 4,
+                                hipMemcpyHostToDevice, e.stream);
+            if (he != hipSuccess) { err = std::string("H2D copy: ") + hipGetErrorString(he); return BNHIP_E_RUNTIME; }
+        }
         launch_activation(e.d_stage_logits, e.d_post_conf, n, n_classes, activation, sensitivity, e.stream);
         launch_topk(e.d_post_conf, n, n_classes, kk, e.d_topk_conf, e.d_topk_idx, e.stream);
         hipMemcpyAsync(out_conf + (size_t)off * kk, e.d_topk_conf, (size_t)n * kk * 4, hipMemcpyDeviceToHost, e.stream);
         hipMemcpyAsync(out_idx + (size_t)off * kk, e.d_topk_idx, (size_t)n * kk * 4, hipMemcpyDeviceToHost, e.stream);
         he = hipStreamSynchronize(e.stream);
-        if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("postprocess: ") + hipGetErrorString(he));
+        if (he != hipSuccess) { err = std::string("top-k: ") + hipGetErrorString(he); return BNHIP_E_RUNTIME; }
     }
     return BNHIP_OK;
+}
+
+int igcd(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+int copy_out(const std::string& s, char* buf, size_t cap) {
+    if (buf && cap) {
+        size_t n = std::min(cap - 1, s.size());
+        memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return (int)s.size() + 1;
+}
+
+}  // namespace
+
+// Streaming resampler state (Resampler, internal/audiocore/resample/resample.go:44-52): the polyphase filter's input
+// history lives on the device between calls so that any chunking of a stream produces the samples of one call over the
+// whole stream, bit for bit.
+struct bnhip_resampler {
+    int device = 0, rate_in = 0, rate_out = 0, L = 1, M = 1, T = 0, half = 0;
+    float* d_table = nullptr;
+    float* d_work = nullptr;      // [hist | new chunk] as float32
+    size_t work_cap = 0;          // floats
+    void* d_in = nullptr;  size_t in_cap = 0;     // raw input staging (bytes)
+    void* d_out = nullptr; size_t out_cap = 0;    // output staging (bytes)
+    long long n_total = 0;        // input samples consumed so far
+    long long i_next = 0;         // next output index
+    long long n_base = 0;         // stream index of d_work[0]
+    int n_hist = 0;               // valid history samples at the front of d_work
+    hipStream_t stream = nullptr;
+};
+
+extern "C" {
+
+const char* bnhip_version(void) { return "bnhip 0.2 (gfx950)"; }
+const char* bnhip_last_error(void) { return g_err.c_str(); }
+
+int bnhip_last_error_copy(char* buf, size_t cap) {
+    if (!buf || !cap) return (int)g_err.size() + 1;
+    size_t n = std::min(cap - 1, g_err.size());
+    memcpy(buf, g_err.data(), n);
+    buf[n] = 0;
+    return (int)g_err.size() + 1;
+}
+
+int bnhip_init(int* n_devices) {
+    BN_GUARD_BEGIN
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    if (g_devices < 0) {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            if (n_devices) *n_devices = 0;
+            return set_err(BNHIP_E_NO_DEVICE, std::string("no HIP device available: ") + hipGetErrorString(e));
+        }
+        int usable = 0;
+        for (int d = 0; d < n; d++) if (is_gfx950(d)) usable++;
+        if (!usable) {
+            if (n_devices) *n_devices = 0;
+            return set_err(BNHIP_E_NO_DEVICE, "no gfx950 (MI355X) device found; this library ships gfx950 code objects only");
+        }
+        g_devices = n;
+    }
+    if (n_devices) *n_devices = g_devices;
+    return BNHIP_OK;
+    BN_GUARD_END((void)0)
+}
+
+void bnhip_shutdown(void) {
+    try {
+        std::lock_guard<std::mutex> lk(g_init_mu);
+        g_devices = -1;
+    } catch (...) {}
+}
+
+int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, bnhip_model** out) {
+    if (!out) return set_err(BNHIP_E_INVALID, "out is NULL");
+    *out = nullptr;
+    bnhip_model* m = nullptr;
+    BN_GUARD_BEGIN
+    if (!blob || n_bytes == 0) return set_err(BNHIP_E_INVALID, "empty model blob");
+    // "plan_only": parse + plan on the CPU, no device touched (diagnostics / CPU-side tests); such a
+    // model answers info/describe and rejects predict calls.
+    const bool plan_only = json_int(opts_json, "plan_only", 0) != 0;
+    std::vector<int> devices = json_int_array(opts_json, "devices");
+    if (devices.empty()) devices.push_back((int)json_int(opts_json, "device", 0));
+    if (devices.size() > 64) return set_err(BNHIP_E_INVALID, "too many devices");
+    int max_batch = (int)json_int(opts_json, "max_batch", 256);
+    if (max_batch < 1 || max_batch > 4096) return set_err(BNHIP_E_INVALID, "max_batch must be in [1, 4096]");
+    if (!plan_only) {
+        int rc = bnhip_init(nullptr);
+        if (rc != BNHIP_OK) return rc;
+        for (int device : devices) {
+            if (device < 0 || device >= g_devices) return set_err(BNHIP_E_INVALID, "device ordinal out of range");
+            if (!is_gfx950(device)) return set_err(BNHIP_E_NO_DEVICE, "selected device is not gfx950");
+        }
+    }
+
+    // container: TFLite flatbuffer ("TFL3" at byte 4) or ONNX protobuf (internal/inference/onnx/classifier.go:268-430)
+    TflModel tm;
+    std::string err;
+    const bool is_tfl = n_bytes >= 8 && memcmp((const char*)blob + 4, "TFL3", 4) == 0;
+    if (is_tfl) {
+        if (!parse_tflite(blob, n_bytes, &tm, &err)) return set_err(BNHIP_E_MODEL, err);
+    } else {
+        int ocode = BNHIP_E_MODEL;
+        if (!parse_onnx(blob, n_bytes, &tm, &err, &ocode)) return set_err(ocode, err);
+    }
+    if (!validate_graph(tm, &err)) return set_err(BNHIP_E_MODEL, err);
+
+    m = new bnhip_model();
+    const char* lenv = getenv("BNHIP_LANES");            // experiment switches; the option wins when given
+    const char* denv = getenv("BNHIP_DEPTH");
+    const char* fenv = getenv("BNHIP_FE_FFT");
+    const char* genv = getenv("BNHIP_GRAPHS");
+    const char* benv = getenv("BNHIP_BF16X3");
+    const int n_eng = (int)devices.size();
+    for (int i = 0; i < n_eng; i++) {
+        std::unique_ptr<Engine> e(new Engine());
+        e->no_reuse = json_int(opts_json, "debug_no_reuse", 0) != 0;
+        e->autotune = json_int(opts_json, "autotune", 1) != 0;
+        e->n_lanes = (int)json_int(opts_json, "lanes", lenv ? atoi(lenv) : 2);
+        e->depth = (int)json_int(opts_json, "depth", denv ? atoi(denv) : 1);
+        e->frontend_fft = (int)json_int(opts_json, "frontend_fft", fenv ? atoi(fenv) : -1);
+        e->use_graphs = json_int(opts_json, "graphs", genv ? atoi(genv) : 0) != 0;
+        e->bf16x3 = (int)json_int(opts_json, "bf16x3", benv ? atoi(benv) : 0);
+        e->defer_weights = i > 0 && !plan_only;
+        int code = BNHIP_E_UNSUPPORTED;
+        TflModel copy = tm;                               // tensors point into the caller's blob / tm-owned storage: cheap
+        if (!e->build(std::move(copy), devices[i], max_batch, plan_only, &err, &code)) {
+            delete m;
+            return set_err(code == BNHIP_OK ? BNHIP_E_UNSUPPORTED : code, err);
+        }
+        m->engs.push_back(std::move(e));
+    }
+    if (n_eng > 1 && !plan_only) {
+        std::string how;
+        std::string rerr = replicate_weights(m, json_str(opts_json, "replicate", "auto"), &how);
+        if (!rerr.empty()) { delete m; return set_err(BNHIP_E_RUNTIME, rerr); }
+        m->replication = how;
+        for (int i = 0; i < n_eng; i++) {
+            m->workers.emplace_back(new Worker());
+            m->workers.back()->start(devices[i]);
+        }
+        // create-time autotune of the deferred engines, concurrently on their own devices
+        for (int i = 1; i < n_eng; i++) {
+            Engine* e = m->engs[i].get();
+            m->workers[i]->submit([e](std::string&) { e->finish_deferred(); return 0; });
+        }
+        for (int i = 1; i < n_eng; i++) m->workers[i]->wait(nullptr);
+        hipSetDevice(devices[0]);
+    } else if (n_eng == 1 && !plan_only && json_str(opts_json, "replicate", "") == "rccl") {
+        // single device, RCCL explicitly requested: run the broadcast code path with one rank (in place) so that the
+        // library load and call sequence are exercised on a one-GPU box
+        std::string how;
+        std::string rerr = replicate_weights(m, "rccl", &how);
+        if (!rerr.empty()) { delete m; return set_err(BNHIP_E_RUNTIME, rerr); }
+        m->replication = how;
+    }
+    *out = m;
+    return BNHIP_OK;
+    BN_GUARD_END(delete m)
+}
+
+int bnhip_model_info(const bnhip_model* m, int* n_samples, int* n_classes, int* emb_dim) {
+    if (!m) return set_err(BNHIP_E_INVALID, "model is NULL");
+    if (n_samples) *n_samples = m->eng().n_samples;
+    if (n_classes) *n_classes = m->eng().n_classes;
+    if (emb_dim) *emb_dim = m->eng().emb_dim;
+    return BNHIP_OK;
+}
+
+int bnhip_model_devices(const bnhip_model* m, int* devices, int cap) {
+    if (!m) return set_err(BNHIP_E_INVALID, "model is NULL");
+    const int n = (int)m->engs.size();
+    for (int i = 0; i < n && i < cap && devices; i++) devices[i] = m->engs[i]->device;
+    return n;
+}
+
+void bnhip_model_destroy(bnhip_model* m) {
+    if (!m) return;
+    try {
+        m->workers.clear();                             // joins the worker threads first
+        for (auto& e : m->engs) {
+            if (e && e->device >= 0) hipSetDevice(e->device);
+            e.reset();
+        }
+        delete m;
+    } catch (...) {}
+}
+
+int bnhip_set_stream(bnhip_model* m, void* hip_stream) {
+    if (!m || m->eng().device < 0) return set_err(BNHIP_E_INVALID, "model is NULL or plan-only");
+    if (m->engs.size() > 1) return set_err(BNHIP_E_INVALID, "bnhip_set_stream: multi-device handles own their streams");
+    BN_GUARD_BEGIN
+    Engine& e = m->eng();
+    hipSetDevice(e.device);
+    e.drop_graphs();                                    // captured on the old stream
+    e.sync_contexts();
+    if (e.own_stream && e.stream) { hipStreamSynchronize(e.stream); hipStreamDestroy(e.stream); }
+    e.stream = reinterpret_cast<hipStream_t>(hip_stream);
+    e.own_stream = false;
+    return BNHIP_OK;
+    BN_GUARD_END((void)0)
+}
+
+int bnhip_synchronize(bnhip_model* m) {
+    if (!m || m->eng().device < 0) return set_err(BNHIP_E_INVALID, "model is NULL or plan-only");
+    BN_GUARD_BEGIN
+    for (auto& ep : m->engs) {
+        Engine& e = *ep;
+        hipSetDevice(e.device);
+        e.sync_contexts();
+        hipError_t he = hipStreamSynchronize(e.stream);
+        if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("hipStreamSynchronize: ") + hipGetErrorString(he));
+    }
+    hipSetDevice(m->eng().device);
+    return BNHIP_OK;
+    BN_GUARD_END((void)0)
+}
+
+int bnhip_predict_device(bnhip_model* m, const float* d_samples, int n_clips, float* d_logits, float* d_emb) {
+    if (!m || !d_samples || !d_logits) return set_err(BNHIP_E_INVALID, "NULL argument");
+    if (n_clips <= 0) return set_err(BNHIP_E_INVALID, "n_clips must be positive");
+    if (m->engs.size() > 1) return set_err(BNHIP_E_INVALID, "bnhip_predict_device: device pointers belong to one device; use a single-device handle");
+    BN_GUARD_BEGIN
+    Engine& e = m->eng();
+    if (e.device < 0) return set_err(BNHIP_E_INVALID, "plan-only model cannot run");
+    if (d_emb && !e.emb_dim) return set_err(BNHIP_E_INVALID, "model has no embedding output");
+    if (hipSetDevice(e.device) != hipSuccess) return set_err(BNHIP_E_RUNTIME, "hipSetDevice failed");
+    std::string err;
+    for (int off = 0; off < n_clips; off += e.max_batch) {
+        int n = std::min(e.max_batch, n_clips - off);
+        if (!e.run_pipelined(d_samples + (size_t)off * e.n_samples, n, d_logits + (size_t)off * e.n_classes,
+                             d_emb ? d_emb + (size_t)off * e.emb_dim : nullptr, &err))
+            return set_err(BNHIP_E_RUNTIME, err);
+    }
+    return BNHIP_OK;
+    BN_GUARD_END((void)0)
+}
+
+int bnhip_predict(bnhip_model* m, const float* samples, int n_clips, float* logits, float* emb) {
+    BN_GUARD_BEGIN
+    return predict_host(m, samples, 0, n_clips, logits, emb);
+    BN_GUARD_END((void)0)
+}
+
+int bnhip_predict_pcm16(bnhip_model* m, const int16_t* pcm, int n_clips, float* logits, float* emb) {
+    BN_GUARD_BEGIN
+    return predict_host(m, pcm, 16, n_clips, logits, emb);
+    BN_GUARD_END((void)0)
+}
+
+int bnhip_predict_pcm(bnhip_model* m, const void* pcm, int bits_per_sample, int n_clips, float* logits, float* emb) {
+    if (bits_per_sample != 16 && bits_per_sample != 24 && bits_per_sample != 32)
+        return set_err(BNHIP_E_INVALID, "unsupported bit depth (supported: 16, 24, 32)");
+    BN_GUARD_BEGIN
+    return predict_host(m, pcm, bits_per_sample, n_clips, logits, emb);
+    BN_GUARD_END((void)0)
+}
+
+int bnhip_postprocess_topk(bnhip_model* m, const float* logits, int n_clips, int n_classes, int activation,
+                           double sensitivity, int k, float* out_conf, int32_t* out_idx) {
+    if (!m || !logits || !out_conf || !out_idx) return set_err(BNHIP_E_INVALID, "NULL argument");
+    BN_GUARD_BEGIN
+    Engine& e = m->eng();
+    if (n_clips <= 0 || k <= 0) return set_err(BNHIP_E_INVALID, "n_clips and k must be positive");
+    if (e.device < 0) return set_err(BNHIP_E_INVALID, "plan-only model cannot run");
+    if (n_classes != e.n_classes) return set_err(BNHIP_E_INVALID, "n_classes does not match the model");
+    if (activation < 0 || activation > 2) return set_err(BNHIP_E_INVALID, "unknown activation");
+    if ((size_t)n_classes * 4 > 150 * 1024) return set_err(BNHIP_E_UNSUPPORTED, "too many classes for the LDS top-k");
+    const int kk = std::min(k, n_classes);
+    return shard_run(m, n_clips, [=](Engine& en, int off, int cnt, std::string& err) {
+        return topk_one(en, nullptr, logits + (size_t)off * n_classes, cnt, activation, sensitivity, k,
+                        out_conf + (size_t)off * kk, out_idx + (size_t)off * kk, err);
+    });
+    BN_GUARD_END((void)0)
 }
 
 int bnhip_predict_topk(bnhip_model* m, const float* samples, int n_clips, int activation, double sensitivity, int k,
                        float* out_conf, int32_t* out_idx) {
     if (!m || !samples || !out_conf || !out_idx) return set_err(BNHIP_E_INVALID, "NULL argument");
-    Engine& e = m->eng;
+    BN_GUARD_BEGIN
+    Engine& e = m->eng();
     if (n_clips <= 0 || k <= 0) return set_err(BNHIP_E_INVALID, "n_clips and k must be positive");
     if (activation < 0 || activation > 2) return set_err(BNHIP_E_INVALID, "unknown activation");
-    if (e.n_classes * 4 > 150 * 1024) return set_err(BNHIP_E_UNSUPPORTED, "too many classes for the LDS top-k");
+    if ((size_t)e.n_classes * 4 > 150 * 1024) return set_err(BNHIP_E_UNSUPPORTED, "too many classes for the LDS top-k");
     if (e.device < 0) return set_err(BNHIP_E_INVALID, "plan-only model cannot run");
-    hipSetDevice(e.device);
-    int kk = std::min(k, e.n_classes);
-    int rc = ensure_topk(e, kk);
-    if (rc) return rc;
-    std::string err;
-    for (int off = 0; off < n_clips; off += e.max_batch) {
-        int n = std::min(e.max_batch, n_clips - off);
-        hipError_t he = hipMemcpyAsync(e.d_stage_in, samples + (size_t)off * e.n_samples, (size_t)n * e.n_samples * 4,
-                                       hipMemcpyHostToDevice, e.stream);
-        if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("H2D copy: ") + hipGetErrorString(he));
-        if (!e.run(e.d_stage_in, n, e.d_stage_logits, nullptr, &err)) return set_err(BNHIP_E_RUNTIME, err);
-        launch_activation(e.d_stage_logits, e.d_post_conf, n, e.n_classes, activation, sensitivity, e.stream);
-        launch_topk(e.d_post_conf, n, e.n_classes, kk, e.d_topk_conf, e.d_topk_idx, e.stream);
-        hipMemcpyAsync(out_conf + (size_t)off * kk, e.d_topk_conf, (size_t)n * kk * 4, hipMemcpyDeviceToHost, e.stream);
-        hipMemcpyAsync(out_idx + (size_t)off * kk, e.d_topk_idx, (size_t)n * kk * 4, hipMemcpyDeviceToHost, e.stream);
-        he = hipStreamSynchronize(e.stream);
-        if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("predict_topk: ") + hipGetErrorString(he));
-    }
-    return BNHIP_OK;
+    const int kk = std::min(k, e.n_classes), ns = e.n_samples;
+    return shard_run(m, n_clips, [=](Engine& en, int off, int cnt, std::string& err) {
+        return topk_one(en, samples + (size_t)off * ns, nullptr, cnt, activation, sensitivity, k, out_conf + (size_t)off * kk,
+                        out_idx + (size_t)off * kk, err);
+    });
+    BN_GUARD_END((void)0)
 }
 
 int bnhip_us_frame_cv(int device, const double* samples, int n_clips, int n, int sample_rate, int fft_size, int hop,
                       int split_hz, double* cv, int32_t* ok) {
     if (!samples || !cv || !ok || n_clips <= 0) return set_err(BNHIP_E_INVALID, "NULL/empty argument");
+    BN_GUARD_BEGIN
     // guards: internal/audiocore/ultrasonic/filter.go:21-37
     bool valid = !(n < fft_size || sample_rate <= 0 || fft_size < 2 || hop <= 0) && (fft_size & (fft_size - 1)) == 0 &&
                  !(split_hz < 0 || split_hz >= sample_rate / 2);
@@ -407,11 +784,13 @@ int bnhip_us_frame_cv(int device, const double* samples, int n_clips, int n, int
     if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("us_frame_cv: ") + hipGetErrorString(he));
     for (int i = 0; i < n_clips; i++) ok[i] = 1;
     return BNHIP_OK;
+    BN_GUARD_END((void)0)
 }
 
 int bnhip_debug_fetch(bnhip_model* m, int tensor_index, int n_clips, float* out, size_t cap_floats) {
-    if (!m || !out || m->eng.device < 0) return set_err(BNHIP_E_INVALID, "NULL argument or plan-only model");
-    Engine& e = m->eng;
+    if (!m || !out || m->eng().device < 0) return set_err(BNHIP_E_INVALID, "NULL argument or plan-only model");
+    BN_GUARD_BEGIN
+    Engine& e = m->eng();
     auto it = e.tensor_value.find(tensor_index);
     if (it == e.tensor_value.end()) return set_err(BNHIP_E_INVALID, "tensor is not materialised by the plan (fused away)");
     const Value& v = e.vals[it->second];
@@ -423,10 +802,10 @@ int bnhip_debug_fetch(bnhip_model* m, int tensor_index, int n_clips, float* out,
     if (hipMemcpy(out, e.value_ptr(it->second), n * 4, hipMemcpyDeviceToHost) != hipSuccess)
         return set_err(BNHIP_E_RUNTIME, "debug fetch copy failed");
     return (int)v.elems;
+    BN_GUARD_END((void)0)
 }
 
-static int igcd(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
-
+// ------------------------------------------------------------------------------------------------ resampler
 int bnhip_resample_length(int n_in, int rate_in, int rate_out) {
     if (n_in <= 0 || rate_in <= 0 || rate_out <= 0) return 0;
     int g = igcd(rate_in, rate_out);
@@ -461,7 +840,7 @@ static int resample_impl(int device, const void* in, bool pcm16, int n_clips, in
     if (he == hipSuccess) he = hipMemcpy(d_tab, table.data(), table.size() * 4, hipMemcpyHostToDevice);
     int lrc = 0;
     if (he == hipSuccess) {
-        lrc = launch_resample(d_in, d_out, d_tab, pcm16, n_clips, n_in, no, L, M, T, half, nullptr);
+        lrc = launch_resample(d_in, d_out, d_tab, pcm16, pcm16, n_clips, n_in, no, L, M, T, half, 0, 0, nullptr);
         if (lrc == 0) he = hipMemcpy(out, d_out, (size_t)n_clips * no * esz, hipMemcpyDeviceToHost);
     }
     if (d_in) hipFree(d_in);
@@ -474,44 +853,217 @@ static int resample_impl(int device, const void* in, bool pcm16, int n_clips, in
 
 int bnhip_resample_f32(int device, const float* in, int n_clips, int n_in, int rate_in, int rate_out, float* out, int n_out_cap,
                        int* n_out) {
+    BN_GUARD_BEGIN
     return resample_impl(device, in, false, n_clips, n_in, rate_in, rate_out, out, n_out_cap, n_out);
+    BN_GUARD_END((void)0)
 }
 
 int bnhip_resample_pcm16(int device, const int16_t* in, int n_clips, int n_in, int rate_in, int rate_out, int16_t* out,
                          int n_out_cap, int* n_out) {
+    BN_GUARD_BEGIN
     return resample_impl(device, in, true, n_clips, n_in, rate_in, rate_out, out, n_out_cap, n_out);
+    BN_GUARD_END((void)0)
 }
 
+// ---- streaming form
+static void resampler_free(bnhip_resampler* r) {
+    if (!r) return;
+    hipSetDevice(r->device);
+    if (r->stream) { hipStreamSynchronize(r->stream); hipStreamDestroy(r->stream); }
+    for (void* p : {(void*)r->d_table, (void*)r->d_work, r->d_in, r->d_out}) if (p) hipFree(p);
+    delete r;
+}
+
+int bnhip_resampler_create(int device, int rate_in, int rate_out, bnhip_resampler** out) {
+    if (!out) return set_err(BNHIP_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (rate_in <= 0 || rate_out <= 0) return set_err(BNHIP_E_INVALID, "sample rates must be positive");
+    if (rate_in == rate_out) return BNHIP_OK;            // NewResampler returns nil, nil: no resampling required (resample.go:58-60)
+    bnhip_resampler* r = nullptr;
+    BN_GUARD_BEGIN
+    int rc = bnhip_init(nullptr);
+    if (rc) return rc;
+    if (device < 0 || device >= g_devices) return set_err(BNHIP_E_INVALID, "device ordinal out of range");
+    hipSetDevice(device);
+    r = new bnhip_resampler();
+    r->device = device; r->rate_in = rate_in; r->rate_out = rate_out;
+    int g = igcd(rate_in, rate_out);
+    r->L = rate_out / g; r->M = rate_in / g;
+    std::vector<float> table;
+    resample_design(r->L, r->M, 5.0, 10, &table, &r->T, &r->half);
+    // same LDS bound as the kernel launch (phase table + worst-case span of 256 outputs)
+    if (((size_t)r->L * r->T + (size_t)(255LL * r->M / r->L + r->T + 2)) * 4 > 150 * 1024) {
+        delete r; r = nullptr;
+        return set_err(BNHIP_E_UNSUPPORTED, "resample ratio needs a phase table larger than LDS");
+    }
+    hipError_t he = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipMalloc((void**)&r->d_table, table.size() * 4);
+    if (he == hipSuccess) he = hipMemcpy(r->d_table, table.data(), table.size() * 4, hipMemcpyHostToDevice);
+    if (he != hipSuccess) { resampler_free(r); r = nullptr; return set_err(BNHIP_E_RUNTIME, std::string("resampler create: ") + hipGetErrorString(he)); }
+    *out = r;
+    return BNHIP_OK;
+    BN_GUARD_END(resampler_free(r))
+}
+
+// outputs computable once n_total inputs are known: every i whose newest tap n0(i) = floor((i*M + half)/L) < n_total
+static long long resampler_ready(const bnhip_resampler* r, long long n_total) {
+    long long num = n_total * r->L - r->half;
+    if (num <= 0) return 0;
+    return (num + r->M - 1) / r->M;
+}
+
+int bnhip_resampler_estimate(const bnhip_resampler* r, int n_in) {
+    if (!r || n_in <= 0) return 0;
+    // EstimateOutput analogue (resample.go:83-88): an upper bound for any call, whatever the state
+    return (int)(((long long)n_in * r->L + r->M - 1) / r->M) + 1;
+}
+
+// flush: 0 = emit what the inputs so far determine; 1 = end of stream (future inputs are zeros), then reset
+static int resampler_run(bnhip_resampler* r, const void* in, bool pcm16, int n_in, void* out, int out_cap, int* n_out, int flush) {
+    if (!r) return set_err(BNHIP_E_INVALID, "resampler is NULL");
+    if (n_out) *n_out = 0;
+    if (n_in < 0 || (n_in > 0 && !in) || !out) return set_err(BNHIP_E_INVALID, "bad resampler arguments");
+    if (n_in == 0 && !flush) return BNHIP_OK;            // empty input: nothing written (resample.go:100-102)
+    const long long n_after = r->n_total + n_in;
+    const long long i_end = flush ? (n_after * r->L + r->M - 1) / r->M : resampler_ready(r, n_after);
+    const long long cnt = i_end - r->i_next;
+    // a too-small destination fails before the state advances (resample.go:137-144)
+    if (cnt > out_cap || (!flush && bnhip_resampler_estimate(r, n_in) > out_cap))
+        return set_err(BNHIP_E_INVALID, "destination buffer too small");
+    hipSetDevice(r->device);
+    const size_t esz = pcm16 ? 2 : 4;
+    const size_t need = (size_t)r->n_hist + (size_t)n_in;
+    if (need > r->work_cap) {
+        size_t cap = std::max<size_t>(need * 2, 4096);
+        float* nw = nullptr;
+        if (hipMalloc((void**)&nw, cap * 4) != hipSuccess) return set_err(BNHIP_E_NOMEM, "device allocation failed (resampler work buffer)");
+        if (r->n_hist) hipMemcpyAsync(nw, r->d_work, (size_t)r->n_hist * 4, hipMemcpyDeviceToDevice, r->stream);
+        hipStreamSynchronize(r->stream);
+        if (r->d_work) hipFree(r->d_work);
+        r->d_work = nw; r->work_cap = cap;
+    }
+    if ((size_t)n_in * esz > r->in_cap) {
+        if (r->d_in) hipFree(r->d_in);
+        r->d_in = nullptr; r->in_cap = 0;
+        size_t cap = std::max<size_t>((size_t)n_in * esz * 2, 8192);
+        if (hipMalloc(&r->d_in, cap) != hipSuccess) return set_err(BNHIP_E_NOMEM, "device allocation failed (resampler input)");
+        r->in_cap = cap;
+    }
+    if (cnt > 0 && (size_t)cnt * esz > r->out_cap) {
+        if (r->d_out) hipFree(r->d_out);
+        r->d_out = nullptr; r->out_cap = 0;
+        size_t cap = std::max<size_t>((size_t)cnt * esz * 2, 8192);
+        if (hipMalloc(&r->d_out, cap) != hipSuccess) return set_err(BNHIP_E_NOMEM, "device allocation failed (resampler output)");
+        r->out_cap = cap;
+    }
+    hipError_t he = hipSuccess;
+    if (n_in > 0) {
+        if (pcm16) {
+            he = hipMemcpyAsync(r->d_in, in, (size_t)n_in * 2, hipMemcpyHostToDevice, r->stream);
+            if (he == hipSuccess) launch_pcm_to_f32(r->d_in, 16, r->d_work + r->n_hist, (size_t)n_in, r->stream);   // float32(int16)/32768, resample.go:120-124
+        } else {
+            he = hipMemcpyAsync(r->d_work + r->n_hist, in, (size_t)n_in * 4, hipMemcpyHostToDevice, r->stream);
+        }
+    }
+    const int n_work = r->n_hist + n_in;
+    if (he == hipSuccess && cnt > 0) {
+        int lrc = launch_resample(r->d_work, r->d_out, r->d_table, 0, pcm16 ? 1 : 0, 1, n_work, (int)cnt, r->L, r->M, r->T, r->half,
+                                  r->i_next, r->n_base, r->stream);
+        if (lrc) return set_err(BNHIP_E_UNSUPPORTED, "resample ratio needs a phase table larger than LDS");
+        he = hipMemcpyAsync(out, r->d_out, (size_t)cnt * esz, hipMemcpyDeviceToHost, r->stream);
+    }
+    if (he == hipSuccess) he = hipStreamSynchronize(r->stream);
+    if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("resampler: ") + hipGetErrorString(he));
+    if (n_out) *n_out = (int)cnt;
+    if (flush) {                                          // back to the initial state: the next call starts a new stream
+        r->n_total = 0; r->i_next = 0; r->n_base = 0; r->n_hist = 0;
+        return BNHIP_OK;
+    }
+    // keep the inputs the next output still needs: from n0(i_end) - (T-1) on
+    r->n_total = n_after; r->i_next = i_end;
+    long long keep_from = (i_end * r->M + r->half) / r->L - (r->T - 1);
+    if (keep_from < r->n_base) keep_from = r->n_base;
+    if (keep_from > n_after) keep_from = n_after;
+    const int drop = (int)(keep_from - r->n_base), keep = n_work - drop;
+    if (drop > 0 && keep > 0) {
+        // overlapping move inside one buffer: stage through the (idle) input buffer when it is large enough, else two-step
+        if ((size_t)keep * 4 <= r->in_cap) {
+            hipMemcpyAsync(r->d_in, r->d_work + drop, (size_t)keep * 4, hipMemcpyDeviceToDevice, r->stream);
+            hipMemcpyAsync(r->d_work, r->d_in, (size_t)keep * 4, hipMemcpyDeviceToDevice, r->stream);
+        } else {
+            float* tmp = nullptr;
+            if (hipMalloc((void**)&tmp, (size_t)keep * 4) != hipSuccess) return set_err(BNHIP_E_NOMEM, "device allocation failed (resampler history)");
+            hipMemcpyAsync(tmp, r->d_work + drop, (size_t)keep * 4, hipMemcpyDeviceToDevice, r->stream);
+            hipMemcpyAsync(r->d_work, tmp, (size_t)keep * 4, hipMemcpyDeviceToDevice, r->stream);
+            hipStreamSynchronize(r->stream);
+            hipFree(tmp);
+        }
+        hipStreamSynchronize(r->stream);
+    }
+    r->n_hist = keep > 0 ? keep : 0;
+    r->n_base = keep_from;
+    return BNHIP_OK;
+}
+
+int bnhip_resampler_process_pcm16(bnhip_resampler* r, const int16_t* in, int n_in, int16_t* out, int out_cap, int* n_out) {
+    BN_GUARD_BEGIN
+    return resampler_run(r, in, true, n_in, out, out_cap, n_out, 0);
+    BN_GUARD_END((void)0)
+}
+int bnhip_resampler_process_f32(bnhip_resampler* r, const float* in, int n_in, float* out, int out_cap, int* n_out) {
+    BN_GUARD_BEGIN
+    return resampler_run(r, in, false, n_in, out, out_cap, n_out, 0);
+    BN_GUARD_END((void)0)
+}
+int bnhip_resampler_flush_pcm16(bnhip_resampler* r, int16_t* out, int out_cap, int* n_out) {
+    BN_GUARD_BEGIN
+    return resampler_run(r, nullptr, true, 0, out, out_cap, n_out, 1);
+    BN_GUARD_END((void)0)
+}
+int bnhip_resampler_flush_f32(bnhip_resampler* r, float* out, int out_cap, int* n_out) {
+    BN_GUARD_BEGIN
+    return resampler_run(r, nullptr, false, 0, out, out_cap, n_out, 1);
+    BN_GUARD_END((void)0)
+}
+void bnhip_resampler_destroy(bnhip_resampler* r) {
+    try { resampler_free(r); } catch (...) {}
+}
+
+// ------------------------------------------------------------------------------------------------ diagnostics
 int bnhip_profile_enable(bnhip_model* m, int on) {
     if (!m) return set_err(BNHIP_E_INVALID, "model is NULL");
-    m->eng.profiling = on != 0;
+    m->eng().profiling = on != 0;
     return BNHIP_OK;
 }
 
 int bnhip_profile_filter(bnhip_model* m, const char* kernel_class) {
     if (!m) return set_err(BNHIP_E_INVALID, "model is NULL");
-    m->eng.profile_filter = kernel_class ? kernel_class : "";
+    BN_GUARD_BEGIN
+    m->eng().profile_filter = kernel_class ? kernel_class : "";
     return BNHIP_OK;
-}
-
-static int copy_out(const std::string& s, char* buf, size_t cap) {
-    if (buf && cap) {
-        size_t n = std::min(cap - 1, s.size());
-        memcpy(buf, s.data(), n);
-        buf[n] = 0;
-    }
-    return (int)s.size() + 1;
+    BN_GUARD_END((void)0)
 }
 
 int bnhip_profile_read(bnhip_model* m, char* buf, size_t cap) {
-    if (!m || m->eng.device < 0) return set_err(BNHIP_E_INVALID, "model is NULL or plan-only");
-    hipSetDevice(m->eng.device);
-    return copy_out(m->eng.profile_read(), buf, cap);
+    if (!m || m->eng().device < 0) return set_err(BNHIP_E_INVALID, "model is NULL or plan-only");
+    BN_GUARD_BEGIN
+    hipSetDevice(m->eng().device);
+    return copy_out(m->eng().profile_read(), buf, cap);
+    BN_GUARD_END((void)0)
 }
 
 int bnhip_model_describe(const bnhip_model* m, char* buf, size_t cap) {
     if (!m) return set_err(BNHIP_E_INVALID, "model is NULL");
-    return copy_out(m->eng.describe(), buf, cap);
+    BN_GUARD_BEGIN
+    std::string d = m->eng().describe();
+    // splice the handle-level facts in front of the engine's description
+    std::string devs = "[";
+    for (size_t i = 0; i < m->engs.size(); i++) devs += (i ? "," : "") + std::to_string(m->engs[i]->device);
+    devs += "]";
+    std::string head = "{\"devices\":" + devs + ",\"weight_replication\":\"" + m->replication + "\",";
+    if (!d.empty() && d[0] == '{') d = head + d.substr(1);
+    return copy_out(d, buf, cap);
+    BN_GUARD_END((void)0)
 }
 
 }  // extern "C"

@@ -40,6 +40,7 @@ struct Planner {
         uses.assign(nt, 0);
         absorbed.assign(m.ops.size(), 0);
         for (int i = 0; i < (int)m.ops.size(); i++) {
+            if (m.ops[i].code == OP_NOP) { absorbed[i] = 1; continue; }      // removed by a graph pass
             for (int o : m.ops[i].outputs) producer[o] = i;
             for (int t : m.ops[i].inputs)
                 if (t >= 0) { consumers[t].push_back(i); uses[t]++; }
@@ -297,46 +298,21 @@ Engine::~Engine() {
     if (own_stream && stream) hipStreamDestroy(stream);
 }
 
-static float half_to_float(uint16_t h) {
-    uint32_t sign = (uint32_t)(h & 0x8000) << 16, exp = (h >> 10) & 0x1f, man = h & 0x3ff, bits;
-    if (exp == 0) {
-        if (man == 0) bits = sign;
-        else { int e = -1; do { man <<= 1; e++; } while (!(man & 0x400)); bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ff) << 13); }
-    } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
-    else bits = sign | ((exp + 112) << 23) | (man << 13);
-    float f; memcpy(&f, &bits, 4); return f;
-}
-
 bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* err, int* code) {
     device = dev;
     max_batch = maxb;
     *code = BNHIP_E_UNSUPPORTED;
-    // FP16-weight models (e.g. the reference's MData range-filter .tflite): DEQUANTIZE(const f16) -> f32 constant
-    std::vector<std::vector<float>> derived_consts;
-    std::vector<int> dequant_ops;
-    for (int i = 0; i < (int)m.ops.size(); i++) {
-        const TflOp& o = m.ops[i];
-        if (o.code != OP_DEQUANTIZE || o.inputs.empty() || o.outputs.empty()) continue;
-        TflTensor& src = m.tensors[o.inputs[0]];
-        if (!src.data || src.type != TT_FLOAT16) { *err = "DEQUANTIZE: only constant float16 inputs are supported"; return false; }
-        derived_consts.emplace_back(src.numel());
-        const uint16_t* h = reinterpret_cast<const uint16_t*>(src.data);
-        for (size_t k = 0; k < src.numel(); k++) derived_consts.back()[k] = half_to_float(h[k]);
-        TflTensor& dst = m.tensors[o.outputs[0]];
-        dst.data = reinterpret_cast<const uint8_t*>(derived_consts.back().data());
-        dst.nbytes = src.numel() * 4;
-        dst.type = TT_FLOAT32;
-        dequant_ops.push_back(i);
-    }
+    // graph rewrites first (float16 constants behind DEQUANTIZE, unfolded batch norm, PAD + VALID convolutions): the
+    // patterns below then see one canonical form whatever the exporter emitted
+    if (!run_graph_passes(&m, err)) { *code = BNHIP_E_UNSUPPORTED; return false; }
     Planner P(m);
-    for (int i : dequant_ops) P.absorbed[i] = 1;
 
     const TflTensor& tin = m.tensors[m.inputs[0]];
-    if (tin.type != TT_FLOAT32 || tin.shape.size() != 2 || tin.shape[0] != 1) {
-        *err = "graph input must be float32 [1, n_samples]";
+    if (tin.type != TT_FLOAT32 || tin.shape.size() < 2 || tin.shape[0] != 1 || tin.numel() == 0 || tin.numel() > ((size_t)1 << 30)) {
+        *err = "graph input must be float32 [1, ...] (one clip / one feature row per batch entry)";
         return false;
     }
-    n_samples = tin.shape[1];
+    n_samples = (int)tin.numel();      // [1, n_samples] for the audio models; any [1, ...] block for generic graphs
 
     // ---------------------------------------------------------------- front-end
     std::vector<FrontendMatch> fms;
@@ -573,8 +549,25 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
         if (s.size() == 2 && s[0] == 1) { *H = 1; *W = 1; *C = s[1]; return true; }
         return false;
     };
-    auto map_act = [&](int fused) -> int {
-        switch (fused) { case 0: return ACT_NONE; case 1: return ACT_RELU; case 3: return ACT_RELU6; default: return -1; }
+    // fused activation of a conv / dense op -> activation the kernels apply; the two the fused kernels do not implement
+    // (RELU_N1_TO_1, TANH) become a separate elementwise step (*post)
+    auto map_act = [&](int fused, int* post = nullptr) -> int {
+        if (post) *post = 0;
+        switch (fused) {
+            case 0: return ACT_NONE; case 1: return ACT_RELU; case 3: return ACT_RELU6;
+            case 2: if (post) { *post = U_RELU_N1_TO_1; return ACT_NONE; } return -1;
+            case 4: if (post) { *post = U_TANH; return ACT_NONE; } return -1;
+            default: return -1;
+        }
+    };
+    // top / left zero padding of a convolution-like op (SAME: TF's rule; VALID: none; explicit: folded-in PAD)
+    auto conv_pads = [&](const TflOp& o, int H, int W, int Ho, int Wo, int kh, int kw, int* pt, int* pl) {
+        *pt = 0; *pl = 0;
+        if (o.explicit_pad) { *pt = o.pad_t; *pl = o.pad_l; return; }
+        if (o.padding == 0) {
+            *pt = std::max((Ho - 1) * o.stride_h + (kh - 1) * o.dil_h + 1 - H, 0) / 2;
+            *pl = std::max((Wo - 1) * o.stride_w + (kw - 1) * o.dil_w + 1 - W, 0) / 2;
+        }
     };
     // trailing swish / sigmoid detection on tensor y produced by op `oi`; returns final tensor and act
     auto trailing_act = [&](int y, int* act) -> int {
@@ -606,6 +599,37 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
             auto it = tv.find(t);
             return it == tv.end() ? -1 : it->second;
         };
+        // binds the step's output to TFLite tensor `outt` and appends it; a fused activation the kernels do not implement
+        // (post != 0) runs as a separate elementwise step on an internal value
+        auto emit = [&](Step st, int outt, size_t elems, int post, size_t o0 = SIZE_MAX, size_t o1 = SIZE_MAX, size_t o2 = SIZE_MAX,
+                        size_t o3 = SIZE_MAX) {
+            if (!post) { st.out = new_val(outt, elems); tv[outt] = st.out; add_step(st, o0, o1, o2, o3); return; }
+            st.out = new_val(-1, elems);
+            add_step(st, o0, o1, o2, o3);
+            Step u; u.kind = S_EW_UNARY; u.kclass = "elementwise"; u.name = st.name + "/act"; u.in0 = st.out; u.op = post;
+            u.out = new_val(outt, elems); tv[outt] = u.out; u.bytes = 8.0 * elems;
+            add_step(u);
+        };
+        // an operand of a generic op: activation value, or constant uploaded to the weight arena
+        struct Operand { int val = -1; size_t woff = SIZE_MAX; bool ok = false; };
+        auto operand = [&](int t) -> Operand {
+            Operand r;
+            if (t < 0) return r;
+            r.val = need_val(t);
+            if (r.val >= 0) { r.ok = true; return r; }
+            if (P.is_const(t) && m.tensors[t].type == TT_FLOAT32) { r.woff = wconst(t); r.ok = true; }
+            return r;
+        };
+        // shape -> rank-5 (batch + 4) by left-padding with 1s; false when the rank is larger or the leading dim is not 1
+        auto shape5 = [&](const std::vector<int>& sh, int out[5]) -> bool {
+            std::vector<int> v = sh;
+            while (v.size() > 5 && v[0] == 1) v.erase(v.begin());
+            if (v.size() > 5) return false;
+            for (int k = 0; k < 5; k++) out[k] = 1;
+            for (size_t k = 0; k < v.size(); k++) out[5 - v.size() + k] = v[k];
+            return out[0] == 1;
+        };
+        auto dense_strides = [&](const int d5[5], long st[5]) { st[4] = 1; for (int k = 3; k >= 0; k--) st[k] = st[k + 1] * d5[k + 1]; };
         switch (o.code) {
             case OP_CONV_2D: {
                 int in_t = o.inputs[0];
@@ -616,15 +640,16 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                     *err = "CONV_2D: unsupported shapes at " + oname; return false;
                 }
                 int kh = w.shape[1], kw = w.shape[2];
-                int act = map_act(o.act);
+                int post = 0;
+                int act = map_act(o.act, &post);
                 if (act < 0) { *err = "CONV_2D: unsupported fused activation"; return false; }
                 int outt = o.outputs[0];
-                if (act == ACT_NONE) outt = trailing_act(outt, &act);
+                if (act == ACT_NONE && !post) outt = trailing_act(outt, &act);
                 size_t boff = (o.inputs.size() > 2 && o.inputs[2] >= 0) ? wconst(o.inputs[2]) : SIZE_MAX;
-                bool pw = kh == 1 && kw == 1 && o.stride_h == 1 && o.stride_w == 1;
+                bool pw = kh == 1 && kw == 1 && o.stride_h == 1 && o.stride_w == 1 && !o.explicit_pad && Ho == H && Wo == W;
                 Step s; s.name = oname; s.H = H; s.W = W; s.C = C; s.Ho = Ho; s.Wo = Wo; s.Co = Co; s.act = act;
                 // ---- MBConv front half: 1x1 expand whose only consumer is a depthwise conv -> one fused kernel
-                if (pw && fuse_expdw && scaled.find(in_t) == scaled.end() && P.uses[outt] == 1 && P.consumers[outt].size() == 1) {
+                if (pw && !post && fuse_expdw && scaled.find(in_t) == scaled.end() && P.uses[outt] == 1 && P.consumers[outt].size() == 1) {
                     int di = P.consumers[outt][0];
                     const TflOp& d = m.ops[di];
                     int dH, dW, dC, dHo, dWo, dCo;
@@ -634,7 +659,8 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                         const TflTensor& wd = m.tensors[d.inputs[1]];
                         int kd = wd.shape.size() == 4 ? wd.shape[1] : 0;
                         int act_d = map_act(d.act);
-                        const int fpt = d.padding == 0 ? std::max((dHo - 1) * d.stride_h + kd - dH, 0) / 2 : 0;
+                        int fpt = 0, fpl = 0;
+                        conv_pads(d, dH, dW, dHo, dWo, kd, kd, &fpt, &fpl);
                         if (kd == wd.shape[2] && wd.shape[3] == dC && act_d >= 0 && expdw_supported(kd, d.stride_h, C, Co) &&
                             expdw_sum_slabs(kd, d.stride_h, dH, dHo, dWo, fpt) > 0 && need_val(in_t) >= 0) {
                             int dout = d.outputs[0];
@@ -644,10 +670,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                             f.in0 = need_val(in_t);
                             f.H = H; f.W = W; f.C = C; f.Co = Co; f.Ho = dHo; f.Wo = dWo; f.kh = kd; f.kw = kd;
                             f.sh = d.stride_h; f.sw = d.stride_w; f.act = act; f.act2 = act_d;
-                            if (d.padding == 0) {
-                                int th = std::max((dHo - 1) * f.sh + kd - dH, 0), tw = std::max((dWo - 1) * f.sw + kd - dW, 0);
-                                f.pt = th / 2; f.pl = tw / 2;
-                            }
+                            f.pt = fpt; f.pl = fpl;
                             f.flops = 2.0 * H * W * C * Co + 2.0 * dHo * dWo * Co * kd * kd;
                             f.bytes = 4.0 * ((double)H * W * C + (double)dHo * dWo * Co);
                             f.wbytes = 4.0 * (C * Co + kd * kd * Co);
@@ -676,7 +699,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                     else s.in0 = need_val(in_t);
                     if (s.in0 < 0) { *err = "CONV_2D: input has no value: " + oname; return false; }
                     // residual ADD fusion
-                    if (P.uses[outt] == 1 && P.consumers[outt].size() == 1) {
+                    if (!post && P.uses[outt] == 1 && P.consumers[outt].size() == 1) {
                         int ai = P.consumers[outt][0];
                         const TflOp& ad = m.ops[ai];
                         if (ad.code == OP_ADD && ad.act == 0 && !P.absorbed[ai]) {
@@ -690,19 +713,27 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                     s.flops = 2.0 * H * W * C * Co;
                     s.bytes = 4.0 * ((double)H * W * C + (double)H * W * Co * (s.in2 >= 0 ? 2 : 1));
                     s.wbytes = 4.0 * C * Co;
-                    s.out = new_val(outt, (size_t)Ho * Wo * Co);
-                    tv[outt] = s.out;
-                    add_step(s, wconst(o.inputs[1]), boff);
+                    emit(s, outt, (size_t)Ho * Wo * Co, post, wconst(o.inputs[1]), boff);
+                } else if (o.dil_h != 1 || o.dil_w != 1 || (Co & 3)) {
+                    // dilated convolutions and channel counts the vectorised kernels do not cover: generic kernel, weights as
+                    // in the file (OHWI)
+                    s.kind = S_CONV_GENERIC; s.kclass = "conv_generic";
+                    auto sc = scaled.find(in_t);
+                    if (sc != scaled.end()) { *err = "CONV_2D: squeeze-excite scale in front of an unsupported convolution at " + oname; return false; }
+                    s.in0 = need_val(in_t);
+                    if (s.in0 < 0) { *err = "CONV_2D: input has no value: " + oname; return false; }
+                    s.kh = kh; s.kw = kw; s.sh = o.stride_h; s.sw = o.stride_w; s.g.dh = o.dil_h; s.g.dw = o.dil_w;
+                    conv_pads(o, H, W, Ho, Wo, kh, kw, &s.pt, &s.pl);
+                    s.flops = 2.0 * Ho * Wo * Co * kh * kw * C;
+                    s.bytes = 4.0 * ((double)H * W * C + (double)Ho * Wo * Co);
+                    emit(s, outt, (size_t)Ho * Wo * Co, post, wconst(o.inputs[1]), boff);
                 } else {
-                    if (o.dil_h != 1 || o.dil_w != 1 || (Co & 3)) { *err = "CONV_2D: unsupported dilation/channels at " + oname; return false; }
                     s.kind = S_CONV_DIRECT; s.kclass = "conv_direct";
+                    if (scaled.find(in_t) != scaled.end()) { *err = "CONV_2D: squeeze-excite scale in front of an unsupported convolution at " + oname; return false; }
                     s.in0 = need_val(in_t);
                     if (s.in0 < 0) { *err = "CONV_2D: input has no value: " + oname; return false; }
                     s.kh = kh; s.kw = kw; s.sh = o.stride_h; s.sw = o.stride_w;
-                    if (o.padding == 0) {   // SAME
-                        int th = std::max((Ho - 1) * s.sh + kh - H, 0), tw = std::max((Wo - 1) * s.sw + kw - W, 0);
-                        s.pt = th / 2; s.pl = tw / 2;
-                    }
+                    conv_pads(o, H, W, Ho, Wo, kh, kw, &s.pt, &s.pl);
                     // re-lay OHWI -> [kh][kw][Cin][Cout]
                     std::vector<float> wt((size_t)kh * kw * C * Co);
                     const float* ws = w.f32();
@@ -713,8 +744,6 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                                     wt[(((size_t)i * kw + j) * C + ic) * Co + oc] = ws[(((size_t)oc * kh + i) * kw + j) * C + ic];
                     s.flops = 2.0 * Ho * Wo * Co * kh * kw * C;
                     s.bytes = 4.0 * ((double)H * W * C + (double)Ho * Wo * Co);
-                    s.out = new_val(outt, (size_t)Ho * Wo * Co);
-                    tv[outt] = s.out;
                     {
                         // second image for the MFMA stem (used when stem_mfma_supported): [Cout][32], kk = i*8 + j*2 + ic
                         ConvParams cp{nullptr, nullptr, nullptr, nullptr, 1, H, W, C, Ho, Wo, Co, kh, kw, s.sh, s.sw, s.pt, s.pl, act};
@@ -728,7 +757,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                             if (o.inputs.size() > 2 && o.inputs[2] >= 0) memcpy(bp.data(), m.tensors[o.inputs[2]].f32(), (size_t)Co * sizeof(float));
                             // ---- stem whose only consumer is a 3x3 stride-1 depthwise conv: one k_expand_dw<STEM> launch; the
                             // stem output (the largest tensor of the network) never reaches HBM
-                            if (fuse_expdw && !getenv("BNHIP_NO_FUSE_STEM") && P.uses[outt] == 1 && P.consumers[outt].size() == 1 && (Co % 32) == 0) {
+                            if (!post && fuse_expdw && !getenv("BNHIP_NO_FUSE_STEM") && P.uses[outt] == 1 && P.consumers[outt].size() == 1 && (Co % 32) == 0) {
                                 int di = P.consumers[outt][0];
                                 const TflOp& d = m.ops[di];
                                 int dH, dW, dC, dHo, dWo, dCo;
@@ -738,8 +767,8 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                                     const TflTensor& wd = m.tensors[d.inputs[1]];
                                     int kd = wd.shape.size() == 4 ? wd.shape[1] : 0;
                                     int act_d = map_act(d.act);
-                                    const int fpt = d.padding == 0 ? std::max((dHo - 1) + kd - dH, 0) / 2 : 0;
-                                    const int fpl = d.padding == 0 ? std::max((dWo - 1) + kd - dW, 0) / 2 : 0;
+                                    int fpt = 0, fpl = 0;
+                                    conv_pads(d, dH, dW, dHo, dWo, kd, kd, &fpt, &fpl);
                                     if (kd == 3 && wd.shape[2] == 3 && wd.shape[3] == dC && act_d >= 0 && s.in0 >= 0 &&
                                         expdw_sum_slabs(kd, 1, dH, dHo, dWo, fpt) > 0) {
                                         int dout = d.outputs[0];
@@ -771,11 +800,11 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                                     }
                                 }
                             }
-                            add_step(s, wpush(wt.data(), wt.size()), boff, wpush(wm.data(), wm.size()), wpush(bp.data(), bp.size()));
+                            emit(s, outt, (size_t)Ho * Wo * Co, post, wpush(wt.data(), wt.size()), boff, wpush(wm.data(), wm.size()), wpush(bp.data(), bp.size()));
                             break;
                         }
                     }
-                    add_step(s, wpush(wt.data(), wt.size()), boff);
+                    emit(s, outt, (size_t)Ho * Wo * Co, post, wpush(wt.data(), wt.size()), boff);
                 }
                 break;
             }
@@ -783,29 +812,33 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                 int in_t = o.inputs[0];
                 const TflTensor& w = m.tensors[o.inputs[1]];
                 int H, W, C, Ho, Wo, Co;
-                if (!P.is_const(o.inputs[1]) || !hwc(in_t, &H, &W, &C) || !hwc(o.outputs[0], &Ho, &Wo, &Co) ||
-                    w.shape.size() != 4 || w.shape[3] != C || Co != C || o.depth_multiplier != 1 || o.dil_h != 1 || o.dil_w != 1) {
-                    *err = "DEPTHWISE_CONV_2D: unsupported configuration at " + oname; return false;
+                if (!P.is_const(o.inputs[1]) || !hwc(in_t, &H, &W, &C) || !hwc(o.outputs[0], &Ho, &Wo, &Co) || w.shape.size() != 4 ||
+                    w.shape[3] != Co || o.depth_multiplier < 1 || Co != C * o.depth_multiplier) {
+                    *err = "DEPTHWISE_CONV_2D: unsupported configuration at " + oname + " (filter must be constant [1,kh,kw,C*depth_multiplier])";
+                    return false;
                 }
-                int act = map_act(o.act);
+                int post = 0;
+                int act = map_act(o.act, &post);
                 if (act < 0) { *err = "DEPTHWISE_CONV_2D: unsupported fused activation"; return false; }
                 int outt = o.outputs[0];
-                if (act == ACT_NONE) outt = trailing_act(outt, &act);
-                Step s; s.kind = S_DW; s.kclass = "dwconv"; s.name = oname;
+                if (act == ACT_NONE && !post) outt = trailing_act(outt, &act);
+                Step s; s.name = oname;
                 s.in0 = need_val(in_t);
                 if (s.in0 < 0) { *err = "DEPTHWISE_CONV_2D: input has no value"; return false; }
-                s.H = H; s.W = W; s.C = C; s.Ho = Ho; s.Wo = Wo; s.Co = C; s.act = act;
+                s.H = H; s.W = W; s.C = C; s.Ho = Ho; s.Wo = Wo; s.Co = Co; s.act = act;
                 s.kh = w.shape[1]; s.kw = w.shape[2]; s.sh = o.stride_h; s.sw = o.stride_w;
-                if (o.padding == 0) {
-                    int th = std::max((Ho - 1) * s.sh + s.kh - H, 0), tw = std::max((Wo - 1) * s.sw + s.kw - W, 0);
-                    s.pt = th / 2; s.pl = tw / 2;
-                }
-                s.flops = 2.0 * Ho * Wo * C * s.kh * s.kw;
-                s.bytes = 4.0 * ((double)H * W * C + (double)Ho * Wo * C);
-                s.out = new_val(outt, (size_t)Ho * Wo * C);
-                tv[outt] = s.out;
+                conv_pads(o, H, W, Ho, Wo, s.kh, s.kw, &s.pt, &s.pl);
+                s.flops = 2.0 * Ho * Wo * Co * s.kh * s.kw;
+                s.bytes = 4.0 * ((double)H * W * C + (double)Ho * Wo * Co);
                 size_t boff = (o.inputs.size() > 2 && o.inputs[2] >= 0) ? wconst(o.inputs[2]) : SIZE_MAX;
-                add_step(s, wconst(o.inputs[1]), boff);
+                if (o.depth_multiplier != 1 || o.dil_h != 1 || o.dil_w != 1) {
+                    // channel multipliers and dilation: generic kernel (out channel oc reads input channel oc / multiplier)
+                    s.kind = S_CONV_GENERIC; s.kclass = "conv_generic";
+                    s.g.dh = o.dil_h; s.g.dw = o.dil_w; s.g.depthwise = 1; s.g.mult = o.depth_multiplier;
+                } else {
+                    s.kind = S_DW; s.kclass = "dwconv";
+                }
+                emit(s, outt, (size_t)Ho * Wo * Co, post, wconst(o.inputs[1]), boff);
                 break;
             }
             case OP_MEAN: {
@@ -814,7 +847,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                 const TflTensor& ax = m.tensors[o.inputs[1]];
                 bool ok = hwc(in_t, &H, &W, &C) && ax.data && ax.numel() == 2 &&
                           ((ax.i32()[0] == 1 && ax.i32()[1] == 2) || (ax.i32()[0] == 2 && ax.i32()[1] == 1));
-                if (!ok) { *err = "MEAN: only spatial (axes 1,2) means are supported at " + oname; return false; }
+                if (!ok) goto generic_reduce;
                 int vin = need_val(in_t);
                 if (vin < 0) { *err = "MEAN: input has no value"; return false; }
                 int S = mean_splits(H * W);
@@ -920,25 +953,46 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
             }
             case OP_FULLY_CONNECTED: {
                 int in_t = o.inputs[0];
-                int H, W, C;
-                if (!P.is_const(o.inputs[1]) || !hwc(in_t, &H, &W, &C) || H * W != 1) { *err = "FULLY_CONNECTED: unsupported input at " + oname; return false; }
+                if (!P.is_const(o.inputs[1])) { *err = "FULLY_CONNECTED: weights must be constant at " + oname; return false; }
                 const TflTensor& w = m.tensors[o.inputs[1]];
-                if (w.shape.size() != 2 || w.shape[1] != C) { *err = "FULLY_CONNECTED: weight shape mismatch"; return false; }
-                int act = map_act(o.act);
+                const int C = w.shape[1], N = w.shape[0];
+                const size_t in_elems = m.tensors[in_t].numel();
+                if (C <= 0 || in_elems % (size_t)C) { *err = "FULLY_CONNECTED: input size is not a multiple of the weight width at " + oname; return false; }
+                const int rows = (int)(in_elems / (size_t)C);          // leading dimensions flatten into GEMM rows
+                int post = 0;
+                int act = map_act(o.act, &post);
                 if (act < 0) { *err = "FULLY_CONNECTED: unsupported fused activation"; return false; }
                 int outt = o.outputs[0];
-                if (act == ACT_NONE && std::find(m.outputs.begin(), m.outputs.end(), outt) == m.outputs.end())
+                if (act == ACT_NONE && !post && std::find(m.outputs.begin(), m.outputs.end(), outt) == m.outputs.end())
                     outt = trailing_act(outt, &act);
                 Step s; s.kind = S_PW; s.kclass = "pw_gemm"; s.name = oname;
                 s.in0 = need_val(in_t);
                 if (s.in0 < 0) { *err = "FULLY_CONNECTED: input has no value"; return false; }
-                s.H = 1; s.W = 1; s.C = C; s.Ho = 1; s.Wo = 1; s.Co = w.shape[0]; s.act = act;
-                s.flops = 2.0 * C * s.Co;
-                s.bytes = 4.0 * (C + s.Co);
-                s.wbytes = 4.0 * C * s.Co;
-                s.out = new_val(outt, (size_t)s.Co); tv[outt] = s.out;
+                s.H = rows; s.W = 1; s.C = C; s.Ho = rows; s.Wo = 1; s.Co = N; s.act = act;
+                s.flops = 2.0 * rows * C * N;
+                s.bytes = 4.0 * rows * (C + N);
+                s.wbytes = 4.0 * C * N;
                 size_t boff = (o.inputs.size() > 2 && o.inputs[2] >= 0) ? wconst(o.inputs[2]) : SIZE_MAX;
-                add_step(s, wconst(o.inputs[1]), boff);
+                emit(s, outt, (size_t)rows * N, post, wconst(o.inputs[1]), boff);
+                break;
+            }
+            case OP_BATCH_MATMUL: {
+                // activation x constant matrix only (a dense layer written as a matmul): W[N][K] = rhs^T at plan time
+                int in_t = o.inputs[0], r_t = o.inputs[1];
+                if (!P.is_const(r_t) || m.tensors[r_t].shape.size() != 2 || o.adj_x) { *err = "BATCH_MATMUL: only activation x constant [K,N] is supported at " + oname; return false; }
+                const TflTensor& r = m.tensors[r_t];
+                const int K = o.adj_y ? r.shape[1] : r.shape[0], N = o.adj_y ? r.shape[0] : r.shape[1];
+                const size_t in_elems = m.tensors[in_t].numel();
+                if (K <= 0 || in_elems % (size_t)K) { *err = "BATCH_MATMUL: inner dimensions disagree at " + oname; return false; }
+                std::vector<float> wt((size_t)N * K);
+                for (int n = 0; n < N; n++)
+                    for (int k = 0; k < K; k++) wt[(size_t)n * K + k] = o.adj_y ? r.f32()[(size_t)n * K + k] : r.f32()[(size_t)k * N + n];
+                const int rows = (int)(in_elems / (size_t)K);
+                Step s; s.kind = S_PW; s.kclass = "pw_gemm"; s.name = oname; s.in0 = need_val(in_t);
+                if (s.in0 < 0) { *err = "BATCH_MATMUL: input has no value"; return false; }
+                s.H = rows; s.W = 1; s.C = K; s.Ho = rows; s.Wo = 1; s.Co = N; s.act = ACT_NONE;
+                s.flops = 2.0 * rows * K * N; s.bytes = 4.0 * rows * (K + N); s.wbytes = 4.0 * K * N;
+                emit(s, o.outputs[0], (size_t)rows * N, 0, wpush(wt.data(), wt.size()));
                 break;
             }
             case OP_LOGISTIC: case OP_RELU: case OP_RELU6: case OP_HARD_SWISH: {
@@ -951,38 +1005,286 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                 add_step(s);
                 break;
             }
-            case OP_ADD: case OP_MUL: case OP_SUB: {
-                int act = map_act(o.act);
-                if (act < 0) { *err = "binary op: unsupported fused activation"; return false; }
-                int a = o.inputs[0], b = o.inputs[1];
-                int va = need_val(a), vb = need_val(b);
-                if (va < 0 && vb >= 0 && o.code != OP_SUB) { std::swap(a, b); std::swap(va, vb); }
-                if (va < 0) { *err = std::string(op_name(o.code)) + ": no activation operand at " + oname; return false; }
-                Step s; s.kind = S_BINARY; s.kclass = "elementwise"; s.name = oname; s.act = act;
-                s.op = o.code == OP_ADD ? 0 : (o.code == OP_MUL ? 1 : 2);
-                s.in0 = va;
-                int H, W, C;
-                if (!hwc(a, &H, &W, &C)) { *err = "binary op: unsupported shape"; return false; }
-                s.H = H; s.W = W; s.C = C;
-                size_t coff = SIZE_MAX;
-                if (vb >= 0) {
-                    s.in1 = vb;
-                    if (vals[vb].elems == vals[va].elems) s.mode = 0;
-                    else if (vals[vb].elems == (size_t)C) s.mode = 1;
-                    else { *err = "binary op: unsupported broadcast at " + oname; return false; }
-                } else {
-                    float c;
-                    if (!P.const_scalar(b, &c)) { *err = "binary op: unsupported constant operand at " + oname; return false; }
-                    s.mode = 2; coff = wconst(b);
-                }
-                s.out = new_val(o.outputs[0], vals[va].elems); tv[o.outputs[0]] = s.out;
-                s.bytes = 4.0 * vals[va].elems * (s.mode == 0 ? 3 : 2);
-                add_step(s, coff);
-                break;
-            }
-            case OP_RESHAPE: case OP_SQUEEZE: case OP_EXPAND_DIMS: {
+            case OP_TANH: case OP_EXP: case OP_LOG: case OP_SQRT: case OP_RSQRT: case OP_ABS: case OP_NEG: case OP_SQUARE:
+            case OP_LEAKY_RELU: case OP_ELU: case OP_SIN: case OP_COS: case OP_FLOOR: case OP_CEIL: case OP_ROUND:
+            case OP_RELU_N1_TO_1: case OP_GELU: {
                 int vin = need_val(o.inputs[0]);
                 if (vin < 0) { *err = std::string(op_name(o.code)) + ": input has no value"; return false; }
+                Step s; s.kind = S_EW_UNARY; s.kclass = "elementwise"; s.name = oname; s.in0 = vin;
+                switch (o.code) {
+                    case OP_TANH: s.op = U_TANH; break; case OP_EXP: s.op = U_EXP; break; case OP_LOG: s.op = U_LOG; break;
+                    case OP_SQRT: s.op = U_SQRT; break; case OP_RSQRT: s.op = U_RSQRT; break; case OP_ABS: s.op = U_ABS; break;
+                    case OP_NEG: s.op = U_NEG; break; case OP_SQUARE: s.op = U_SQUARE; break; case OP_LEAKY_RELU: s.op = U_LEAKY_RELU; break;
+                    case OP_ELU: s.op = U_ELU; break; case OP_SIN: s.op = U_SIN; break; case OP_COS: s.op = U_COS; break;
+                    case OP_FLOOR: s.op = U_FLOOR; break; case OP_CEIL: s.op = U_CEIL; break; case OP_ROUND: s.op = U_ROUND; break;
+                    case OP_RELU_N1_TO_1: s.op = U_RELU_N1_TO_1; break;
+                    default: s.op = o.approximate ? U_GELU_TANH : U_GELU; break;
+                }
+                s.g.alpha = o.alpha;
+                s.out = new_val(o.outputs[0], vals[vin].elems); tv[o.outputs[0]] = s.out;
+                s.bytes = 8.0 * vals[vin].elems;
+                add_step(s);
+                break;
+            }
+            case OP_ADD: case OP_MUL: case OP_SUB: case OP_DIV: case OP_POW: case OP_MAXIMUM: case OP_MINIMUM:
+            case OP_SQUARED_DIFFERENCE: {
+                // numpy-style broadcasting over right-aligned shapes; either operand may be a constant
+                if (o.act < 0 || o.act > 4) { *err = "binary op: unsupported fused activation"; return false; }
+                Operand A = operand(o.inputs[0]), B = operand(o.inputs[1]);
+                if (!A.ok || !B.ok) { *err = std::string(op_name(o.code)) + ": operand has no value at " + oname; return false; }
+                if (A.val < 0 && B.val < 0) { *err = std::string(op_name(o.code)) + ": constant expression (no activation operand) at " + oname; return false; }
+                int da[5], db[5], dz[5];
+                if (!shape5(m.tensors[o.inputs[0]].shape, da) || !shape5(m.tensors[o.inputs[1]].shape, db) ||
+                    !shape5(m.tensors[o.outputs[0]].shape, dz)) { *err = "binary op: rank > 4 (+batch) unsupported at " + oname; return false; }
+                for (int k = 0; k < 5; k++)
+                    if ((da[k] != dz[k] && da[k] != 1) || (db[k] != dz[k] && db[k] != 1)) { *err = "binary op: shapes do not broadcast at " + oname; return false; }
+                long sta[5], stb[5];
+                dense_strides(da, sta); dense_strides(db, stb);
+                Step s; s.kind = S_EW_BINARY; s.kclass = "elementwise"; s.name = oname; s.act = o.act;
+                s.op = o.code == OP_ADD ? B_ADD : o.code == OP_MUL ? B_MUL : o.code == OP_SUB ? B_SUB : o.code == OP_DIV ? B_DIV :
+                       o.code == OP_POW ? B_POW : o.code == OP_MAXIMUM ? B_MAX : o.code == OP_MINIMUM ? B_MIN : B_SQDIFF;
+                for (int k = 0; k < 4; k++) {
+                    s.g.d[k] = dz[k + 1];
+                    s.g.sa[k] = da[k + 1] == 1 ? 0 : sta[k + 1];
+                    s.g.sb[k] = db[k + 1] == 1 ? 0 : stb[k + 1];
+                }
+                s.in0 = A.val; s.in1 = B.val; s.g.a_const = A.val < 0; s.g.b_const = B.val < 0;
+                const size_t elems = m.tensors[o.outputs[0]].numel();
+                s.out = new_val(o.outputs[0], elems); tv[o.outputs[0]] = s.out;
+                s.bytes = 12.0 * elems;
+                add_step(s, A.woff, B.woff);
+                break;
+            }
+            case OP_AVERAGE_POOL_2D: case OP_MAX_POOL_2D: {
+                int H, W, C, Ho, Wo, Co;
+                if (!hwc(o.inputs[0], &H, &W, &C) || !hwc(o.outputs[0], &Ho, &Wo, &Co) || Co != C || o.filter_h < 1 || o.filter_w < 1) {
+                    *err = std::string(op_name(o.code)) + ": unsupported shapes at " + oname; return false;
+                }
+                if (o.act < 0 || o.act > 4) { *err = "pool: unsupported fused activation"; return false; }
+                int vin = need_val(o.inputs[0]);
+                if (vin < 0) { *err = std::string(op_name(o.code)) + ": input has no value"; return false; }
+                Step s; s.kind = S_POOL; s.kclass = "pool"; s.name = oname; s.in0 = vin; s.act = o.act;
+                s.mode = o.code == OP_AVERAGE_POOL_2D ? 0 : 1;
+                s.H = H; s.W = W; s.C = C; s.Ho = Ho; s.Wo = Wo; s.Co = C; s.kh = o.filter_h; s.kw = o.filter_w; s.sh = o.stride_h; s.sw = o.stride_w;
+                if (o.padding == 0) {
+                    s.pt = std::max((Ho - 1) * s.sh + s.kh - H, 0) / 2;
+                    s.pl = std::max((Wo - 1) * s.sw + s.kw - W, 0) / 2;
+                }
+                s.out = new_val(o.outputs[0], (size_t)Ho * Wo * C); tv[o.outputs[0]] = s.out;
+                s.bytes = 4.0 * ((double)H * W * C + (double)Ho * Wo * C);
+                add_step(s);
+                break;
+            }
+            case OP_SOFTMAX: {
+                int vin = need_val(o.inputs[0]);
+                const auto& sh = m.tensors[o.inputs[0]].shape;
+                if (vin < 0 || sh.empty()) { *err = "SOFTMAX: input has no value"; return false; }
+                Step s; s.kind = S_SOFTMAX; s.kclass = "softmax"; s.name = oname; s.in0 = vin;
+                s.C = sh.back(); s.H = (int)(vals[vin].elems / (size_t)std::max(s.C, 1)); s.g.alpha = o.beta;
+                s.out = new_val(o.outputs[0], vals[vin].elems); tv[o.outputs[0]] = s.out;
+                s.bytes = 8.0 * vals[vin].elems;
+                add_step(s);
+                break;
+            }
+            case OP_CONCATENATION: {
+                int dz[5];
+                const int rank = (int)m.tensors[o.outputs[0]].shape.size();
+                if (!shape5(m.tensors[o.outputs[0]].shape, dz) || rank < 1) { *err = "CONCATENATION: rank unsupported at " + oname; return false; }
+                int ax = o.axis < 0 ? o.axis + rank : o.axis;
+                if (ax < 0 || ax >= rank) { *err = "CONCATENATION: axis out of range at " + oname; return false; }
+                const int ax5 = ax + (5 - std::min(rank, 5));
+                if (ax5 < 1) { *err = "CONCATENATION: cannot concatenate along the batch dimension at " + oname; return false; }
+                if (o.act != 0) { *err = "CONCATENATION: fused activation unsupported"; return false; }
+                long sto[5]; dense_strides(dz, sto);
+                const size_t elems = m.tensors[o.outputs[0]].numel();
+                const int vout = new_val(o.outputs[0], elems);
+                tv[o.outputs[0]] = vout;
+                long off = 0; int total_ax = 0;
+                for (size_t ii = 0; ii < o.inputs.size(); ii++) {
+                    Operand A = operand(o.inputs[ii]);
+                    int di[5];
+                    if (!A.ok || !shape5(m.tensors[o.inputs[ii]].shape, di)) { *err = "CONCATENATION: operand has no value at " + oname; return false; }
+                    for (int k = 0; k < 5; k++) if (k != ax5 && di[k] != dz[k]) { *err = "CONCATENATION: operand shapes disagree at " + oname; return false; }
+                    long sti[5]; dense_strides(di, sti);
+                    Step s; s.kind = S_COPY; s.kclass = "copy"; s.name = oname + "/" + std::to_string(ii); s.in0 = A.val; s.out = vout;
+                    s.g.a_const = A.val < 0;
+                    for (int k = 0; k < 4; k++) { s.g.d[k] = di[k + 1]; s.g.sa[k] = sti[k + 1]; s.g.so[k] = sto[k + 1]; }
+                    s.g.offo = off * sto[ax5];
+                    s.bytes = 8.0 * m.tensors[o.inputs[ii]].numel();
+                    add_step(s, A.woff);
+                    off += di[ax5]; total_ax += di[ax5];
+                }
+                if (total_ax != dz[ax5]) { *err = "CONCATENATION: operand sizes do not add up at " + oname; return false; }
+                break;
+            }
+            case OP_STRIDED_SLICE: case OP_SLICE: {
+                int vin = need_val(o.inputs[0]);
+                const auto& ish = m.tensors[o.inputs[0]].shape;
+                const int rank = (int)ish.size();
+                if (vin < 0) { *err = std::string(op_name(o.code)) + ": input has no value at " + oname; return false; }
+                for (size_t k = 1; k < o.inputs.size(); k++)
+                    if (!P.is_const(o.inputs[k]) || (int)m.tensors[o.inputs[k]].numel() != rank) { *err = std::string(op_name(o.code)) + ": begin/end/strides must be constant vectors of the input rank at " + oname; return false; }
+                if (o.code == OP_STRIDED_SLICE && (o.ellipsis_mask || o.new_axis_mask)) { *err = "STRIDED_SLICE: ellipsis / new-axis masks unsupported at " + oname; return false; }
+                int di[5];
+                if (!shape5(ish, di) || rank > 5) { *err = std::string(op_name(o.code)) + ": rank unsupported at " + oname; return false; }
+                const int lead = 5 - rank;
+                long sti[5]; dense_strides(di, sti);
+                int cnt5[5] = {1, 1, 1, 1, 1}; long st5[5] = {0, 0, 0, 0, 0}; long off = 0;
+                const int32_t* bg = m.tensors[o.inputs[1]].i32();
+                const int32_t* en = m.tensors[o.inputs[2]].i32();
+                const int32_t* sr = o.code == OP_STRIDED_SLICE ? m.tensors[o.inputs[3]].i32() : nullptr;
+                size_t total = 1;
+                for (int k = 0; k < rank; k++) {
+                    const int dim = ish[k];
+                    long b, e, st;
+                    if (o.code == OP_SLICE) {                              // begin / size; size -1 = to the end
+                        b = bg[k]; st = 1; e = en[k] < 0 ? dim : b + en[k];
+                    } else {
+                        st = sr[k];
+                        if (st == 0) { *err = "STRIDED_SLICE: zero stride at " + oname; return false; }
+                        b = bg[k]; e = en[k];
+                        if (b < 0) b += dim;
+                        if (e < 0) e += dim;
+                        if ((o.begin_mask >> k) & 1) b = st > 0 ? 0 : dim - 1;
+                        if ((o.end_mask >> k) & 1) e = st > 0 ? dim : -1;
+                        if ((o.shrink_axis_mask >> k) & 1) { e = b + 1; st = 1; }
+                        if (st > 0) { b = std::min<long>(std::max<long>(b, 0), dim); e = std::min<long>(std::max<long>(e, 0), dim); }
+                        else { b = std::min<long>(std::max<long>(b, -1), dim - 1); e = std::min<long>(std::max<long>(e, -1), dim - 1); }
+                    }
+                    long n = st > 0 ? (e > b ? (e - b + st - 1) / st : 0) : (b > e ? (b - e - st - 1) / (-st) : 0);
+                    if (n <= 0 || b < 0 || b >= dim || b + (n - 1) * st < 0 || b + (n - 1) * st >= dim) { *err = std::string(op_name(o.code)) + ": empty or out-of-range slice at " + oname; return false; }
+                    cnt5[lead + k] = (int)n; st5[lead + k] = st * sti[lead + k]; off += b * sti[lead + k];
+                    total *= (size_t)n;
+                }
+                if (cnt5[0] != 1 || total != m.tensors[o.outputs[0]].numel()) { *err = std::string(op_name(o.code)) + ": slice does not match the output shape at " + oname; return false; }
+                Step s; s.kind = S_COPY; s.kclass = "copy"; s.name = oname; s.in0 = vin;
+                long so = 1;
+                for (int k = 3; k >= 0; k--) { s.g.d[k] = cnt5[k + 1]; s.g.sa[k] = st5[k + 1]; s.g.so[k] = so; so *= cnt5[k + 1]; }
+                s.g.offa = off;
+                s.out = new_val(o.outputs[0], total); tv[o.outputs[0]] = s.out;
+                s.bytes = 8.0 * total;
+                add_step(s);
+                break;
+            }
+            case OP_TRANSPOSE: case OP_REVERSE_V2: {
+                int vin = need_val(o.inputs[0]);
+                const auto& ish = m.tensors[o.inputs[0]].shape;
+                const int rank = (int)ish.size();
+                int di[5];
+                if (vin < 0 || !P.is_const(o.inputs[1]) || !shape5(ish, di) || rank > 5) { *err = std::string(op_name(o.code)) + ": unsupported operands at " + oname; return false; }
+                const int lead = 5 - rank;
+                long sti[5]; dense_strides(di, sti);
+                int dz[5]; long st5[5]; long off = 0;
+                const TflTensor& pt = m.tensors[o.inputs[1]];
+                if (o.code == OP_TRANSPOSE) {
+                    if ((int)pt.numel() != rank) { *err = "TRANSPOSE: permutation length != rank at " + oname; return false; }
+                    int perm5[5]; std::vector<char> seen(5, 0);
+                    for (int k = 0; k < lead; k++) perm5[k] = k;
+                    for (int k = 0; k < rank; k++) { int pk = pt.i32()[k]; if (pk < 0 || pk >= rank) { *err = "TRANSPOSE: bad permutation at " + oname; return false; } perm5[lead + k] = lead + pk; }
+                    for (int k = 0; k < 5; k++) { if (seen[perm5[k]]) { *err = "TRANSPOSE: bad permutation at " + oname; return false; } seen[perm5[k]] = 1; }
+                    if (perm5[0] != 0) { *err = "TRANSPOSE: the batch dimension cannot move at " + oname; return false; }
+                    for (int k = 0; k < 5; k++) { dz[k] = di[perm5[k]]; st5[k] = sti[perm5[k]]; }
+                } else {
+                    for (int k = 0; k < 5; k++) { dz[k] = di[k]; st5[k] = sti[k]; }
+                    for (size_t q = 0; q < pt.numel(); q++) {
+                        int ax = pt.i32()[q]; if (ax < 0) ax += rank;
+                        if (ax < 0 || ax >= rank || lead + ax == 0) { *err = "REVERSE_V2: bad axis at " + oname; return false; }
+                        off += (long)(di[lead + ax] - 1) * sti[lead + ax]; st5[lead + ax] = -sti[lead + ax];
+                    }
+                }
+                Step s; s.kind = S_COPY; s.kclass = "copy"; s.name = oname; s.in0 = vin;
+                long so = 1;
+                for (int k = 3; k >= 0; k--) { s.g.d[k] = dz[k + 1]; s.g.sa[k] = st5[k + 1]; s.g.so[k] = so; so *= dz[k + 1]; }
+                s.g.offa = off;
+                s.out = new_val(o.outputs[0], vals[vin].elems); tv[o.outputs[0]] = s.out;
+                s.bytes = 8.0 * vals[vin].elems;
+                add_step(s);
+                break;
+            }
+            case OP_PAD: case OP_PADV2: {
+                int vin = need_val(o.inputs[0]);
+                const auto& ish = m.tensors[o.inputs[0]].shape;
+                const int rank = (int)ish.size();
+                int di[5], dz[5];
+                if (vin < 0 || !P.is_const(o.inputs[1]) || (int)m.tensors[o.inputs[1]].numel() != 2 * rank || !shape5(ish, di) ||
+                    !shape5(m.tensors[o.outputs[0]].shape, dz) || rank > 5) { *err = std::string(op_name(o.code)) + ": unsupported operands at " + oname; return false; }
+                float fillv = 0.0f;
+                if (o.code == OP_PADV2 && !P.const_scalar(o.inputs[2], &fillv)) { *err = "PADV2: pad value must be a scalar constant at " + oname; return false; }
+                const int lead = 5 - rank;
+                const int32_t* pv = m.tensors[o.inputs[1]].i32();
+                long sto[5]; dense_strides(dz, sto);
+                long off = 0;
+                for (int k = 0; k < rank; k++) {
+                    if (pv[2 * k] < 0 || pv[2 * k + 1] < 0 || di[lead + k] + pv[2 * k] + pv[2 * k + 1] != dz[lead + k]) { *err = std::string(op_name(o.code)) + ": paddings disagree with the output shape at " + oname; return false; }
+                    off += (long)pv[2 * k] * sto[lead + k];
+                }
+                if (dz[0] != 1) { *err = std::string(op_name(o.code)) + ": batch padding unsupported at " + oname; return false; }
+                Step s; s.kind = S_COPY; s.kclass = "copy"; s.name = oname; s.in0 = vin;
+                long si = 1;
+                for (int k = 3; k >= 0; k--) { s.g.d[k] = di[k + 1]; s.g.sa[k] = si; si *= di[k + 1]; s.g.so[k] = sto[k + 1]; }
+                s.g.offo = off; s.g.fill = true; s.g.alpha = fillv;
+                const size_t elems = m.tensors[o.outputs[0]].numel();
+                s.out = new_val(o.outputs[0], elems); tv[o.outputs[0]] = s.out;
+                s.bytes = 4.0 * (elems + vals[vin].elems);
+                add_step(s);
+                break;
+            }
+            case OP_SPLIT: {
+                // inputs: axis (constant scalar), value; outputs: num_splits equal slices along the axis
+                int vin = need_val(o.inputs[1]);
+                const auto& ish = m.tensors[o.inputs[1]].shape;
+                const int rank = (int)ish.size();
+                int di[5];
+                if (vin < 0 || !P.is_const(o.inputs[0]) || m.tensors[o.inputs[0]].numel() != 1 || !shape5(ish, di) || rank > 5) { *err = "SPLIT: unsupported operands at " + oname; return false; }
+                int ax = m.tensors[o.inputs[0]].i32()[0]; if (ax < 0) ax += rank;
+                const int lead = 5 - rank, nsp = (int)o.outputs.size();
+                if (ax < 0 || ax >= rank || lead + ax == 0 || nsp < 1 || di[lead + ax] % nsp) { *err = "SPLIT: bad axis or split count at " + oname; return false; }
+                long sti[5]; dense_strides(di, sti);
+                int dz[5]; for (int k = 0; k < 5; k++) dz[k] = di[k];
+                dz[lead + ax] = di[lead + ax] / nsp;
+                size_t elems = 1; for (int k = 0; k < 5; k++) elems *= (size_t)dz[k];
+                for (int q = 0; q < nsp; q++) {
+                    if (m.tensors[o.outputs[q]].numel() != elems) { *err = "SPLIT: output shape mismatch at " + oname; return false; }
+                    Step s; s.kind = S_COPY; s.kclass = "copy"; s.name = m.tensors[o.outputs[q]].name; s.in0 = vin;
+                    long so = 1;
+                    for (int k = 3; k >= 0; k--) { s.g.d[k] = dz[k + 1]; s.g.sa[k] = sti[k + 1]; s.g.so[k] = so; so *= dz[k + 1]; }
+                    s.g.offa = (long)q * dz[lead + ax] * sti[lead + ax];
+                    s.out = new_val(o.outputs[q], elems); tv[o.outputs[q]] = s.out;
+                    s.bytes = 8.0 * elems;
+                    add_step(s);
+                }
+                break;
+            }
+            case OP_SUM: case OP_REDUCE_MAX: case OP_REDUCE_MIN: case OP_REDUCE_PROD:
+            generic_reduce: {
+                int vin = need_val(o.inputs[0]);
+                const auto& ish = m.tensors[o.inputs[0]].shape;
+                const int rank = (int)ish.size();
+                int di[5];
+                if (vin < 0 || !P.is_const(o.inputs[1]) || !shape5(ish, di) || rank > 5) { *err = std::string(op_name(o.code)) + ": unsupported operands at " + oname; return false; }
+                const int lead = 5 - rank;
+                const TflTensor& ax = m.tensors[o.inputs[1]];
+                Step s; s.kind = S_REDUCE; s.kclass = "reduce"; s.name = oname; s.in0 = vin;
+                for (size_t q = 0; q < ax.numel(); q++) {
+                    int a = ax.i32()[q]; if (a < 0) a += rank;
+                    if (a < 0 || a >= rank || lead + a == 0) { *err = std::string(op_name(o.code)) + ": bad axis at " + oname; return false; }
+                    s.g.mask |= 1 << (lead + a - 1);
+                }
+                size_t elems = 1;
+                for (int k = 0; k < 4; k++) { s.g.d[k] = di[k + 1]; if (!((s.g.mask >> k) & 1)) elems *= (size_t)di[k + 1]; }
+                if (elems != m.tensors[o.outputs[0]].numel()) { *err = std::string(op_name(o.code)) + ": output shape mismatch at " + oname; return false; }
+                s.op = o.code == OP_MEAN ? R_MEAN : o.code == OP_SUM ? R_SUM : o.code == OP_REDUCE_MAX ? R_MAX : o.code == OP_REDUCE_MIN ? R_MIN : R_PROD;
+                s.out = new_val(o.outputs[0], elems); tv[o.outputs[0]] = s.out;
+                s.bytes = 4.0 * (vals[vin].elems + elems);
+                add_step(s);
+                break;
+            }
+            case OP_RESHAPE: case OP_SQUEEZE: case OP_EXPAND_DIMS: case OP_CAST: {
+                int vin = need_val(o.inputs[0]);
+                if (vin < 0) { *err = std::string(op_name(o.code)) + ": input has no value"; return false; }
+                if (o.code == OP_CAST && (m.tensors[o.inputs[0]].type != TT_FLOAT32 || m.tensors[o.outputs[0]].type != TT_FLOAT32)) {
+                    *err = "CAST: only float32 -> float32 outside the recognised front-end at " + oname; return false;
+                }
                 if (m.tensors[o.outputs[0]].numel() != vals[vin].elems) { *err = "reshape changes element count"; return false; }
                 tv[o.outputs[0]] = vin;   // contiguous alias
                 break;
@@ -1102,7 +1404,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
     }
     own_stream = true;
     HIPCHK(hipMalloc((void**)&w_arena, std::max<size_t>(w_bytes, 256)));
-    HIPCHK(hipMemcpy(w_arena, wimg.data(), w_bytes, hipMemcpyHostToDevice));
+    if (!defer_weights) HIPCHK(hipMemcpy(w_arena, wimg.data(), w_bytes, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&act_arena, std::max<size_t>(act_bytes, 256)));
     depth = std::max(1, std::min(depth, kMaxDepth));
     if (depth > 1) {
@@ -1132,9 +1434,16 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
     HIPCHK(hipMalloc((void**)&d_stage_logits, (size_t)max_batch * n_classes * 4));
     HIPCHK(hipMalloc((void**)&d_post_conf, (size_t)max_batch * n_classes * 4));
     if (emb_dim) HIPCHK(hipMalloc((void**)&d_stage_emb, (size_t)max_batch * emb_dim * 4));
-    if (autotune) { autotune_pw(); autotune_expdw(); }
+    if (autotune && !defer_weights) { autotune_pw(); autotune_expdw(); }
     *code = BNHIP_OK;
     return true;
+}
+
+void Engine::finish_deferred() {
+    if (device < 0) return;
+    hipSetDevice(device);
+    if (autotune) { autotune_pw(); autotune_expdw(); }
+    defer_weights = false;
 }
 
 // Per-layer choice of the pw_gemm N-tile width: the best width depends on (M, N, K) through occupancy, grid size and
@@ -1438,6 +1747,47 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
                 launch_binary(in0, s.mode == 2 ? s.w0 : in1, out, vals[s.in0].elems * (size_t)n, s.op, s.mode, s.H * s.W, s.C,
                               s.act, stream);
                 break;
+            case S_EW_UNARY:
+                launch_unary_op(in0, out, vals[s.in0].elems * (size_t)n, s.op, s.g.alpha, stream);
+                break;
+            case S_EW_BINARY: {
+                BcastParams p;
+                p.a = s.g.a_const ? s.w0 : in0; p.b = s.g.b_const ? s.w1 : in1; p.out = out;
+                for (int k = 0; k < 4; k++) { p.d[k] = s.g.d[k]; p.sa[k] = s.g.sa[k]; p.sb[k] = s.g.sb[k]; }
+                p.bsa = s.g.a_const ? 0 : (long)vals[s.in0].elems; p.bsb = s.g.b_const ? 0 : (long)vals[s.in1].elems;
+                p.op = s.op; p.act = s.act;
+                launch_binary_bcast(p, n, stream);
+                break;
+            }
+            case S_POOL: {
+                PoolParams p{in0, out, n, s.H, s.W, s.C, s.Ho, s.Wo, s.kh, s.kw, s.sh, s.sw, s.pt, s.pl, s.mode, s.act};
+                launch_pool2d(p, stream);
+                break;
+            }
+            case S_COPY: {
+                if (s.g.fill) launch_fill(out, vals[s.out].elems * (size_t)n, s.g.alpha, stream);
+                CopyParams p;
+                p.in = s.g.a_const ? s.w0 : in0; p.out = out;
+                for (int k = 0; k < 4; k++) { p.d[k] = s.g.d[k]; p.si[k] = s.g.sa[k]; p.so[k] = s.g.so[k]; }
+                p.offi = s.g.offa; p.offo = s.g.offo;
+                p.bsi = s.g.a_const ? 0 : (long)vals[s.in0].elems; p.bso = (long)vals[s.out].elems;
+                launch_copy_view(p, n, stream);
+                break;
+            }
+            case S_SOFTMAX:
+                launch_softmax_rows(in0, out, (size_t)s.H * (size_t)n, s.C, s.g.alpha, stream);
+                break;
+            case S_REDUCE: {
+                ReduceParams p{in0, out, {s.g.d[0], s.g.d[1], s.g.d[2], s.g.d[3]}, s.g.mask, s.op};
+                launch_reduce(p, n, stream);
+                break;
+            }
+            case S_CONV_GENERIC: {
+                GenConvParams p{in0, s.w0, s.w1, out, n, s.H, s.W, s.C, s.Ho, s.Wo, s.Co, s.kh, s.kw, s.sh, s.sw, s.g.dh, s.g.dw,
+                                s.pt, s.pl, s.act, s.g.depthwise, s.g.mult};
+                launch_conv_generic(p, stream);
+                break;
+            }
         }
         if (prof_this) { hipEventRecord(pe.b, stream); prof.push_back(pe); }
       }

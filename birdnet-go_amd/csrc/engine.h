@@ -11,7 +11,20 @@
 
 namespace bnhip {
 
-enum StepKind { S_MINMAX, S_FRONTEND, S_NORMALIZE, S_STFT, S_MELFIN, S_MELBAND, S_CONV_DIRECT, S_PW, S_DW, S_EXPAND_DW, S_MEAN_PARTIAL, S_MEAN_FINISH, S_SE, S_UNARY, S_BINARY };
+enum StepKind { S_MINMAX, S_FRONTEND, S_NORMALIZE, S_STFT, S_MELFIN, S_MELBAND, S_CONV_DIRECT, S_PW, S_DW, S_EXPAND_DW, S_MEAN_PARTIAL, S_MEAN_FINISH, S_SE, S_UNARY, S_BINARY,
+                // generic tier (generic.hip): any float op the fused plan does not absorb
+                S_EW_UNARY, S_EW_BINARY, S_POOL, S_COPY, S_SOFTMAX, S_REDUCE, S_CONV_GENERIC };
+
+struct GenGeom {             // per-clip 4-D view geometry of a generic step (see kernels.h BcastParams / CopyParams)
+    int d[4] = {1, 1, 1, 1};
+    long sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0}, so[4] = {0, 0, 0, 0};
+    long offa = 0, offo = 0;
+    bool a_const = false, b_const = false;     // operand lives in the weight arena (no clip stride)
+    int mask = 0;                              // S_REDUCE: reduced dims
+    float alpha = 0.f;                         // S_EW_UNARY: LEAKY_RELU slope; S_COPY with fill: pad value; S_SOFTMAX: beta
+    bool fill = false;                         // S_COPY: fill the output with alpha first (PAD)
+    int dh = 1, dw = 1, depthwise = 0, mult = 1;   // S_CONV_GENERIC
+};
 
 struct Step {
     StepKind kind;
@@ -30,6 +43,7 @@ struct Step {
     int nt_full = 0, wm_full = 0;   // same, tuned at max_batch (calls that run unsplit: pipelined contexts, profiling)
     // front-end
     int spec = -1;
+    GenGeom g;
     // accounting per clip
     double flops = 0, bytes = 0, wbytes = 0;   // wbytes: weight bytes per launch
 };
@@ -68,7 +82,15 @@ class Engine {
     int device = 0, max_batch = 256;
     bool no_reuse = false;              // diagnostics: every activation keeps its own buffer
     bool autotune = true;               // time pw_gemm tile widths per layer at create time (a few ms)
+    // multi-device handles: every engine plans the same weight image; only the first uploads it from the host, the others
+    // allocate their weight arena and receive the bytes device-to-device (RCCL broadcast / peer copy, see api.cpp) before
+    // finish_deferred() runs the create-time autotune
+    bool defer_weights = false;
+    void finish_deferred();
+    char* weights_ptr() const { return w_arena; }
+    size_t weights_bytes() const { return w_bytes; }
     int frontend_fft = -1;              // -1 / 1: FFT path where the frame length is supported (512/1024/2048), 0: folded-GEMM kernel for real-part graphs
+    int bf16x3 = 0;                     // 1: late pointwise layers run on the split-bf16 MFMA path (see kernels.hip k_pw_bf16x3)
     bool use_graphs = false;            // opt-in: replay the plan as a hipGraph once a (pointers, n) combination repeats (measured: no gain on ROCm 7.2)
     void drop_graphs();
     void autotune_expdw();
@@ -109,6 +131,7 @@ class Engine {
     // second staging set + copy stream: host-pointer calls with more than max_batch clips overlap the H2D copy of
     // chunk i+1 with the compute of chunk i
     float* d_stage_in2 = nullptr; float* d_stage_logits2 = nullptr; float* d_stage_emb2 = nullptr;
+    bool staging2_ready = false;      // set only when the whole second set (buffers, copy stream, events) exists
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     int16_t* d_stage_pcm = nullptr;      // PCM staging of the bnhip_predict_pcm* entries (16/24/32-bit: sized in bytes)

@@ -7,7 +7,7 @@
 
 namespace bnhip {
 
-enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 3, ACT_SWISH = 100, ACT_SIGMOID = 101, ACT_HARD_SWISH = 102 };
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU_N1_TO_1 = 2, ACT_RELU6 = 3, ACT_TANH = 4, ACT_SWISH = 100, ACT_SIGMOID = 101, ACT_HARD_SWISH = 102 };
 
 // ---- ingest
 void launch_pcm_to_f32(const void* pcm, int bits /*16, 24, 32*/, float* out, size_t n, hipStream_t s);
@@ -133,6 +133,35 @@ void launch_unary(const float* in, float* out, size_t n, int act, hipStream_t s)
 // mode 0: same shape; mode 1: b is [B,1,1,C] broadcast over HW (a is [B,HW,C]); mode 2: b scalar
 void launch_binary(const float* a, const float* b, float* out, size_t n, int op /*0 add 1 mul 2 sub*/, int mode,
                    int HW, int C, int act, hipStream_t s);
+
+// ---- generic fallbacks, second tier (generic.hip): any float op the fused plan does not absorb
+enum UnaryOp : int { U_ABS = 200, U_SQRT, U_RSQRT, U_LOG, U_EXP, U_NEG, U_SQUARE, U_TANH, U_LEAKY_RELU, U_ELU, U_SIN, U_COS,
+                     U_FLOOR, U_CEIL, U_ROUND, U_RELU_N1_TO_1, U_LOGISTIC, U_RELU, U_RELU6, U_HARD_SWISH, U_GELU, U_GELU_TANH };
+enum BinaryOp : int { B_ADD = 0, B_MUL = 1, B_SUB = 2, B_DIV = 3, B_POW = 4, B_MAX = 5, B_MIN = 6, B_SQDIFF = 7 };
+enum ReduceOp : int { R_SUM = 0, R_MEAN = 1, R_MAX = 2, R_MIN = 3, R_PROD = 4 };
+void launch_unary_op(const float* in, float* out, size_t n, int op, float alpha, hipStream_t s);
+struct BcastParams {      // out[clip][i0..i3] = act(a (op) b); per-clip 4-D output dims, operand strides 0 on broadcast dims
+    const float* a; const float* b; float* out;
+    int d[4]; long sa[4], sb[4]; long bsa, bsb;      // bs*: clip stride (0 for a constant operand)
+    int op, act;
+};
+void launch_binary_bcast(const BcastParams& p, int n_clips, hipStream_t s);
+struct CopyParams {       // strided view copy, see generic.hip
+    const float* in; float* out;
+    int d[4]; long si[4], so[4]; long offi, offo, bsi, bso;
+};
+void launch_copy_view(const CopyParams& p, int n_clips, hipStream_t s);
+void launch_fill(float* out, size_t n, float v, hipStream_t s);
+struct PoolParams { const float* in; float* out; int B, H, W, C, Ho, Wo, kh, kw, sh, sw, pt, pl, mode /*0 avg, 1 max*/, act; };
+void launch_pool2d(const PoolParams& p, hipStream_t s);
+void launch_softmax_rows(const float* in, float* out, size_t rows, int n, float beta, hipStream_t s);
+struct ReduceParams { const float* in; float* out; int d[4]; int mask /*bit k: dim k is reduced*/; int op; };
+void launch_reduce(const ReduceParams& p, int n_clips, hipStream_t s);
+struct GenConvParams {    // weights as in the file: OHWI (conv) or [1][kh][kw][Cout] (depthwise, Cout = Cin * mult)
+    const float* in; const float* w; const float* bias; float* out;
+    int B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, dh, dw, pt, pl, act, depthwise, mult;
+};
+void launch_conv_generic(const GenConvParams& p, hipStream_t s);
 
 // ---- post-processing
 // activation 0: float32(1/(1+exp(-sens*float64(x)))); 1: softmax (f32 max-sub, f64 exp, f32 sum); 2: f32-div sigmoid

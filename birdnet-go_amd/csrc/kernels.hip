@@ -1990,7 +1990,8 @@ __global__ __launch_bounds__(256) void k_topk(const float* __restrict__ conf, in
     __shared__ float rv[4];
     __shared__ int ri[4];
     const float* row = conf + (size_t)blockIdx.x * n;
-    for (int i = threadIdx.x; i < n; i += 256) v[i] = row[i];
+    // NaN confidences (non-finite logits) rank below everything: loaded as -inf, so every emitted index is in [0, n)
+    for (int i = threadIdx.x; i < n; i += 256) { float x = row[i]; v[i] = x != x ? -INFINITY : x; }
     __syncthreads();
     int kk = k < n ? k : n;
     for (int r = 0; r < kk; r++) {
@@ -2010,13 +2011,15 @@ __global__ __launch_bounds__(256) void k_topk(const float* __restrict__ conf, in
                 if (rv[w] > best || (rv[w] == best && ri[w] < bi)) { best = rv[w]; bi = ri[w]; }
             oc[(size_t)blockIdx.x * k + r] = best;
             oi[(size_t)blockIdx.x * k + r] = bi;
-            if (bi >= 0 && bi < n) v[bi] = -INFINITY;
+            if (bi >= 0 && bi < n) v[bi] = __builtin_nanf("");      // taken: NaN never compares > or ==, so -inf ties stay selectable
         }
         __syncthreads();
     }
 }
 void launch_topk(const float* conf, int n_clips, int n_classes, int k, float* out_conf, int32_t* out_idx,
                  hipStream_t s) {
+    if ((size_t)n_classes * sizeof(float) > 48 * 1024)      // class counts above 12 K need more than the default dynamic LDS (per device: not cached)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     hipLaunchKernelGGL(k_topk, dim3(n_clips), dim3(256), (size_t)n_classes * sizeof(float), s, conf, n_classes, k,
                        out_conf, out_idx);
 }

@@ -61,9 +61,11 @@ void resample_design(int L, int M, double beta, int half_factor, std::vector<flo
     *half_out = half;
 }
 
-template <bool PCM16>
+// i_base / n_base (streaming form, api.cpp bnhip_resampler_*): stream index of this launch's first output and of in[0]; the
+// one-shot entries pass 0 / 0.  Inputs before the stream start and beyond the supplied span read as zero.
+template <bool IN_PCM16, bool OUT_PCM16>
 __global__ __launch_bounds__(256) void k_resample(const void* __restrict__ in_, void* __restrict__ out_, const float* __restrict__ table,
-                                                  int n_in, int n_out, int L, int M, int T, int half) {
+                                                  int n_in, int n_out, int L, int M, int T, int half, long long i_base, long long n_base) {
     extern __shared__ float sm[];
     float* tab = sm;                       // [L*T]
     float* xs = sm + L * T;                // input span of this block
@@ -71,15 +73,15 @@ __global__ __launch_bounds__(256) void k_resample(const void* __restrict__ in_, 
     const int i0 = blockIdx.x * 256;
     const int i1 = min(n_out, i0 + 256);
     for (int k = threadIdx.x; k < L * T; k += 256) tab[k] = table[k];
-    // inputs touched by outputs [i0, i1): n from (i0*M+half)/L - (T-1) to ((i1-1)*M+half)/L
-    const long long lo = ((long long)i0 * M + half) / L - (T - 1);
-    const long long hi = ((long long)(i1 - 1) * M + half) / L;
+    // inputs touched by outputs [i0, i1): n from (i0*M+half)/L - (T-1) to ((i1-1)*M+half)/L   (stream indices)
+    const long long lo = ((i_base + i0) * M + half) / L - (T - 1);
+    const long long hi = ((i_base + i1 - 1) * M + half) / L;
     const int span = (int)(hi - lo + 1);
     for (int k = threadIdx.x; k < span; k += 256) {
-        long long n = lo + k;
+        long long n = lo + k - n_base;     // index into this launch's input
         float v = 0.0f;
-        if (n >= 0 && n < n_in) {
-            if (PCM16) v = (float)reinterpret_cast<const int16_t*>(in_)[(size_t)clip * n_in + n] / 32768.0f;
+        if (lo + k >= 0 && n >= 0 && n < n_in) {
+            if (IN_PCM16) v = (float)reinterpret_cast<const int16_t*>(in_)[(size_t)clip * n_in + n] / 32768.0f;
             else v = reinterpret_cast<const float*>(in_)[(size_t)clip * n_in + n];
         }
         xs[k] = v;
@@ -87,13 +89,13 @@ __global__ __launch_bounds__(256) void k_resample(const void* __restrict__ in_, 
     __syncthreads();
     const int i = i0 + threadIdx.x;
     if (i >= i1) return;
-    const long long pos = (long long)i * M + half;
+    const long long pos = (i_base + i) * M + half;
     const int p = (int)(pos % L);
     const int n0 = (int)(pos / L - lo);            // index of the newest input in xs
     const float* tp = tab + p * T;
     float acc = 0.0f;
     for (int t = 0; t < T; t++) acc = fmaf(xs[n0 - t], tp[t], acc);
-    if (PCM16) {
+    if (OUT_PCM16) {
         float f = fminf(fmaxf(acc, -1.0f), 1.0f);
         reinterpret_cast<int16_t*>(out_)[(size_t)clip * n_out + i] = (int16_t)(f * 32767.0f);     // truncation toward zero
     } else {
@@ -102,20 +104,23 @@ __global__ __launch_bounds__(256) void k_resample(const void* __restrict__ in_, 
 }
 
 // returns 0 on success, -1 if the geometry does not fit LDS
-int launch_resample(const void* d_in, void* d_out, const float* d_table, bool pcm16, int n_clips, int n_in, int n_out, int L,
-                    int M, int T, int half, hipStream_t s) {
+int launch_resample(const void* d_in, void* d_out, const float* d_table, int in_pcm16, int out_pcm16, int n_clips, int n_in,
+                    int n_out, int L, int M, int T, int half, long long i_base, long long n_base, hipStream_t s) {
     // worst-case input span of 256 outputs
     long long span = ((long long)255 * M) / L + T + 2;
     size_t lds = ((size_t)L * T + (size_t)span) * sizeof(float);
     if (lds > 150 * 1024) return -1;
     dim3 grid((n_out + 255) / 256, n_clips);
-    if (pcm16) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(k_resample<true>, grid, dim3(256), lds, s, d_in, d_out, d_table, n_in, n_out, L, M, T, half);
-    } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(k_resample<false>, grid, dim3(256), lds, s, d_in, d_out, d_table, n_in, n_out, L, M, T, half);
-    }
+#define BN_RS(IP, OP)                                                                                                        \
+    do {                                                                                                                     \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample<IP, OP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((k_resample<IP, OP>), grid, dim3(256), lds, s, d_in, d_out, d_table, n_in, n_out, L, M, T, half, i_base, n_base); \
+    } while (0)
+    if (in_pcm16 && out_pcm16) BN_RS(true, true);
+    else if (!in_pcm16 && out_pcm16) BN_RS(false, true);
+    else if (!in_pcm16 && !out_pcm16) BN_RS(false, false);
+    else return -1;
+#undef BN_RS
     return 0;
 }
 

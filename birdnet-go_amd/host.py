@@ -28,7 +28,10 @@ SYMBOLS = ["bnhip_init", "bnhip_shutdown", "bnhip_model_create", "bnhip_model_in
            "bnhip_us_frame_cv", "bnhip_set_stream", "bnhip_synchronize", "bnhip_profile_enable",
            "bnhip_profile_read", "bnhip_model_describe", "bnhip_model_destroy", "bnhip_last_error",
            "bnhip_version", "bnhip_debug_fetch", "bnhip_profile_filter", "bnhip_resample_length",
-           "bnhip_resample_f32", "bnhip_resample_pcm16"]
+           "bnhip_resample_f32", "bnhip_resample_pcm16", "bnhip_model_devices", "bnhip_last_error_copy",
+           "bnhip_resampler_create", "bnhip_resampler_estimate", "bnhip_resampler_process_pcm16",
+           "bnhip_resampler_process_f32", "bnhip_resampler_flush_pcm16", "bnhip_resampler_flush_f32",
+           "bnhip_resampler_destroy"]
 
 
 class HipError(RuntimeError):
@@ -98,10 +101,17 @@ class HipClassifier:
     """inference.Classifier + EmbeddingExtractor over libbnhip.so.  NOT thread-safe (backend.go:7)."""
 
     def __init__(self, model_bytes: bytes, device=0, max_batch=256, plan_only=False, debug_no_reuse=False,
-                 graphs=None, frontend_fft=None, depth=None, lanes=None, autotune=None):
+                 graphs=None, frontend_fft=None, depth=None, lanes=None, autotune=None, devices=None, replicate=None,
+                 bf16x3=None):
         self._lib = load_library()
         self._h = C.c_void_p()
         o = {"device": device, "max_batch": max_batch, "plan_only": int(plan_only), "debug_no_reuse": int(debug_no_reuse)}
+        if devices is not None:          # one handle sharding every call over several GPUs (bnhip.h "devices")
+            o["devices"] = [int(d) for d in devices]
+        if replicate is not None:
+            o["replicate"] = str(replicate)
+        if bf16x3 is not None:
+            o["bf16x3"] = int(bf16x3)
         if graphs is not None:
             o["graphs"] = int(graphs)
         if frontend_fft is not None:
@@ -392,6 +402,89 @@ class Resampler:
                 raise HipError(E_INVALID, f"input length {len(pcm16)} is not a multiple of 2 (16-bit PCM requires even byte count)")
             return self._run(self._lib.bnhip_resample_pcm16, np.frombuffer(pcm16, "<i2"), np.int16).tobytes()
         return self._run(self._lib.bnhip_resample_pcm16, pcm16, np.int16)
+
+
+class StreamResampler:
+    """The reference's stateful Resampler (internal/audiocore/resample/resample.go:44-224), method for method:
+    NewResampler(from, to) returns None for equal rates; resample_to / resample_into consume 16-bit PCM frames of any size
+    and return what the stream so far determines; the FIR history stays on the GPU between calls, so the concatenated
+    output of any chunking equals one one-shot call over the whole stream, bit for bit (after `flush`)."""
+
+    def __init__(self, from_rate, to_rate, device=0):
+        self._lib = load_library()
+        L = self._lib
+        L.bnhip_resampler_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.bnhip_resampler_estimate.argtypes = [C.c_void_p, C.c_int]
+        for fn in (L.bnhip_resampler_process_pcm16, L.bnhip_resampler_process_f32):
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        for fn in (L.bnhip_resampler_flush_pcm16, L.bnhip_resampler_flush_f32):
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.bnhip_resampler_destroy.argtypes = [C.c_void_p]
+        self.from_rate, self.to_rate = int(from_rate), int(to_rate)
+        self._h = C.c_void_p()
+        _check(L, L.bnhip_resampler_create(device, self.from_rate, self.to_rate, C.byref(self._h)))
+
+    @classmethod
+    def new(cls, from_rate, to_rate, device=0):
+        """NewResampler: None when no resampling is required (resample.go:58-60)."""
+        return None if from_rate == to_rate else cls(from_rate, to_rate, device)
+
+    def estimate_output_bytes(self, input_bytes):
+        if input_bytes <= 0:
+            return 0
+        return int(self._lib.bnhip_resampler_estimate(self._h, input_bytes // 2)) * 2
+
+    def resample_to(self, pcm: bytes, dst: bytearray):
+        """ResampleTo(input, dst) -> bytes written; errors leave the stream state untouched."""
+        self._alive()
+        if len(pcm) == 0:
+            return 0
+        if len(pcm) % 2:
+            raise HipError(E_INVALID, f"input length {len(pcm)} is not a multiple of 2 (16-bit PCM requires even byte count)")
+        x = np.frombuffer(pcm, "<i2")
+        buf = (C.c_char * len(dst)).from_buffer(dst)
+        n = C.c_int(0)
+        _check(self._lib, self._lib.bnhip_resampler_process_pcm16(self._h, x.ctypes.data, x.size, C.addressof(buf), len(dst) // 2, C.byref(n)))
+        return n.value * 2
+
+    def resample_into(self, pcm: bytes) -> bytes:
+        dst = bytearray(self.estimate_output_bytes(len(pcm)))
+        n = self.resample_to(pcm, dst)
+        return bytes(dst[:n])
+
+    def process_f32(self, samples):
+        self._alive()
+        x = np.ascontiguousarray(samples, np.float32).reshape(-1)
+        out = np.empty(int(self._lib.bnhip_resampler_estimate(self._h, x.size)) if x.size else 0, np.float32)
+        if not x.size:
+            return out
+        n = C.c_int(0)
+        _check(self._lib, self._lib.bnhip_resampler_process_f32(self._h, x.ctypes.data, x.size, out.ctypes.data, out.size, C.byref(n)))
+        return out[:n.value]
+
+    def flush(self, pcm16=True, cap=1 << 16):
+        """End of stream: the tail that needed future (zero) input; resets the state."""
+        self._alive()
+        out = np.empty(cap, np.int16 if pcm16 else np.float32)
+        n = C.c_int(0)
+        fn = self._lib.bnhip_resampler_flush_pcm16 if pcm16 else self._lib.bnhip_resampler_flush_f32
+        _check(self._lib, fn(self._h, out.ctypes.data, out.size, C.byref(n)))
+        return out[:n.value].tobytes() if pcm16 else out[:n.value]
+
+    def close(self):
+        if self._h:
+            self._lib.bnhip_resampler_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def _alive(self):
+        if not self._h:
+            raise HipError(E_INVALID, "resampler is closed")
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class BirdNET:

@@ -37,6 +37,10 @@ class GraphBuilder:
         code = S.OP[opname]
         if code not in self.opcodes:
             self.opcodes.append(code)
+        if out_shape and isinstance(out_shape[0], (list, tuple)):      # several outputs (SPLIT): list of shapes
+            outs = [self.tensor(sh, out_dtype, (name + f":{i}") if name else None) for i, sh in enumerate(out_shape)]
+            self.ops.append(dict(op=opname, inputs=list(inputs), outputs=outs, options=options or {}))
+            return outs
         out = self.tensor(out_shape, out_dtype, name)
         self.ops.append(dict(op=opname, inputs=list(inputs), outputs=[out], options=options or {}))
         return out

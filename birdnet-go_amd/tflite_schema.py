@@ -29,12 +29,13 @@ ACT_NONE, ACT_RELU, ACT_RELU_N1_TO_1, ACT_RELU6, ACT_TANH = 0, 1, 2, 3, 4
 
 # ---- BuiltinOperator codes (subset this engine understands)
 OP = dict(
-    ADD=0, AVERAGE_POOL_2D=1, CONCATENATION=2, CONV_2D=3, DEPTHWISE_CONV_2D=4, DEQUANTIZE=6,
-    FULLY_CONNECTED=9, LOGISTIC=14, MAX_POOL_2D=17, MUL=18, RELU=19, RELU6=21, RESHAPE=22,
-    SOFTMAX=25, PAD=34, GATHER=36, TRANSPOSE=39, MEAN=40, SUB=41, DIV=42, SQUEEZE=43,
-    STRIDED_SLICE=45, CAST=53, EXPAND_DIMS=70, SUM=74, POW=78, REDUCE_MAX=82, REDUCE_MIN=89,
-    REVERSE_V2=105, HARD_SWISH=117, BATCH_MATMUL=126, RFFT2D=131, IMAG=133, REAL=134,
-    COMPLEX_ABS=135,
+    ADD=0, AVERAGE_POOL_2D=1, CONCATENATION=2, CONV_2D=3, DEPTHWISE_CONV_2D=4, DEQUANTIZE=6, FLOOR=8,
+    FULLY_CONNECTED=9, LOGISTIC=14, MAX_POOL_2D=17, MUL=18, RELU=19, RELU_N1_TO_1=20, RELU6=21, RESHAPE=22,
+    SOFTMAX=25, TANH=28, PAD=34, GATHER=36, TRANSPOSE=39, MEAN=40, SUB=41, DIV=42, SQUEEZE=43,
+    STRIDED_SLICE=45, EXP=47, SPLIT=49, CAST=53, MAXIMUM=55, MINIMUM=57, NEG=59, PADV2=60, SLICE=65, SIN=66,
+    EXPAND_DIMS=70, LOG=73, SUM=74, SQRT=75, RSQRT=76, POW=78, REDUCE_PROD=81, REDUCE_MAX=82, REDUCE_MIN=89,
+    SQUARE=92, LEAKY_RELU=98, SQUARED_DIFFERENCE=99, ABS=101, CEIL=104, REVERSE_V2=105, COS=108, ELU=111,
+    ROUND=116, HARD_SWISH=117, BATCH_MATMUL=126, RFFT2D=131, IMAG=133, REAL=134, COMPLEX_ABS=135, GELU=150,
 )
 OP_NAME = {v: k for k, v in OP.items()}
 
@@ -45,7 +46,8 @@ OPT = dict(
     PadOptions=22, GatherOptions=23, TransposeOptions=26, ReducerOptions=27, SubOptions=28,
     DivOptions=29, SqueezeOptions=30, StridedSliceOptions=32, CastOptions=37,
     ExpandDimsOptions=52, PowOptions=56, ReverseV2Options=81, HardSwishOptions=91,
-    BatchMatMulOptions=101, Rfft2dOptions=105,
+    BatchMatMulOptions=101, Rfft2dOptions=105, SplitOptions=35, MaximumMinimumOptions=39, PadV2Options=43,
+    SliceOptions=48, LeakyReluOptions=75, SquaredDifferenceOptions=76, GeluOptions=123,
 )
 
 # ---- option tables: name -> ordered [(field, kind)]; kind in i8,i32,f32,bool,vec_i32
@@ -83,6 +85,10 @@ OPTION_FIELDS = dict(
     BatchMatMulOptions=[("adj_x", "bool"), ("adj_y", "bool"),
                         ("asymmetric_quantize_inputs", "bool")],
     Rfft2dOptions=[],
+    SplitOptions=[("num_splits", "i32")],
+    MaximumMinimumOptions=[], PadV2Options=[], SliceOptions=[], SquaredDifferenceOptions=[],
+    LeakyReluOptions=[("alpha", "f32")],
+    GeluOptions=[("approximate", "bool")],
 )
 
 # which options table each builtin op carries
@@ -98,6 +104,11 @@ OP_OPTIONS = dict(
     REDUCE_MIN="ReducerOptions", REVERSE_V2="ReverseV2Options", HARD_SWISH="HardSwishOptions",
     BATCH_MATMUL="BatchMatMulOptions", RFFT2D="Rfft2dOptions", IMAG=None, REAL=None,
     COMPLEX_ABS=None,
+    FLOOR=None, RELU_N1_TO_1=None, TANH=None, EXP=None, SPLIT="SplitOptions", MAXIMUM="MaximumMinimumOptions",
+    MINIMUM="MaximumMinimumOptions", NEG=None, PADV2="PadV2Options", SLICE="SliceOptions", SIN=None, LOG=None,
+    SQRT=None, RSQRT=None, REDUCE_PROD="ReducerOptions", SQUARE=None, LEAKY_RELU="LeakyReluOptions",
+    SQUARED_DIFFERENCE="SquaredDifferenceOptions", ABS=None, CEIL=None, COS=None, ELU=None, ROUND=None,
+    GELU="GeluOptions",
 )
 
 FILE_IDENTIFIER = b"TFL3"

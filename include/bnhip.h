@@ -12,8 +12,12 @@
  *
  * Threading contract (same as the reference's backends, backend.go:7 "NOT goroutine-safe; callers
  * must synchronize"): a bnhip_model may be used by one thread at a time.  Every entry point calls
- * hipSetDevice for the model's device first, so the Go side does not need runtime.LockOSThread
- * for correctness (HIP's current device is thread-local; cf. backend_openvino.go:478-481).
+ * hipSetDevice for the model's device first, so results never depend on the calling thread.  The error TEXT does:
+ * bnhip_last_error() is thread-local, so a cgo caller must fetch it on the OS thread that made the failing call -
+ * runtime.LockOSThread around call + fetch, exactly as the OpenVINO shim does (backend_openvino.go:480,581,729,805);
+ * the Go binding in birdnet-go_amd/go does so.
+ * No entry point lets a C++ exception escape: allocation failure is BNHIP_E_NOMEM, anything else BNHIP_E_RUNTIME
+ * ("never panic; any failure => fall back", internal/classifier/model_openvino.go:227-230).
  */
 #ifndef BNHIP_H
 #define BNHIP_H
@@ -45,15 +49,28 @@ int bnhip_init(int* n_devices);
 /* Releases process-global state (replaces DestroyOV, backend_openvino.go:512-536). */
 void bnhip_shutdown(void);
 
-/* Build a classifier from in-memory TFLite model bytes — the same byte slice the reference hands to
- * NewTFLiteClassifier(modelData []byte, ...) (internal/inference/tflite/classifier.go:38).  The blob
- * is consumed during the call and may be freed afterwards (classifier.go:37).
- * opts_json (nullable): {"device":0,"max_batch":256,"plan_only":0,"debug_no_reuse":0,"autotune":1,"graphs":0,"lanes":2,"frontend_fft":-1,"depth":1}; plan_only builds the
- * kernel plan on the CPU without touching a device (info/describe work, predict is rejected).
+/* Build a classifier from in-memory model bytes - the same byte slice the reference hands to
+ * NewTFLiteClassifier(modelData []byte, ...) (internal/inference/tflite/classifier.go:38), or the bytes of an ONNX file
+ * (the reference's ONNX backend takes a path, internal/inference/onnx/classifier.go:268-289; dense heads such as the
+ * CustomClassifier / BattyBirdNET regional heads, onnx/custom_classifier.go:148-174, classifier/bat_onnx.go:252-282).  The
+ * container is sniffed: "TFL3" at byte 4 = TFLite flatbuffer, otherwise ONNX ModelProto.  The blob is consumed during the
+ * call and may be freed afterwards (classifier.go:37).
+ * opts_json (nullable): {"device":0,"devices":[0,1,..],"replicate":"auto","max_batch":256,"plan_only":0,"debug_no_reuse":0,
+ *                        "autotune":1,"graphs":0,"lanes":2,"frontend_fft":-1,"depth":1,"bf16x3":0}
+ * "devices": one handle over several GPUs: one engine per listed device, the clips of every host-
+ *          pointer call are sharded index-contiguously over them and run concurrently (one worker thread per device, own
+ *          streams and pinned-order staging per device).  The frozen weights are uploaded to the first device only and
+ *          replicated device-to-device: "replicate":"auto" (default) = RCCL ncclBroadcast over xGMI when librccl is loadable
+ *          and the devices are distinct, hipMemcpyPeer otherwise; "rccl" / "peer" force one (the same device may be listed
+ *          twice with "peer": two shards on one GPU, used by the 1-GPU test of the sharding code).  The device-pointer entry
+ *          bnhip_predict_device needs a single-device handle.
+ * "plan_only": builds the kernel plan on the CPU without touching a device (info/describe work, predict is rejected).
  * "lanes": batches of >= 32 clips are split over this many concurrent streams inside one call (default 2).
  * "depth": > 1 lets successive bnhip_predict_device calls overlap on alternating contexts (own stream and activation
  *          arena each); their outputs are complete after bnhip_synchronize, not merely in the caller's stream order.
- * "frontend_fft": 0 selects the folded-GEMM mel front-end for real-part graphs instead of the FFT path.  */
+ * "frontend_fft": 0 selects the folded-GEMM mel front-end for real-part graphs instead of the FFT path.
+ * "bf16x3": 1 runs the MFMA-bound pointwise layers on the split-bf16 path (three bf16 terms per fp32 operand, six
+ *          v_mfma_f32_32x32x16_bf16 products, fp32 accumulation: fp32-equivalent products).  */
 int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, bnhip_model** out);
 
 /* n_samples: exact input length per clip (tflite/classifier.go:100-104); n_classes: size of the logits
@@ -113,6 +130,25 @@ int bnhip_resample_f32(int device, const float* in, int n_clips, int n_in, int r
 int bnhip_resample_pcm16(int device, const int16_t* in, int n_clips, int n_in, int rate_in, int rate_out, int16_t* out,
                          int n_out_cap, int* n_out);
 
+/* Streaming form = the reference's stateful Resampler (internal/audiocore/resample/resample.go:44-172; call sites feed it
+ * ~100 ms frames: analysis/buffer_consumer.go:118,192).  The filter history lives on the device between calls, so ANY
+ * chunking of a stream yields, concatenated, exactly the samples one bnhip_resample_* call over the whole stream
+ * produces (bit for bit; the flush emits the tail that needs zero-padded future input).
+ *   create:   equal rates -> *out = NULL and BNHIP_OK (NewResampler returns nil, nil: resample.go:58-60).
+ *   estimate: upper bound of samples one process call of n_in samples may emit (EstimateOutputBytes, :83-88).
+ *   process:  empty input writes nothing (:100-102); a destination smaller than the estimate fails BEFORE the state
+ *             advances (:137-144); *n_out = samples written.  PCM16 edges as in the one-shot entry (:120-124,161-169).
+ *   flush:    end of stream: emits the remaining ceil(N*L/M) - emitted samples and resets the state for a new stream.
+ *   destroy:  Close (:212-224); NULL is accepted. */
+typedef struct bnhip_resampler bnhip_resampler;
+int bnhip_resampler_create(int device, int rate_in, int rate_out, bnhip_resampler** out);
+int bnhip_resampler_estimate(const bnhip_resampler* r, int n_in);
+int bnhip_resampler_process_pcm16(bnhip_resampler* r, const int16_t* in, int n_in, int16_t* out, int out_cap, int* n_out);
+int bnhip_resampler_process_f32(bnhip_resampler* r, const float* in, int n_in, float* out, int out_cap, int* n_out);
+int bnhip_resampler_flush_pcm16(bnhip_resampler* r, int16_t* out, int out_cap, int* n_out);
+int bnhip_resampler_flush_f32(bnhip_resampler* r, float* out, int out_cap, int* n_out);
+void bnhip_resampler_destroy(bnhip_resampler* r);
+
 /* Stream plumbing for hosts that own a HIP stream (bench harness: torch's current stream). */
 int bnhip_set_stream(bnhip_model* m, void* hip_stream);
 int bnhip_synchronize(bnhip_model* m);
@@ -136,10 +172,16 @@ int bnhip_model_describe(const bnhip_model* m, char* buf, size_t cap);
  * arena slot may already have been recycled). Returns floats per clip, or a negative error. */
 int bnhip_debug_fetch(bnhip_model* m, int tensor_index, int n_clips, float* out, size_t cap_floats);
 
+/* Devices of a handle: returns their count and writes up to cap ordinals (1 for a plain "device" handle). */
+int bnhip_model_devices(const bnhip_model* m, int* devices, int cap);
+
 /* Idempotent; frees device memory now (BirdNET.Delete, classifier/birdnet.go:972-984). */
 void bnhip_model_destroy(bnhip_model* m);
 
 const char* bnhip_last_error(void);
+/* Same text copied into the caller's buffer (NUL-terminated, truncated to cap); returns the bytes needed.  For hosts that
+ * prefer an out-buffer to a thread-local pointer. */
+int bnhip_last_error_copy(char* buf, size_t cap);
 const char* bnhip_version(void);
 
 #ifdef __cplusplus

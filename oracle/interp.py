@@ -80,20 +80,24 @@ def conv2d(x, w, b, o):
 
 
 def depthwise_conv2d(x, w, b, o):
-    """TFLite DEPTHWISE_CONV_2D: w [1,kh,kw,C*mult]; only depth_multiplier 1 is needed here."""
+    """TFLite DEPTHWISE_CONV_2D: w [1,kh,kw,C*mult]; output channel c*mult+q reads input channel c
+    (tflite reference depthwiseconv_float.h)."""
     N, H, W, C = x.shape
     _, kh, kw, CO = w.shape
-    if CO != C:
-        raise ValueError("depth_multiplier != 1 unsupported in oracle")
+    if CO % C:
+        raise ValueError("depthwise filter channels are not a multiple of the input channels")
+    mult = CO // C
     sh, sw = o.get("stride_h") or 1, o.get("stride_w") or 1
     dh, dw = o.get("dil_h") or 1, o.get("dil_w") or 1
     Ho, pt, pb = _geom(H, kh, sh, dh, o.get("padding", 0))
     Wo, pl, pr = _geom(W, kw, sw, dw, o.get("padding", 0))
     xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
-    y = np.zeros((N, Ho, Wo, C), x.dtype)
+    y = np.zeros((N, Ho, Wo, CO), x.dtype)
     for i in range(kh):
         for j in range(kw):
             sl = xp[:, i * dh:i * dh + (Ho - 1) * sh + 1:sh, j * dw:j * dw + (Wo - 1) * sw + 1:sw, :]
+            if mult != 1:
+                sl = np.repeat(sl, mult, axis=3)
             y += sl * w[0, i, j, :]
     if b is not None:
         y = y + b
@@ -164,7 +168,8 @@ class Interpreter:
         self.fdt = np.float32 if precision == "f32" else np.float64
         self.cdt = np.complex64 if precision == "f32" else np.complex128
         inp = self.m.tensors[self.m.inputs[0]]
-        self.n_samples = int(inp.shape[-1])       # clip length, or feature width for dense-only graphs
+        self.in_shape = [int(v) for v in inp.shape[1:]]      # per-clip input block ([n_samples] for the audio models)
+        self.n_samples = int(np.prod(self.in_shape))        # clip length, or feature width for dense-only graphs
         self.out_dims = [int(self.m.tensors[o].shape[-1]) for o in self.m.outputs]
 
     def _const(self, idx):
@@ -180,9 +185,11 @@ class Interpreter:
         x = np.asarray(samples, np.float32)
         if x.ndim == 1:
             x = x[None, :]
+        x = x.reshape(x.shape[0], -1)
         if x.shape[1] != self.n_samples:
             raise ValueError(f"input size mismatch: expected {self.n_samples} samples, got {x.shape[1]}")
         B = x.shape[0]
+        x = x.reshape([B] + self.in_shape)
         vals = {self.m.inputs[0]: x.astype(self.fdt)}
 
         def get(i):
@@ -247,7 +254,10 @@ class Interpreter:
             elif n == "TRANSPOSE":
                 y = np.transpose(a[0], [int(v) for v in a[1]])
             elif n == "CONCATENATION":
-                y = _act(np.concatenate(a, axis=o.get("axis", 0)), o.get("act", 0))
+                # constants are authored for batch 1: repeat them along the batch like every per-clip tensor
+                parts = [np.repeat(v, B, axis=0) if (v.ndim and v.shape[0] == 1 and B > 1 and any(u.shape[0] == B for u in a)) else v
+                         for v in a]
+                y = _act(np.concatenate(parts, axis=o.get("axis", 0)), o.get("act", 0))
             elif n == "PAD":
                 y = np.pad(a[0], [(int(p[0]), int(p[1])) for p in a[1]])
             elif n == "GATHER":
@@ -298,12 +308,54 @@ class Interpreter:
                     else:
                         sl.append(slice(b0, e0, strides[d]))
                 y = a[0][tuple(sl)]
+            elif n in ("MAXIMUM", "MINIMUM"):
+                y = (np.maximum if n == "MAXIMUM" else np.minimum)(a[0], a[1])
+            elif n == "SQUARED_DIFFERENCE":
+                d = np.subtract(a[0], a[1])
+                y = d * d
+            elif n in ("EXP", "LOG", "SQRT", "ABS", "NEG", "SQUARE", "TANH", "SIN", "COS", "FLOOR", "CEIL", "ROUND", "RSQRT"):
+                f = {"EXP": np.exp, "LOG": np.log, "SQRT": np.sqrt, "ABS": np.abs, "NEG": np.negative, "SQUARE": np.square,
+                     "TANH": np.tanh, "SIN": np.sin, "COS": np.cos, "FLOOR": np.floor, "CEIL": np.ceil,
+                     "ROUND": np.rint,                       # TFLite round.h: round half to even
+                     "RSQRT": lambda v: 1.0 / np.sqrt(v)}[n]
+                with np.errstate(all="ignore"):
+                    y = np.asarray(f(a[0]), a[0].dtype)
+            elif n == "LEAKY_RELU":
+                y = np.where(a[0] > 0, a[0], a[0] * np.asarray(o.get("alpha", 0.0), a[0].dtype))
+            elif n == "ELU":
+                y = np.where(a[0] > 0, a[0], np.expm1(np.minimum(a[0], 0))).astype(a[0].dtype)
+            elif n == "RELU_N1_TO_1":
+                y = np.clip(a[0], -1, 1)
+            elif n == "GELU":
+                x64 = a[0].astype(np.float64)
+                if o.get("approximate"):
+                    y = 0.5 * x64 * (1.0 + np.tanh(0.7978845608028654 * (x64 + 0.044715 * x64 ** 3)))
+                else:
+                    from scipy.special import erf
+                    y = 0.5 * x64 * (1.0 + erf(x64 / np.sqrt(2.0)))
+                y = y.astype(a[0].dtype)
+            elif n == "REDUCE_PROD":
+                axes = tuple(int(v) % a[0].ndim for v in np.atleast_1d(a[1]))
+                y = np.asarray(np.prod(a[0], axis=axes, keepdims=bool(o.get("keep_dims"))), a[0].dtype)
+            elif n == "PADV2":
+                y = np.pad(a[0], [(int(p[0]), int(p[1])) for p in a[1]], constant_values=float(np.asarray(a[2]).reshape(-1)[0]))
+            elif n == "SLICE":
+                begin, size = [int(v) for v in a[1]], [int(v) for v in a[2]]
+                y = a[0][tuple(slice(b, None if sz < 0 else b + sz) for b, sz in zip(begin, size))]
+            elif n == "SPLIT":
+                # inputs: axis, value (tflite split.cc); equal parts
+                parts = np.split(a[1], len(op.outputs), axis=int(np.asarray(a[0]).reshape(-1)[0]))
+                for t, part in zip(op.outputs, parts):
+                    vals[t] = part
+                    if keep is not None:
+                        keep[t] = part
+                continue
             else:
                 raise ValueError(f"oracle: unsupported op {n}")
             vals[op.outputs[0]] = y
             if keep is not None:
                 keep[op.outputs[0]] = y
-        return [np.asarray(vals[o], np.float32) for o in self.m.outputs]
+        return [np.asarray(vals[o], np.float32).reshape(B, -1) for o in self.m.outputs]
 
     # reference-shaped convenience (inference.Classifier semantics, backend.go:8-19)
     def predict(self, samples):

@@ -13,12 +13,14 @@ import numpy as np
 # slot numbers restated from TFLite schema.fbs (kept literal here on purpose: the oracle must not
 # share constants with the product package)
 _OPNAMES = {0: "ADD", 1: "AVERAGE_POOL_2D", 2: "CONCATENATION", 3: "CONV_2D", 4: "DEPTHWISE_CONV_2D", 6: "DEQUANTIZE",
-            9: "FULLY_CONNECTED", 14: "LOGISTIC", 17: "MAX_POOL_2D", 18: "MUL", 19: "RELU", 21: "RELU6",
-            22: "RESHAPE", 25: "SOFTMAX", 34: "PAD", 36: "GATHER", 39: "TRANSPOSE", 40: "MEAN",
-            41: "SUB", 42: "DIV", 43: "SQUEEZE", 45: "STRIDED_SLICE", 53: "CAST", 70: "EXPAND_DIMS",
-            74: "SUM", 78: "POW", 82: "REDUCE_MAX", 89: "REDUCE_MIN", 105: "REVERSE_V2",
-            117: "HARD_SWISH", 126: "BATCH_MATMUL", 131: "RFFT2D", 133: "IMAG", 134: "REAL",
-            135: "COMPLEX_ABS"}
+            8: "FLOOR", 9: "FULLY_CONNECTED", 14: "LOGISTIC", 17: "MAX_POOL_2D", 18: "MUL", 19: "RELU", 20: "RELU_N1_TO_1",
+            21: "RELU6", 22: "RESHAPE", 25: "SOFTMAX", 28: "TANH", 34: "PAD", 36: "GATHER", 39: "TRANSPOSE", 40: "MEAN",
+            41: "SUB", 42: "DIV", 43: "SQUEEZE", 45: "STRIDED_SLICE", 47: "EXP", 49: "SPLIT", 53: "CAST", 55: "MAXIMUM",
+            57: "MINIMUM", 59: "NEG", 60: "PADV2", 65: "SLICE", 66: "SIN", 70: "EXPAND_DIMS", 73: "LOG",
+            74: "SUM", 75: "SQRT", 76: "RSQRT", 78: "POW", 81: "REDUCE_PROD", 82: "REDUCE_MAX", 89: "REDUCE_MIN",
+            92: "SQUARE", 98: "LEAKY_RELU", 99: "SQUARED_DIFFERENCE", 101: "ABS", 104: "CEIL", 105: "REVERSE_V2",
+            108: "COS", 111: "ELU", 116: "ROUND", 117: "HARD_SWISH", 126: "BATCH_MATMUL", 131: "RFFT2D", 133: "IMAG",
+            134: "REAL", 135: "COMPLEX_ABS", 150: "GELU"}
 _DTYPES = {0: np.float32, 2: np.int32, 4: np.int64, 8: np.complex64, 3: np.uint8, 9: np.int8,
            1: np.float16, 6: np.bool_, 10: np.float64}
 
@@ -38,7 +40,8 @@ _OPTS = {"CONV_2D": _CONV, "DEPTHWISE_CONV_2D": _DW, "AVERAGE_POOL_2D": _POOL, "
          "STRIDED_SLICE": [("begin_mask", "i"), ("end_mask", "i"), ("ellipsis_mask", "i"),
                            ("new_axis_mask", "i"), ("shrink_axis_mask", "i")],
          "CAST": [("in_type", "b"), ("out_type", "b")],
-         "BATCH_MATMUL": [("adj_x", "?"), ("adj_y", "?")]}
+         "BATCH_MATMUL": [("adj_x", "?"), ("adj_y", "?")], "REDUCE_PROD": [("keep_dims", "?")],
+         "SPLIT": [("num_splits", "i")], "LEAKY_RELU": [("alpha", "f")], "GELU": [("approximate", "?")]}
 
 
 class FB:
