@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-oracle-check", action="store_true", help="skip the max-abs probability diff vs the oracle (3 rows, outside the timed region)")
     ap.add_argument("--cpu-clips", type=int, default=0, help="clips in the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-profile", action="store_true", help="disable per-kernel HIP-event timing")
     ap.add_argument("--detail", action="store_true", help="print a per-launch table to stderr")
@@ -228,10 +229,27 @@ def main():
     # throughput measured with a wrong kernel is not a result (this check caught an LDS staging overflow in round 1)
     if not (consist <= 1e-3):
         print(f"[bench] CONSISTENCY CHECK FAILED: full-batch logits differ from the small-batch path by {consist}", file=sys.stderr)
+    # second half of BASELINE's metric: max-abs probability diff of the timed configuration's own output (full batch, pipelined
+    # engine) against the CPU restatement, on a few rows, outside the timed region.  The oracle is the checker here, nothing
+    # measured runs through it.
+    prob_diff = top1_same = None
+    oracle_rows = sorted({0, B // 2 - 1 if B > 1 else 0, B - 1})
+    if rank == 0 and not args.no_oracle_check:
+        from oracle.interp import Interpreter
+        ref = Interpreter(blob, conv_backend="torch").invoke(x_host[oracle_rows])[0]
+        got = logits[oracle_rows].float().cpu().numpy()
+        sg = lambda v: 1.0 / (1.0 + np.exp(-v.astype(np.float64)))
+        prob_diff = float(np.abs(sg(got) - sg(ref)).max())
+        top1_same = bool((got.argmax(1) == ref.argmax(1)).all())
+        if not (prob_diff <= 1e-4 and top1_same):
+            print(f"[bench] PARITY CHECK FAILED: max-abs prob diff vs oracle {prob_diff}, top-1 identical {top1_same}", file=sys.stderr)
     if rank == 0:
         total_clips = B * world * args.steps
         out = {
-            "metric": "3s-48kHz clips/sec (whole node), BirdNET v2.4", "value": total_clips / dt, "unit": "clips/s",
+            "metric": "3s-48kHz clips/sec (whole node) + max-abs prob diff vs TFLite, BirdNET v2.4", "value": total_clips / dt, "unit": "clips/s",
+            "max_abs_prob_diff_vs_oracle": prob_diff, "top1_identical_vs_oracle": top1_same,
+            "prob_diff_reference": f"oracle restatement of the TFLite float op semantics on rows {oracle_rows} of the timed batch "
+                                   "(tolerance 1e-4; no TFLite runtime or real weights exist in this environment)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic sine+noise clips (SURVEY 8d cfg 2); random-init BirdNET-v2.4-topology weights "

@@ -581,9 +581,13 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                 bool ok = P.uses[sgt] == 1 && ((mi[0] == y && mi[1] == sgt) || (mi[1] == y && mi[0] == sgt));
                 if (ok) { P.absorbed[lg] = 1; P.absorbed[mu] = 1; *act = ACT_SWISH; return m.ops[mu].outputs[0]; }
             }
-        } else if (P.uses[y] == 1 && P.consumers[y].size() == 1 && m.ops[P.consumers[y][0]].code == OP_LOGISTIC) {
-            int lg = P.consumers[y][0];
-            P.absorbed[lg] = 1; *act = ACT_SIGMOID; return m.ops[lg].outputs[0];
+        } else if (P.uses[y] == 1 && P.consumers[y].size() == 1 && !P.absorbed[P.consumers[y][0]]) {
+            // a stand-alone activation op right behind the producer (ONNX lowerings, unfused exports)
+            const int ci = P.consumers[y][0];
+            const int cc = m.ops[ci].code;
+            const int a = cc == OP_LOGISTIC ? ACT_SIGMOID : cc == OP_RELU ? ACT_RELU : cc == OP_RELU6 ? ACT_RELU6 :
+                          cc == OP_HARD_SWISH ? ACT_HARD_SWISH : -1;
+            if (a >= 0) { P.absorbed[ci] = 1; *act = a; return m.ops[ci].outputs[0]; }
         }
         return y;
     };

@@ -349,7 +349,7 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
             const bool tb = gemm && nd.ai("transB", 0) != 0;
             if (gemm && nd.ai("transA", 0) != 0) return fail("ONNX: " + where + ": transA is not supported");
             const int K = (int)(tb ? bd[1] : bd[0]), N = (int)(tb ? bd[0] : bd[1]);
-            const auto& ash = m.tensors[a].shape;
+            const std::vector<int> ash = m.tensors[a].shape;      // by value: add_const_f32 below reallocates m.tensors
             if (ash.empty() || ash.back() != K) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": inner dimensions disagree"); }
             std::vector<float> W((size_t)N * K);
             for (int n = 0; n < N; n++)

@@ -6,15 +6,21 @@
 // Shape follows the reference's own native-accelerator precedent, the OpenVINO cgo shim
 // (internal/inference/openvino/backend_openvino.go): dlopen'd library, process-global init under a
 // mutex, one native handle per classifier, C-allocated input staging, sentinel "unavailable" error so
-// callers fall back (internal/classifier/birdnet.go:321-335).  NOTE: this file cannot be compiled in
-// the build environment of this repo (no Go toolchain); it is the binding a birdnet-go maintainer
-// drops into internal/inference/hip/ (see INTEGRATION.md).
+// callers fall back (internal/classifier/birdnet.go:321-335), and - because the native error text is
+// thread-local - runtime.LockOSThread around every native call plus its error fetch
+// (backend_openvino.go:480,581,729,805).
+//
+// NOTE: no Go toolchain exists in this repository's build environment.  The C preamble below is
+// nevertheless compiled and executed: tests/test_cabi.py extracts it verbatim, builds it with
+// `gcc -Wall -Wextra -Werror` and drives exactly the call sequence of this file through it
+// (tests/native/cabi_driver.c), on the CPU for the error paths and on the GPU for the full sequence.
 package hip
 
 /*
 #cgo LDFLAGS: -ldl
 #include <dlfcn.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -36,33 +42,49 @@ typedef struct {
 static bnbind_t BN;
 static char bnbind_errbuf[256];
 
+// A failed resolve closes the library and clears the table: the next bnbind_load starts from scratch
+// ("idempotent and retryable", backend_openvino.go:477-506) instead of returning success with NULL pointers.
+static const char* bnbind_fail(const char* what, const char* detail) {
+    snprintf(bnbind_errbuf, sizeof bnbind_errbuf, "%s%s", what, detail ? detail : "");
+    if (BN.handle) dlclose(BN.handle);
+    memset(&BN, 0, sizeof BN);
+    return bnbind_errbuf;
+}
 #define BN_RESOLVE(field, sym) do { *(void**)(&BN.field) = dlsym(BN.handle, sym); \
-    if (!BN.field) { snprintf(bnbind_errbuf, sizeof bnbind_errbuf, "missing symbol %s", sym); return bnbind_errbuf; } } while (0)
+    if (!BN.field) return bnbind_fail("missing symbol ", sym); } while (0)
 
 static const char* bnbind_load(const char* path) {
     if (BN.handle) return NULL;
     BN.handle = dlopen(path, RTLD_NOW | RTLD_LOCAL);
-    if (!BN.handle) { snprintf(bnbind_errbuf, sizeof bnbind_errbuf, "%s", dlerror()); return bnbind_errbuf; }
+    if (!BN.handle) return bnbind_fail("", dlerror());
     BN_RESOLVE(init, "bnhip_init"); BN_RESOLVE(shutdown, "bnhip_shutdown");
     BN_RESOLVE(model_create, "bnhip_model_create"); BN_RESOLVE(model_info, "bnhip_model_info");
     BN_RESOLVE(predict, "bnhip_predict"); BN_RESOLVE(predict_topk, "bnhip_predict_topk");
     BN_RESOLVE(model_destroy, "bnhip_model_destroy"); BN_RESOLVE(last_error, "bnhip_last_error");
     return NULL;
 }
+static void bnbind_unload(void) {
+    if (BN.shutdown) BN.shutdown();
+    if (BN.handle) dlclose(BN.handle);
+    memset(&BN, 0, sizeof BN);
+}
 // fixed-arity wrappers (cgo cannot call function pointers directly)
 static int bnbind_init(int* n) { return BN.init(n); }
 static int bnbind_model_create(const void* b, size_t n, const char* o, bnhip_model** m) { return BN.model_create(b, n, o, m); }
 static int bnbind_model_info(const bnhip_model* m, int* a, int* b, int* c) { return BN.model_info(m, a, b, c); }
 static int bnbind_predict(bnhip_model* m, const float* s, int n, float* l, float* e) { return BN.predict(m, s, n, l, e); }
+static int bnbind_predict_topk(bnhip_model* m, const float* s, int n, int act, double sens, int k, float* c, int32_t* i) {
+    return BN.predict_topk(m, s, n, act, sens, k, c, i);
+}
 static void bnbind_model_destroy(bnhip_model* m) { BN.model_destroy(m); }
 static const char* bnbind_last_error(void) { return BN.last_error ? BN.last_error() : ""; }
-#include <stdio.h>
 */
 import "C"
 
 import (
 	"errors"
 	"fmt"
+	"runtime"
 	"sync"
 	"unsafe"
 )
@@ -78,6 +100,10 @@ var (
 	initDone bool
 )
 
+// lastError must run on the OS thread that made the failing call (the text is thread-local in the
+// library); every caller below holds runtime.LockOSThread across call + fetch.
+func lastError() string { return C.GoString(C.bnbind_last_error()) }
+
 // Init loads libbnhip.so and initialises the HIP runtime. Idempotent and retryable.
 func Init(libraryPath string) error {
 	initMu.Lock()
@@ -85,6 +111,8 @@ func Init(libraryPath string) error {
 	if initDone {
 		return nil
 	}
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
 	cpath := C.CString(libraryPath)
 	defer C.free(unsafe.Pointer(cpath))
 	if msg := C.bnbind_load(cpath); msg != nil {
@@ -92,7 +120,9 @@ func Init(libraryPath string) error {
 	}
 	var n C.int
 	if rc := C.bnbind_init(&n); rc != 0 {
-		return fmt.Errorf("%w: %s", ErrHIPUnavailable, C.GoString(C.bnbind_last_error()))
+		err := fmt.Errorf("%w: %s", ErrHIPUnavailable, lastError())
+		C.bnbind_unload() // retryable: the next Init reloads
+		return err
 	}
 	initDone = true
 	return nil
@@ -110,15 +140,28 @@ type Classifier struct {
 
 // NewClassifier builds a classifier from the same in-memory model bytes the TFLite backend takes
 // (tflite.NewTFLiteClassifier(modelData []byte, ...), internal/inference/tflite/classifier.go:38).
-func NewClassifier(modelData []byte, device int) (*Classifier, error) {
+// devices: one ordinal = one GPU; several = one handle sharding every batch over them.
+func NewClassifier(modelData []byte, devices ...int) (*Classifier, error) {
 	if len(modelData) == 0 {
 		return nil, errors.New("hip: empty model data")
 	}
-	opts := C.CString(fmt.Sprintf(`{"device":%d,"max_batch":256}`, device))
+	if len(devices) == 0 {
+		devices = []int{0}
+	}
+	list := ""
+	for i, d := range devices {
+		if i > 0 {
+			list += ","
+		}
+		list += fmt.Sprint(d)
+	}
+	opts := C.CString(fmt.Sprintf(`{"devices":[%s],"max_batch":256}`, list))
 	defer C.free(unsafe.Pointer(opts))
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
 	var h *C.bnhip_model
 	if rc := C.bnbind_model_create(unsafe.Pointer(&modelData[0]), C.size_t(len(modelData)), opts, &h); rc != 0 {
-		msg := C.GoString(C.bnbind_last_error())
+		msg := lastError()
 		if rc == -2 {
 			return nil, fmt.Errorf("%w: %s", ErrHIPUnavailable, msg)
 		}
@@ -161,8 +204,10 @@ func (c *Classifier) predict(samples []float32, wantEmb bool) ([]float32, []floa
 		emb = make([]float32, c.embDim)
 		ep = (*C.float)(unsafe.Pointer(&emb[0]))
 	}
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
 	if rc := C.bnbind_predict(c.h, c.in, 1, (*C.float)(unsafe.Pointer(&logits[0])), ep); rc != 0 {
-		return nil, nil, fmt.Errorf("hip: predict failed (%d): %s", int(rc), C.GoString(C.bnbind_last_error()))
+		return nil, nil, fmt.Errorf("hip: predict failed (%d): %s", int(rc), lastError())
 	}
 	return logits, emb, nil
 }
@@ -177,11 +222,36 @@ func (c *Classifier) PredictBatch(flat []float32, batchSize int) ([]float32, err
 		return nil, fmt.Errorf("input size mismatch: expected %d samples, got %d", batchSize*c.nSamples, len(flat))
 	}
 	out := make([]float32, batchSize*c.nClasses)
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
 	if rc := C.bnbind_predict(c.h, (*C.float)(unsafe.Pointer(&flat[0])), C.int(batchSize),
 		(*C.float)(unsafe.Pointer(&out[0])), nil); rc != 0 {
-		return nil, fmt.Errorf("hip: predict failed (%d): %s", int(rc), C.GoString(C.bnbind_last_error()))
+		return nil, fmt.Errorf("hip: predict failed (%d): %s", int(rc), lastError())
 	}
 	return out, nil
+}
+
+// PredictTopK runs predict + sigmoid(sensitivity) + top-k on the device ((*BirdNET).Predict's
+// post-processing, classifier/analyze.go:113-115,197-253): confidences and label indices, descending.
+func (c *Classifier) PredictTopK(flat []float32, batchSize, k int, sensitivity float64) ([]float32, []int32, error) {
+	if c.h == nil {
+		return nil, nil, errors.New("hip: classifier is closed")
+	}
+	if batchSize <= 0 || k <= 0 || len(flat) != batchSize*c.nSamples {
+		return nil, nil, fmt.Errorf("input size mismatch: expected %d samples, got %d", batchSize*c.nSamples, len(flat))
+	}
+	if k > c.nClasses {
+		k = c.nClasses
+	}
+	conf := make([]float32, batchSize*k)
+	idx := make([]int32, batchSize*k)
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	if rc := C.bnbind_predict_topk(c.h, (*C.float)(unsafe.Pointer(&flat[0])), C.int(batchSize), 0, C.double(sensitivity),
+		C.int(k), (*C.float)(unsafe.Pointer(&conf[0])), (*C.int32_t)(unsafe.Pointer(&idx[0]))); rc != 0 {
+		return nil, nil, fmt.Errorf("hip: predict_topk failed (%d): %s", int(rc), lastError())
+	}
+	return conf, idx, nil
 }
 
 // NumSpecies comes from the model output, not the label list (inference/openvino.go:72-81).

@@ -80,13 +80,25 @@ def frame_clips(samples, sample_rate, clip_seconds=3.0, overlap_seconds=0.0, min
     return clips, np.asarray(starts, np.float64) / sample_rate
 
 
-def analyze_file(path, classifier, labels=None, sensitivity=1.0, overlap_seconds=0.0, top_k=10, threshold=0.0):
-    """File analysis = read -> frame -> batched predict_topk. Returns rows (start_s, end_s, label|index, confidence)."""
+def analyze_file(path, classifier, labels=None, sensitivity=1.0, overlap_seconds=0.0, top_k=10, threshold=0.0,
+                 model_rate=48000, device=0):
+    """File analysis = read -> (resample to the model's rate) -> frame -> batched predict_topk.
+    Returns rows (start_s, end_s, label|index, confidence).
+
+    `model_rate` is the sample rate the classifier's clip length is expressed in (48 kHz for BirdNET v2.4,
+    `internal/classifier/model_registry.go:138-153`).  A file at another rate is resampled on the GPU first, as the
+    reference resamples file input to the model rate (`internal/audiocore/resample/resample.go`, call sites
+    `analysis/buffer_consumer.go:118,192`); window times are in seconds of audio, whatever the file's rate."""
     s, rate, _ = read_wav(path)
-    clip_seconds = classifier.n_samples / 48000.0 if rate == 48000 else classifier.n_samples / rate
-    if int(round(clip_seconds * rate)) != classifier.n_samples:
-        raise WavError(f"sample rate {rate} does not match the model's clip length; resample first")
-    clips, starts = frame_clips(s, rate, clip_seconds, overlap_seconds)
+    if model_rate <= 0:
+        raise WavError(f"invalid model sample rate {model_rate}")
+    if rate != model_rate:
+        from . import host                               # GPU resampler (bnhip_resample_f32); fails loudly without a device
+        s = host.Resampler(rate, model_rate, device=device).resample_f32(s)
+    clip_seconds = classifier.n_samples / float(model_rate)
+    clips, starts = frame_clips(s, model_rate, clip_seconds, overlap_seconds)
+    if clips.shape[1] != classifier.n_samples:
+        raise WavError(f"framed clip length {clips.shape[1]} != model input {classifier.n_samples}")
     conf, idx = classifier.predict_topk(clips.reshape(-1), clips.shape[0], k=top_k, sensitivity=sensitivity)
     rows = []
     for i in range(clips.shape[0]):

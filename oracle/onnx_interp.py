@@ -1,0 +1,215 @@
+"""ORACLE (test infrastructure only — never imported by the product path).
+
+Independent reader + numpy executor for the ONNX graphs the reference runs through ONNX Runtime 1.25.1
+(`github.com/yalue/onnxruntime_go v1.30.1`, third-party, absent from /root/reference): secondary dense heads
+(`internal/inference/onnx/custom_classifier.go:148-174` CustomClassifier.PredictRaw; `internal/classifier/bat_onnx.go:252-282`).
+Each operator restates the ONNX operator specification (Gemm: Y = alpha*A'*B' + beta*C; MatMul; BatchNormalization
+inference form; Softmax over `axis`; elementwise ops with numpy broadcasting).  PARITY UNPINNED against ONNX Runtime itself
+(no runtime and no real head files exist here); what this pins is engine-vs-specification on files both readers parse.
+
+The protobuf wire parser below shares no code with the product's C++ reader or with birdnet-go_amd/onnx_build.py.
+"""
+import struct
+
+import numpy as np
+
+
+def _fields(buf):
+    """yield (field, wire, value) with value = int (wire 0), bytes (wire 1, 2, 5)."""
+    mv = memoryview(buf)
+    i, n = 0, len(mv)
+    while i < n:
+        key = 0
+        shift = 0
+        while True:
+            b = mv[i]
+            i += 1
+            key |= (b & 0x7F) << shift
+            shift += 7
+            if not b & 0x80:
+                break
+        field, wire = key >> 3, key & 7
+        if wire == 0:
+            v = 0
+            shift = 0
+            while True:
+                b = mv[i]
+                i += 1
+                v |= (b & 0x7F) << shift
+                shift += 7
+                if not b & 0x80:
+                    break
+            yield field, wire, v
+        elif wire == 1:
+            yield field, wire, bytes(mv[i:i + 8])
+            i += 8
+        elif wire == 5:
+            yield field, wire, bytes(mv[i:i + 4])
+            i += 4
+        elif wire == 2:
+            ln = 0
+            shift = 0
+            while True:
+                b = mv[i]
+                i += 1
+                ln |= (b & 0x7F) << shift
+                shift += 7
+                if not b & 0x80:
+                    break
+            yield field, wire, bytes(mv[i:i + ln])
+            i += ln
+        else:
+            raise ValueError(f"unsupported wire type {wire}")
+
+
+def _signed(v):
+    return v - (1 << 64) if v >= 1 << 63 else v
+
+
+def _packed_varints(b):
+    out, v, shift = [], 0, 0
+    for byte in b:
+        v |= (byte & 0x7F) << shift
+        shift += 7
+        if not byte & 0x80:
+            out.append(_signed(v))
+            v, shift = 0, 0
+    return out
+
+
+_NP = {1: np.float32, 6: np.int32, 7: np.int64, 10: np.float16, 11: np.float64}
+
+
+def _tensor(buf):
+    dims, dtype, name, raw, fdata, idata = [], 0, "", None, [], []
+    for f, w, v in _fields(buf):
+        if f == 1:
+            dims += [_signed(v)] if w == 0 else _packed_varints(v)
+        elif f == 2:
+            dtype = v
+        elif f == 8:
+            name = v.decode()
+        elif f == 9:
+            raw = v
+        elif f == 4:
+            fdata += [struct.unpack("<f", v)[0]] if w == 5 else list(np.frombuffer(v, "<f4"))
+        elif f == 7:
+            idata += [_signed(v)] if w == 0 else _packed_varints(v)
+    if raw is not None:
+        a = np.frombuffer(raw, _NP[dtype]).reshape(dims)
+    elif fdata:
+        a = np.asarray(fdata, np.float32).reshape(dims)
+    else:
+        a = np.asarray(idata, np.int64).reshape(dims)
+    return name, a
+
+
+def _attr(buf):
+    name, val = "", None
+    for f, w, v in _fields(buf):
+        if f == 1:
+            name = v.decode()
+        elif f == 2:
+            val = struct.unpack("<f", v)[0]
+        elif f == 3:
+            val = _signed(v)
+        elif f == 4:
+            val = v.decode()
+        elif f == 5:
+            val = _tensor(v)[1]
+        elif f == 7:
+            val = (val or []) + ([struct.unpack("<f", v)[0]] if w == 5 else list(np.frombuffer(v, "<f4")))
+        elif f == 8:
+            val = (val or []) + ([_signed(v)] if w == 0 else _packed_varints(v))
+    return name, val
+
+
+def _value_name(buf):
+    for f, w, v in _fields(buf):
+        if f == 1:
+            return v.decode()
+    return ""
+
+
+class OnnxModel:
+    def __init__(self, blob):
+        graph = None
+        for f, w, v in _fields(blob):
+            if f == 7:
+                graph = v
+        if graph is None:
+            raise ValueError("not an ONNX ModelProto")
+        self.nodes, self.inits, self.inputs, self.outputs = [], {}, [], []
+        for f, w, v in _fields(graph):
+            if f == 1:
+                ins, outs, op, attrs = [], [], "", {}
+                for f2, w2, v2 in _fields(v):
+                    if f2 == 1:
+                        ins.append(v2.decode())
+                    elif f2 == 2:
+                        outs.append(v2.decode())
+                    elif f2 == 4:
+                        op = v2.decode()
+                    elif f2 == 5:
+                        k, a = _attr(v2)
+                        attrs[k] = a
+                self.nodes.append((op, ins, outs, attrs))
+            elif f == 5:
+                name, a = _tensor(v)
+                self.inits[name] = a
+            elif f == 11:
+                self.inputs.append(_value_name(v))
+            elif f == 12:
+                self.outputs.append(_value_name(v))
+        self.runtime_inputs = [n for n in self.inputs if n not in self.inits]
+
+
+def run(blob, x, precision="f32"):
+    """x [B, dim] -> list of outputs (float32)."""
+    m = blob if isinstance(blob, OnnxModel) else OnnxModel(blob)
+    fdt = np.float32 if precision == "f32" else np.float64
+    vals = {k: (v.astype(fdt) if v.dtype.kind == "f" else v) for k, v in m.inits.items()}
+    vals[m.runtime_inputs[0]] = np.asarray(x, np.float32).astype(fdt)
+    for op, ins, outs, at in m.nodes:
+        a = [vals[i] if i else None for i in ins]
+        if op == "Gemm":
+            A = a[0].T if at.get("transA") else a[0]
+            B = a[1].T if at.get("transB") else a[1]
+            y = np.asarray(at.get("alpha", 1.0), fdt) * (A @ B)
+            if len(a) > 2 and a[2] is not None:
+                y = y + np.asarray(at.get("beta", 1.0), fdt) * a[2]
+        elif op == "MatMul":
+            y = a[0] @ a[1]
+        elif op in ("Add", "Sub", "Mul", "Div", "Pow", "Max", "Min"):
+            y = {"Add": np.add, "Sub": np.subtract, "Mul": np.multiply, "Div": np.divide, "Pow": np.power, "Max": np.maximum,
+                 "Min": np.minimum}[op](a[0], a[1])
+        elif op == "Relu":
+            y = np.maximum(a[0], 0)
+        elif op == "Sigmoid":
+            y = (1.0 / (1.0 + np.exp(-a[0]))).astype(fdt)
+        elif op == "Tanh":
+            y = np.tanh(a[0])
+        elif op == "LeakyRelu":
+            y = np.where(a[0] > 0, a[0], a[0] * np.asarray(at.get("alpha", 0.01), fdt))
+        elif op == "Softmax":
+            ax = at.get("axis", -1)
+            z = a[0] - a[0].max(axis=ax, keepdims=True)
+            e = np.exp(z)
+            y = e / e.sum(axis=ax, keepdims=True)
+        elif op == "BatchNormalization":
+            x_, sc, bi, mu, va = a[:5]
+            y = (x_ - mu) / np.sqrt(va + np.asarray(at.get("epsilon", 1e-5), fdt)) * sc + bi
+        elif op in ("Identity", "Dropout"):
+            y = a[0]
+        elif op == "Flatten":
+            y = a[0].reshape(a[0].shape[0], -1)
+        elif op == "Clip":
+            lo = at.get("min", a[1] if len(a) > 1 and a[1] is not None else -np.inf)
+            hi = at.get("max", a[2] if len(a) > 2 and a[2] is not None else np.inf)
+            y = np.clip(a[0], lo, hi)
+        elif op == "Concat":
+            y = np.concatenate(a, axis=at.get("axis", 1))
+        else:
+            raise ValueError(f"oracle: unsupported ONNX op {op}")
+        vals[outs[0]] = np.asarray(y, fdt)
+    return [np.asarray(vals[o], np.float32) for o in m.outputs]

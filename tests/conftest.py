@@ -37,3 +37,11 @@ def tiny_blob(tiny_cfg):
 def full_blob():
     from birdnet_go_amd import synth_model as sm
     return sm.build_model(sm.SynthConfig())
+
+
+@pytest.fixture(scope="session")
+def gpu(built_lib):
+    """A usable gfx950 device behind the C ABI (GPU tests fail loudly here when the HIP library or device is missing)."""
+    from birdnet_go_amd import host
+    assert host.init() >= 1
+    return True

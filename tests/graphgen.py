@@ -290,6 +290,7 @@ class Gen:
             y = g.op("FULLY_CONNECTED", [r, g.const(self.w(n_cls, sh[3])), -1], [1, rows, n_cls],
                      dict(fused_activation_function=self.pick([S.ACT_NONE, S.ACT_TANH]), keep_num_dims=1))
             y = g.op("RESHAPE", [y, g.const(i32([1, rows * n_cls]))], [1, rows * n_cls], dict(new_shape=[1, rows * n_cls]))
+        self.io = (x, y)
         return g.finish([x], [y]), (H, W, C)
 
 
@@ -302,3 +303,37 @@ def random_graph(seed):
 
 def random_input(seed, shape, batch):
     return np.random.default_rng(10_000 + seed).standard_normal((batch,) + tuple(shape)).astype(np.float32)
+
+
+def mutated_graph(seed, mut_seed):
+    """A random graph whose operator records were corrupted before serialisation (well-framed flatbuffer, malformed graph):
+    operand indices dropped / set to -1 / redirected, constants re-typed, outputs removed, weight shapes changed."""
+    gen = Gen(seed)
+    gen.build()
+    g, rng = gen.g, np.random.default_rng(mut_seed)
+    nt = len(g.tensors)
+    for _ in range(int(rng.integers(1, 4))):
+        o = g.ops[int(rng.integers(0, len(g.ops)))]
+        kind = int(rng.integers(0, 8))
+        if kind == 0 and o["inputs"]:
+            o["inputs"][int(rng.integers(0, len(o["inputs"])))] = -1
+        elif kind == 1 and o["inputs"]:
+            o["inputs"][int(rng.integers(0, len(o["inputs"])))] = int(rng.integers(0, nt))
+        elif kind == 2 and o["inputs"]:
+            o["inputs"].pop()
+        elif kind == 3:
+            o["outputs"] = []
+        elif kind == 4:
+            o["inputs"] = o["inputs"] + [int(rng.integers(0, nt))]
+        elif kind == 5:                                   # re-type a constant (float weights become int32 / float16 bits)
+            consts = [t for t in g.tensors if t["buffer"]]
+            if consts:
+                t = consts[int(rng.integers(0, len(consts)))]
+                t["type"] = int(rng.choice([S.INT32, S.FLOAT16, S.INT8, S.FLOAT32]))
+        elif kind == 6:                                   # change a declared shape without touching the data
+            t = g.tensors[int(rng.integers(0, nt))]
+            if t["shape"]:
+                t["shape"][int(rng.integers(0, len(t["shape"])))] = int(rng.integers(0, 9))
+        else:
+            o["outputs"] = [int(rng.integers(0, nt))]
+    return g.finish([gen.io[0]], [gen.io[1]])

@@ -69,3 +69,70 @@ def test_us_guards_need_no_gpu(built_lib):
     assert not ok.any()
     cv, ok = host.us_frame_cv(np.zeros((1, 8192)), 256000)
     assert not ok.any()
+
+
+# ------------------------------------------------------------------------------------------------ the cgo preamble, compiled
+GO_SHIM = os.path.join(ROOT, "birdnet-go_amd", "go", "internal", "inference", "hip", "backend_hip.go")
+
+
+def extract_preamble():
+    """The C preamble of the cgo file, verbatim (everything between the `/*` that follows `package hip` and `*/ import "C"`)."""
+    src = open(GO_SHIM).read()
+    m = re.search(r"package hip\s*/\*(.*?)\*/\s*import \"C\"", src, flags=re.S)
+    assert m, "cgo preamble not found"
+    return m.group(1)
+
+
+@pytest.fixture(scope="module")
+def cabi_driver(tmp_path_factory, built_lib):
+    import subprocess
+    d = tmp_path_factory.mktemp("cabi")
+    pre = "\n".join(l for l in extract_preamble().splitlines() if not l.startswith("#cgo"))
+    (d / "preamble_extracted.h").write_text(pre)
+    exe = str(d / "cabi_driver")
+    # gcc, C11, warnings are errors: `snprintf` before <stdio.h> (ADVICE r1) would stop the build here
+    subprocess.check_call(["gcc", "-std=c11", "-D_DEFAULT_SOURCE", "-Wall", "-Wextra", "-Werror", "-O1", "-I", str(d),
+                           os.path.join(ROOT, "tests", "native", "cabi_driver.c"), "-o", exe, "-ldl"])
+    return exe
+
+
+def test_cgo_preamble_compiles_and_go_call_sequence_cpu(cabi_driver, built_lib, tmp_path):
+    """The Go shim's C half under -Wall -Wextra -Werror, and its call sequence's error paths on the CPU: missing library,
+    garbage / truncated model, invalid option, plan-only handle, predict rejected with a message, unload + retry."""
+    import subprocess
+    from birdnet_go_amd import synth_model as sm
+    model = tmp_path / "dense.tflite"
+    model.write_bytes(sm.build_dense_model([64, 16, 5]))
+    r = subprocess.run([cabi_driver, built_lib, str(model), "cpu"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "cpu sequence ok" in r.stdout
+
+
+def test_go_shim_pins_the_os_thread_around_error_fetch():
+    src = open(GO_SHIM).read()
+    # every exported entry that can fail fetches the thread-local error text: each must hold the OS thread (ADVICE r1)
+    for fn in ("func Init(", "func NewClassifier(", "func (c *Classifier) predict(", "func (c *Classifier) PredictBatch(",
+               "func (c *Classifier) PredictTopK("):
+        body = src[src.index(fn):]
+        body = body[:body.index("\n}\n")]
+        assert "runtime.LockOSThread()" in body and "defer runtime.UnlockOSThread()" in body, fn
+    assert src.index("#include <stdio.h>") < src.index("snprintf")
+
+
+@pytest.mark.gpu
+def test_go_call_sequence_on_gpu(cabi_driver, built_lib, tmp_path, tiny_blob, tiny_cfg, gpu):
+    """Init -> NewClassifier -> Predict -> PredictBatch -> PredictTopK -> Close from a plain C host, results vs the oracle."""
+    import subprocess
+    from birdnet_go_amd import synth_model as sm
+    from oracle.interp import Interpreter
+    model = tmp_path / "tiny.tflite"
+    model.write_bytes(tiny_blob)
+    x = sm.synth_clips(5, tiny_cfg.n_samples, tiny_cfg.sample_rate)
+    (tmp_path / "in.f32").write_bytes(x.tobytes())
+    r = subprocess.run([cabi_driver, built_lib, str(model), "gpu", str(tmp_path / "in.f32"), str(tmp_path / "out.f32"), "5"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(tmp_path / "out.f32", np.float32).reshape(5, -1)
+    ref = Interpreter(tiny_blob).invoke(x)[0]
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v.astype(np.float64)))
+    assert (got.argmax(1) == ref.argmax(1)).all() and np.abs(sig(got) - sig(ref)).max() <= 1e-4

@@ -37,8 +37,15 @@ def _worker(rank, world, port, q):
     lo, hi = shard.shard_range(n, rank, world)
     x = sm.synth_clips(hi - lo, cfg.n_samples, cfg.sample_rate, first=lo)
     out = Interpreter(blob).invoke(x)[0]
+    # the ENGINE on every rank, as far as a CPU goes: the broadcast bytes go through the C ABI's reader and planner
+    # (plan_only), and every rank must arrive at the same plan as rank 0's local build
+    from birdnet_go_amd import host
+    clf = host.HipClassifier(blob, plan_only=True, max_batch=hi - lo)
+    d = clf.describe()
+    plan = (clf.n_samples, clf.num_species(), d["weight_bytes"], tuple((s["kernel"], s["name"]) for s in d["steps"]))
+    clf.close()
     dist.barrier()
-    q.put((rank, lo, hi, len(blob), out))
+    q.put((rank, lo, hi, len(blob), out, plan))
     dist.destroy_process_group()
 
 
@@ -63,4 +70,9 @@ def test_gloo_world2_broadcast_and_shard():
     whole = Interpreter(blob).invoke(sm.synth_clips(5, cfg.n_samples, cfg.sample_rate))[0]
     got = np.concatenate([r[4] for r in res])
     assert (res[0][1], res[0][2], res[1][1], res[1][2]) == (0, 3, 3, 5)
+    from birdnet_go_amd import host
+    c = host.HipClassifier(blob, plan_only=True, max_batch=3)
+    d = c.describe()
+    want = (c.n_samples, c.num_species(), d["weight_bytes"], tuple((s["kernel"], s["name"]) for s in d["steps"]))
+    assert res[0][5] == want and res[1][5] == want           # both ranks planned the broadcast model identically
     assert np.abs(got - whole).max() < 1e-5

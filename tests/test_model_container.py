@@ -212,3 +212,48 @@ def test_oracle_torch_conv_backend_equals_numpy_ops(tiny_blob, tiny_cfg):
     a = Interpreter(tiny_blob).invoke(x)[0]
     b = Interpreter(tiny_blob, conv_backend="torch").invoke(x)[0]
     assert np.abs(a - b).max() < 2e-5
+
+
+def test_malformed_graphs_are_model_errors_not_crashes(built_lib):
+    """operand counts, absent (-1) operands and constant dtypes are validated before the planner indexes
+    anything; a well-framed file with a corrupted operator list returns BNHIP_E_MODEL (or plans, when the mutation happens
+    to be harmless) - it never takes the process down."""
+    from graphgen import mutated_graph
+    outcomes = {"ok": 0, "model": 0, "other": 0}
+    for seed in range(24):
+        for mut in range(12):
+            blob = mutated_graph(seed, 1000 * seed + mut)
+            try:
+                host.HipClassifier(blob, plan_only=True).close()
+                outcomes["ok"] += 1
+            except host.HipError as e:
+                assert e.code in (host.E_MODEL, host.E_UNSUPPORTED, host.E_INVALID), (seed, mut, str(e))
+                outcomes["model" if e.code == host.E_MODEL else "other"] += 1
+    assert outcomes["model"] > 20, outcomes
+
+
+def test_specific_malformations_name_the_problem(built_lib):
+    def conv_graph(mut):
+        g = GraphBuilder()
+        x = g.tensor([1, 8, 8, 4], name="INPUT")
+        w = g.const(np.zeros((8, 3, 3, 4), np.float32))
+        b = g.const(np.zeros(8, np.float32))
+        y = g.op("CONV_2D", [x, w, b], [1, 8, 8, 8], dict(padding=0, stride_w=1, stride_h=1, fused_activation_function=0,
+                                                          dilation_w_factor=1, dilation_h_factor=1))
+        m = g.op("MEAN", [y, g.const(np.asarray([1, 2], np.int32))], [1, 8], dict(keep_dims=0))
+        mut(g)
+        return g.finish([x], [m])
+
+    cases = {
+        "required operand": lambda g: g.ops[0]["inputs"].__setitem__(1, -1),
+        "no outputs": lambda g: g.ops[0].__setitem__("outputs", []),
+        "must be float32": lambda g: g.tensors[1].__setitem__("type", S.INT32),
+        "must be int32": lambda g: g.tensors[4].__setitem__("type", S.FLOAT32),
+        "filter dimensions": lambda g: g.tensors[3].__setitem__("shape", [1, 8, 8, 16]),
+        "bias length": lambda g: (g.tensors[2].__setitem__("shape", [4]), g.buffers.__setitem__(2, np.zeros(4, np.float32))),
+        "operands, got": lambda g: g.ops[1]["inputs"].pop(),
+    }
+    for needle, mut in cases.items():
+        with pytest.raises(host.HipError, match=needle) as e:
+            host.HipClassifier(conv_graph(mut), plan_only=True)
+        assert e.value.code == host.E_MODEL, needle

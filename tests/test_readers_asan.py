@@ -1,0 +1,67 @@
+"""The C++ model readers, operand validation and graph passes under AddressSanitizer + UBSan ("a well-framed
+but malformed .tflite causes out-of-bounds reads"): mutated TFLite and ONNX files - byte flips, truncations, corrupted
+operand lists and constant dtypes - must be accepted or rejected, never read out of bounds.  Builds with plain g++."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import birdnet_go_amd  # noqa: F401
+from birdnet_go_amd import onnx_build as ob, synth_model as sm
+
+from graphgen import random_graph
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "..", "birdnet-go_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def fuzz_bin(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("asan") / "reader_fuzz")
+    srcs = [os.path.join(HERE, "native", "reader_fuzz_main.cpp")] + [os.path.join(CSRC, f) for f in
+                                                                     ("model_onnx.cpp", "tflite_model.cpp", "graph_passes.cpp")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-fno-omit-frame-pointer"] + srcs + ["-o", out])
+    return out
+
+
+def _mutations(blob, rng, n, window=None):
+    out = []
+    hi = min(len(blob), window or len(blob))
+    for _ in range(n):
+        b = bytearray(blob)
+        for p in rng.integers(0, hi, int(rng.integers(1, 6))):
+            b[p] ^= int(rng.integers(1, 256))
+        out.append(bytes(b))
+    for cut in rng.integers(1, len(blob), max(n // 8, 2)):
+        out.append(blob[:int(cut)])
+    return out
+
+
+def test_readers_never_read_out_of_bounds(fuzz_bin, tmp_path, tiny_blob):
+    rng = np.random.default_rng(2024)
+    corpus = []
+    seeds = [tiny_blob, sm.build_dense_model([3, 16, 8], final_sigmoid=True, fp16_weights=True)]
+    seeds += [random_graph(s)[0] for s in (1, 5, 9, 12)]
+    for b in seeds:
+        corpus.append(b)
+        corpus += _mutations(b, rng, 120)
+        # the flatbuffer's tables (operators, tensors, vtables) sit at the end of the file, the weights at the start
+        tail = b[-4096:]
+        for m in _mutations(tail, rng, 120):
+            corpus.append(b[:-len(tail)] + m[:len(tail)].ljust(len(tail), b"\0"))
+    for style in ("gemm", "matmul", "bn"):
+        ox, _ = ob.build_dense_head([16, 8, 4], style=style, final="Softmax")
+        corpus.append(ox)
+        corpus += _mutations(ox, rng, 300)
+    path = tmp_path / "corpus.bin"
+    with open(path, "wb") as f:
+        for b in corpus:
+            f.write(struct.pack("<I", len(b)) + b)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([fuzz_bin, str(path)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-6000:])
+    n, acc = [int(v) for v in r.stdout.split()[1::2]]
+    assert n == len(corpus) and acc >= len(seeds) + 3          # the unmutated files are all accepted
