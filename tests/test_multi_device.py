@@ -29,25 +29,25 @@ def test_two_shards_on_one_device_match_single_engine_and_oracle(gpu, tiny_blob,
         assert d["devices"] == [0, 0] and d["weight_replication"] == "peer-copy"
         a = single.predict_batch(x.reshape(-1), 11)
         b = multi.predict_batch(x.reshape(-1), 11)                  # shards of 6 and 5 clips, each chunked by max_batch 4
-        assert np.array_equal(a, b)
+        assert np.abs(a - b).max() < 1e-4              # each engine autotunes its own tiles: another fp32 summation order
         ref = Interpreter(tiny_blob).invoke(x)[0]
         assert np.abs(b - ref).max() < 1e-4
         # fewer clips than engines: the empty shard is skipped
-        assert np.array_equal(multi.predict_batch(x[:1].reshape(-1), 1), a[:1])
+        assert np.abs(multi.predict_batch(x[:1].reshape(-1), 1) - a[:1]).max() < 1e-4
         # every host-pointer entry shards: PCM16 and the fused top-k
         pcm = (x * 32767).astype(np.int16)
-        assert np.array_equal(multi.predict_pcm16(pcm.reshape(-1), 11), single.predict_pcm16(pcm.reshape(-1), 11))
+        assert np.abs(multi.predict_pcm16(pcm.reshape(-1), 11) - single.predict_pcm16(pcm.reshape(-1), 11)).max() < 1e-4
         c1, i1 = single.predict_topk(x.reshape(-1), 11, k=5)
         c2, i2 = multi.predict_topk(x.reshape(-1), 11, k=5)
-        assert np.array_equal(c1, c2) and np.array_equal(i1, i2)
-        c3, i3 = multi.postprocess_topk(a, k=5)
-        assert np.array_equal(c1, c3) and np.array_equal(i1, i3)
+        assert np.abs(c1 - c2).max() < 1e-5 and np.array_equal(i1, i2)
+        c3, i3 = multi.postprocess_topk(a, k=5)                     # same logits in: the sharded post-processing is bit-exact
+        c4, i4 = single.postprocess_topk(a, k=5)
+        assert np.array_equal(c4, c3) and np.array_equal(i4, i3)
         # device pointers belong to one device: rejected on a multi-device handle
         with pytest.raises(host.HipError, match="single-device"):
             multi.predict_device(1, 1, 1)
         # an error inside a shard surfaces on the calling thread with its message
-        with pytest.raises(host.HipError):
-            multi._lib.bnhip_predict.restype = None
+        with pytest.raises(host.HipError, match="NULL"):
             host._check(multi._lib, multi._lib.bnhip_predict(multi._h, None, 3, None, None))
     finally:
         single.close(); multi.close()
