@@ -382,9 +382,21 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
     v_mm = new_val(-1, 2);
 
     std::vector<size_t> step_w[4];   // per-step weight offsets (SIZE_MAX = none)
+    std::vector<size_t> step_bx;     // per-step offset of the split-bf16 weight image (S_PW steps of a bf16x3 engine)
     auto add_step = [&](Step s, size_t o0 = SIZE_MAX, size_t o1 = SIZE_MAX, size_t o2 = SIZE_MAX, size_t o3 = SIZE_MAX) {
         steps.push_back(s);
         step_w[0].push_back(o0); step_w[1].push_back(o1); step_w[2].push_back(o2); step_w[3].push_back(o3);
+        size_t obx = SIZE_MAX;
+        if (bf16x3 && s.kind == S_PW && o0 != SIZE_MAX && pw_bx3_ok(s.C)) {
+            // three exact bf16 pieces of every weight, in the kernel's slab / lane order (1.5x the fp32 bytes)
+            std::vector<float> wsrc(wimg.begin() + o0, wimg.begin() + o0 + (size_t)s.Co * s.C);
+            std::vector<uint16_t> img = pw_bx3_image(wsrc.data(), s.Co, s.C);
+            std::vector<float> asf((img.size() + 1) / 2);
+            memcpy(asf.data(), img.data(), img.size() * 2);
+            obx = wpush(asf.data(), asf.size());
+            if (bf16x3 >= 2) steps.back().wm = steps.back().wm_full = 6;      // forced: 128-row tiles (the autotuner refines)
+        }
+        step_bx.push_back(obx);
     };
 
     // front-end steps
@@ -1424,6 +1436,9 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
         const float** slots[4] = {&steps[si].w0, &steps[si].w1, &steps[si].w2, &steps[si].w3};
         for (int k = 0; k < 4; k++)
             if (step_w[k][si] != SIZE_MAX) *slots[k] = reinterpret_cast<const float*>(w_arena) + step_w[k][si];
+        if (step_bx[si] != SIZE_MAX) {
+            steps[si].wbx = reinterpret_cast<const uint16_t*>(reinterpret_cast<const float*>(w_arena) + step_bx[si]);
+        }
         if (steps[si].kind == S_FRONTEND) {
             specs[steps[si].spec].G = reinterpret_cast<const double*>(steps[si].w0);
             specs[steps[si].spec].window = steps[si].w1;
@@ -1536,6 +1551,26 @@ void Engine::autotune_pw() {
                     const bool less_work = by_work && work < best_work * 0.99;
                     if (less_work || ms < best * 0.98f) { best = ms; best_nt = nt; best_wm = wm; best_work = std::min(best_work, work); }
                 }
+            }
+            if (s.wbx && bf16x3) {
+                // split-bf16 candidates (wm 5 / 6 = 64- / 128-row tiles): taken where measured faster than the best fp32 tile
+                // (bf16x3 = 2: always, by their own best time)
+                float bbest = 1e30f; int bnt = 0, bwm = 0;
+                for (int wm = 6; wm >= 5; wm--)
+                    for (int nt = 1; nt <= 8; nt++) {
+                        long cols = (long)((s.Co + nt * 16 - 1) / (nt * 16)) * nt * 16;
+                        if (cols * 100 > (long)((s.Co + 15) / 16 * 16) * 130) continue;
+                        PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, nt, wm};
+                        launch_pw_bx3(p, s.wbx, stream);
+                        hipEventRecord(a, stream);
+                        for (int r = 0; r < 3; r++) launch_pw_bx3(p, s.wbx, stream);
+                        hipEventRecord(b, stream);
+                        hipEventSynchronize(b);
+                        float ms = 0; hipEventElapsedTime(&ms, a, b);
+                        if (getenv("BNHIP_DEBUG")) fprintf(stderr, "[bnhip] tune %-16s n=%d M=%d N=%d K=%d nt=%d wm=%d (bf16x3): %.1f us (%.1f TF fp32-equivalent)\n", s.name.c_str(), n, n * s.H * s.W, s.Co, s.C, nt, wm, ms / 3 * 1e3, 2.0 * n * s.H * s.W * s.Co * s.C / (ms / 3 * 1e-3) / 1e12);
+                        if (ms < bbest * 0.98f) { bbest = ms; bnt = nt; bwm = wm; }
+                    }
+                if (bnt && (bf16x3 >= 2 || bbest < best * 0.97f)) { best_nt = bnt; best_wm = bwm; }
             }
             if (pass == 0) { s.nt = best_nt; s.wm = best_wm; } else { s.nt_full = best_nt; s.wm_full = best_wm; }
         }
@@ -1718,7 +1753,8 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
             case S_PW: {
                 PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, nl > 1 ? s.nt : s.nt_full,
                            nl > 1 ? s.wm : s.wm_full};
-                launch_pw_gemm(p, stream);
+                if (p.wm >= 5 && s.wbx) launch_pw_bx3(p, s.wbx, stream);
+                else launch_pw_gemm(p, stream);
                 break;
             }
             case S_DW: {

@@ -34,6 +34,7 @@ struct Step {
     int in0 = -1, in1 = -1, in2 = -1, out = -1, out2 = -1;
     // weights (device pointers into the weight arena)
     const float *w0 = nullptr, *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;
+    const uint16_t* wbx = nullptr;   // S_PW: split-bf16 weight image (pw_bx3_image) when the engine was created with bf16x3
     // geometry per clip
     int H = 0, W = 0, C = 0, Ho = 0, Wo = 0, Co = 0, kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0;
     int act = 0, act2 = 0, op = 0, mode = 0, S = 1, Cr = 0;
@@ -90,7 +91,8 @@ class Engine {
     char* weights_ptr() const { return w_arena; }
     size_t weights_bytes() const { return w_bytes; }
     int frontend_fft = -1;              // -1 / 1: FFT path where the frame length is supported (512/1024/2048), 0: folded-GEMM kernel for real-part graphs
-    int bf16x3 = 0;                     // 1: late pointwise layers run on the split-bf16 MFMA path (see kernels.hip k_pw_bf16x3)
+    int bf16x3 = 0;                     // split-bf16 MFMA path for pointwise / dense layers (k_pw_bx3): 0 off, 1 per layer where the
+                                        // create-time autotuner measures it faster, 2 every eligible layer (parity tests)
     bool use_graphs = false;            // opt-in: replay the plan as a hipGraph once a (pointers, n) combination repeats (measured: no gain on ROCm 7.2)
     void drop_graphs();
     void autotune_expdw();

@@ -85,6 +85,13 @@ struct PwParams {         // pointwise conv / fully-connected as GEMM: out[M,N] 
 void launch_pw_gemm(const PwParams& p, hipStream_t s);
 bool pw_pipe_ok(int nt, int wm, int K);   // PwParams::wm = 2 + wm selects the software-pipelined kernel (k_pw_pipe)
 int pw_default_nt(int M, int N);
+// split-bf16 variant (k_pw_bx3): the same GEMM on v_mfma_f32_16x16x32_bf16 with fp32-equivalent products (three exact bf16
+// pieces per operand, six products).  Needs whole 32-wide K slabs and the plan-time weight image; PwParams::wm 5 / 6 select
+// its 64- / 128-row tiles.
+bool pw_bx3_ok(int K);
+int pw_bx3_npad(int N);
+std::vector<uint16_t> pw_bx3_image(const float* W, int N, int K);
+void launch_pw_bx3(const PwParams& p, const uint16_t* Wimg, hipStream_t s);
 
 struct DwParams {
     const float* in; const float* w /*[kh][kw][C]*/; const float* bias; float* out;

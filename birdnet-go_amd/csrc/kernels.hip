@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace bnhip {
 
@@ -1036,6 +1037,203 @@ __global__ __launch_bounds__(256) void k_pw_pipe(PwParams p, int nblk_n, unsigne
     slab(sl, std::false_type{}, std::false_type{});
 
     pw_epilogue<NT, WM>(p, acc, lds, m0, n0);
+}
+
+// ------------------------------------------------------------------------------------------ split-bf16 pointwise GEMM
+// The same GEMM on the bf16 matrix pipe with fp32-equivalent products.  The f32-input MFMA runs at the vector rate (157 TF);
+// v_mfma_f32_16x16x32_bf16 is 16x faster per MAC, and an fp32 value splits EXACTLY into three bf16 pieces by truncation:
+//     x = hi + mid + lo,   hi = bf16(x), mid = bf16(x - hi), lo = x - hi - mid      (round to nearest even)
+// (each subtraction is exact in fp32: the remainder of an 8-significant-bit rounding has at most 16 significant bits, the
+// next one at most 8, so lo is a bf16 too; |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|).  Then
+//     x * w = hi*whi + (hi*wmid + mid*whi) + (hi*wlo + mid*wmid + lo*whi)  +  [mid*wlo + lo*wmid + lo*wlo]
+// where every bf16 x bf16 product is exact in the MFMA's fp32 accumulator and the bracketed terms are <= 2^-23 |x w|
+// (the rounding of an fp32 product itself is <= 2^-24 |x w|): six products per k instead of one reproduce the fp32 product
+// to within two units of its own rounding.  Accumulation stays fp32.  (|x| above the largest bf16, 3.39e38, is the one
+// range the split cannot represent: hi overflows to infinity.)  The weights are split once at plan time (pw_bx3_image); activations are split in registers right after the
+// fragment read - every activation row belongs to exactly one wave, so nothing is split twice, and the f32 operand tile in
+// LDS (and the squeeze-excite multiply at store time) stays as in k_pw_gemm.
+// K order: lane kq of a 32-wide slab holds k = 4kq..4kq+3 and 16+4kq..16+4kq+3 (the two conflict-free b128 slots of the
+// f32 tile); the weight image uses the same order.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bx3_split8(const f32x4& a, const f32x4& b, bf16x8* hi, bf16x8* mid, bf16x8* lo) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    u32x4 h, m, l;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        // v_cvt_pk_bf16_f32 (round to nearest even) per pair, remainders by exact fp32 subtraction
+        const f32x2 v = {x[2 * q], x[2 * q + 1]};
+        const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+        const f32x2 r = v - (f32x2){__uint_as_float(hb << 16), __uint_as_float(hb & 0xffff0000u)};
+        const unsigned mb = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+        const f32x2 t = r - (f32x2){__uint_as_float(mb << 16), __uint_as_float(mb & 0xffff0000u)};
+        h[q] = hb; m[q] = mb; l[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+    }
+    *hi = __builtin_bit_cast(bf16x8, h); *mid = __builtin_bit_cast(bf16x8, m); *lo = __builtin_bit_cast(bf16x8, l);
+}
+
+static int pick_nt(int M, int N);
+template <int NT, bool SC, int WM>
+__global__ __launch_bounds__(256) void k_pw_bx3(PwParams p, const uint16_t* __restrict__ Wimg, int Npad, int nblk_n, unsigned nblk,
+                                                 FDiv dn, FDiv dhw) {
+    constexpr int BM = 64 * WM;
+    constexpr int XQ = BM * PW_C4 / 256;
+    constexpr int WSLOTS = 12 * NT * 16;                   // 16-byte slots of the weight tile: [plane 3][kq 4][row NT*16]
+    constexpr int WQ = (WSLOTS + 255) / 256;
+    constexpr int TILE_F = BM * PW_LS + WSLOTS * 4;        // floats
+    constexpr int STG = 4 * 16 * (NT * 16 + 4);
+    constexpr int LDSN = TILE_F > STG ? TILE_F : STG;
+    __shared__ __attribute__((aligned(16))) float lds[LDSN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const unsigned L = xcd_remap(blockIdx.x, nblk);
+    const int mblk = (int)fdiv(L, dn);
+    const int m0 = mblk * BM;
+    const int n0 = ((int)L - mblk * nblk_n) * (NT * 16);
+    const int K = p.K;
+
+    unsigned xoff[XQ], soff[SC ? XQ : 1], woff[WQ];
+    const int lbase = (tid / PW_C4) * PW_LS + 4 * (tid % PW_C4);
+    constexpr int LQ = (256 / PW_C4) * PW_LS;
+#pragma unroll
+    for (int q = 0; q < XQ; q++) {
+        const int idx = tid + 256 * q, row = idx / PW_C4, c4 = idx % PW_C4;
+        const int m = min(m0 + row, p.M - 1);
+        xoff[q] = (unsigned)m * (unsigned)K + 4 * c4;
+        if (SC) soff[SC ? q : 0] = fdiv((unsigned)m, dhw) * (unsigned)K + 4 * c4;
+    }
+#pragma unroll
+    for (int q = 0; q < WQ; q++) {
+        const int slot = min(tid + 256 * q, WSLOTS - 1);
+        const int plkq = slot / (NT * 16), r = slot - plkq * (NT * 16);
+        woff[q] = (unsigned)plkq * (unsigned)Npad + (unsigned)min(n0 + r, Npad - 1);          // in 16-byte units
+    }
+    float4 xreg[XQ], sreg[SC ? XQ : 1];
+    u32x4 wreg[WQ];
+    const u32x4* W16 = reinterpret_cast<const u32x4*>(Wimg);
+    auto gload = [&](int sl) {
+        const float* Ak = p.A + sl * PW_BK;
+#pragma unroll
+        for (int q = 0; q < XQ; q++) {
+            xreg[q] = *reinterpret_cast<const float4*>(Ak + xoff[q]);
+            if (SC) sreg[SC ? q : 0] = *reinterpret_cast<const float4*>(p.ascale + sl * PW_BK + soff[SC ? q : 0]);
+        }
+        const u32x4* Ws = W16 + (size_t)sl * 12 * Npad;
+#pragma unroll
+        for (int q = 0; q < WQ; q++) wreg[q] = Ws[woff[q]];
+    };
+    u32x4* Wl = reinterpret_cast<u32x4*>(lds + BM * PW_LS);
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < XQ; q++) {
+            float4 v = xreg[q];
+            if (SC) { const float4 sc = sreg[SC ? q : 0]; v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+            *reinterpret_cast<float4*>(&lds[lbase + q * LQ]) = v;
+        }
+#pragma unroll
+        for (int q = 0; q < WQ; q++)
+            if (WSLOTS % 256 == 0 || tid + 256 * q < WSLOTS) Wl[tid + 256 * q] = wreg[q];
+    };
+
+    f32x4 acc[NT][WM];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int mt = 0; mt < WM; mt++) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nslab = K / PW_BK;
+    gload(0);
+    lstore();
+    if (nslab > 1) gload(1);
+    __syncthreads();
+    for (int sl = 0; sl < nslab; sl++) {
+        bf16x8 ah[WM], am[WM], al[WM];
+#pragma unroll
+        for (int mt = 0; mt < WM; mt++) {
+            const float* xr = &lds[(16 * WM * wave + 16 * mt + li) * PW_LS + 4 * kq];
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xr), x1 = *reinterpret_cast<const f32x4*>(xr + 16);
+            bx3_split8(x0, x1, &ah[mt], &am[mt], &al[mt]);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, Wl[(0 * 4 + kq) * (NT * 16) + 16 * t + li]);
+            const bf16x8 wm = __builtin_bit_cast(bf16x8, Wl[(1 * 4 + kq) * (NT * 16) + 16 * t + li]);
+            const bf16x8 wl = __builtin_bit_cast(bf16x8, Wl[(2 * 4 + kq) * (NT * 16) + 16 * t + li]);
+#pragma unroll
+            for (int mt = 0; mt < WM; mt++) {
+                f32x4 c = acc[t][mt];                        // smallest terms first
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[mt], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[mt], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, am[mt], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, ah[mt], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, am[mt], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[mt], c, 0, 0, 0);
+                acc[t][mt] = c;
+            }
+        }
+        if (sl + 1 < nslab) {
+            __syncthreads();                 // everyone is done reading the single operand buffer
+            lstore();
+            if (sl + 2 < nslab) gload(sl + 2);
+        }
+        __syncthreads();
+    }
+    pw_epilogue<NT, WM>(p, acc, lds, m0, n0);
+}
+
+// Plan-time weight image for k_pw_bx3: W [N][K] fp32 -> uint16 [K/32 slabs][3 planes][4 kq][Npad rows][8], Npad = N rounded up
+// to 16 (rows beyond N are zeros), the 8 values of a (row, kq) slot being k = 32 s + 4 kq + (0..3) and 32 s + 16 + 4 kq + (0..3).
+bool pw_bx3_ok(int K) { return K >= PW_BK && K % PW_BK == 0; }
+int pw_bx3_npad(int N) { return (N + 15) / 16 * 16; }
+std::vector<uint16_t> pw_bx3_image(const float* W, int N, int K) {
+    const int Npad = pw_bx3_npad(N), nslab = K / PW_BK;
+    std::vector<uint16_t> img((size_t)nslab * 12 * Npad * 8, 0);
+    for (int n = 0; n < N; n++)
+        for (int k = 0; k < K; k++) {
+            // round-to-nearest-even bf16 pieces with exact fp32 remainders (same decomposition as bx3_split8)
+            auto rne = [](float f) -> uint16_t {
+                unsigned u; memcpy(&u, &f, 4);
+                if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);      // NaN stays NaN
+                return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+            };
+            auto widen = [](uint16_t h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; };
+            const float x = W[(size_t)n * K + k];
+            uint16_t piece[3];
+            piece[0] = rne(x);
+            const float r = x - widen(piece[0]);
+            piece[1] = rne(r);
+            const float q = r - widen(piece[1]);
+            piece[2] = rne(q);
+            const int s = k / PW_BK, kk = k % PW_BK, half = kk / 16, kq = (kk % 16) / 4, j = half * 4 + (kk % 4);
+            for (int pl = 0; pl < 3; pl++)
+                img[((((size_t)s * 3 + pl) * 4 + kq) * Npad + n) * 8 + j] = piece[pl];
+        }
+    return img;
+}
+
+void launch_pw_bx3(const PwParams& p, const uint16_t* Wimg, hipStream_t s) {
+    int nt = (p.nt >= 1 && p.nt <= 8) ? p.nt : pick_nt(p.M, p.N);
+    int wm = p.wm == 5 ? 1 : 2;                            // PwParams::wm 5 / 6: 64- / 128-row tiles on the split-bf16 kernel
+    int bm = 64 * wm;
+    int nblk_n = (p.N + nt * 16 - 1) / (nt * 16);
+    unsigned nblk = (unsigned)((p.M + bm - 1) / bm) * nblk_n;
+    if (nblk < 64 && (nt > 1 || wm > 1)) {                 // a handful of clips: smallest tile, as in launch_pw_gemm
+        nt = 1; wm = 1; bm = 64;
+        nblk_n = (p.N + 15) / 16;
+        nblk = (unsigned)((p.M + bm - 1) / bm) * nblk_n;
+    }
+    const int Npad = pw_bx3_npad(p.N);
+    const FDiv dn = make_fdiv((unsigned)nblk_n), dhw = make_fdiv((unsigned)std::max(p.HW, 1));
+    const bool sc = p.ascale != nullptr;
+    dim3 grid(nblk);
+#define BX_LAUNCH(NT_, SC_, WM_) hipLaunchKernelGGL((k_pw_bx3<NT_, SC_, WM_>), grid, dim3(256), 0, s, p, Wimg, Npad, nblk_n, nblk, dn, dhw)
+#define BX_CASE(NT_) case NT_: if (sc) { if (wm == 1) BX_LAUNCH(NT_, true, 1); else BX_LAUNCH(NT_, true, 2); } \
+                     else { if (wm == 1) BX_LAUNCH(NT_, false, 1); else BX_LAUNCH(NT_, false, 2); } break;
+    switch (nt) { BX_CASE(1) BX_CASE(2) BX_CASE(3) BX_CASE(4) BX_CASE(5) BX_CASE(6) BX_CASE(7) default: BX_CASE(8) }
+#undef BX_LAUNCH
+#undef BX_CASE
 }
 
 // scalar fallback for K not a multiple of 4 (never hit by EfficientNet-style graphs; kept for drop-in safety)

@@ -1,0 +1,103 @@
+"""Split-bf16 MFMA path (VERDICT r1 "Next" #5): fp32 operands as three exact bf16 pieces, six products on
+v_mfma_f32_16x16x32_bf16, fp32 accumulation.  This is arithmetic that EMULATES fp32, so the gate is an error comparison
+against the float64 arbiter next to the plain-fp32 engine, not just the probability tolerance."""
+import numpy as np
+import pytest
+
+from birdnet_go_amd import host, synth_model as sm
+from oracle.interp import Interpreter
+
+
+def test_bf16x3_plans_weight_images(built_lib, full_blob):
+    a = host.HipClassifier(full_blob, plan_only=True)
+    b = host.HipClassifier(full_blob, plan_only=True, bf16x3=2)
+    da, db = a.describe(), b.describe()
+    pw = [s for s in db["steps"] if s["kernel"] == "pw_gemm"]
+    forced = [s for s in pw if s["wm_full"] == 6]
+    assert len(forced) >= 16 and all(s["C"] % 32 == 0 for s in forced)       # every layer with whole 32-wide K slabs
+    assert all(s["wm_full"] != 6 for s in pw if s["C"] % 32)                 # b1 (K=32 ok) ... K=16/24/40 layers stay fp32
+    assert db["weight_bytes"] > 2.0 * da["weight_bytes"]                     # + 1.5x image of every eligible layer
+    a.close(); b.close()
+
+
+def _bf16_rne(x):
+    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+
+
+def _split3(x):
+    """the kernel's decomposition, restated in numpy: x = hi + mid + lo, bf16 pieces by round-to-nearest-even"""
+    x = np.asarray(x, np.float32)
+    hi = _bf16_rne(x)
+    r = x - hi
+    mid = _bf16_rne(r)
+    lo = r - mid
+    return hi, mid, lo
+
+
+def test_three_way_split_is_exact_and_dropped_terms_are_below_one_ulp():
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(200000) * 10.0 ** rng.uniform(-30, 30, 200000)).astype(np.float32)
+    x[:3] = [0.0, -0.0, np.float32(1.0) + np.float32(2.0) ** -23]
+    hi, mid, lo = _split3(x)
+    assert np.array_equal((hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64)).astype(np.float32), x)
+    for piece in (hi, mid, lo):                                              # each piece IS a bf16: low 16 bits clear
+        assert not (piece.view(np.uint32) & 0xFFFF).any()
+    assert (np.abs(mid) <= 2.0 ** -8 * np.abs(x)).all() and (np.abs(lo) <= 2.0 ** -16 * np.abs(x)).all()
+    # the three dropped cross terms together stay below 2^-23 |x w| (an fp32 product's own rounding is <= 2^-24 |x w|)
+    w = rng.standard_normal(200000).astype(np.float32)
+    wh, wm, wl = _split3(w)
+    f = lambda v: v.astype(np.float64)
+    kept = f(hi) * f(wh) + f(hi) * f(wm) + f(mid) * f(wh) + f(hi) * f(wl) + f(lo) * f(wh) + f(mid) * f(wm)
+    exact = f(x) * f(w)
+    ok = (np.abs(exact) > 1e-30) & (np.abs(exact) < 1e30)
+    assert (np.abs(kept - exact)[ok] <= 2.0 ** -23 * np.abs(exact)[ok] * 1.01).all()
+
+
+@pytest.mark.gpu
+def test_bf16x3_gemm_error_vs_f64_next_to_fp32(gpu):
+    """Dense stack, K = 1024 / 1536, inputs spanning six decades: the split-bf16 engine's error against float64 must be of
+    the fp32 engine's order (both are dominated by fp32 accumulation), and far below a plain bf16 GEMM's (~4e-3)."""
+    dims = [1024, 1536, 640]
+    blob = sm.build_dense_model(dims, hidden_act="none", seed=3)
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((96, 1024)) * 10.0 ** rng.uniform(-3, 3, (96, 1))).astype(np.float32)
+    ref = Interpreter(blob, "f64").invoke(x)[0].astype(np.float64)
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    errs = {}
+    for mode in (0, 2):
+        clf = host.HipClassifier(blob, max_batch=128, bf16x3=mode)
+        kinds = [(s["kernel"], s["wm_full"]) for s in clf.describe()["steps"]]
+        assert all(k == "pw_gemm" for k, _ in kinds) and all((w >= 5) == (mode == 2) for _, w in kinds), kinds
+        got = clf.predict_batch(x.reshape(-1), 96).astype(np.float64)
+        clf.close()
+        errs[mode] = float((np.abs(got - ref) / scale).max())
+    print(f"max relative error vs f64: fp32 MFMA {errs[0]:.3e}, split-bf16 {errs[2]:.3e}")
+    assert errs[2] <= 3.0 * errs[0] + 1e-7 and errs[2] < 5e-6
+
+
+@pytest.mark.gpu
+def test_bf16x3_full_model_parity_and_error(gpu, full_blob):
+    from test_parity_gpu import assert_parity
+    x = sm.synth_clips(3, 144000, 48000)
+    ref32 = Interpreter(full_blob).invoke(x)[0]
+    ref64 = Interpreter(full_blob, "f64").invoke(x[:1])[0]
+    out = {}
+    for mode in (0, 2):
+        clf = host.HipClassifier(full_blob, max_batch=4, bf16x3=mode)
+        out[mode] = clf.predict_batch(x.reshape(-1), 3)
+        clf.close()
+        assert_parity(out[mode], ref32)
+    e0, e2 = np.abs(out[0][:1] - ref64).max(), np.abs(out[2][:1] - ref64).max()
+    print(f"max |logit - f64 arbiter|: fp32 engine {e0:.3e}, split-bf16 engine {e2:.3e}, oracle f32 {np.abs(ref32[:1] - ref64).max():.3e}")
+    assert e2 <= 3.0 * e0 + 2e-6
+    assert (out[2].argmax(1) == out[0].argmax(1)).all()
+    # batch through the autotuned choice (bf16x3 = 1) and SE-scaled + residual layers at batch size
+    xb = sm.synth_clips(40, 144000, 48000)
+    a = host.HipClassifier(full_blob, max_batch=40)
+    b = host.HipClassifier(full_blob, max_batch=40, bf16x3=1)
+    ya, yb = a.predict_batch(xb.reshape(-1), 40), b.predict_batch(xb.reshape(-1), 40)
+    picked = sum(1 for s in b.describe()["steps"] if s["kernel"] == "pw_gemm" and (s["wm"] >= 5 or s["wm_full"] >= 5))
+    print("layers the autotuner moved to the split-bf16 kernel:", picked)
+    a.close(); b.close()
+    assert np.abs(ya - yb).max() < 1e-4 and (ya.argmax(1) == yb.argmax(1)).all()
