@@ -32,6 +32,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bf16x3", type=int, default=None, help="split-bf16 MFMA path for the pointwise layers: 0 off, 1 where the "
+                    "autotuner measures it faster, 2 everywhere eligible (default: the library's)")
     ap.add_argument("--no-oracle-check", action="store_true", help="skip the max-abs probability diff vs the oracle (3 rows, outside the timed region)")
     ap.add_argument("--cpu-clips", type=int, default=0, help="clips in the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-profile", action="store_true", help="disable per-kernel HIP-event timing")
@@ -165,7 +167,7 @@ def main():
 
     B = args.batch
     depth = max(1, args.depth)
-    clf = host.HipClassifier(blob, device=local_rank, max_batch=B, depth=depth, lanes=1 if depth > 1 else None)
+    clf = host.HipClassifier(blob, device=local_rank, max_batch=B, depth=depth, lanes=1 if depth > 1 else None, bf16x3=args.bf16x3)
     lo, _ = shard.shard_range(B * world, rank, world)       # weak scaling: B clips per rank, distinct seeds
     x_host = sm.synth_clips(B, cfg.n_samples, cfg.sample_rate, first=lo)
     x = torch.from_numpy(x_host).to(dev)

@@ -1556,10 +1556,11 @@ void Engine::autotune_pw() {
                 // split-bf16 candidates (wm 5 / 6 = 64- / 128-row tiles): taken where measured faster than the best fp32 tile
                 // (bf16x3 = 2: always, by their own best time)
                 float bbest = 1e30f; int bnt = 0, bwm = 0;
-                for (int wm = 6; wm >= 5; wm--)
+                for (int wm = 8; wm >= 5; wm--)
                     for (int nt = 1; nt <= 8; nt++) {
                         long cols = (long)((s.Co + nt * 16 - 1) / (nt * 16)) * nt * 16;
                         if (cols * 100 > (long)((s.Co + 15) / 16 * 16) * 130) continue;
+                        if (wm >= 7 && !pw_bx3p_ok(nt, wm - 6, s.C)) continue;
                         PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, nt, wm};
                         launch_pw_bx3(p, s.wbx, stream);
                         hipEventRecord(a, stream);

@@ -89,6 +89,7 @@ int pw_default_nt(int M, int N);
 // pieces per operand, six products).  Needs whole 32-wide K slabs and the plan-time weight image; PwParams::wm 5 / 6 select
 // its 64- / 128-row tiles.
 bool pw_bx3_ok(int K);
+bool pw_bx3p_ok(int nt, int wm /*1 | 2*/, int K);     // PwParams::wm 7 / 8: software-pipelined form (k_pw_bx3p)
 int pw_bx3_npad(int N);
 std::vector<uint16_t> pw_bx3_image(const float* W, int N, int K);
 void launch_pw_bx3(const PwParams& p, const uint16_t* Wimg, hipStream_t s);

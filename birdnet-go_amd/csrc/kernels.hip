@@ -1058,6 +1058,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// exact fp32 subtraction kept scalar: under -O3 the compiler SLP-packs the two remainders of a pair into v_pk_add_f32, which
+// costs ~13 cycles beside MFMAs on this chip (MI355X_MICROARCH.md, "price of one filler") against ~4 for a plain v_sub_f32
+__device__ __forceinline__ float bx3_sub(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void bx3_split8(const f32x4& a, const f32x4& b, bf16x8* hi, bf16x8* mid, bf16x8* lo) {
     const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     u32x4 h, m, l;
@@ -1066,9 +1073,9 @@ __device__ __forceinline__ void bx3_split8(const f32x4& a, const f32x4& b, bf16x
         // v_cvt_pk_bf16_f32 (round to nearest even) per pair, remainders by exact fp32 subtraction
         const f32x2 v = {x[2 * q], x[2 * q + 1]};
         const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-        const f32x2 r = v - (f32x2){__uint_as_float(hb << 16), __uint_as_float(hb & 0xffff0000u)};
+        const f32x2 r = {bx3_sub(v[0], __uint_as_float(hb << 16)), bx3_sub(v[1], __uint_as_float(hb & 0xffff0000u))};
         const unsigned mb = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
-        const f32x2 t = r - (f32x2){__uint_as_float(mb << 16), __uint_as_float(mb & 0xffff0000u)};
+        const f32x2 t = {bx3_sub(r[0], __uint_as_float(mb << 16)), bx3_sub(r[1], __uint_as_float(mb & 0xffff0000u))};
         h[q] = hb; m[q] = mb; l[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
     }
     *hi = __builtin_bit_cast(bf16x8, h); *mid = __builtin_bit_cast(bf16x8, m); *lo = __builtin_bit_cast(bf16x8, l);
@@ -1156,11 +1163,20 @@ __global__ __launch_bounds__(256) void k_pw_bx3(PwParams p, const uint16_t* __re
             const f32x4 x0 = *reinterpret_cast<const f32x4*>(xr), x1 = *reinterpret_cast<const f32x4*>(xr + 16);
             bx3_split8(x0, x1, &ah[mt], &am[mt], &al[mt]);
         }
+        // weight fragments of tile t + 1 are requested before the MFMAs of tile t (the ISA of the first version waited a full
+        // LDS round trip in front of every tile: with ~2 waves per SIMD on the late layers nothing else covered it)
+        u32x4 wfr[2][3];
+#pragma unroll
+        for (int pl3 = 0; pl3 < 3; pl3++) wfr[0][pl3] = Wl[(pl3 * 4 + kq) * (NT * 16) + li];
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-            const bf16x8 wh = __builtin_bit_cast(bf16x8, Wl[(0 * 4 + kq) * (NT * 16) + 16 * t + li]);
-            const bf16x8 wm = __builtin_bit_cast(bf16x8, Wl[(1 * 4 + kq) * (NT * 16) + 16 * t + li]);
-            const bf16x8 wl = __builtin_bit_cast(bf16x8, Wl[(2 * 4 + kq) * (NT * 16) + 16 * t + li]);
+            if (t + 1 < NT) {
+#pragma unroll
+                for (int pl3 = 0; pl3 < 3; pl3++) wfr[(t + 1) & 1][pl3] = Wl[(pl3 * 4 + kq) * (NT * 16) + 16 * (t + 1) + li];
+            }
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, wfr[t & 1][0]);
+            const bf16x8 wm = __builtin_bit_cast(bf16x8, wfr[t & 1][1]);
+            const bf16x8 wl = __builtin_bit_cast(bf16x8, wfr[t & 1][2]);
 #pragma unroll
             for (int mt = 0; mt < WM; mt++) {
                 f32x4 c = acc[t][mt];                        // smallest terms first
@@ -1182,6 +1198,132 @@ __global__ __launch_bounds__(256) void k_pw_bx3(PwParams p, const uint16_t* __re
     }
     pw_epilogue<NT, WM>(p, acc, lds, m0, n0);
 }
+
+// Software-pipelined form (the k_pw_pipe structure): the late layers have M = 12 288 rows at batch 256, i.e. only ~2 blocks
+// per CU and 1-2 waves per SIMD, so nothing hides a wave's own global -> LDS refill; with the bf16 MFMA phase 2.5x shorter
+// than the fp32 one that refill dominated the slab period of k_pw_bx3.  Here it rides in the wave's MFMA shadow: two LDS
+// operand buffers (dynamic LDS: up to 80 KB), slab s+1 is stored while slab s computes, slab s+2 is in flight in registers,
+// one barrier per slab.
+template <int NT, bool SC, int WM>
+__global__ __launch_bounds__(256) void k_pw_bx3p(PwParams p, const uint16_t* __restrict__ Wimg, int Npad, int nblk_n, unsigned nblk,
+                                                  FDiv dn, FDiv dhw) {
+    constexpr int BM = 64 * WM;
+    constexpr int XQ = BM * PW_C4 / 256;
+    constexpr int WSLOTS = 12 * NT * 16;
+    constexpr int WQ = (WSLOTS + 255) / 256;
+    constexpr int TILE_F = BM * PW_LS + WSLOTS * 4;
+    extern __shared__ __attribute__((aligned(16))) float bx3p_lds[];  // 2 * TILE_F floats (>= the epilogue staging area)
+    float* lds = bx3p_lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const unsigned L = xcd_remap(blockIdx.x, nblk);
+    const int mblk = (int)fdiv(L, dn);
+    const int m0 = mblk * BM;
+    const int n0 = ((int)L - mblk * nblk_n) * (NT * 16);
+    const int K = p.K;
+
+    unsigned xoff[XQ], soff[SC ? XQ : 1], woff[WQ];
+    const int lbase = (tid / PW_C4) * PW_LS + 4 * (tid % PW_C4);
+    constexpr int LQ = (256 / PW_C4) * PW_LS;
+#pragma unroll
+    for (int q = 0; q < XQ; q++) {
+        const int idx = tid + 256 * q, row = idx / PW_C4, c4 = idx % PW_C4;
+        const int m = min(m0 + row, p.M - 1);
+        xoff[q] = (unsigned)m * (unsigned)K + 4 * c4;
+        if (SC) soff[SC ? q : 0] = fdiv((unsigned)m, dhw) * (unsigned)K + 4 * c4;
+    }
+#pragma unroll
+    for (int q = 0; q < WQ; q++) {
+        const int slot = min(tid + 256 * q, WSLOTS - 1);
+        const int plkq = slot / (NT * 16), r = slot - plkq * (NT * 16);
+        woff[q] = (unsigned)plkq * (unsigned)Npad + (unsigned)min(n0 + r, Npad - 1);
+    }
+    float4 xreg[XQ], sreg[SC ? XQ : 1];
+    u32x4 wreg[WQ];
+    const u32x4* W16 = reinterpret_cast<const u32x4*>(Wimg);
+    auto gload = [&](int sl) {
+        const float* Ak = p.A + sl * PW_BK;
+#pragma unroll
+        for (int q = 0; q < XQ; q++) {
+            xreg[q] = *reinterpret_cast<const float4*>(Ak + xoff[q]);
+            if (SC) sreg[SC ? q : 0] = *reinterpret_cast<const float4*>(p.ascale + sl * PW_BK + soff[SC ? q : 0]);
+        }
+        const u32x4* Ws = W16 + (size_t)sl * 12 * Npad;
+#pragma unroll
+        for (int q = 0; q < WQ; q++) wreg[q] = Ws[woff[q]];
+    };
+    auto lstore = [&](float* buf) {
+#pragma unroll
+        for (int q = 0; q < XQ; q++) {
+            float4 v = xreg[q];
+            if (SC) { const float4 sc = sreg[SC ? q : 0]; v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+            *reinterpret_cast<float4*>(&buf[lbase + q * LQ]) = v;
+        }
+        u32x4* Wl = reinterpret_cast<u32x4*>(buf + BM * PW_LS);
+#pragma unroll
+        for (int q = 0; q < WQ; q++)
+            if (WSLOTS % 256 == 0 || tid + 256 * q < WSLOTS) Wl[tid + 256 * q] = wreg[q];
+    };
+
+    f32x4 acc[NT][WM];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int mt = 0; mt < WM; mt++) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nslab = K / PW_BK;
+    gload(0);
+    lstore(lds);
+    if (nslab > 1) gload(1);
+    __syncthreads();
+    auto slab = [&](int sl, auto DS, auto DL) {
+        const float* Xs = lds + (sl & 1) * TILE_F;
+        const u32x4* Wl = reinterpret_cast<const u32x4*>(Xs + BM * PW_LS);
+        float* nxt = lds + ((sl + 1) & 1) * TILE_F;
+        bf16x8 ah[WM], am[WM], al[WM];
+#pragma unroll
+        for (int mt = 0; mt < WM; mt++) {
+            const float* xr = &Xs[(16 * WM * wave + 16 * mt + li) * PW_LS + 4 * kq];
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xr), x1 = *reinterpret_cast<const f32x4*>(xr + 16);
+            bx3_split8(x0, x1, &ah[mt], &am[mt], &al[mt]);
+        }
+        u32x4 wfr[2][3];
+#pragma unroll
+        for (int pl3 = 0; pl3 < 3; pl3++) wfr[0][pl3] = Wl[(pl3 * 4 + kq) * (NT * 16) + li];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            if (t + 1 < NT) {
+#pragma unroll
+                for (int pl3 = 0; pl3 < 3; pl3++) wfr[(t + 1) & 1][pl3] = Wl[(pl3 * 4 + kq) * (NT * 16) + 16 * (t + 1) + li];
+            }
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, wfr[t & 1][0]);
+            const bf16x8 wm = __builtin_bit_cast(bf16x8, wfr[t & 1][1]);
+            const bf16x8 wl = __builtin_bit_cast(bf16x8, wfr[t & 1][2]);
+            if (t == 0 && decltype(DS)::value) lstore(nxt);
+            if (t == NT - 1 && decltype(DL)::value) gload(sl + 2);
+#pragma unroll
+            for (int mt = 0; mt < WM; mt++) {
+                f32x4 c = acc[t][mt];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[mt], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[mt], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, am[mt], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, ah[mt], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, am[mt], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[mt], c, 0, 0, 0);
+                acc[t][mt] = c;
+            }
+        }
+        __syncthreads();
+    };
+    int sl = 0;
+    for (; sl + 2 < nslab; sl++) slab(sl, std::true_type{}, std::true_type{});
+    if (nslab >= 2) { slab(sl, std::true_type{}, std::false_type{}); sl++; }
+    slab(sl, std::false_type{}, std::false_type{});
+
+    pw_epilogue<NT, WM>(p, acc, lds, m0, n0);
+}
+static size_t bx3p_lds_bytes(int nt, int wm) { return 2 * ((size_t)64 * wm * PW_LS + (size_t)12 * nt * 16 * 4) * sizeof(float); }
+bool pw_bx3p_ok(int nt, int wm, int K) { return K % PW_BK == 0 && K >= 2 * PW_BK && bx3p_lds_bytes(nt, wm) <= 80 * 1024; }
 
 // Plan-time weight image for k_pw_bx3: W [N][K] fp32 -> uint16 [K/32 slabs][3 planes][4 kq][Npad rows][8], Npad = N rounded up
 // to 16 (rows beyond N are zeros), the 8 values of a (row, kq) slot being k = 32 s + 4 kq + (0..3) and 32 s + 16 + 4 kq + (0..3).
@@ -1215,12 +1357,13 @@ std::vector<uint16_t> pw_bx3_image(const float* W, int N, int K) {
 
 void launch_pw_bx3(const PwParams& p, const uint16_t* Wimg, hipStream_t s) {
     int nt = (p.nt >= 1 && p.nt <= 8) ? p.nt : pick_nt(p.M, p.N);
-    int wm = p.wm == 5 ? 1 : 2;                            // PwParams::wm 5 / 6: 64- / 128-row tiles on the split-bf16 kernel
+    int wm = (p.wm == 5 || p.wm == 7) ? 1 : 2;             // PwParams::wm 5 / 6: 64- / 128-row tiles on the split-bf16 kernel, 7 / 8: pipelined
+    bool pipe = (p.wm == 7 || p.wm == 8) && pw_bx3p_ok(nt, wm, p.K);
     int bm = 64 * wm;
     int nblk_n = (p.N + nt * 16 - 1) / (nt * 16);
     unsigned nblk = (unsigned)((p.M + bm - 1) / bm) * nblk_n;
     if (nblk < 64 && (nt > 1 || wm > 1)) {                 // a handful of clips: smallest tile, as in launch_pw_gemm
-        nt = 1; wm = 1; bm = 64;
+        nt = 1; wm = 1; bm = 64; pipe = false;
         nblk_n = (p.N + 15) / 16;
         nblk = (unsigned)((p.M + bm - 1) / bm) * nblk_n;
     }
@@ -1231,6 +1374,17 @@ void launch_pw_bx3(const PwParams& p, const uint16_t* Wimg, hipStream_t s) {
 #define BX_LAUNCH(NT_, SC_, WM_) hipLaunchKernelGGL((k_pw_bx3<NT_, SC_, WM_>), grid, dim3(256), 0, s, p, Wimg, Npad, nblk_n, nblk, dn, dhw)
 #define BX_CASE(NT_) case NT_: if (sc) { if (wm == 1) BX_LAUNCH(NT_, true, 1); else BX_LAUNCH(NT_, true, 2); } \
                      else { if (wm == 1) BX_LAUNCH(NT_, false, 1); else BX_LAUNCH(NT_, false, 2); } break;
+    if (pipe) {
+        const size_t ldsb = bx3p_lds_bytes(nt, wm);
+#define BP_LAUNCH(NT_, SC_, WM_) do { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_bx3p<NT_, SC_, WM_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+        hipLaunchKernelGGL((k_pw_bx3p<NT_, SC_, WM_>), grid, dim3(256), ldsb, s, p, Wimg, Npad, nblk_n, nblk, dn, dhw); } while (0)
+#define BP_CASE(NT_) case NT_: if (sc) { if (wm == 1) BP_LAUNCH(NT_, true, 1); else BP_LAUNCH(NT_, true, 2); } \
+                     else { if (wm == 1) BP_LAUNCH(NT_, false, 1); else BP_LAUNCH(NT_, false, 2); } break;
+        switch (nt) { BP_CASE(1) BP_CASE(2) BP_CASE(3) BP_CASE(4) BP_CASE(5) BP_CASE(6) BP_CASE(7) default: BP_CASE(8) }
+#undef BP_LAUNCH
+#undef BP_CASE
+        return;
+    }
     switch (nt) { BX_CASE(1) BX_CASE(2) BX_CASE(3) BX_CASE(4) BX_CASE(5) BX_CASE(6) BX_CASE(7) default: BX_CASE(8) }
 #undef BX_LAUNCH
 #undef BX_CASE
