@@ -578,7 +578,9 @@ int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, 
         e->depth = (int)json_int(opts_json, "depth", denv ? atoi(denv) : 1);
         e->frontend_fft = (int)json_int(opts_json, "frontend_fft", fenv ? atoi(fenv) : -1);
         e->use_graphs = json_int(opts_json, "graphs", genv ? atoi(genv) : 0) != 0;
-        e->bf16x3 = (int)json_int(opts_json, "bf16x3", benv ? atoi(benv) : 0);
+        // default 1: per layer where the create-time autotuner measures the split-bf16 kernel faster (fp32-equivalent
+        // products; tests/test_bf16x3.py holds the error comparison against the float64 arbiter that decided the default)
+        e->bf16x3 = (int)json_int(opts_json, "bf16x3", benv ? atoi(benv) : 1);
         e->defer_weights = i > 0 && !plan_only;
         int code = BNHIP_E_UNSUPPORTED;
         TflModel copy = tm;                               // tensors point into the caller's blob / tm-owned storage: cheap
@@ -774,7 +776,7 @@ int bnhip_us_frame_cv(int device, const double* samples, int n_clips, int n, int
     if (he == hipSuccess) he = hipMalloc((void**)&d_cv, (size_t)n_clips * 8);
     if (he == hipSuccess) he = hipMemcpy(d_s, samples, (size_t)n_clips * n * 8, hipMemcpyHostToDevice);
     if (he == hipSuccess) {
-        launch_us_frame_power(d_s, n_clips, n, fft_size, hop, frames, split_bin, d_p, nullptr);
+        launch_us_frame_power(d_s, 0, n_clips, n, fft_size, hop, frames, split_bin, d_p, nullptr);
         launch_us_cv(d_p, n_clips, frames, d_cv, nullptr);
         he = hipMemcpy(cv, d_cv, (size_t)n_clips * 8, hipMemcpyDeviceToHost);
     }
@@ -784,6 +786,31 @@ int bnhip_us_frame_cv(int device, const double* samples, int n_clips, int n, int
     if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("us_frame_cv: ") + hipGetErrorString(he));
     for (int i = 0; i < n_clips; i++) ok[i] = 1;
     return BNHIP_OK;
+    BN_GUARD_END((void)0)
+}
+
+// Device-resident form: samples (float64, or raw int16 PCM) and results stay in HBM, work is enqueued on `hip_stream`
+// (NULL = the default stream) and not synchronised.  d_scratch holds n_clips * frames float64 frame powers.
+int bnhip_us_frame_cv_device(int device, const void* d_samples, int pcm16, int n_clips, int n, int sample_rate, int fft_size, int hop,
+                             int split_hz, double* d_scratch, double* d_cv, void* hip_stream) {
+    if (!d_samples || !d_cv || !d_scratch || n_clips <= 0) return set_err(BNHIP_E_INVALID, "NULL/empty argument");
+    BN_GUARD_BEGIN
+    bool valid = !(n < fft_size || sample_rate <= 0 || fft_size < 2 || hop <= 0) && (fft_size & (fft_size - 1)) == 0 &&
+                 !(split_hz < 0 || split_hz >= sample_rate / 2);
+    int frames = valid ? 1 + (n - fft_size) / hop : 0;
+    if (!valid || frames < 2) return set_err(BNHIP_E_INVALID, "geometry rejected by the filter's guards (filter.go:21-37): use the host entry for the (0, false) answer");
+    if ((size_t)fft_size * 16 > 160 * 1024 - 256) return set_err(BNHIP_E_UNSUPPORTED, "FFT size exceeds the LDS-resident limit (8192)");
+    int rc = bnhip_init(nullptr);
+    if (rc) return rc;
+    if (device < 0 || device >= g_devices) return set_err(BNHIP_E_INVALID, "device ordinal out of range");
+    hipSetDevice(device);
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    const int split_bin = (int)((double)split_hz / ((double)sample_rate / (double)fft_size));
+    launch_us_frame_power(d_samples, pcm16 != 0, n_clips, n, fft_size, hop, frames, split_bin, d_scratch, st);
+    launch_us_cv(d_scratch, n_clips, frames, d_cv, st);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("us_frame_cv_device: ") + hipGetErrorString(he));
+    return frames;
     BN_GUARD_END((void)0)
 }
 

@@ -179,8 +179,8 @@ void launch_topk(const float* conf, int n_clips, int n_classes, int k, float* ou
                  hipStream_t s);
 
 // ---- ultrasonic frame-CV (float64)
-void launch_us_frame_power(const double* samples, int n_clips, int n, int fft_size, int hop, int frames,
-                           int split_bin, double* powers /*[n_clips, frames]*/, hipStream_t s);
+void launch_us_frame_power(const void* samples /* float64, or int16 PCM when pcm16 */, int pcm16, int n_clips, int n, int fft_size,
+                           int hop, int frames, int split_bin, double* powers /*[n_clips, frames]*/, hipStream_t s);
 void launch_us_cv(const double* powers, int n_clips, int frames, double* cv, hipStream_t s);
 
 }  // namespace bnhip

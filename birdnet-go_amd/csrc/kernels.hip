@@ -2381,19 +2381,22 @@ void launch_topk(const float* conf, int n_clips, int n_classes, int k, float* ou
 // complex128 FFT lives entirely in LDS (128 KiB of the CU's 160 KiB): bit-reversed load with the symmetric
 // Hann window applied, radix-2 DIT stages with directly evaluated twiddles (the Go code's w *= wn recurrence
 // only adds rounding noise), then the one-sided power sum above the split bin.
-__global__ __launch_bounds__(1024) void k_us_frame_power(const double* __restrict__ samples, int n, int fft, int hop,
+// T = double (the reference's float64 samples) or int16_t (raw PCM: int16 / 32768 as float64, convert/pcm.go:108-113)
+template <typename T>
+__global__ __launch_bounds__(1024) void k_us_frame_power(const T* __restrict__ samples, int n, int fft, int hop,
                                                          int frames, int split_bin, int log2n,
                                                          double* __restrict__ powers) {
     extern __shared__ __attribute__((aligned(16))) double lds[];   // re[fft], im[fft]
     double* re = lds; double* im = lds + fft;
     __shared__ double red[16];
     const int frame = blockIdx.x, clip = blockIdx.y;
-    const double* x = samples + (size_t)clip * n + (size_t)frame * hop;
+    const T* x = samples + (size_t)clip * n + (size_t)frame * hop;
     const double tw = 6.283185307179586476925286766559 / (double)(fft - 1);
     for (int i = threadIdx.x; i < fft; i += blockDim.x) {
         double w = 0.5 * (1.0 - cos(tw * (double)i));        // filter.go:139-145
         unsigned j = __brev((unsigned)i) >> (32 - log2n);
-        re[j] = x[i] * w; im[j] = 0.0;
+        const double xv = std::is_same<T, int16_t>::value ? (double)x[i] / 32768.0 : (double)x[i];
+        re[j] = xv * w; im[j] = 0.0;
     }
     __syncthreads();
     for (int size = 2; size <= fft; size <<= 1) {
@@ -2425,15 +2428,20 @@ __global__ __launch_bounds__(1024) void k_us_frame_power(const double* __restric
         powers[(size_t)clip * frames + frame] = sum;
     }
 }
-void launch_us_frame_power(const double* samples, int n_clips, int n, int fft_size, int hop, int frames, int split_bin,
+void launch_us_frame_power(const void* samples, int pcm16, int n_clips, int n, int fft_size, int hop, int frames, int split_bin,
                            double* powers, hipStream_t s) {
     int log2n = 0; while ((1 << log2n) < fft_size) log2n++;
     size_t lds = (size_t)fft_size * 2 * sizeof(double);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_us_frame_power), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024 - 256);
     int threads = fft_size / 2 < 1024 ? (fft_size / 2 < 64 ? 64 : fft_size / 2) : 1024;
-    hipLaunchKernelGGL(k_us_frame_power, dim3(frames, n_clips), dim3(threads), lds, s, samples, n, fft_size, hop,
-                       frames, split_bin, log2n, powers);
+    if (pcm16) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_us_frame_power<int16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        hipLaunchKernelGGL(k_us_frame_power<int16_t>, dim3(frames, n_clips), dim3(threads), lds, s, static_cast<const int16_t*>(samples), n,
+                           fft_size, hop, frames, split_bin, log2n, powers);
+    } else {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_us_frame_power<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        hipLaunchKernelGGL(k_us_frame_power<double>, dim3(frames, n_clips), dim3(threads), lds, s, static_cast<const double*>(samples), n,
+                           fft_size, hop, frames, split_bin, log2n, powers);
+    }
 }
 // filter.go:76-97, sequential like the Go loop
 __global__ void k_us_cv(const double* __restrict__ powers, int frames, double* __restrict__ cv) {

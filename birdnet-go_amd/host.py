@@ -31,7 +31,7 @@ SYMBOLS = ["bnhip_init", "bnhip_shutdown", "bnhip_model_create", "bnhip_model_in
            "bnhip_resample_f32", "bnhip_resample_pcm16", "bnhip_model_devices", "bnhip_last_error_copy",
            "bnhip_resampler_create", "bnhip_resampler_estimate", "bnhip_resampler_process_pcm16",
            "bnhip_resampler_process_f32", "bnhip_resampler_flush_pcm16", "bnhip_resampler_flush_f32",
-           "bnhip_resampler_destroy"]
+           "bnhip_resampler_destroy", "bnhip_us_frame_cv_device"]
 
 
 class HipError(RuntimeError):

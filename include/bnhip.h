@@ -56,7 +56,7 @@ void bnhip_shutdown(void);
  * container is sniffed: "TFL3" at byte 4 = TFLite flatbuffer, otherwise ONNX ModelProto.  The blob is consumed during the
  * call and may be freed afterwards (classifier.go:37).
  * opts_json (nullable): {"device":0,"devices":[0,1,..],"replicate":"auto","max_batch":256,"plan_only":0,"debug_no_reuse":0,
- *                        "autotune":1,"graphs":0,"lanes":2,"frontend_fft":-1,"depth":1,"bf16x3":0}
+ *                        "autotune":1,"graphs":0,"lanes":2,"frontend_fft":-1,"depth":1,"bf16x3":1}
  * "devices": one handle over several GPUs: one engine per listed device, the clips of every host-
  *          pointer call are sharded index-contiguously over them and run concurrently (one worker thread per device, own
  *          streams and pinned-order staging per device).  The frozen weights are uploaded to the first device only and
@@ -69,8 +69,10 @@ void bnhip_shutdown(void);
  * "depth": > 1 lets successive bnhip_predict_device calls overlap on alternating contexts (own stream and activation
  *          arena each); their outputs are complete after bnhip_synchronize, not merely in the caller's stream order.
  * "frontend_fft": 0 selects the folded-GEMM mel front-end for real-part graphs instead of the FFT path.
- * "bf16x3": 1 runs the MFMA-bound pointwise layers on the split-bf16 path (three bf16 terms per fp32 operand, six
- *          v_mfma_f32_32x32x16_bf16 products, fp32 accumulation: fp32-equivalent products).  */
+ * "bf16x3": pointwise / dense layers on the split-bf16 MFMA path (three exact bf16 pieces per fp32 operand, six
+ *          v_mfma_f32_16x16x32_bf16 products per k, fp32 accumulation: every product is reproduced to within 2^-23, see
+ *          DESIGN.md): 1 (default) = per layer where the create-time autotuner measures it faster, 0 = f32 MFMA only,
+ *          2 = every eligible layer (K a multiple of 32).  */
 int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, bnhip_model** out);
 
 /* n_samples: exact input length per clip (tflite/classifier.go:100-104); n_classes: size of the logits
@@ -117,6 +119,14 @@ int bnhip_predict_topk(bnhip_model* m, const float* samples, int n_clips, int ac
  * cv/ok: [n_clips]. device: HIP device ordinal. */
 int bnhip_us_frame_cv(int device, const double* samples, int n_clips, int n, int sample_rate, int fft_size,
                       int hop, int split_hz, double* cv, int32_t* ok);
+
+/* Device-resident form of the same filter for batched pipelines (BASELINE config 4: 256 kHz bat material): d_samples is
+ * float64 [n_clips * n] or, with pcm16 != 0, raw int16 PCM converted in the kernel as int16 / 32768 in float64
+ * (convert/pcm.go:108-113); d_scratch is float64 [n_clips * frames] (frames = 1 + (n - fft_size) / hop), d_cv float64
+ * [n_clips].  Enqueued on hip_stream (NULL = default stream), not synchronised.  Returns the frame count (> 0) or a
+ * negative error; geometries the filter's guards reject (filter.go:21-37) are BNHIP_E_INVALID here. */
+int bnhip_us_frame_cv_device(int device, const void* d_samples, int pcm16, int n_clips, int n, int sample_rate, int fft_size,
+                             int hop, int split_hz, double* d_scratch, double* d_cv, void* hip_stream);
 
 /* Polyphase resampler for the step upstream of the classifier (Resampler.ResampleTo, internal/audiocore/resample/
  * resample.go:99-172).  Stateless per clip; n_out = ceil(n_in * rate_out / rate_in) (bnhip_resample_length); equal rates

@@ -9,7 +9,7 @@ from oracle.interp import Interpreter
 
 
 def test_bf16x3_plans_weight_images(built_lib, full_blob):
-    a = host.HipClassifier(full_blob, plan_only=True)
+    a = host.HipClassifier(full_blob, plan_only=True, bf16x3=0)
     b = host.HipClassifier(full_blob, plan_only=True, bf16x3=2)
     da, db = a.describe(), b.describe()
     pw = [s for s in db["steps"] if s["kernel"] == "pw_gemm"]
@@ -94,7 +94,7 @@ def test_bf16x3_full_model_parity_and_error(gpu, full_blob):
     assert (out[2].argmax(1) == out[0].argmax(1)).all()
     # batch through the autotuned choice (bf16x3 = 1) and SE-scaled + residual layers at batch size
     xb = sm.synth_clips(40, 144000, 48000)
-    a = host.HipClassifier(full_blob, max_batch=40)
+    a = host.HipClassifier(full_blob, max_batch=40, bf16x3=0)
     b = host.HipClassifier(full_blob, max_batch=40, bf16x3=1)
     ya, yb = a.predict_batch(xb.reshape(-1), 40), b.predict_batch(xb.reshape(-1), 40)
     picked = sum(1 for s in b.describe()["steps"] if s["kernel"] == "pw_gemm" and (s["wm"] >= 5 or s["wm_full"] >= 5))
