@@ -166,6 +166,20 @@ int launch_resample(const void* d_in, void* d_out, const float* d_table, int in_
 
 namespace {
 
+// twiddle tables of the ultrasonic FFT, one per (device, fft size), uploaded on first use and kept for the process
+std::mutex g_tw_mu;
+std::vector<std::pair<std::pair<int, int>, double*>> g_tw;
+const double* us_twiddles(int device, int fft_size) {
+    std::lock_guard<std::mutex> lk(g_tw_mu);
+    for (auto& e : g_tw) if (e.first.first == device && e.first.second == fft_size) return e.second;
+    std::vector<double> t = us_twiddle_table(fft_size);
+    double* d = nullptr;
+    if (hipMalloc((void**)&d, t.size() * 8) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, t.data(), t.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return nullptr; }
+    g_tw.push_back({{device, fft_size}, d});
+    return d;
+}
+
 // ---------------------------------------------------------------------------------------------- RCCL (optional, dlopen'd)
 // Weights of a multi-device handle are uploaded to the first device only and replicated device-to-device: RCCL
 // ncclBroadcast over xGMI when librccl is loadable and the devices are distinct, hipMemcpyPeer otherwise.  The library is
@@ -776,7 +790,9 @@ int bnhip_us_frame_cv(int device, const double* samples, int n_clips, int n, int
     if (he == hipSuccess) he = hipMalloc((void**)&d_cv, (size_t)n_clips * 8);
     if (he == hipSuccess) he = hipMemcpy(d_s, samples, (size_t)n_clips * n * 8, hipMemcpyHostToDevice);
     if (he == hipSuccess) {
-        launch_us_frame_power(d_s, 0, n_clips, n, fft_size, hop, frames, split_bin, d_p, nullptr);
+        const double* d_tw = us_twiddles(device, fft_size);
+        if (!d_tw) he = hipErrorOutOfMemory;
+        else launch_us_frame_power(d_s, 0, n_clips, n, fft_size, hop, frames, split_bin, d_tw, d_p, nullptr);
         launch_us_cv(d_p, n_clips, frames, d_cv, nullptr);
         he = hipMemcpy(cv, d_cv, (size_t)n_clips * 8, hipMemcpyDeviceToHost);
     }
@@ -806,7 +822,9 @@ int bnhip_us_frame_cv_device(int device, const void* d_samples, int pcm16, int n
     hipSetDevice(device);
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
     const int split_bin = (int)((double)split_hz / ((double)sample_rate / (double)fft_size));
-    launch_us_frame_power(d_samples, pcm16 != 0, n_clips, n, fft_size, hop, frames, split_bin, d_scratch, st);
+    const double* d_tw = us_twiddles(device, fft_size);
+    if (!d_tw) return set_err(BNHIP_E_NOMEM, "device allocation failed (FFT twiddle table)");
+    launch_us_frame_power(d_samples, pcm16 != 0, n_clips, n, fft_size, hop, frames, split_bin, d_tw, d_scratch, st);
     launch_us_cv(d_scratch, n_clips, frames, d_cv, st);
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("us_frame_cv_device: ") + hipGetErrorString(he));

@@ -179,8 +179,9 @@ void launch_topk(const float* conf, int n_clips, int n_classes, int k, float* ou
                  hipStream_t s);
 
 // ---- ultrasonic frame-CV (float64)
+std::vector<double> us_twiddle_table(int fft_size);      // fft/2 (cos, -sin)(2 pi j / fft) pairs + the symmetric Hann window [fft]; uploaded once per (device, size)
 void launch_us_frame_power(const void* samples /* float64, or int16 PCM when pcm16 */, int pcm16, int n_clips, int n, int fft_size,
-                           int hop, int frames, int split_bin, double* powers /*[n_clips, frames]*/, hipStream_t s);
+                           int hop, int frames, int split_bin, const double* d_tw, double* powers /*[n_clips, frames]*/, hipStream_t s);
 void launch_us_cv(const double* powers, int n_clips, int frames, double* cv, hipStream_t s);
 
 }  // namespace bnhip

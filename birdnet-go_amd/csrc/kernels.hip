@@ -2385,27 +2385,31 @@ void launch_topk(const float* conf, int n_clips, int n_classes, int k, float* ou
 template <typename T>
 __global__ __launch_bounds__(1024) void k_us_frame_power(const T* __restrict__ samples, int n, int fft, int hop,
                                                          int frames, int split_bin, int log2n,
+                                                         const double2* __restrict__ tw /* [fft/2] (cos, -sin)(2 pi j / fft), then the Hann window [fft] */,
                                                          double* __restrict__ powers) {
     extern __shared__ __attribute__((aligned(16))) double lds[];   // re[fft], im[fft]
     double* re = lds; double* im = lds + fft;
     __shared__ double red[16];
     const int frame = blockIdx.x, clip = blockIdx.y;
     const T* x = samples + (size_t)clip * n + (size_t)frame * hop;
-    const double tw = 6.283185307179586476925286766559 / (double)(fft - 1);
+    const double* __restrict__ hann = reinterpret_cast<const double*>(tw + fft / 2);    // symmetric Hann window, filter.go:139-145
     for (int i = threadIdx.x; i < fft; i += blockDim.x) {
-        double w = 0.5 * (1.0 - cos(tw * (double)i));        // filter.go:139-145
+        double w = hann[i];
         unsigned j = __brev((unsigned)i) >> (32 - log2n);
         const double xv = std::is_same<T, int16_t>::value ? (double)x[i] / 32768.0 : (double)x[i];
         re[j] = xv * w; im[j] = 0.0;
     }
     __syncthreads();
-    for (int size = 2; size <= fft; size <<= 1) {
+    // twiddles from a plan-time table (L1 / L2 resident, 64 KiB for 8192 points): evaluating sincos in float64 per butterfly
+    // was ~5x the butterfly arithmetic itself (2.0 ms for 256 x 34 frames; the Go code's w *= wn recurrence only adds noise)
+    int shift = log2n - 1;
+    for (int size = 2; size <= fft; size <<= 1, shift--) {
         int half = size >> 1;
-        double ang = -6.283185307179586476925286766559 / (double)size;
         for (int t = threadIdx.x; t < fft / 2; t += blockDim.x) {
             int k = t & (half - 1);
             int i0 = ((t - k) << 1) + k, i1 = i0 + half;
-            double s, c; sincos(ang * (double)k, &s, &c);
+            const double2 w = tw[k << shift];
+            const double c = w.x, s = w.y;
             double vr = c * re[i1] - s * im[i1], vi = c * im[i1] + s * re[i1];
             double ur = re[i0], ui = im[i0];
             re[i0] = ur + vr; im[i0] = ui + vi; re[i1] = ur - vr; im[i1] = ui - vi;
@@ -2428,19 +2432,30 @@ __global__ __launch_bounds__(1024) void k_us_frame_power(const T* __restrict__ s
         powers[(size_t)clip * frames + frame] = sum;
     }
 }
+std::vector<double> us_twiddle_table(int fft_size) {
+    std::vector<double> t((size_t)2 * fft_size);             // fft/2 (cos, -sin) pairs, then the fft window coefficients
+    for (int j = 0; j < fft_size / 2; j++) {
+        const double a = 6.283185307179586476925286766559 * (double)j / (double)fft_size;
+        t[2 * j] = std::cos(a); t[2 * j + 1] = -std::sin(a);
+    }
+    const double hw = 6.283185307179586476925286766559 / (double)(fft_size - 1);
+    for (int i = 0; i < fft_size; i++) t[(size_t)fft_size + i] = 0.5 * (1.0 - std::cos(hw * (double)i));   // filter.go:139-145
+    return t;
+}
 void launch_us_frame_power(const void* samples, int pcm16, int n_clips, int n, int fft_size, int hop, int frames, int split_bin,
-                           double* powers, hipStream_t s) {
+                           const double* d_tw, double* powers, hipStream_t s) {
+    const double2* tw = reinterpret_cast<const double2*>(d_tw);
     int log2n = 0; while ((1 << log2n) < fft_size) log2n++;
     size_t lds = (size_t)fft_size * 2 * sizeof(double);
     int threads = fft_size / 2 < 1024 ? (fft_size / 2 < 64 ? 64 : fft_size / 2) : 1024;
     if (pcm16) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_us_frame_power<int16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         hipLaunchKernelGGL(k_us_frame_power<int16_t>, dim3(frames, n_clips), dim3(threads), lds, s, static_cast<const int16_t*>(samples), n,
-                           fft_size, hop, frames, split_bin, log2n, powers);
+                           fft_size, hop, frames, split_bin, log2n, tw, powers);
     } else {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_us_frame_power<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         hipLaunchKernelGGL(k_us_frame_power<double>, dim3(frames, n_clips), dim3(threads), lds, s, static_cast<const double*>(samples), n,
-                           fft_size, hop, frames, split_bin, log2n, powers);
+                           fft_size, hop, frames, split_bin, log2n, tw, powers);
     }
 }
 // filter.go:76-97, sequential like the Go loop
