@@ -1778,6 +1778,7 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
                 break;
             case S_SE: {
                 SeParams p{in0, s.S, s.H * s.W, s.w0, s.w1, s.w2, s.w3, out, n, s.C, s.Cr, s.act, s.act2};
+                if (cur_stream) p.threads = 256;      // pipelined call: 4-wave workgroups slot in beside the other context's kernels
                 launch_se(p, stream);
                 break;
             }

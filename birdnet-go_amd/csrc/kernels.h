@@ -133,6 +133,7 @@ struct SeParams {         // squeeze-excite FCs on pooled sums
     const float* w2; const float* b2;            // w2 TRANSPOSED to [Cr, C] at plan time; [C]
     float* scale;                                // [B, C]
     int B, C, Cr, act1, act2;
+    int threads = 0;                             // workgroup size (0 = 1024); see launch_se
 };
 void launch_se(const SeParams& p, hipStream_t s);
 

@@ -2167,11 +2167,12 @@ __global__ __launch_bounds__(1024) void k_se(SeParams p) {
     float* mean = sm;            // [C]
     float* r = sm + p.C;         // [Cr]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NTHR = blockDim.x, NW = NTHR >> 6;      // block size is a launch parameter (see launch_se)
     const float inv = 1.0f / (float)p.HW;
     // the per-slab sums: P threads per channel walk interleaved slab subsets (a 96-slab layer with 96 channels used to
     // be 96 threads x 96 serial loads), then fold through LDS in a fixed order
     int P = 1;
-    while (P * 2 * p.C <= 1024 && P * 2 <= p.S) P *= 2;
+    while (P * 2 * p.C <= NTHR && P * 2 <= p.S) P *= 2;
     float* part = sm + ((p.C + p.Cr + 3) & ~3);      // [P][C] / float4 [G][C/4] scratch, 16-byte aligned
     if (P > 1) {
         const int c = tid % p.C, q = tid / p.C;
@@ -2182,13 +2183,13 @@ __global__ __launch_bounds__(1024) void k_se(SeParams p) {
             part[q * p.C + c] = sum;
         }
         __syncthreads();
-        for (int c2 = tid; c2 < p.C; c2 += 1024) {
+        for (int c2 = tid; c2 < p.C; c2 += NTHR) {
             float sum = 0.f;
             for (int q2 = 0; q2 < P; q2++) sum += part[q2 * p.C + c2];
             mean[c2] = sum * inv;
         }
     } else {
-        for (int c = tid; c < p.C; c += 1024) {
+        for (int c = tid; c < p.C; c += NTHR) {
             float sum = 0.f;
 #pragma unroll 4
             for (int sidx = 0; sidx < p.S; sidx++) sum += p.partial[((size_t)b * p.S + sidx) * p.C + c];
@@ -2198,7 +2199,7 @@ __global__ __launch_bounds__(1024) void k_se(SeParams p) {
     __syncthreads();
     const bool v4 = (p.C & 3) == 0;
     // FC1: one wave per output, 16-byte loads (the scalar form was ~54 dependent 4-byte loads per thread per FC)
-    for (int j = wave; j < p.Cr; j += 16) {
+    for (int j = wave; j < p.Cr; j += NW) {
         float acc = 0.f;
         const float* wr = p.w1 + (size_t)j * p.C;
         if (v4) {
@@ -2221,8 +2222,9 @@ __global__ __launch_bounds__(1024) void k_se(SeParams p) {
     if (v4) {
         const int C4 = p.C / 4;
         int G = 1;
-        while (G * 2 * C4 <= 1024 && G * 2 <= p.Cr) G *= 2;
+        while (G * 2 * C4 <= NTHR && G * 2 <= p.Cr) G *= 2;
         float4* part4 = reinterpret_cast<float4*>(part);           // [G][C4] (G * C <= 4096 floats <= scratch? see launch)
+        // (C4 <= NTHR is guaranteed by launch_se: a block is never smaller than the channel-quad count)
         const int c4 = tid % C4, g = tid / C4;
         if (g < G) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2243,7 +2245,7 @@ __global__ __launch_bounds__(1024) void k_se(SeParams p) {
         }
         if (G > 1) {
             __syncthreads();
-            for (int c = tid; c < C4; c += 1024) {
+            for (int c = tid; c < C4; c += NTHR) {
                 float4 acc = part4[c];
                 for (int g2 = 1; g2 < G; g2++) { float4 v = part4[g2 * C4 + c]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
                 float4 bb = p.b2 ? reinterpret_cast<const float4*>(p.b2)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2253,7 +2255,7 @@ __global__ __launch_bounds__(1024) void k_se(SeParams p) {
             }
         }
     } else {
-        for (int c = tid; c < p.C; c += 1024) {
+        for (int c = tid; c < p.C; c += NTHR) {
             float acc = 0.f;
 #pragma unroll 8
             for (int j = 0; j < p.Cr; j++) acc = fmaf(p.w2[(size_t)j * p.C + c], r[j], acc);
@@ -2263,7 +2265,15 @@ __global__ __launch_bounds__(1024) void k_se(SeParams p) {
 }
 void launch_se(const SeParams& p, hipStream_t s) {
     size_t lds = (size_t)(p.C + p.Cr + 4096 + 16) * sizeof(float);   // mean, r, [P][C] / [G][C] scratch (<= 1024 float4)
-    hipLaunchKernelGGL(k_se, dim3(p.B), dim3(1024), lds, s, p);
+    // Block size: 1024 threads finish a clip fastest when the kernel owns the GPU, but a 16-wave workgroup needs a whole
+    // CU's worth of free wave slots and, beside another context's kernels, waited for one 5-30x its own run time
+    // (rocprofv3, timed window: avg 50 us, max 330 us against 6-18 us alone) - stalling the dependent projection GEMM.
+    // A pipelined engine therefore launches 4-wave blocks that slot in anywhere (BNHIP_SE_THREADS overrides).
+    static const int env = getenv("BNHIP_SE_THREADS") ? atoi(getenv("BNHIP_SE_THREADS")) : 0;
+    int thr = env ? env : (p.threads ? p.threads : 1024);
+    thr = std::max(64, std::min(1024, thr / 64 * 64));
+    while (thr < 1024 && (p.C + 3) / 4 > thr) thr *= 2;              // FC2 maps one thread to a channel quad
+    hipLaunchKernelGGL(k_se, dim3(p.B), dim3(thr), lds, s, p);
 }
 
 // ------------------------------------------------------------------------------------------ generic elementwise
