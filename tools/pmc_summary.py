@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Per-kernel PMC sums from rocprofv3 rocpd databases (one db per --pmc pass).
-Usage: python tools/pmc_summary.py [--traffic-json OUT] <db> [<db> ...]
+Usage: python tools/pmc_summary.py [--traffic-json OUT] [--window SKIP:COUNT] <db> [<db> ...]
+  --window: only COUNT consecutive engine dispatches ending SKIP before the last (e.g. the timed steps: skips the create-time
+    autotune launches, which would otherwise pollute the per-kernel averages with other layers' shapes)
   -> CSV on stdout (kernel, dispatches, avg_us, counter sums per dispatch)
   --traffic-json: also write {kernel: {dispatches, hbm_bytes_per_launch, fetch_kib_raw, write_kib}} where
     hbm bytes = FETCH_SIZE[KiB] * 1024 * 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE[KiB] * 1024."""
@@ -16,6 +18,9 @@ def short(name):
     return name.replace("void ", "").replace("bnhip::", "")[:48]
 
 
+WINDOW = None
+
+
 def load(path):
     db = sqlite3.connect(path)
     cur = db.cursor()
@@ -26,9 +31,14 @@ def load(path):
     ip = [t for t in tabs if "info_pmc" in t][0]
     # per dispatch: name, grid, duration
     disp = {}
-    for eid, name, gx, gy, gz, wx, st, en in cur.execute(
-            f"select d.event_id, s.display_name, d.grid_size_x, d.grid_size_y, d.grid_size_z, d.workgroup_size_x, d.start, d.end "
-            f"from {kd} d join {ks} s on d.kernel_id = s.id"):
+    rows = list(cur.execute(
+        f"select d.event_id, s.display_name, d.grid_size_x, d.grid_size_y, d.grid_size_z, d.workgroup_size_x, d.start, d.end "
+        f"from {kd} d join {ks} s on d.kernel_id = s.id order by d.start"))
+    if WINDOW:          # keep COUNT consecutive bnhip dispatches ending SKIP dispatches before the last one (the timed steps)
+        skip, count = WINDOW
+        mine = [r for r in rows if "bnhip" in r[1]]
+        rows = mine[len(mine) - skip - count:len(mine) - skip]
+    for eid, name, gx, gy, gz, wx, st, en in rows:
         disp[eid] = (short(name), gx * gy * gz // max(wx, 1), en - st)
     vals = defaultdict(lambda: defaultdict(float))
     for eid, cname, v in cur.execute(f"select e.event_id, p.name, e.value from {pm} e join {ip} p on e.pmc_id = p.id"):
@@ -43,8 +53,12 @@ def main():
     counters = []
     argv = sys.argv[1:]
     tj = None
-    if argv and argv[0] == "--traffic-json":
-        tj = argv[1]
+    global WINDOW
+    while argv and argv[0] in ("--traffic-json", "--window"):
+        if argv[0] == "--traffic-json":
+            tj = argv[1]
+        else:
+            WINDOW = tuple(int(v) for v in argv[1].split(":"))
         argv = argv[2:]
     sys.argv = [sys.argv[0]] + argv
     for path in sys.argv[1:]:

@@ -30,6 +30,6 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU
   rocprofv3 --pmc $c -d /tmp/pmc$i -o p -- $PB > /dev/null 2>&1
   DBS="$DBS $(find /tmp/pmc$i -name '*.db' | head -1)"
 done
-python tools/pmc_summary.py --traffic-json $OUT/${TAG}_traffic.json $DBS > $OUT/${TAG}_pmc.csv
+python tools/pmc_summary.py --traffic-json $OUT/${TAG}_traffic.json --window $NL:$((5 * NL)) $DBS > $OUT/${TAG}_pmc.csv
 python bench.py --depth 1 --detail --steps 5 --warmup 3 --no-cpu-baseline --no-fp32-run --no-oracle-check > /dev/null 2> $OUT/${TAG}_step_detail_depth1.txt
 echo done
