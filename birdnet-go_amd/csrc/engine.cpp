@@ -704,6 +704,13 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                             size_t o_we = wpush(wep.data(), wep.size()), o_be = wpush(bep.data(), bep.size());
                             size_t o_wd = wpush(wdp.data(), wdp.size()), o_bd = wpush(bdp.data(), bdp.size());
                             add_step(f, o_we, o_be, o_wd, o_bd);
+                            if (bf16x3 && expdw_bx_ok(C)) {          // split-bf16 image of the expand weights (autotuned per layer)
+                                std::vector<uint16_t> img = expdw_bx_image(wsrc, Co, C);
+                                std::vector<float> asf((img.size() + 1) / 2);
+                                memcpy(asf.data(), img.data(), img.size() * 2);
+                                step_bx.back() = wpush(asf.data(), asf.size());
+                                if (bf16x3 >= 2) steps.back().bx = 1;
+                            }
                             break;
                         }
                     }
@@ -1481,24 +1488,29 @@ void Engine::autotune_expdw() {
         float* in0 = vptr(s.in0, d_stage_in, d_stage_logits, nullptr);
         float* out = vptr(s.out, d_stage_in, d_stage_logits, nullptr);
         float* out2 = vptr(s.out2, d_stage_in, d_stage_logits, nullptr);
-        float best = 1e30f; int best_idx = -1;
+        float best = 1e30f; int best_idx = -1, best_bx = 0;
+        const bool can_bx = s.wbx != nullptr && s.mode != 1 && bf16x3;
         for (int idx = 0; idx < expdw_num_shapes(); idx++) {
             if (!expdw_shape_fits(idx, s.kh, s.sh, s.H, s.Ho, s.Wo, s.pt)) continue;
-            auto go = [&]() {
-                StemGeom sg{s.H2, s.W2, s.pt2, s.pl2};
-                launch_expand_dw(in0, s.w0, s.w1, s.w2, s.w3, out, out2, n, s.H, s.W, s.C, s.Co, s.Ho, s.Wo, s.kh, s.sh, s.pt, s.pl,
-                                 s.act, s.act2, idx, s.mode == 1 ? &sg : nullptr, stream);
-            };
-            go();
-            hipEventRecord(a, stream);
-            for (int r = 0; r < 3; r++) go();
-            hipEventRecord(b, stream);
-            hipEventSynchronize(b);
-            float ms = 0; hipEventElapsedTime(&ms, a, b);
-            if (ms < best * 0.98f) { best = ms; best_idx = idx; }
+            for (int bx = (can_bx && bf16x3 >= 2) ? 1 : 0; bx <= (can_bx ? 1 : 0); bx++) {
+                auto go = [&]() {
+                    StemGeom sg{s.H2, s.W2, s.pt2, s.pl2};
+                    launch_expand_dw(in0, s.w0, s.w1, s.w2, s.w3, out, out2, n, s.H, s.W, s.C, s.Co, s.Ho, s.Wo, s.kh, s.sh, s.pt, s.pl,
+                                     s.act, s.act2, idx, s.mode == 1 ? &sg : nullptr, stream, bx ? s.wbx : nullptr);
+                };
+                go();
+                hipEventRecord(a, stream);
+                for (int r = 0; r < 3; r++) go();
+                hipEventRecord(b, stream);
+                hipEventSynchronize(b);
+                float ms = 0; hipEventElapsedTime(&ms, a, b);
+                if (getenv("BNHIP_DEBUG")) fprintf(stderr, "[bnhip] tune %-16s expand_dw shape=%d bx=%d: %.1f us\n", s.name.c_str(), idx, bx, ms / 3 * 1e3);
+                if (ms < best * 0.98f) { best = ms; best_idx = idx; best_bx = bx; }
+            }
         }
         if (best_idx < 0) continue;
         s.shape = best_idx;
+        s.bx = best_bx;
         if (s.out2 >= 0) {                       // the consumers of the per-tile sums index them by tile count
             s.S = expdw_shape_slabs(best_idx, s.Ho, s.Wo);
             for (auto& c : steps) if (&c != &s && c.in0 == s.out2) c.S = s.S;
@@ -1767,7 +1779,8 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
                 {
                     StemGeom sg{s.H2, s.W2, s.pt2, s.pl2};
                     launch_expand_dw(in0, s.w0, s.w1, s.w2, s.w3, out, out2, n, s.H, s.W, s.C, s.Co,
-                                     s.Ho, s.Wo, s.kh, s.sh, s.pt, s.pl, s.act, s.act2, s.shape, s.mode == 1 ? &sg : nullptr, stream);
+                                     s.Ho, s.Wo, s.kh, s.sh, s.pt, s.pl, s.act, s.act2, s.shape, s.mode == 1 ? &sg : nullptr, stream,
+                                     s.bx ? s.wbx : nullptr);
                 }
                 break;
             case S_MEAN_PARTIAL:
@@ -1874,7 +1887,7 @@ std::string Engine::describe() const {
         jesc(os, s.name);
         os << "\",\"H\":" << s.H << ",\"W\":" << s.W << ",\"C\":" << s.C << ",\"Co\":" << s.Co << ",\"k\":" << s.kh
            << ",\"stride\":" << s.sh << ",\"act\":" << s.act << ",\"fused_scale\":" << (s.kind == S_PW && s.in1 >= 0 ? 1 : 0)
-           << ",\"shape\":" << s.shape << ",\"nt\":" << s.nt << ",\"wm\":" << s.wm << ",\"nt_full\":" << s.nt_full << ",\"wm_full\":" << s.wm_full << ",\"fused_res\":" << (s.kind == S_PW && s.in2 >= 0 ? 1 : 0) << ",\"fused_sum\":" << (s.out2 >= 0 ? 1 : 0) << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << ",\"wbytes\":" << s.wbytes << "}";
+           << ",\"shape\":" << s.shape << ",\"bx\":" << s.bx << ",\"nt\":" << s.nt << ",\"wm\":" << s.wm << ",\"nt_full\":" << s.nt_full << ",\"wm_full\":" << s.wm_full << ",\"fused_res\":" << (s.kind == S_PW && s.in2 >= 0 ? 1 : 0) << ",\"fused_sum\":" << (s.out2 >= 0 ? 1 : 0) << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << ",\"wbytes\":" << s.wbytes << "}";
     }
     os << "]}";
     return os.str();

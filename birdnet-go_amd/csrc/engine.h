@@ -34,7 +34,8 @@ struct Step {
     int in0 = -1, in1 = -1, in2 = -1, out = -1, out2 = -1;
     // weights (device pointers into the weight arena)
     const float *w0 = nullptr, *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;
-    const uint16_t* wbx = nullptr;   // S_PW: split-bf16 weight image (pw_bx3_image) when the engine was created with bf16x3
+    const uint16_t* wbx = nullptr;   // S_PW / S_EXPAND_DW: split-bf16 weight image (pw_bx3_image / expdw_bx_image) of a bf16x3 engine
+    int bx = 0;                      // S_EXPAND_DW: 1 = phase 1 on the split-bf16 MFMA (autotuned per layer; bf16x3 = 2 forces it)
     // geometry per clip
     int H = 0, W = 0, C = 0, Ho = 0, Wo = 0, Co = 0, kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0;
     int act = 0, act2 = 0, op = 0, mode = 0, S = 1, Cr = 0;

@@ -119,7 +119,10 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
                       float* partial, int B, int H, int W, int Cin, int Cmid, int Ho, int Wo, int k, int s, int pt,
                       int pl, int act_e, int act_d, int shape /* index into the shape table; -1 = cost model */,
                       const StemGeom* stem /* non-null: x is the raw image and the expand is the 3x3/2 stem (see kernels.hip) */,
-                      hipStream_t st);
+                      hipStream_t st, const uint16_t* wep = nullptr /* non-null: phase 1 on the split-bf16 MFMA (expdw_bx_image) */);
+bool expdw_bx_ok(int Cin);
+int expdw_kp(int Cin);
+std::vector<uint16_t> expdw_bx_image(const float* We /*[Cmid][Cin]*/, int Cmid, int Cin);
 
 // mean over H*W: in [B,HW,C] -> partial [B,S,C] (sums), S = number of pixel splits
 int mean_splits(int HW);

@@ -1688,6 +1688,7 @@ struct ExpDwParams {
     // STEM variant: x is the raw [B, Hin, Win, 2] image and the "expand" is the 3x3 stride-2 stem conv seen as an implicit
     // GEMM (K layout of k_stem_mfma); H, W above are then the stem's output size
     int Hin = 0, Win = 0, pts = 0, pls = 0;
+    const uint16_t* wep = nullptr; int Kp = 0;   // BX variant: split-bf16 expand weights [Cp][3][Kp]
     FDiv d_bpc{}, d_cch{}, d_tw{};      // blocks per clip, channel chunks, tiles per row (set by the launcher)
 };
 #define ED_ES 36     // E row stride (floats)
@@ -1720,8 +1721,19 @@ struct ExpDwParams {
 __device__ __forceinline__ int ed_perm(unsigned long long magic, int lane) {
     return (int)((magic >> ((lane >> 2) * 4)) & 15ull) * 4 + (lane & 3);
 }
-template <int K, int S, int TOH, int TOW, int TRH, bool STEM = false, bool H8 = STEM>
-__global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk) {
+// BX: phase 1 on the split-bf16 MFMA (see k_pw_bx3): the expand weights come pre-split ([Cp][3 planes][Kp] bf16, Kp = K rounded
+// up to 32), the lane's 8 input channels of a 32-wide slab are split in registers.  The split is amortised over only two
+// 16-channel tiles here (a block owns one 32-channel chunk), so it pays where the f32 MFMA dominates the wave (Cin >= 40:
+// 16 MFMAs x 32 cycles per tile and slab become 12 x 16 + ~36 VALU) and not in the VALU-bound early layers: the
+// create-time autotuner picks per layer.
+// (the BX instantiations of the common shapes come out 2-4 registers above 128: the occupancy bound keeps them at four
+// waves per SIMD like their f32 twins)
+constexpr int expdw_min_waves(int K, int S, int TOW, int TRH) {
+    const int tiw = (TOW - 1) * S + K, jt = (TRH * tiw + 15) / 16, jtw = (jt + 3) / 4;
+    return jtw <= 4 ? 4 : (jtw == 5 ? 3 : 2);
+}
+template <int K, int S, int TOH, int TOW, int TRH, bool STEM = false, bool H8 = STEM, bool BX = false>
+__global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void k_expand_dw(ExpDwParams p, unsigned nblk) {
     constexpr int TIH = (TOH - 1) * S + K, TIW = (TOW - 1) * S + K;
     static_assert(TRH <= TIH, "TRH is a cap on the footprint rows");
     constexpr int NPIX = TRH * TIW, NPIXP = (NPIX + 15) / 16 * 16;
@@ -1775,7 +1787,7 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
         xin[a] = j < nvalid && iw >= 0 && iw < p.W;
         int ihc = min(ih0 + vr0 + r, p.H - 1), iwc = min(max(iw, 0), p.W - 1);
         if (STEM) { xoff[a] = ihc * 2 - p.pts; scol[a] = iwc * 2 - p.pls + (kq & 1) * 2; }
-        else { xoff[a] = (((b * p.H + ihc) * p.W) + iwc) * Cin + 4 * kq; scol[a] = 0; }
+        else { xoff[a] = (((b * p.H + ihc) * p.W) + iwc) * Cin + (BX ? 8 : 4) * kq; scol[a] = 0; }
     }
     const float* xb = STEM ? p.x + (size_t)b * p.Hin * p.Win * 2 : p.x;
     const float* wrow0 = p.we + (size_t)(n_base + li) * Kw + 4 * kq;
@@ -1859,7 +1871,40 @@ __global__ __launch_bounds__(256) void k_expand_dw(ExpDwParams p, unsigned nblk)
     // H8 (compile time: the half slab costs ~10 VGPRs when it is a run-time option, which drops every shape at 120
     // VGPRs from four waves per SIMD to three) = Kw is 8 mod 16
     const int Kfull = Kw & ~15;
-    if (!H8) {
+    if (BX) {
+        const u32x4* wimg = reinterpret_cast<const u32x4*>(p.wep);          // 16-byte units: (n * 3 + plane) * Kp / 8 + k / 8
+        const unsigned kp8 = (unsigned)p.Kp >> 3;
+        const unsigned wr0 = (unsigned)(n_base + li) * 3u * kp8 + (unsigned)kq, wr1 = wr0 + 48u * kp8;
+        for (int s32 = 0; s32 < (p.Kp >> 5); s32++) {
+            u32x4 wq[2][3];
+#pragma unroll
+            for (int pl3 = 0; pl3 < 3; pl3++) { wq[0][pl3] = wimg[wr0 + pl3 * kp8 + 4 * s32]; wq[1][pl3] = wimg[wr1 + pl3 * kp8 + 4 * s32]; }
+            // this lane's 8 channels lie inside the real K, or their weights are zero and any valid address will do
+            const int kx = (32 * s32 + 8 * kq + 7 < Cin) ? 32 * s32 : -8 * kq;
+#pragma unroll
+            for (int a = 0; a < JTW; a++) {
+                if (wave + 4 * a < jtv) {
+                    const float* xq = p.x + (size_t)xoff[a] + kx;
+                    const float4 t0 = *reinterpret_cast<const float4*>(xq), t1 = *reinterpret_cast<const float4*>(xq + 4);
+                    bf16x8 xh, xm, xl;
+                    bx3_split8((f32x4){t0.x, t0.y, t0.z, t0.w}, (f32x4){t1.x, t1.y, t1.z, t1.w}, &xh, &xm, &xl);
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[t][0]), wm = __builtin_bit_cast(bf16x8, wq[t][1]),
+                                     wl = __builtin_bit_cast(bf16x8, wq[t][2]);
+                        f32x4 c = acc[a][t];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, c, 0, 0, 0);
+                        acc[a][t] = c;
+                    }
+                }
+            }
+        }
+    } else if (!H8) {
         if (Kw <= 16) {
             f32x4 wA0, wA1, xA[JTW];
             fload(0, wA0, wA1, xA);
@@ -2074,6 +2119,27 @@ int expdw_max_slabs(int k, int s, int H, int Ho, int Wo, int pt) {
         if (expdw_shape_fits(i, k, s, H, Ho, Wo, pt)) mx = std::max(mx, expdw_shape_slabs(i, Ho, Wo));
     return mx;
 }
+// split-bf16 expand weights: [Cp][3][Kp] bf16 in natural k order (a lane reads 8 consecutive k = one 16-byte unit per plane)
+bool expdw_bx_ok(int Cin) { return (Cin & 7) == 0 && Cin >= 16; }
+int expdw_kp(int Cin) { return (Cin + 31) / 32 * 32; }
+std::vector<uint16_t> expdw_bx_image(const float* We /*[Cmid][Cin]*/, int Cmid, int Cin) {
+    const int Cp = expdw_cp(Cmid), Kp = expdw_kp(Cin);
+    std::vector<uint16_t> img((size_t)Cp * 3 * Kp, 0);
+    auto rne = [](float f) -> uint16_t {
+        unsigned u; memcpy(&u, &f, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+        return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    };
+    auto widen = [](uint16_t h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; };
+    for (int n = 0; n < Cmid; n++)
+        for (int k = 0; k < Cin; k++) {
+            const float x = We[(size_t)n * Cin + k];
+            const uint16_t h = rne(x); const float r = x - widen(h);
+            const uint16_t m = rne(r); const float q = r - widen(m);
+            img[((size_t)n * 3 + 0) * Kp + k] = h; img[((size_t)n * 3 + 1) * Kp + k] = m; img[((size_t)n * 3 + 2) * Kp + k] = rne(q);
+        }
+    return img;
+}
 bool expdw_supported(int k, int s, int Cin, int Cmid) {
     // measured on MI355X at batch 256: beyond ~128 input channels the unpipelined K loop of the fused kernel loses
     // to the separate pw_gemm + dwconv pair (b13-b16 of the B0 stack: 126 us vs 176 us), so those stay unfused
@@ -2081,7 +2147,7 @@ bool expdw_supported(int k, int s, int Cin, int Cmid) {
 }
 void launch_expand_dw(const float* x, const float* we, const float* be, const float* wd, const float* bd, float* y,
                       float* partial, int B, int H, int W, int Cin, int Cmid, int Ho, int Wo, int k, int s, int pt,
-                      int pl, int act_e, int act_d, int shape, const StemGeom* stem, hipStream_t st) {
+                      int pl, int act_e, int act_d, int shape, const StemGeom* stem, hipStream_t st, const uint16_t* wep) {
     if (!expdw_shape_fits(shape, k, s, H, Ho, Wo, pt)) shape = expdw_default_shape(k, s, H, Ho, Wo, pt);
     if (shape < 0) return;                             // the planner only fuses layers some shape accepts
     const ExpDwShape* sh = &kExpDwShapes[shape];
@@ -2091,6 +2157,8 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
     p.d_bpc = make_fdiv((unsigned)(p.tiles_h * p.tiles_w * p.cchunks));
     p.d_cch = make_fdiv((unsigned)p.cchunks);
     p.d_tw = make_fdiv((unsigned)p.tiles_w);
+    const bool bx = wep != nullptr && !stem && expdw_bx_ok(Cin);
+    if (bx) { p.wep = wep; p.Kp = expdw_kp(Cin); }
     if (stem) {
         p.Hin = stem->Hin; p.Win = stem->Win; p.pts = stem->pt; p.pls = stem->pl; p.Kw = 24;    // 3 rows x 4 columns x 2 channels
 #define ED_STEM(TH_, TW_, TR_)                                                                                \
@@ -2104,7 +2172,8 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
     }
 #define ED_CASE(K_, S_, TH_, TW_, TR_)                                                                        \
     if (sh->k == K_ && sh->s == S_ && sh->toh == TH_ && sh->tow == TW_ && sh->trh == TR_) {                   \
-        if (p.Kw & 8) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        if (bx) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        else if (p.Kw & 8) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         else hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_>), dim3(nblk), dim3(256), 0, st, p, nblk);  \
         return;                                                                                               \
     }

@@ -101,3 +101,35 @@ def test_bf16x3_full_model_parity_and_error(gpu, full_blob):
     print("layers the autotuner moved to the split-bf16 kernel:", picked)
     a.close(); b.close()
     assert np.abs(ya - yb).max() < 1e-4 and (ya.argmax(1) == yb.argmax(1)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", [0, 1, 2, 4, 6])
+def test_bf16x3_forced_on_geometry_sweep(gpu, i):
+    """Every eligible layer forced onto the split-bf16 kernels - pointwise GEMMs (K % 32 == 0) and the expand GEMM inside the
+    fused expand+depthwise kernel (Cin % 8 == 0, K tails zero-padded to 32) - on the geometry-sweep models: tile shapes,
+    strides, ragged edges and K tails the v2.4 topology does not have, vs the oracle."""
+    from test_parity_gpu import _geo_cfg, assert_parity
+    cfg = _geo_cfg(i)
+    blob = sm.build_model(cfg)
+    x = sm.synth_clips(5, cfg.n_samples, cfg.sample_rate, first=3 * i)
+    ref = Interpreter(blob).invoke(x)[0]
+    for opts in (dict(), dict(lanes=1, autotune=False)):
+        c = host.HipClassifier(blob, max_batch=64 if not opts else 5, bf16x3=2, **opts)
+        try:
+            got = c.predict_batch(x.reshape(-1), 5)
+            steps = c.describe()["steps"]
+        finally:
+            c.close()
+        assert_parity(got, ref)
+        assert steps
+
+
+@pytest.mark.gpu
+def test_bf16x3_expand_dw_variant_is_exercised(gpu, full_blob):
+    c = host.HipClassifier(full_blob, max_batch=8, bf16x3=2)
+    try:
+        ed = [s for s in c.describe()["steps"] if s["kernel"] == "expand_dw"]
+        assert sum(s["bx"] for s in ed) >= 10, [(s["name"], s["bx"]) for s in ed]      # b2..b12 (the fused stem stays f32)
+    finally:
+        c.close()
