@@ -98,7 +98,12 @@ struct FrontendMatch {
     float p1 = 1.f, p2 = 1.f, eps = 0.f, norm_sub = 0.f, norm_mul = 1.f;
     bool reverse = false;
     bool magnitude = false;  // COMPLEX_ABS instead of the real part
-    int out_tensor = -1;     // [1, n_mels, F, 1]
+    bool normalize = true;   // per-clip min/max normalisation in front of the framing (false: raw samples)
+    int pad_left = 0, pad_right = 0;   // zero samples the graph PADs around the clip before framing
+    bool log_compress = false;         // scale * log(max(x, floor)) instead of the two POWs
+    float log_floor = 0.f, log_scale = 1.f;
+    bool time_major = false; // image is [1, F, n_mels, 1] (no TRANSPOSE) instead of [1, n_mels, F, 1]
+    int out_tensor = -1;     // [1, n_mels, F, 1] or [1, F, n_mels, 1]
 };
 
 // Recognise one MelSpec branch around RFFT2D op `ri` (see header comment in synth_model.py for the graph).
@@ -115,6 +120,18 @@ bool match_frontend(Planner& P, int ri, FrontendMatch* fm) {
     // ---- upstream: window MUL <- framing GATHER <- normalisation chain <- graph input
     int t = P.skip_up(R.inputs[0]);
     int pi = P.producer[t];
+    // frames shorter than the transform: tf.signal.stft zero-pads them at the end (PAD on the last axis only)
+    if (pi >= 0 && m.ops[pi].code == OP_PAD) {
+        const TflOp& pd = m.ops[pi];
+        const TflTensor& pv = P.T(pd.inputs[1]);
+        const int rank = (int)P.T(pd.inputs[0]).shape.size();
+        if (!pv.data || (int)pv.numel() != 2 * rank) return P.fail("front-end: frame PAD needs constant paddings");
+        for (int d = 0; d < 2 * rank - 1; d++)
+            if (pv.i32()[d] != 0) return P.fail("front-end: frames may only be zero-padded at the end of the last axis");
+        P.absorbed[pi] = 1;
+        t = P.skip_up(pd.inputs[0]);
+        pi = P.producer[t];
+    }
     int frames_t = t;
     if (pi >= 0 && m.ops[pi].code == OP_MUL) {
         const TflOp& mu = m.ops[pi];
@@ -150,8 +167,21 @@ bool match_frontend(Planner& P, int ri, FrontendMatch* fm) {
     if ((int)fm->window.size() != fm->L) return P.fail("front-end: window length != frame length");
     if (fm->L > fm->Lfft) return P.fail("front-end: frame length > fft length");
 
-    // normalisation: MUL(SUB(DIV(SUB(x, REDUCE_MIN x), ADD(REDUCE_MAX(.), eps)), c_sub), c_mul)
-    {
+    // optional zero padding of the whole clip ([1, n] -> [1, pad_left + n + pad_right])
+    if (P.producer[t] >= 0 && m.ops[P.producer[t]].code == OP_PAD) {
+        const TflOp& pd = m.ops[P.producer[t]];
+        const TflTensor& pv = P.T(pd.inputs[1]);
+        const auto& ish = P.T(pd.inputs[0]).shape;
+        if (!pv.data || pv.numel() != 4 || ish.size() != 2 || pv.i32()[0] != 0 || pv.i32()[1] != 0 || pv.i32()[2] < 0 || pv.i32()[3] < 0)
+            return P.fail("front-end: clip PAD must be constant [[0,0],[left,right]] on a [1, n] tensor");
+        fm->pad_left = pv.i32()[2]; fm->pad_right = pv.i32()[3];
+        P.absorbed[P.producer[t]] = 1;
+        t = P.skip_up(pd.inputs[0]);
+    }
+    // normalisation: MUL(SUB(DIV(SUB(x, REDUCE_MIN x), ADD(REDUCE_MAX(.), eps)), c_sub), c_mul) - or none at all
+    if (t == m.inputs[0]) {
+        fm->normalize = false;
+    } else {
         int p_mul = P.producer[t];
         if (p_mul < 0 || m.ops[p_mul].code != OP_MUL) return P.fail("front-end: normalisation (MUL) not found");
         int n2 = P.bin_const(m.ops[p_mul], &fm->norm_mul);
@@ -203,8 +233,26 @@ bool match_frontend(Planner& P, int ri, FrontendMatch* fm) {
         P.absorbed[ci] = 1;
         t = P.skip_down(fc.outputs[0]);
     }
+    // log compression: MUL(LOG(MAXIMUM(x, floor)), scale)
+    ci = P.only_consumer(t);
+    if (ci >= 0 && m.ops[ci].code == OP_MAXIMUM) {
+        int src = P.bin_const(m.ops[ci], &fm->log_floor);
+        if (src < 0 || !(fm->log_floor > 0.f)) return P.fail("front-end: log compression needs MAXIMUM with a positive scalar floor");
+        P.absorbed[ci] = 1;
+        t = P.skip_down(m.ops[ci].outputs[0]);
+        ci = P.only_consumer(t);
+        if (ci < 0 || m.ops[ci].code != OP_LOG) return P.fail("front-end: LOG after MAXIMUM not found");
+        P.absorbed[ci] = 1;
+        t = P.skip_down(m.ops[ci].outputs[0]);
+        fm->log_compress = true;
+        ci = P.only_consumer(t);
+        if (ci >= 0 && m.ops[ci].code == OP_MUL && P.bin_const(m.ops[ci], &fm->log_scale) >= 0) {
+            P.absorbed[ci] = 1;
+            t = P.skip_down(m.ops[ci].outputs[0]);
+        } else fm->log_scale = 1.f;
+    }
     int npow = 0;
-    while ((ci = P.only_consumer(t)) >= 0 && m.ops[ci].code == OP_POW && npow < 2) {
+    while (!fm->log_compress && (ci = P.only_consumer(t)) >= 0 && m.ops[ci].code == OP_POW && npow < 2) {
         float e;
         if (!P.const_scalar(m.ops[ci].inputs[1], &e)) return P.fail("front-end: POW exponent must be a scalar constant");
         (npow == 0 ? fm->p1 : fm->p2) = e;
@@ -222,6 +270,15 @@ bool match_frontend(Planner& P, int ri, FrontendMatch* fm) {
         P.absorbed[ci] = 1;
         t = P.skip_down(m.ops[ci].outputs[0]);
         ci = P.only_consumer(t);
+    }
+    {
+        // time-major image: the [1, F, n_mels] tensor is only reshaped to [1, F, n_mels, 1]
+        const auto& ts = P.T(t).shape;
+        if (!fm->reverse && ts.size() == 4 && ts[0] == 1 && ts[1] == fm->F && ts[2] == fm->n_mels && ts[3] == 1) {
+            fm->time_major = true;
+            fm->out_tensor = t;
+            return true;
+        }
     }
     if (ci < 0 || m.ops[ci].code != OP_TRANSPOSE) return P.fail("front-end: TRANSPOSE to [mel, time] not found");
     {
@@ -401,9 +458,16 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
 
     // front-end steps
     if (!dense_only) {
-        Step s; s.kind = S_MINMAX; s.name = "clip_minmax"; s.kclass = "clip_minmax"; s.in0 = v_input; s.out = v_mm;
-        s.bytes = (double)n_samples * 4;
-        add_step(s);
+        for (auto& fm : fms)
+            if (fm.normalize != fms[0].normalize || fm.pad_left != fms[0].pad_left || fm.pad_right != fms[0].pad_right) {
+                *err = "front-end: branches disagree on normalisation / clip padding";
+                return false;
+            }
+        if (fms[0].normalize) {
+            Step s; s.kind = S_MINMAX; s.name = "clip_minmax"; s.kclass = "clip_minmax"; s.in0 = v_input; s.out = v_mm;
+            s.bytes = (double)n_samples * 4;
+            add_step(s);
+        }
         int v_spec = new_val(spec_tensor, (size_t)fms[0].n_mels * fms[0].F * C_spec);
         int v_xn = -1;                      // normalised clip (FFT front-end only)
         struct FftFin { int v_bins, spec; size_t o_mel, o_span; bool banded; };
@@ -421,6 +485,14 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                 return false;
             }
             fs.p1 = fm.p1; fs.p2 = fm.p2; fs.eps = fm.eps; fs.norm_sub = fm.norm_sub; fs.norm_mul = fm.norm_mul;
+            fs.normalize = fm.normalize; fs.log_compress = fm.log_compress; fs.time_major = fm.time_major;
+            fs.pad_left = fm.pad_left; fs.log_floor = fm.log_floor; fs.log_scale = fm.log_scale;
+            if ((long)(fm.F - 1) * fm.hop + fm.L > (long)n_samples + fm.pad_left + fm.pad_right) {
+                *code = BNHIP_E_MODEL;
+                *err = "front-end: the framing selector reaches beyond the (padded) clip";
+                return false;
+            }
+            if (fm.time_major != fms[0].time_major) { *err = "front-end: branches disagree on the image layout"; return false; }
             // bins the mel matrix actually uses (DFT truncation)
             std::vector<int> bins;
             {
@@ -438,9 +510,17 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                 *err = "front-end: magnitude STFT (COMPLEX_ABS) is only implemented for fft_length 512 / 1024 / 2048";
                 return false;
             }
-            fs.fft = fm.magnitude || (frontend_fft != 0 && can_fft);     // measured faster than the folded GEMM (0.95 vs 1.05 ms)
+            // the folded-GEMM kernel only knows the v2.4 layer (normalised clip, power compression, [mel, time] image)
+            const bool variant = !fm.normalize || fm.log_compress || fm.time_major || fm.pad_left || fm.pad_right;
+            if (variant && !can_fft) {
+                *code = BNHIP_E_UNSUPPORTED;
+                *err = "front-end: log-mel / unnormalised / padded front-ends are only implemented for fft_length 512 / 1024 / 2048";
+                return false;
+            }
+            fs.fft = fm.magnitude || variant || (frontend_fft != 0 && can_fft);     // measured faster than the folded GEMM (0.95 vs 1.05 ms)
             if (fs.fft) {
                 // normalise (once) -> STFT bins -> mel GEMM -> pow + NHWC store
+                if (!fm.normalize) v_xn = v_input;
                 if (v_xn < 0) {
                     v_xn = new_val(-1, n_samples);
                     Step nz; nz.kind = S_NORMALIZE; nz.name = "normalize"; nz.kclass = "frontend"; nz.in0 = v_input; nz.in1 = v_mm;
@@ -515,7 +595,9 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
         for (size_t k = 0; k < fft_fin.size();) {
             const FrontSpec& a = specs[fft_fin[k].spec];
             bool pair = k + 1 < fft_fin.size() && specs[fft_fin[k + 1].spec].c == a.c + 1 && (a.c & 1) == 0 &&
-                        specs[fft_fin[k + 1].spec].F == a.F && specs[fft_fin[k + 1].spec].n_mels == a.n_mels;
+                        specs[fft_fin[k + 1].spec].F == a.F && specs[fft_fin[k + 1].spec].n_mels == a.n_mels &&
+                        specs[fft_fin[k + 1].spec].log_compress == a.log_compress && specs[fft_fin[k + 1].spec].log_floor == a.log_floor &&
+                        specs[fft_fin[k + 1].spec].log_scale == a.log_scale;
             const int nch = pair ? 2 : 1;
             bool banded = fft_fin[k].banded && (!pair || fft_fin[k + 1].banded) &&
                           mel_banded_supported(a.n_mels, a.nbp, pair ? specs[fft_fin[k + 1].spec].nbp : 0);
@@ -1737,7 +1819,7 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
                 break;
             case S_STFT: {
                 const FrontSpec& fs = specs[s.spec];
-                StftParams p{in0, fs.window_full, fs.bins, out, n_samples, fs.Lfft, fs.L, fs.hop, fs.F, fs.nb, fs.nbp, fs.mode, n, fs.stft_tw};
+                StftParams p{in0, fs.window_full, fs.bins, out, n_samples, fs.Lfft, fs.L, fs.hop, fs.F, fs.nb, fs.nbp, fs.mode, n, fs.stft_tw, fs.pad_left};
                 launch_stft_bins(p, stream);
                 break;
             }
@@ -1746,14 +1828,16 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
                 const FrontSpec& fb = specs[s.S == 2 ? s.op : s.spec];
                 MelBandParams p{{in0, s.S == 2 ? in1 : in0}, {s.w0, s.S == 2 ? s.w2 : s.w0},
                                 {reinterpret_cast<const int*>(s.w1), reinterpret_cast<const int*>(s.S == 2 ? s.w3 : s.w1)},
-                                {fa.nbp, fb.nbp}, {fa.p1, fb.p1}, {fa.p2, fb.p2}, out, fa.F, fa.n_mels, C_spec, fa.c};
+                                {fa.nbp, fb.nbp}, {fa.p1, fb.p1}, {fa.p2, fb.p2}, out, fa.F, fa.n_mels, C_spec, fa.c,
+                                fa.log_compress ? 1 : 0, fa.log_floor, fa.log_scale, fa.time_major ? 1 : 0};
                 launch_mel_banded(p, s.S, n, stream);
                 break;
             }
             case S_MELFIN: {
                 const FrontSpec& fa = specs[s.spec];
                 const FrontSpec& fb = specs[s.S == 2 ? s.op : s.spec];
-                MelFinParams p{{in0, s.S == 2 ? in1 : in0}, {fa.p1, fb.p1}, {fa.p2, fb.p2}, out, fa.F, fa.n_mels, fa.n_mels, C_spec, fa.c};
+                MelFinParams p{{in0, s.S == 2 ? in1 : in0}, {fa.p1, fb.p1}, {fa.p2, fb.p2}, out, fa.F, fa.n_mels, fa.n_mels, C_spec, fa.c,
+                               fa.log_compress ? 1 : 0, fa.log_floor, fa.log_scale, fa.time_major ? 1 : 0};
                 launch_mel_finish(p, s.S, n, stream);
                 break;
             }

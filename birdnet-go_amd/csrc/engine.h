@@ -70,6 +70,10 @@ struct FrontSpec {
     const float* window_full = nullptr;
     const double* stft_tw = nullptr;   // twiddle image of the STFT step (stft_build_tables)
     const int* bins = nullptr;
+    // front-end variants beyond the v2.4 MelSpec layer (Perch-style log-mel): see FrontendMatch
+    bool normalize = true, log_compress = false, time_major = false;
+    int pad_left = 0;
+    float log_floor = 0.f, log_scale = 1.f;
 };
 
 struct ProfEntry { hipEvent_t a, b; int step; int n; };

@@ -39,6 +39,7 @@ struct StftParams {
     float* out;             // [B, F, nbp]; columns nb..nbp-1 are written as zeros
     int n_samples, Lfft, L, hop, F, nb, nbp, mode /*0 real part, 1 magnitude*/, n_clips;
     const double* tw = nullptr;   // plan-time twiddle image (stft_build_tables)
+    int pad_left = 0;             // frame f starts at sample f * hop - pad_left; samples outside [0, n_samples) are zero
     int nb_cap = 0, fpw = 0;    // set by the launcher
 };
 std::vector<double> stft_build_tables(int Lfft, const int* bins, int nb);
@@ -51,6 +52,9 @@ struct MelFinParams {
     float p1[2], p2[2];
     float* out;             // [B, n_mels, F, Ctot]
     int F, n_mels, ldt, Ctot, c0;   // c0 = first channel written (two channels are written as one float2 when c0 is even)
+    int log = 0;            // 1: lscale * log(max(v, lfloor)) instead of the two powers (all channels of the launch)
+    float lfloor = 0.f, lscale = 1.f;
+    int time_major = 0;     // 1: out is [B, F, n_mels, Ctot]
 };
 void launch_mel_finish(const MelFinParams& p, int nch, int n_clips, hipStream_t s);
 struct MelBandParams {      // banded mel filterbank + pow + NHWC store, one or two channels per launch
@@ -61,6 +65,9 @@ struct MelBandParams {      // banded mel filterbank + pow + NHWC store, one or 
     float p1[2], p2[2];
     float* out;             // [B, n_mels, F, Ctot]
     int F, n_mels, Ctot, c0;
+    int log = 0;            // as in MelFinParams
+    float lfloor = 0.f, lscale = 1.f;
+    int time_major = 0;
 };
 bool mel_banded_supported(int n_mels, int nbp0, int nbp1);
 void launch_mel_banded(const MelBandParams& p, int nch, int n_clips, hipStream_t s);

@@ -150,17 +150,23 @@ __global__ __launch_bounds__(64 * W) void k_stft_bins(StftParams p) {
     // otherwise be an exposed L2 round trip per frame with two waves per SIMD)
     float2 nx[P];
     auto fetch = [&](int f) {
-        const int s0 = f * p.hop + 2 * lane;
-        if (f * p.hop + N <= p.n_samples && ((f * p.hop) & 1) == 0) {        // whole frame in range, 8-byte aligned
+        // chunks of 128 samples that lie wholly beyond the frame (frame shorter than the transform) are not loaded: their
+        // window taps are zero
+        const int first = f * p.hop - p.pad_left;
+        const int s0 = first + 2 * lane;
+        if (first >= 0 && first + N <= p.n_samples && (first & 1) == 0) {        // whole transform window in range, 8-byte aligned
 #pragma unroll
-            for (int n1 = 0; n1 < P; n1++) nx[n1] = *reinterpret_cast<const float2*>(xc + s0 + 128 * n1);
+            for (int n1 = 0; n1 < P; n1++)
+                nx[n1] = 128 * n1 < p.L ? *reinterpret_cast<const float2*>(xc + s0 + 128 * n1) : make_float2(0.f, 0.f);
         } else {
 #pragma unroll
             for (int n1 = 0; n1 < P; n1++) {
                 int s = s0 + 128 * n1;
                 float2 v = make_float2(0.f, 0.f);
-                if (s < p.n_samples) v.x = xc[s];
-                if (s + 1 < p.n_samples) v.y = xc[s + 1];
+                if (128 * n1 < p.L) {
+                    if (s >= 0 && s < p.n_samples) v.x = xc[s];
+                    if (s + 1 >= 0 && s + 1 < p.n_samples) v.y = xc[s + 1];
+                }
                 nx[n1] = v;
             }
         }
@@ -284,7 +290,7 @@ size_t stft_lds_bytes(int P, int nb_cap) {
 bool stft_supported(int Lfft, int nb) {
     if (Lfft != 2048 && Lfft != 1024 && Lfft != 512) return false;
     int P = Lfft / 128, cap = (nb + 63) / 64 * 64;
-    return nb <= 508 && stft_lds_bytes(P, cap) <= 160 * 1024;      // 8 bins per lane are held in registers
+    return nb <= 512 && stft_lds_bytes(P, cap) <= 160 * 1024;      // 8 bins per lane are held in registers
 }
 void launch_stft_bins(const StftParams& p0, hipStream_t s) {
     StftParams p = p0;
@@ -319,6 +325,10 @@ __device__ __forceinline__ float mel_pow(float v, float p1, float p2) {
     if (y >= 0.0f) return y == 0.0f ? 0.0f : __builtin_amdgcn_exp2f(p2 * __builtin_amdgcn_logf(y));
     return powf(y, p2);
 }
+// log compression of the Perch-style front-end: MAXIMUM, LOG, MUL as the graph orders them (v_log_f32 is log2, 1 ulp)
+__device__ __forceinline__ float mel_log(float v, float lfloor, float lscale) {
+    return lscale * (0.6931471805599453f * __builtin_amdgcn_logf(fmaxf(v, lfloor)));
+}
 template <int C>
 __global__ __launch_bounds__(256) void k_mel_finish(MelFinParams p) {
     __shared__ float tile[C][32][33];
@@ -329,10 +339,24 @@ __global__ __launch_bounds__(256) void k_mel_finish(MelFinParams p) {
         for (int r = ty; r < 32; r += 8) {
             int f = f0 + r, m = m0 + tx;
             float v = 0.f;
-            if (f < p.F && m < p.n_mels) v = mel_pow(p.T[c][((size_t)b * p.F + f) * p.ldt + m], p.p1[c], p.p2[c]);
+            if (f < p.F && m < p.n_mels) {
+                const float t = p.T[c][((size_t)b * p.F + f) * p.ldt + m];
+                v = p.log ? mel_log(t, p.lfloor, p.lscale) : mel_pow(t, p.p1[c], p.p2[c]);
+            }
             tile[c][r][tx] = v;
         }
     __syncthreads();
+    if (p.time_major) {                                  // [B, F, n_mels, Ctot]: no transpose, mel index fastest
+        for (int r = ty; r < 32; r += 8) {
+            int f = f0 + r, m = m0 + tx;
+            if (f < p.F && m < p.n_mels) {
+                float* o = p.out + (((size_t)b * p.F + f) * p.n_mels + m) * p.Ctot + p.c0;
+                if (C == 2) *reinterpret_cast<float2*>(o) = make_float2(tile[0][r][tx], tile[1][r][tx]);
+                else o[0] = tile[0][r][tx];
+            }
+        }
+        return;
+    }
     for (int r = ty; r < 32; r += 8) {
         int m = m0 + r, f = f0 + tx;
         if (f < p.F && m < p.n_mels) {
@@ -355,29 +379,29 @@ __global__ __launch_bounds__(256) void k_mel_finish(MelFinParams p) {
 // Bands are dealt to waves in order (wave w: bands 32 w ..), so the wide top bands do not set the trip count of every wave.
 #define MSP_F 16
 template <int C>
-__global__ __launch_bounds__(192) void k_mel_banded(MelBandParams p) {
+__global__ __launch_bounds__(256) void k_mel_banded(MelBandParams p) {
     extern __shared__ __attribute__((aligned(16))) float msm[];
     float* rows[2];
     rows[0] = msm;
     rows[1] = msm + (size_t)MSP_F * p.nbp[0];
     float* tile = rows[C - 1] + (size_t)MSP_F * p.nbp[C - 1];          // [C][MSP_F][n_mels + 1]
     const int TS = p.n_mels + 1;
-    const int b = blockIdx.y, f0 = blockIdx.x * MSP_F, nf = min(MSP_F, p.F - f0), tid = threadIdx.x;
+    const int b = blockIdx.y, f0 = blockIdx.x * MSP_F, nf = min(MSP_F, p.F - f0), tid = threadIdx.x, nthr = blockDim.x;
 #pragma unroll
     for (int c = 0; c < C; c++) {
         const float4* src = reinterpret_cast<const float4*>(p.bins[c] + ((size_t)b * p.F + f0) * p.nbp[c]);
         float4* dst = reinterpret_cast<float4*>(rows[c]);
         const int n4 = nf * p.nbp[c] / 4, n4all = MSP_F * p.nbp[c] / 4;  // nbp is a multiple of 4
-        for (int base = 0; base < n4all; base += 4 * 192) {              // four loads in flight per thread
+        for (int base = 0; base < n4all; base += 4 * nthr) {             // four loads in flight per thread
             float4 v[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int i = base + tid + 192 * j;
+                const int i = base + tid + nthr * j;
                 v[j] = i < n4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int i = base + tid + 192 * j;
+                const int i = base + tid + nthr * j;
                 if (i < n4all) dst[i] = v[j];
             }
         }
@@ -410,11 +434,23 @@ __global__ __launch_bounds__(192) void k_mel_banded(MelBandParams p) {
                 }
             }
 #pragma unroll
-            for (int i = 0; i < MSP_F / 2; i++) tile[(c * MSP_F + g * (MSP_F / 2) + i) * TS + m] = mel_pow(acc[i], p.p1[c], p.p2[c]);
+            for (int i = 0; i < MSP_F / 2; i++)
+                tile[(c * MSP_F + g * (MSP_F / 2) + i) * TS + m] = p.log ? mel_log(acc[i], p.lfloor, p.lscale) : mel_pow(acc[i], p.p1[c], p.p2[c]);
         }
     }
     __syncthreads();
-    for (int it = tid; it < p.n_mels * MSP_F; it += 192) {
+    if (p.time_major) {                                  // [B, F, n_mels, Ctot]: mel index fastest
+        for (int it = tid; it < p.n_mels * MSP_F; it += nthr) {
+            const int f = it / p.n_mels, mm = it - f * p.n_mels;
+            if (f < nf) {
+                float* o = p.out + (((size_t)b * p.F + f0 + f) * p.n_mels + mm) * p.Ctot + p.c0;
+                if (C == 2) *reinterpret_cast<float2*>(o) = make_float2(tile[f * TS + mm], tile[(MSP_F + f) * TS + mm]);
+                else o[0] = tile[f * TS + mm];
+            }
+        }
+        return;
+    }
+    for (int it = tid; it < p.n_mels * MSP_F; it += nthr) {
         const int mm = it / MSP_F, f = it % MSP_F;
         if (f < nf) {
             float* o = p.out + (((size_t)b * p.n_mels + mm) * p.F + f0 + f) * p.Ctot + p.c0;
@@ -425,13 +461,14 @@ __global__ __launch_bounds__(192) void k_mel_banded(MelBandParams p) {
 }
 bool mel_banded_supported(int n_mels, int nbp0, int nbp1) {
     size_t lds = (size_t)MSP_F * (nbp0 + nbp1) * 4 + (size_t)2 * MSP_F * (n_mels + 1) * 4;
-    return n_mels <= 96 && (nbp0 & 3) == 0 && (nbp1 & 3) == 0 && lds <= 64 * 1024;
+    return n_mels <= 128 && (nbp0 & 3) == 0 && (nbp1 & 3) == 0 && lds <= 64 * 1024;
 }
 void launch_mel_banded(const MelBandParams& p, int nch, int n_clips, hipStream_t s) {
     size_t lds = (size_t)MSP_F * (p.nbp[0] + (nch == 2 ? p.nbp[1] : 0)) * 4 + (size_t)nch * MSP_F * (p.n_mels + 1) * 4;
     dim3 grid((p.F + MSP_F - 1) / MSP_F, n_clips);
-    if (nch == 2) hipLaunchKernelGGL((k_mel_banded<2>), grid, dim3(192), lds, s, p);
-    else hipLaunchKernelGGL((k_mel_banded<1>), grid, dim3(192), lds, s, p);
+    const dim3 block(p.n_mels <= 96 ? 192 : 256);        // two frame groups of 8 per band
+    if (nch == 2) hipLaunchKernelGGL((k_mel_banded<2>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((k_mel_banded<1>), grid, block, lds, s, p);
 }
 
 void launch_mel_finish(const MelFinParams& p, int nch, int n_clips, hipStream_t s) {

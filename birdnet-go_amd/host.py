@@ -487,6 +487,31 @@ class StreamResampler:
             pass
 
 
+class Perch:
+    """Perch.Predict (classifier/perch_onnx.go:216-255): 160000 samples (32 kHz x 5 s) -> logits (graph output 3 of the
+    reference's ONNX artefact, `:28`) -> perchSoftmax (`:315-335`: max-subtract, exp in float64, float32 running sum) ->
+    label pairing -> top-10, with softmax + top-k on device.  `predict_with_embeddings` is the EmbeddingExtractor face
+    (embedding = graph output 0, [1536])."""
+
+    TOP_K = 10
+
+    def __init__(self, classifier: HipClassifier, labels):
+        if len(labels) != classifier.num_species():
+            raise HipError(E_INVALID, f"label count {len(labels)} != model outputs {classifier.num_species()}")
+        self.classifier, self.labels = classifier, list(labels)
+
+    def predict(self, samples):
+        conf, idx = self.classifier.predict_topk(np.asarray(samples, np.float32), 1, self.TOP_K, 1)
+        return [(self.labels[i], float(c)) for c, i in zip(conf[0], idx[0])]
+
+    def predict_batch(self, flat, batch_size):
+        conf, idx = self.classifier.predict_topk(flat, batch_size, self.TOP_K, 1)
+        return [[(self.labels[i], float(c)) for c, i in zip(cr, ir)] for cr, ir in zip(conf, idx)]
+
+    def predict_with_embeddings(self, samples):
+        return self.classifier.predict_with_embeddings(samples)
+
+
 class BirdNET:
     """(*BirdNET).Predict (classifier/analyze.go:25-110): backend logits -> sigmoid(sensitivity) ->
     label pairing -> top-10, with the post-processing on device."""

@@ -35,6 +35,7 @@ class SpecConfig:
     frame_step: int
     fmin: float
     fmax: float
+    fft_length: int = 0              # 0: = frame_length; larger: frames are zero-padded (PAD) before RFFT2D, as tf.signal.stft does
 
 
 @dataclass
@@ -45,6 +46,12 @@ class SynthConfig:
     n_mels: int = 96
     mag_scale: float = 1.23
     complex_mode: str = "real"       # "real" (CAST complex->float) or "abs" (COMPLEX_ABS)
+    normalize: bool = True           # per-clip min/max normalisation in front of the STFT (v2.4); False: raw samples (Perch-style)
+    pad: tuple = (0, 0)              # zero samples added left / right of the clip before framing (PAD)
+    compress: str = "pow"            # "pow": x^2 then x^(1/(1+exp(mag_scale))) (v2.4);  "log": log_scale * log(max(x, log_floor))
+    log_floor: float = 1e-2
+    log_scale: float = 0.1
+    time_major: bool = False         # True: spectrogram image is [1, frames, mel, 1] (no REVERSE / TRANSPOSE), Perch-style
     stem: int = 32
     # (expand_ratio, kernel, stride, out_channels, repeats)
     blocks: tuple = ((1, 3, 1, 16, 1), (6, 3, 2, 24, 2), (6, 5, 2, 40, 2), (6, 3, 2, 80, 3),
@@ -65,6 +72,33 @@ def tiny_config(**kw):
                 n_mels=32, stem=8,
                 blocks=((1, 3, 1, 8, 1), (6, 3, 2, 12, 2), (6, 5, 2, 20, 1), (6, 3, 1, 24, 1)),
                 top=64, n_classes=50, name="birdnet_tiny_synth")
+    base.update(kw)
+    return SynthConfig(**base)
+
+
+def perch_config(**kw):
+    """Stand-in for Google Perch v2 at its published dimensions (internal/classifier/model_registry.go:168-178: 32 kHz, 5 s,
+    14795 classes; output shapes internal/inference/onnx/classifier.go:495-505: embedding [B,1536], spatial embedding
+    [B,16,4,1536], spectrogram [B,500,128], logits [B,14795]): log-mel front-end (20 ms window / 10 ms hop, 128 bands,
+    60 Hz - 16 kHz, 0.1 * log(max(mag, 1e-2))) producing a 500 x 128 time-major image, EfficientNet-B3-shaped MBConv stack
+    (which turns 500 x 128 into exactly the 16 x 4 x 1536 spatial embedding the reference lists), 1536-d embedding, 14795
+    logits.  The real artefact ships as ONNX and is absent from the snapshot: topology and front-end constants are
+    [EXTERNAL - unverified]; this pins the workload size of BASELINE configs[4], not Perch's numerics."""
+    base = dict(n_samples=160000, sample_rate=32000, specs=(SpecConfig(640, 320, 60.0, 16000.0, 1024),), n_mels=128,
+                complex_mode="abs", normalize=False, pad=(160, 160), compress="log", time_major=True, stem=40,
+                blocks=((1, 3, 1, 24, 2), (6, 3, 2, 32, 3), (6, 5, 2, 48, 3), (6, 3, 2, 96, 5), (6, 5, 1, 136, 5),
+                        (6, 5, 2, 232, 6), (6, 3, 1, 384, 2)),
+                top=1536, n_classes=14795, emit_embeddings=True, head_bias=0.0, seed=2025, name="perch_v2_like_synth")
+    base.update(kw)
+    return SynthConfig(**base)
+
+
+def tiny_perch_config(**kw):
+    """Small geometry with the Perch-style front-end (log-mel, time-major, padded clip, frames shorter than the FFT)."""
+    base = dict(n_samples=8000, sample_rate=32000, specs=(SpecConfig(320, 160, 60.0, 16000.0, 512),), n_mels=32,
+                complex_mode="abs", normalize=False, pad=(80, 80), compress="log", time_major=True, stem=8,
+                blocks=((1, 3, 1, 8, 2), (6, 3, 2, 12, 2), (6, 5, 2, 20, 1), (6, 3, 1, 24, 1)),
+                top=64, n_classes=50, emit_embeddings=True, head_bias=0.0, name="perch_tiny_synth")
     base.update(kw)
     return SynthConfig(**base)
 
@@ -108,22 +142,29 @@ def build_model(cfg: SynthConfig = None) -> bytes:
 
     # ------------------------------------------------------------------ front-end
     chans = []
+    n_pad = cfg.n_samples + cfg.pad[0] + cfg.pad[1]
     for ci, sp in enumerate(cfg.specs):
         L, hop = sp.frame_length, sp.frame_step
-        F = n_frames(cfg.n_samples, L, hop)
-        nb = L // 2 + 1
+        Lfft = sp.fft_length or L
+        F = n_frames(n_pad, L, hop)
+        nb = Lfft // 2 + 1
         pre = f"MEL{ci}/"
-        ax1 = g.const(i32([1]), pre + "axis")
-        mn = g.op("REDUCE_MIN", [x, ax1], [1, 1], dict(keep_dims=1))
-        s1 = g.op("SUB", [x, mn], [1, cfg.n_samples], {})
-        mx = g.op("REDUCE_MAX", [s1, ax1], [1, 1], dict(keep_dims=1))
-        dn = g.op("ADD", [mx, g.const(f32(1e-6))], [1, 1], {})
-        nm = g.op("DIV", [s1, dn], [1, cfg.n_samples], {})
-        n2 = g.op("SUB", [nm, g.const(f32(0.5))], [1, cfg.n_samples], {})
-        xn = g.op("MUL", [n2, g.const(f32(2.0))], [1, cfg.n_samples], {})
+        if cfg.normalize:
+            ax1 = g.const(i32([1]), pre + "axis")
+            mn = g.op("REDUCE_MIN", [x, ax1], [1, 1], dict(keep_dims=1))
+            s1 = g.op("SUB", [x, mn], [1, cfg.n_samples], {})
+            mx = g.op("REDUCE_MAX", [s1, ax1], [1, 1], dict(keep_dims=1))
+            dn = g.op("ADD", [mx, g.const(f32(1e-6))], [1, 1], {})
+            nm = g.op("DIV", [s1, dn], [1, cfg.n_samples], {})
+            n2 = g.op("SUB", [nm, g.const(f32(0.5))], [1, cfg.n_samples], {})
+            xn = g.op("MUL", [n2, g.const(f32(2.0))], [1, cfg.n_samples], {})
+        else:
+            xn = x
+        if cfg.pad != (0, 0):
+            xn = g.op("PAD", [xn, g.const(i32([[0, 0], list(cfg.pad)]), pre + "clip_pad")], [1, n_pad], {})
         # tf.signal.frame: sub-frames of gcd(L,hop) samples, gathered
         sub = gcd(L, hop)
-        nsub = cfg.n_samples // sub
+        nsub = n_pad // sub
         r1 = g.op("RESHAPE", [xn, g.const(i32([1, nsub, sub]))], [1, nsub, sub],
                   dict(new_shape=[1, nsub, sub]))
         sel = (np.arange(F)[:, None] * (hop // sub) + np.arange(L // sub)[None, :]).astype(np.int32)
@@ -131,9 +172,11 @@ def build_model(cfg: SynthConfig = None) -> bytes:
                   dict(axis=1, batch_dims=0))
         fr = g.op("RESHAPE", [ga, g.const(i32([1, F, L]))], [1, F, L], dict(new_shape=[1, F, L]))
         wn = g.op("MUL", [fr, g.const(hann_periodic(L), pre + "hann")], [1, F, L], {})
-        e1 = g.op("RESHAPE", [wn, g.const(i32([1, F, 1, L]))], [1, F, 1, L],
-                  dict(new_shape=[1, F, 1, L]))
-        ft = g.op("RFFT2D", [e1, g.const(i32([1, L]), pre + "fft_length")], [1, F, 1, nb], {},
+        if Lfft != L:
+            wn = g.op("PAD", [wn, g.const(i32([[0, 0], [0, 0], [0, Lfft - L]]), pre + "frame_pad")], [1, F, Lfft], {})
+        e1 = g.op("RESHAPE", [wn, g.const(i32([1, F, 1, Lfft]))], [1, F, 1, Lfft],
+                  dict(new_shape=[1, F, 1, Lfft]))
+        ft = g.op("RFFT2D", [e1, g.const(i32([1, Lfft]), pre + "fft_length")], [1, F, 1, nb], {},
                   out_dtype=S.COMPLEX64)
         sq = g.op("RESHAPE", [ft, g.const(i32([1, F, nb]))], [1, F, nb],
                   dict(new_shape=[1, F, nb]), out_dtype=S.COMPLEX64)
@@ -147,17 +190,27 @@ def build_model(cfg: SynthConfig = None) -> bytes:
                   [F, cfg.n_mels], dict(fused_activation_function=S.ACT_NONE))
         r3 = g.op("RESHAPE", [mm, g.const(i32([1, F, cfg.n_mels]))], [1, F, cfg.n_mels],
                   dict(new_shape=[1, F, cfg.n_mels]))
-        p1 = g.op("POW", [r3, g.const(f32(2.0))], [1, F, cfg.n_mels], {})
-        expo = 1.0 / (1.0 + np.exp(cfg.mag_scale))
-        p2 = g.op("POW", [p1, g.const(f32(expo), pre + "mag_exponent")], [1, F, cfg.n_mels], {})
-        rv = g.op("REVERSE_V2", [p2, g.const(i32([2]))], [1, F, cfg.n_mels], {})
-        tr = g.op("TRANSPOSE", [rv, g.const(i32([0, 2, 1]))], [1, cfg.n_mels, F], {})
-        ex = g.op("RESHAPE", [tr, g.const(i32([1, cfg.n_mels, F, 1]))], [1, cfg.n_mels, F, 1],
-                  dict(new_shape=[1, cfg.n_mels, F, 1]))
+        if cfg.compress == "pow":
+            p1 = g.op("POW", [r3, g.const(f32(2.0))], [1, F, cfg.n_mels], {})
+            expo = 1.0 / (1.0 + np.exp(cfg.mag_scale))
+            cz = g.op("POW", [p1, g.const(f32(expo), pre + "mag_exponent")], [1, F, cfg.n_mels], {})
+        else:
+            fl = g.op("MAXIMUM", [r3, g.const(f32(cfg.log_floor), pre + "log_floor")], [1, F, cfg.n_mels], {})
+            lg = g.op("LOG", [fl], [1, F, cfg.n_mels], {})
+            cz = g.op("MUL", [lg, g.const(f32(cfg.log_scale), pre + "log_scale")], [1, F, cfg.n_mels], {})
+        if cfg.time_major:
+            ex = g.op("RESHAPE", [cz, g.const(i32([1, F, cfg.n_mels, 1]))], [1, F, cfg.n_mels, 1],
+                      dict(new_shape=[1, F, cfg.n_mels, 1]))
+        else:
+            rv = g.op("REVERSE_V2", [cz, g.const(i32([2]))], [1, F, cfg.n_mels], {})
+            tr = g.op("TRANSPOSE", [rv, g.const(i32([0, 2, 1]))], [1, cfg.n_mels, F], {})
+            ex = g.op("RESHAPE", [tr, g.const(i32([1, cfg.n_mels, F, 1]))], [1, cfg.n_mels, F, 1],
+                      dict(new_shape=[1, cfg.n_mels, F, 1]))
         chans.append(ex)
-    H, W = cfg.n_mels, n_frames(cfg.n_samples, cfg.specs[0].frame_length, cfg.specs[0].frame_step)
+    F0 = n_frames(n_pad, cfg.specs[0].frame_length, cfg.specs[0].frame_step)
+    H, W = (F0, cfg.n_mels) if cfg.time_major else (cfg.n_mels, F0)
     for sp in cfg.specs[1:]:
-        assert n_frames(cfg.n_samples, sp.frame_length, sp.frame_step) == W
+        assert n_frames(n_pad, sp.frame_length, sp.frame_step) == F0
     C = len(chans)
     t = g.op("CONCATENATION", chans, [1, H, W, C], dict(axis=3)) if C > 1 else chans[0]
 

@@ -1,0 +1,105 @@
+"""BASELINE configs[4] (Google Perch v2): the log-mel front-end variant and an EfficientNet-B3-shaped stack at Perch's published
+dimensions (synth_model.perch_config: 160000 samples in, 500 x 128 time-major log-mel image, 16 x 4 x 1536 spatial
+embedding, 1536-d embedding, 14795 logits - the shapes the reference lists in internal/inference/onnx/classifier.go:495-505).
+The real artefact is ONNX and absent from the snapshot, so these pin the engine against the oracle on a stand-in, not
+Perch's numerics.  Softmax / top-k follow perchSoftmax (internal/classifier/perch_onnx.go:315-335)."""
+import numpy as np
+import pytest
+
+from birdnet_go_amd import host, synth_model as sm
+from oracle import gofuncs as G
+from oracle.interp import Interpreter
+
+
+def softmax64(v):
+    z = np.asarray(v, np.float64)
+    e = np.exp(z - z.max(axis=-1, keepdims=True))
+    return e / e.sum(axis=-1, keepdims=True)
+
+
+def test_perch_like_plans_with_log_mel_front_end(built_lib):
+    """CPU: the matcher accepts the variant (clip PAD, frames shorter than the FFT, no normalisation, MAXIMUM/LOG/MUL
+    compression, time-major image) and the Perch-size graph plans with every op on a fused kernel."""
+    for cfg, shape in ((sm.tiny_perch_config(), (8000, 50, 64)), (sm.perch_config(), (160000, 14795, 1536))):
+        c = host.HipClassifier(sm.build_model(cfg), plan_only=True)
+        try:
+            assert (c.n_samples, c.num_species(), c.emb_dim) == shape
+            kinds = [s["kernel"] for s in c.describe()["steps"]]
+            assert kinds[:2] == ["stft", "frontend"] and "clip_minmax" not in kinds      # raw samples: no min/max pass
+            assert "elementwise" not in kinds and not any(k.startswith("generic") for k in kinds)
+        finally:
+            c.close()
+
+
+def test_perch_like_oracle_shapes():
+    """CPU: the stand-in's tensors have the shapes the reference lists for Perch v2's outputs."""
+    from oracle.tflite_reader import read_model
+    m = read_model(sm.build_model(sm.perch_config()))
+    shapes = {tuple(int(d) for d in t.shape) for t in m.tensors}
+    assert (1, 500, 128, 1) in shapes and (1, 16, 4, 1536) in shapes and (1, 1536) in shapes and (1, 14795) in shapes
+
+
+def test_front_end_variant_rejects_what_it_cannot_do(built_lib):
+    """CPU: a selector that reaches beyond the padded clip is a malformed graph, not an out-of-bounds read."""
+    cfg = sm.tiny_perch_config(pad=(0, 0))                      # builder sizes the selector from n + pads: consistent
+    host.HipClassifier(sm.build_model(cfg), plan_only=True).close()
+    blob = bytearray(sm.build_model(sm.tiny_perch_config()))
+    # shrink the clip PAD constant [[0,0],[80,80]] -> [[0,0],[0,0]] in place: the selector now overruns
+    pat = np.asarray([[0, 0], [80, 80]], np.int32).tobytes()
+    i = bytes(blob).find(pat)
+    assert i > 0
+    blob[i:i + len(pat)] = np.zeros(4, np.int32).tobytes()
+    with pytest.raises(host.HipError):
+        host.HipClassifier(bytes(blob), plan_only=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["tiny", "tiny_two_lanes", "tiny_fft1024"])
+def test_tiny_perch_like_vs_oracle(gpu, variant):
+    cfg = sm.tiny_perch_config()
+    if variant == "tiny_fft1024":
+        cfg = sm.tiny_perch_config(specs=(sm.SpecConfig(640, 320, 60.0, 16000.0, 1024),), n_samples=16000, pad=(160, 160), n_mels=128)
+    blob = sm.build_model(cfg)
+    n = 37 if variant == "tiny_two_lanes" else 5
+    x = sm.synth_clips(n, cfg.n_samples, cfg.sample_rate)
+    x[1] = 0.0                                                   # silence: every band sits on the log floor
+    x[2, : cfg.n_samples // 2] = 0.0
+    ref = Interpreter(blob).invoke(x)
+    c = host.HipClassifier(blob, max_batch=64)
+    try:
+        got, emb = c.predict_batch(x.reshape(-1), n, want_embeddings=True)
+        assert np.isfinite(got).all()
+        assert (got.argmax(1) == ref[0].argmax(1)).all()
+        assert np.abs(softmax64(got) - softmax64(ref[0])).max() <= 1e-4
+        assert np.abs(got - ref[0]).max() < 1e-3 and np.abs(emb - ref[1]).max() < 1e-3
+        spec_t = next(s for s in c.describe()["steps"] if s["kernel"] == "frontend")
+        assert spec_t
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
+def test_perch_size_vs_oracle_and_softmax_topk(gpu):
+    """Perch dimensions, 3 clips (one silent): logits within the reference's own "EQUIVALENT" band (< 1e-3,
+    cmd/perch-benchmark/main.go:455-462), softmax within 1e-4, embedding within 1e-3; device softmax + top-10 vs the Go
+    restatement of perchSoftmax."""
+    cfg = sm.perch_config()
+    blob = sm.build_model(cfg)
+    x = sm.synth_clips(3, cfg.n_samples, cfg.sample_rate)
+    x[2] = 0.0
+    ref = Interpreter(blob).invoke(x)
+    c = host.HipClassifier(blob, max_batch=8)
+    try:
+        got, emb = c.predict_batch(x.reshape(-1), 3, want_embeddings=True)
+        assert (got.argmax(1) == ref[0].argmax(1)).all()
+        assert np.abs(got - ref[0]).max() < 1e-3 and np.abs(emb - ref[1]).max() < 1e-3
+        assert np.abs(softmax64(got) - softmax64(ref[0])).max() <= 1e-4
+        p = host.Perch(c, [f"sp{i}" for i in range(cfg.n_classes)])
+        top = p.predict_batch(x.reshape(-1), 3)
+        want = np.stack([G.softmax(r) for r in ref[0]])
+        for r in range(3):
+            assert top[r][0][0] == f"sp{int(want[r].argmax())}"
+            assert abs(top[r][0][1] - float(want[r].max())) <= 1e-4
+            assert [t[1] for t in top[r]] == sorted((t[1] for t in top[r]), reverse=True)
+    finally:
+        c.close()
