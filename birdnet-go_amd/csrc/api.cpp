@@ -595,6 +595,15 @@ int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, 
         // default 1: per layer where the create-time autotuner measures the split-bf16 kernel faster (fp32-equivalent
         // products; tests/test_bf16x3.py holds the error comparison against the float64 arbiter that decided the default)
         e->bf16x3 = (int)json_int(opts_json, "bf16x3", benv ? atoi(benv) : 1);
+        {
+            // "precision": "f32" (default) | "bf16": MFMA operands rounded to bf16, fp32 accumulate and storage (BASELINE
+            // configs[4] asks for this on Perch; never the default: v2.4 in reduced precision is known to fail, model_openvino.go:99-103)
+            const char* penv = getenv("BNHIP_PRECISION");
+            std::string prec = json_str(opts_json, "precision", penv ? penv : "f32");
+            if (prec != "f32" && prec != "bf16") { delete m; return set_err(BNHIP_E_INVALID, "precision must be \"f32\" or \"bf16\""); }
+            e->precision = prec == "bf16" ? 1 : 0;
+            if (e->precision && !e->bf16x3) e->bf16x3 = 1;      // the bf16 kernels read the split weight images' first plane
+        }
         e->defer_weights = i > 0 && !plan_only;
         int code = BNHIP_E_UNSUPPORTED;
         TflModel copy = tm;                               // tensors point into the caller's blob / tm-owned storage: cheap

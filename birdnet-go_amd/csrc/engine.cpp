@@ -760,7 +760,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                         int fpt = 0, fpl = 0;
                         conv_pads(d, dH, dW, dHo, dWo, kd, kd, &fpt, &fpl);
                         if (kd == wd.shape[2] && wd.shape[3] == dC && act_d >= 0 && expdw_supported(kd, d.stride_h, C, Co) &&
-                            expdw_sum_slabs(kd, d.stride_h, dH, dHo, dWo, fpt) > 0 && need_val(in_t) >= 0) {
+                            expdw_sum_slabs(ExpDwGeo{kd, d.stride_h, dH, dW, dHo, dWo, fpt, fpl}) > 0 && need_val(in_t) >= 0) {
                             int dout = d.outputs[0];
                             if (act_d == ACT_NONE) dout = trailing_act(dout, &act_d);
                             P.absorbed[di] = 1;
@@ -875,7 +875,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                                     int fpt = 0, fpl = 0;
                                     conv_pads(d, dH, dW, dHo, dWo, kd, kd, &fpt, &fpl);
                                     if (kd == 3 && wd.shape[2] == 3 && wd.shape[3] == dC && act_d >= 0 && s.in0 >= 0 &&
-                                        expdw_sum_slabs(kd, 1, dH, dHo, dWo, fpt) > 0) {
+                                        expdw_sum_slabs(ExpDwGeo{kd, 1, dH, dW, dHo, dWo, fpt, fpl, true}) > 0) {
                                         int dout = d.outputs[0];
                                         if (act_d == ACT_NONE) dout = trailing_act(dout, &act_d);
                                         P.absorbed[di] = 1;
@@ -961,12 +961,13 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                 mp.in0 = vin; mp.H = H; mp.W = W; mp.C = C;
                 if (!steps.empty() && steps.back().kind == S_EXPAND_DW && steps.back().out == vin) {
                     const Step& d = steps.back();
-                    int slabs = expdw_sum_slabs(d.kh, d.sh, d.H, d.Ho, d.Wo, d.pt);
+                    const ExpDwGeo dg{d.kh, d.sh, d.H, d.W, d.Ho, d.Wo, d.pt, d.pl, d.mode == 1};
+                    int slabs = expdw_sum_slabs(dg);
                     if (slabs > 0) {
                         S = slabs;
                         fused_sum = true;
                         // sized for the candidate shape with the most tiles: the autotuner may pick another one
-                        mp.out = new_val(-1, (size_t)expdw_max_slabs(d.kh, d.sh, d.H, d.Ho, d.Wo, d.pt) * C);
+                        mp.out = new_val(-1, (size_t)expdw_max_slabs(dg) * C);
                         steps.back().out2 = mp.out;
                         steps.back().S = S;
                     }
@@ -1572,13 +1573,14 @@ void Engine::autotune_expdw() {
         float* out2 = vptr(s.out2, d_stage_in, d_stage_logits, nullptr);
         float best = 1e30f; int best_idx = -1, best_bx = 0;
         const bool can_bx = s.wbx != nullptr && s.mode != 1 && bf16x3;
+        const ExpDwGeo sg0{s.kh, s.sh, s.H, s.W, s.Ho, s.Wo, s.pt, s.pl, s.mode == 1};
         for (int idx = 0; idx < expdw_num_shapes(); idx++) {
-            if (!expdw_shape_fits(idx, s.kh, s.sh, s.H, s.Ho, s.Wo, s.pt)) continue;
+            if (!expdw_shape_fits(idx, sg0)) continue;
             for (int bx = (can_bx && bf16x3 >= 2) ? 1 : 0; bx <= (can_bx ? 1 : 0); bx++) {
                 auto go = [&]() {
                     StemGeom sg{s.H2, s.W2, s.pt2, s.pl2};
                     launch_expand_dw(in0, s.w0, s.w1, s.w2, s.w3, out, out2, n, s.H, s.W, s.C, s.Co, s.Ho, s.Wo, s.kh, s.sh, s.pt, s.pl,
-                                     s.act, s.act2, idx, s.mode == 1 ? &sg : nullptr, stream, bx ? s.wbx : nullptr);
+                                     s.act, s.act2, idx, s.mode == 1 ? &sg : nullptr, stream, bx ? s.wbx : nullptr, precision);
                 };
                 go();
                 hipEventRecord(a, stream);
@@ -1594,7 +1596,7 @@ void Engine::autotune_expdw() {
         s.shape = best_idx;
         s.bx = best_bx;
         if (s.out2 >= 0) {                       // the consumers of the per-tile sums index them by tile count
-            s.S = expdw_shape_slabs(best_idx, s.Ho, s.Wo);
+            s.S = expdw_shape_slabs(best_idx, sg0);
             for (auto& c : steps) if (&c != &s && c.in0 == s.out2) c.S = s.S;
         }
     }
@@ -1656,6 +1658,7 @@ void Engine::autotune_pw() {
                         if (cols * 100 > (long)((s.Co + 15) / 16 * 16) * 130) continue;
                         if (wm >= 7 && !pw_bx3p_ok(nt, wm - 6, s.C)) continue;
                         PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, nt, wm};
+                        p.prec = precision;
                         launch_pw_bx3(p, s.wbx, stream);
                         hipEventRecord(a, stream);
                         for (int r = 0; r < 3; r++) launch_pw_bx3(p, s.wbx, stream);
@@ -1665,7 +1668,7 @@ void Engine::autotune_pw() {
                         if (getenv("BNHIP_DEBUG")) fprintf(stderr, "[bnhip] tune %-16s n=%d M=%d N=%d K=%d nt=%d wm=%d (bf16x3): %.1f us (%.1f TF fp32-equivalent)\n", s.name.c_str(), n, n * s.H * s.W, s.Co, s.C, nt, wm, ms / 3 * 1e3, 2.0 * n * s.H * s.W * s.Co * s.C / (ms / 3 * 1e-3) / 1e12);
                         if (ms < bbest * 0.98f) { bbest = ms; bnt = nt; bwm = wm; }
                     }
-                if (bnt && (bf16x3 >= 2 || bbest < best * 0.97f)) { best_nt = bnt; best_wm = bwm; }
+                if (bnt && (bf16x3 >= 2 || bbest < best * (precision ? 1.0f : 0.97f))) { best_nt = bnt; best_wm = bwm; }
             }
             if (pass == 0) { s.nt = best_nt; s.wm = best_wm; } else { s.nt_full = best_nt; s.wm_full = best_wm; }
         }
@@ -1850,6 +1853,7 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
             case S_PW: {
                 PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, nl > 1 ? s.nt : s.nt_full,
                            nl > 1 ? s.wm : s.wm_full};
+                p.prec = precision;
                 if (p.wm >= 5 && s.wbx) launch_pw_bx3(p, s.wbx, stream);
                 else launch_pw_gemm(p, stream);
                 break;
@@ -1864,7 +1868,7 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
                     StemGeom sg{s.H2, s.W2, s.pt2, s.pl2};
                     launch_expand_dw(in0, s.w0, s.w1, s.w2, s.w3, out, out2, n, s.H, s.W, s.C, s.Co,
                                      s.Ho, s.Wo, s.kh, s.sh, s.pt, s.pl, s.act, s.act2, s.shape, s.mode == 1 ? &sg : nullptr, stream,
-                                     s.bx ? s.wbx : nullptr);
+                                     s.bx ? s.wbx : nullptr, precision);
                 }
                 break;
             case S_MEAN_PARTIAL:
@@ -1956,7 +1960,7 @@ static void jesc(std::ostringstream& os, const std::string& s) {
 std::string Engine::describe() const {
     std::ostringstream os;
     os << "{\"n_samples\":" << n_samples << ",\"n_classes\":" << n_classes << ",\"emb_dim\":" << emb_dim
-       << ",\"max_batch\":" << max_batch << ",\"lanes\":" << n_lanes << ",\"lane_min_batch\":" << dual_lane_min << ",\"act_arena_bytes\":" << act_bytes << ",\"weight_bytes\":" << w_bytes
+       << ",\"max_batch\":" << max_batch << ",\"precision\":\"" << (precision ? "bf16" : "f32") << "\",\"lanes\":" << n_lanes << ",\"lane_min_batch\":" << dual_lane_min << ",\"act_arena_bytes\":" << act_bytes << ",\"weight_bytes\":" << w_bytes
        << ",\"specs\":[";
     for (size_t i = 0; i < specs.size(); i++) {
         const FrontSpec& f = specs[i];

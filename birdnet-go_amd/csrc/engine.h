@@ -96,6 +96,8 @@ class Engine {
     char* weights_ptr() const { return w_arena; }
     size_t weights_bytes() const { return w_bytes; }
     int frontend_fft = -1;              // -1 / 1: FFT path where the frame length is supported (512/1024/2048), 0: folded-GEMM kernel for real-part graphs
+    int precision = 0;                  // 0: fp32 products everywhere (f32 MFMA or the six-product split); 1 ("precision":"bf16"): the MFMA
+                                        // layers round their operands to bf16 (one product, fp32 accumulate) - Perch-style deployments
     int bf16x3 = 0;                     // split-bf16 MFMA path for pointwise / dense layers (k_pw_bx3): 0 off, 1 per layer where the
                                         // create-time autotuner measures it faster, 2 every eligible layer (parity tests)
     bool use_graphs = false;            // opt-in: replay the plan as a hipGraph once a (pointers, n) combination repeats (measured: no gain on ROCm 7.2)

@@ -88,6 +88,8 @@ struct PwParams {         // pointwise conv / fully-connected as GEMM: out[M,N] 
     int M, N, K, HW, act;
     int nt = 0;           // N-tile width in 16-column units (1..8); 0 = built-in heuristic
     int wm = 0;           // row tile: 1 = 64 rows per block, otherwise 128; 3 / 4 = the same tiles on k_pw_pipe
+    int prec = 0;         // k_pw_bx3 only: 0 = six bf16 products per fp32 product (fp32-equivalent), 1 = one (plain bf16 operands,
+                          // fp32 accumulate: the "precision":"bf16" engines)
 };
 void launch_pw_gemm(const PwParams& p, hipStream_t s);
 bool pw_pipe_ok(int nt, int wm, int K);   // PwParams::wm = 2 + wm selects the software-pipelined kernel (k_pw_pipe)
@@ -112,12 +114,17 @@ void launch_dwconv(const DwParams& p, float* partial, hipStream_t s);
 
 // fused MBConv front half: y = act_d(dwconv(act_e(x We^T + be)) + bd); partial (nullable) [B, slabs, Cmid]
 bool expdw_supported(int k, int s, int Cin, int Cmid);
-int expdw_sum_slabs(int k, int s, int H, int Ho, int Wo, int pt);   // slabs of the cost-model shape; 0 = no tile shape fits (do not fuse)
-int expdw_num_shapes();
-bool expdw_shape_fits(int idx, int k, int s, int H, int Ho, int Wo, int pt);
-int expdw_shape_slabs(int idx, int Ho, int Wo);
-int expdw_default_shape(int k, int s, int H, int Ho, int Wo, int pt);
-int expdw_max_slabs(int k, int s, int H, int Ho, int Wo, int pt);
+// Layer geometry for the tile-shape helpers.  Shape indices 0 .. n-1 are the instantiated tile shapes in image orientation;
+// n .. 2n-1 the same shapes with the roles of rows and columns swapped (tall, narrow images - a time-major spectrogram -
+// tile badly with 16- / 32-column tiles): the kernel then walks the image through pixel strides and reads the depthwise taps
+// transposed.  `stem` layers (raw-image variant) only exist in image orientation.
+struct ExpDwGeo { int k, s, H, W, Ho, Wo, pt, pl; bool stem = false; };
+int expdw_sum_slabs(const ExpDwGeo& g);   // slabs of the cost-model shape; 0 = no tile shape fits (do not fuse)
+int expdw_num_shapes();                   // 2n
+bool expdw_shape_fits(int idx, const ExpDwGeo& g);
+int expdw_shape_slabs(int idx, const ExpDwGeo& g);
+int expdw_default_shape(const ExpDwGeo& g);
+int expdw_max_slabs(const ExpDwGeo& g);
 struct StemGeom { int Hin, Win, pt, pl; };   // raw image size and the stem conv's top/left padding
 // parameters are the planner's padded copies: we [expdw_cp(Cmid)][expdw_kw(Cin)], be/bd [Cp], wd [k*k][Cp] (zeros beyond)
 int expdw_kw(int Cin);
@@ -126,7 +133,8 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
                       float* partial, int B, int H, int W, int Cin, int Cmid, int Ho, int Wo, int k, int s, int pt,
                       int pl, int act_e, int act_d, int shape /* index into the shape table; -1 = cost model */,
                       const StemGeom* stem /* non-null: x is the raw image and the expand is the 3x3/2 stem (see kernels.hip) */,
-                      hipStream_t st, const uint16_t* wep = nullptr /* non-null: phase 1 on the split-bf16 MFMA (expdw_bx_image) */);
+                      hipStream_t st, const uint16_t* wep = nullptr /* non-null: phase 1 on the split-bf16 MFMA (expdw_bx_image) */,
+                      int prec = 0 /* with wep: 1 = plain bf16 operands (one product) */);
 bool expdw_bx_ok(int Cin);
 int expdw_kp(int Cin);
 std::vector<uint16_t> expdw_bx_image(const float* We /*[Cmid][Cin]*/, int Cmid, int Cin);

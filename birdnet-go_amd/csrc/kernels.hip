@@ -1081,6 +1081,16 @@ __device__ __forceinline__ void bx3_split8(const f32x4& a, const f32x4& b, bf16x
     *hi = __builtin_bit_cast(bf16x8, h); *mid = __builtin_bit_cast(bf16x8, m); *lo = __builtin_bit_cast(bf16x8, l);
 }
 
+// plain bf16 operands (PwParams::prec = 1): round to nearest even, no remainders
+__device__ __forceinline__ bf16x8 bx1_cvt8(const f32x4& a, const f32x4& b) {
+    u32x4 h;
+    h[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a[0], a[1]}, bf16x2));
+    h[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a[2], a[3]}, bf16x2));
+    h[2] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){b[0], b[1]}, bf16x2));
+    h[3] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){b[2], b[3]}, bf16x2));
+    return __builtin_bit_cast(bf16x8, h);
+}
+
 static int pick_nt(int M, int N);
 template <int NT, bool SC, int WM>
 __global__ __launch_bounds__(256) void k_pw_bx3(PwParams p, const uint16_t* __restrict__ Wimg, int Npad, int nblk_n, unsigned nblk,
@@ -1102,6 +1112,9 @@ __global__ __launch_bounds__(256) void k_pw_bx3(PwParams p, const uint16_t* __re
     const int K = p.K;
 
     unsigned xoff[XQ], soff[SC ? XQ : 1], woff[WQ];
+    const bool one = p.prec == 1;                          // plain bf16: only the hi plane of the weights, one product
+    const int wslots = one ? WSLOTS / 3 : WSLOTS;
+    const int kc4 = 4 * (tid % PW_C4);                     // this thread's column inside a slab (the same for every q: 256 % PW_C4 == 0)
     const int lbase = (tid / PW_C4) * PW_LS + 4 * (tid % PW_C4);
     constexpr int LQ = (256 / PW_C4) * PW_LS;
 #pragma unroll
@@ -1122,14 +1135,16 @@ __global__ __launch_bounds__(256) void k_pw_bx3(PwParams p, const uint16_t* __re
     const u32x4* W16 = reinterpret_cast<const u32x4*>(Wimg);
     auto gload = [&](int sl) {
         const float* Ak = p.A + sl * PW_BK;
+        const bool kin = sl * PW_BK + kc4 < K;             // K tail (K % 32 != 0): columns beyond K are zeros (their weights too)
 #pragma unroll
         for (int q = 0; q < XQ; q++) {
-            xreg[q] = *reinterpret_cast<const float4*>(Ak + xoff[q]);
-            if (SC) sreg[SC ? q : 0] = *reinterpret_cast<const float4*>(p.ascale + sl * PW_BK + soff[SC ? q : 0]);
+            xreg[q] = kin ? *reinterpret_cast<const float4*>(Ak + xoff[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (SC) sreg[SC ? q : 0] = kin ? *reinterpret_cast<const float4*>(p.ascale + sl * PW_BK + soff[SC ? q : 0]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const u32x4* Ws = W16 + (size_t)sl * 12 * Npad;
 #pragma unroll
-        for (int q = 0; q < WQ; q++) wreg[q] = Ws[woff[q]];
+        for (int q = 0; q < WQ; q++)
+            if (tid + 256 * q < wslots) wreg[q] = Ws[woff[q]];
     };
     u32x4* Wl = reinterpret_cast<u32x4*>(lds + BM * PW_LS);
     auto lstore = [&]() {
@@ -1141,7 +1156,7 @@ __global__ __launch_bounds__(256) void k_pw_bx3(PwParams p, const uint16_t* __re
         }
 #pragma unroll
         for (int q = 0; q < WQ; q++)
-            if (WSLOTS % 256 == 0 || tid + 256 * q < WSLOTS) Wl[tid + 256 * q] = wreg[q];
+            if (tid + 256 * q < wslots) Wl[tid + 256 * q] = wreg[q];
     };
 
     f32x4 acc[NT][WM];
@@ -1150,13 +1165,26 @@ __global__ __launch_bounds__(256) void k_pw_bx3(PwParams p, const uint16_t* __re
 #pragma unroll
         for (int mt = 0; mt < WM; mt++) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nslab = K / PW_BK;
+    const int nslab = (K + PW_BK - 1) / PW_BK;
     gload(0);
     lstore();
     if (nslab > 1) gload(1);
     __syncthreads();
     for (int sl = 0; sl < nslab; sl++) {
         bf16x8 ah[WM], am[WM], al[WM];
+        if (one) {
+#pragma unroll
+            for (int mt = 0; mt < WM; mt++) {
+                const float* xr = &lds[(16 * WM * wave + 16 * mt + li) * PW_LS + 4 * kq];
+                ah[mt] = bx1_cvt8(*reinterpret_cast<const f32x4*>(xr), *reinterpret_cast<const f32x4*>(xr + 16));
+            }
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const bf16x8 wh = __builtin_bit_cast(bf16x8, Wl[kq * (NT * 16) + 16 * t + li]);
+#pragma unroll
+                for (int mt = 0; mt < WM; mt++) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[mt], acc[t][mt], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int mt = 0; mt < WM; mt++) {
             const float* xr = &lds[(16 * WM * wave + 16 * mt + li) * PW_LS + 4 * kq];
@@ -1188,6 +1216,7 @@ __global__ __launch_bounds__(256) void k_pw_bx3(PwParams p, const uint16_t* __re
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[mt], c, 0, 0, 0);
                 acc[t][mt] = c;
             }
+        }
         }
         if (sl + 1 < nslab) {
             __syncthreads();                 // everyone is done reading the single operand buffer
@@ -1223,6 +1252,9 @@ __global__ __launch_bounds__(256) void k_pw_bx3p(PwParams p, const uint16_t* __r
     const int K = p.K;
 
     unsigned xoff[XQ], soff[SC ? XQ : 1], woff[WQ];
+    const bool one = p.prec == 1;                          // plain bf16: only the hi plane of the weights, one product
+    const int wslots = one ? WSLOTS / 3 : WSLOTS;
+    const int kc4 = 4 * (tid % PW_C4);                     // this thread's column inside a slab (the same for every q: 256 % PW_C4 == 0)
     const int lbase = (tid / PW_C4) * PW_LS + 4 * (tid % PW_C4);
     constexpr int LQ = (256 / PW_C4) * PW_LS;
 #pragma unroll
@@ -1243,14 +1275,16 @@ __global__ __launch_bounds__(256) void k_pw_bx3p(PwParams p, const uint16_t* __r
     const u32x4* W16 = reinterpret_cast<const u32x4*>(Wimg);
     auto gload = [&](int sl) {
         const float* Ak = p.A + sl * PW_BK;
+        const bool kin = sl * PW_BK + kc4 < K;             // K tail (K % 32 != 0): columns beyond K are zeros (their weights too)
 #pragma unroll
         for (int q = 0; q < XQ; q++) {
-            xreg[q] = *reinterpret_cast<const float4*>(Ak + xoff[q]);
-            if (SC) sreg[SC ? q : 0] = *reinterpret_cast<const float4*>(p.ascale + sl * PW_BK + soff[SC ? q : 0]);
+            xreg[q] = kin ? *reinterpret_cast<const float4*>(Ak + xoff[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (SC) sreg[SC ? q : 0] = kin ? *reinterpret_cast<const float4*>(p.ascale + sl * PW_BK + soff[SC ? q : 0]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const u32x4* Ws = W16 + (size_t)sl * 12 * Npad;
 #pragma unroll
-        for (int q = 0; q < WQ; q++) wreg[q] = Ws[woff[q]];
+        for (int q = 0; q < WQ; q++)
+            if (tid + 256 * q < wslots) wreg[q] = Ws[woff[q]];
     };
     auto lstore = [&](float* buf) {
 #pragma unroll
@@ -1262,7 +1296,7 @@ __global__ __launch_bounds__(256) void k_pw_bx3p(PwParams p, const uint16_t* __r
         u32x4* Wl = reinterpret_cast<u32x4*>(buf + BM * PW_LS);
 #pragma unroll
         for (int q = 0; q < WQ; q++)
-            if (WSLOTS % 256 == 0 || tid + 256 * q < WSLOTS) Wl[tid + 256 * q] = wreg[q];
+            if (tid + 256 * q < wslots) Wl[tid + 256 * q] = wreg[q];
     };
 
     f32x4 acc[NT][WM];
@@ -1271,7 +1305,7 @@ __global__ __launch_bounds__(256) void k_pw_bx3p(PwParams p, const uint16_t* __r
 #pragma unroll
         for (int mt = 0; mt < WM; mt++) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nslab = K / PW_BK;
+    const int nslab = (K + PW_BK - 1) / PW_BK;
     gload(0);
     lstore(lds);
     if (nslab > 1) gload(1);
@@ -1281,6 +1315,24 @@ __global__ __launch_bounds__(256) void k_pw_bx3p(PwParams p, const uint16_t* __r
         const u32x4* Wl = reinterpret_cast<const u32x4*>(Xs + BM * PW_LS);
         float* nxt = lds + ((sl + 1) & 1) * TILE_F;
         bf16x8 ah[WM], am[WM], al[WM];
+        if (one) {
+#pragma unroll
+            for (int mt = 0; mt < WM; mt++) {
+                const float* xr = &Xs[(16 * WM * wave + 16 * mt + li) * PW_LS + 4 * kq];
+                ah[mt] = bx1_cvt8(*reinterpret_cast<const f32x4*>(xr), *reinterpret_cast<const f32x4*>(xr + 16));
+            }
+            bf16x8 wh1[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) wh1[t] = __builtin_bit_cast(bf16x8, Wl[kq * (NT * 16) + 16 * t + li]);
+            if (decltype(DS)::value) lstore(nxt);
+            if (decltype(DL)::value) gload(sl + 2);
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int mt = 0; mt < WM; mt++) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh1[t], ah[mt], acc[t][mt], 0, 0, 0);
+            __syncthreads();
+            return;
+        }
 #pragma unroll
         for (int mt = 0; mt < WM; mt++) {
             const float* xr = &Xs[(16 * WM * wave + 16 * mt + li) * PW_LS + 4 * kq];
@@ -1323,14 +1375,15 @@ __global__ __launch_bounds__(256) void k_pw_bx3p(PwParams p, const uint16_t* __r
     pw_epilogue<NT, WM>(p, acc, lds, m0, n0);
 }
 static size_t bx3p_lds_bytes(int nt, int wm) { return 2 * ((size_t)64 * wm * PW_LS + (size_t)12 * nt * 16 * 4) * sizeof(float); }
-bool pw_bx3p_ok(int nt, int wm, int K) { return K % PW_BK == 0 && K >= 2 * PW_BK && bx3p_lds_bytes(nt, wm) <= 80 * 1024; }
+bool pw_bx3p_ok(int nt, int wm, int K) { return pw_bx3_ok(K) && K > PW_BK && bx3p_lds_bytes(nt, wm) <= 80 * 1024; }
 
-// Plan-time weight image for k_pw_bx3: W [N][K] fp32 -> uint16 [K/32 slabs][3 planes][4 kq][Npad rows][8], Npad = N rounded up
-// to 16 (rows beyond N are zeros), the 8 values of a (row, kq) slot being k = 32 s + 4 kq + (0..3) and 32 s + 16 + 4 kq + (0..3).
-bool pw_bx3_ok(int K) { return K >= PW_BK && K % PW_BK == 0; }
+// Plan-time weight image for k_pw_bx3: W [N][K] fp32 -> uint16 [ceil(K/32) slabs][3 planes][4 kq][Npad rows][8], Npad = N rounded
+// up to 16 (rows beyond N are zeros), the 8 values of a (row, kq) slot being k = 32 s + 4 kq + (0..3) and 32 s + 16 + 4 kq + (0..3);
+// a K tail (K % 32 != 0, K % 4 == 0) is zero weights against zero-filled operand columns.
+bool pw_bx3_ok(int K) { return K >= 16 && K % 4 == 0; }
 int pw_bx3_npad(int N) { return (N + 15) / 16 * 16; }
 std::vector<uint16_t> pw_bx3_image(const float* W, int N, int K) {
-    const int Npad = pw_bx3_npad(N), nslab = K / PW_BK;
+    const int Npad = pw_bx3_npad(N), nslab = (K + PW_BK - 1) / PW_BK;
     std::vector<uint16_t> img((size_t)nslab * 12 * Npad * 8, 0);
     for (int n = 0; n < N; n++)
         for (int k = 0; k < K; k++) {
@@ -1689,6 +1742,11 @@ struct ExpDwParams {
     // GEMM (K layout of k_stem_mfma); H, W above are then the stem's output size
     int Hin = 0, Win = 0, pts = 0, pls = 0;
     const uint16_t* wep = nullptr; int Kp = 0;   // BX variant: split-bf16 expand weights [Cp][3][Kp]
+    int prec = 0;                                // BX variant: 1 = plain bf16 operands (one product), as PwParams::prec
+    // pixel strides of the input / output image as the kernel's (row, column) walk them: (W, 1) / (Wo, 1) in image orientation,
+    // (1, W') / (1, Wo') when rows and columns are swapped (tr = 1: H, W, Ho, Wo, pt, pl above are then the swapped values and
+    // the depthwise taps are read transposed)
+    int xsh = 0, xsw = 1, ysh = 0, ysw = 1, tr = 0;
     FDiv d_bpc{}, d_cch{}, d_tw{};      // blocks per clip, channel chunks, tiles per row (set by the launcher)
 };
 #define ED_ES 36     // E row stride (floats)
@@ -1770,7 +1828,10 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
     const int pl = ed_perm(PERM, lane);                  // logical lane: tx * 8 + c4
     const int c4 = pl & 7, tt = (wave << 3) | (pl >> 3);
     float4 wdreg = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < K * K * 8) wdreg = *reinterpret_cast<const float4*>(p.wd + (size_t)(tid >> 3) * p.Cp + n_base + 4 * (tid & 7));
+    if (tid < K * K * 8) {
+        const int tap = tid >> 3, tsrc = p.tr ? (tap % K) * K + tap / K : tap;
+        wdreg = *reinterpret_cast<const float4*>(p.wd + (size_t)tsrc * p.Cp + n_base + 4 * (tid & 7));
+    }
     const float4 bq0 = *reinterpret_cast<const float4*>(p.be + n_base + 4 * kq);
     const float4 bq1 = *reinterpret_cast<const float4*>(p.be + n_base + 16 + 4 * kq);
     const float4 bv = *reinterpret_cast<const float4*>(p.bd + n_base + 4 * c4);
@@ -1787,7 +1848,7 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
         xin[a] = j < nvalid && iw >= 0 && iw < p.W;
         int ihc = min(ih0 + vr0 + r, p.H - 1), iwc = min(max(iw, 0), p.W - 1);
         if (STEM) { xoff[a] = ihc * 2 - p.pts; scol[a] = iwc * 2 - p.pls + (kq & 1) * 2; }
-        else { xoff[a] = (((b * p.H + ihc) * p.W) + iwc) * Cin + (BX ? 8 : 4) * kq; scol[a] = 0; }
+        else { xoff[a] = (b * p.H * p.W + ihc * p.xsh + iwc * p.xsw) * Cin + (BX ? 8 : 4) * kq; scol[a] = 0; }
     }
     const float* xb = STEM ? p.x + (size_t)b * p.Hin * p.Win * 2 : p.x;
     const float* wrow0 = p.we + (size_t)(n_base + li) * Kw + 4 * kq;
@@ -1876,11 +1937,25 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
         const unsigned kp8 = (unsigned)p.Kp >> 3;
         const unsigned wr0 = (unsigned)(n_base + li) * 3u * kp8 + (unsigned)kq, wr1 = wr0 + 48u * kp8;
         for (int s32 = 0; s32 < (p.Kp >> 5); s32++) {
+            // this lane's 8 channels lie inside the real K, or their weights are zero and any valid address will do
+            const int kx = (32 * s32 + 8 * kq + 7 < Cin) ? 32 * s32 : -8 * kq;
+            if (p.prec == 1) {                               // plain bf16 operands: hi plane only, one product
+                const bf16x8 w0 = __builtin_bit_cast(bf16x8, wimg[wr0 + 4 * s32]), w1 = __builtin_bit_cast(bf16x8, wimg[wr1 + 4 * s32]);
+#pragma unroll
+                for (int a = 0; a < JTW; a++) {
+                    if (wave + 4 * a < jtv) {
+                        const float* xq = p.x + (size_t)xoff[a] + kx;
+                        const float4 t0 = *reinterpret_cast<const float4*>(xq), t1 = *reinterpret_cast<const float4*>(xq + 4);
+                        const bf16x8 xh = bx1_cvt8((f32x4){t0.x, t0.y, t0.z, t0.w}, (f32x4){t1.x, t1.y, t1.z, t1.w});
+                        acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xh, acc[a][0], 0, 0, 0);
+                        acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xh, acc[a][1], 0, 0, 0);
+                    }
+                }
+                continue;
+            }
             u32x4 wq[2][3];
 #pragma unroll
             for (int pl3 = 0; pl3 < 3; pl3++) { wq[0][pl3] = wimg[wr0 + pl3 * kp8 + 4 * s32]; wq[1][pl3] = wimg[wr1 + pl3 * kp8 + 4 * s32]; }
-            // this lane's 8 channels lie inside the real K, or their weights are zero and any valid address will do
-            const int kx = (32 * s32 + 8 * kq + 7 < Cin) ? 32 * s32 : -8 * kq;
 #pragma unroll
             for (int a = 0; a < JTW; a++) {
                 if (wave + 4 * a < jtv) {
@@ -2029,7 +2104,7 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
                 int ow = ow0 + tx * SW + c;
                 if (ow >= p.Wo) continue;
                 float4 v = acc2[a][c];
-                *reinterpret_cast<float4*>(p.y + (((size_t)b * p.Ho + oh) * p.Wo + ow) * p.Cmid + n) = v;
+                *reinterpret_cast<float4*>(p.y + ((size_t)b * p.Ho * p.Wo + (size_t)oh * p.ysh + (size_t)ow * p.ysw) * p.Cmid + n) = v;
                 sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
             }
         }
@@ -2081,42 +2156,58 @@ static long expdw_cost(const ExpDwShape& sh, int H, int Ho, int Wo, int pt, bool
     }
     return rows * tiw * tw;
 }
-int expdw_num_shapes() { return (int)(sizeof(kExpDwShapes) / sizeof(kExpDwShapes[0])); }
-bool expdw_shape_fits(int idx, int k, int s, int H, int Ho, int Wo, int pt) {
-    if (idx < 0 || idx >= expdw_num_shapes()) return false;
-    const ExpDwShape& sh = kExpDwShapes[idx];
-    if (sh.k != k || sh.s != s) return false;
+static const int kNumExpDwShapes = (int)(sizeof(kExpDwShapes) / sizeof(kExpDwShapes[0]));
+int expdw_num_shapes() { return 2 * kNumExpDwShapes; }
+// the geometry as the kernel walks it for shape index idx (rows and columns swapped for idx >= n)
+static ExpDwGeo expdw_oriented(int idx, const ExpDwGeo& g) {
+    if (idx < kNumExpDwShapes) return g;
+    ExpDwGeo t = g;
+    t.H = g.W; t.W = g.H; t.Ho = g.Wo; t.Wo = g.Ho; t.pt = g.pl; t.pl = g.pt;
+    return t;
+}
+bool expdw_shape_fits(int idx, const ExpDwGeo& g0) {
+    if (idx < 0 || idx >= 2 * kNumExpDwShapes) return false;
+    if (idx >= kNumExpDwShapes && g0.stem) return false;
+    if (!g0.stem) {                                      // BNHIP_EXPDW_ORIENT = n | t: one orientation only (tests, A/B runs)
+        const char* oe = getenv("BNHIP_EXPDW_ORIENT");
+        if (oe && ((oe[0] == 'n' && idx >= kNumExpDwShapes) || (oe[0] == 't' && idx < kNumExpDwShapes))) return false;
+    }
+    const ExpDwShape& sh = kExpDwShapes[idx % kNumExpDwShapes];
+    if (sh.k != g0.k || sh.s != g0.s) return false;
+    const ExpDwGeo g = expdw_oriented(idx, g0);
     bool fits;
-    (void)expdw_cost(sh, H, Ho, Wo, pt, &fits);
+    (void)expdw_cost(sh, g.H, g.Ho, g.Wo, g.pt, &fits);
     return fits;
 }
-int expdw_shape_slabs(int idx, int Ho, int Wo) {
-    const ExpDwShape& sh = kExpDwShapes[idx];
-    return ((Ho + sh.toh - 1) / sh.toh) * ((Wo + sh.tow - 1) / sh.tow);
+int expdw_shape_slabs(int idx, const ExpDwGeo& g0) {
+    const ExpDwShape& sh = kExpDwShapes[idx % kNumExpDwShapes];
+    const ExpDwGeo g = expdw_oriented(idx, g0);
+    return ((g.Ho + sh.toh - 1) / sh.toh) * ((g.Wo + sh.tow - 1) / sh.tow);
 }
 // cost-model choice (fewest expanded pixels); the engine's create-time autotuner may override it per layer
-int expdw_default_shape(int k, int s, int H, int Ho, int Wo, int pt) {
+int expdw_default_shape(const ExpDwGeo& g0) {
     int best = -1;
     long best_cost = 0;
-    for (int i = 0; i < expdw_num_shapes(); i++) {
-        if (!expdw_shape_fits(i, k, s, H, Ho, Wo, pt)) continue;
+    for (int i = 0; i < 2 * kNumExpDwShapes; i++) {
+        if (!expdw_shape_fits(i, g0)) continue;
+        const ExpDwGeo g = expdw_oriented(i, g0);
+        const ExpDwShape& sh = kExpDwShapes[i % kNumExpDwShapes];
         bool fits;
-        long c = expdw_cost(kExpDwShapes[i], H, Ho, Wo, pt, &fits);
-        const ExpDwShape& sh = kExpDwShapes[i];
+        long c = expdw_cost(sh, g.H, g.Ho, g.Wo, g.pt, &fits);
         const long lds = (long)sh.trh * ((sh.tow - 1) * sh.s + sh.k) * ED_ES * 4;
         if (lds > 51 * 1024) c += c / 3;                // fewer than three blocks per CU: measured to outweigh a smaller halo
         if (best < 0 || c < best_cost) { best = i; best_cost = c; }
     }
     return best;
 }
-int expdw_sum_slabs(int k, int s, int H, int Ho, int Wo, int pt) {
-    int idx = expdw_default_shape(k, s, H, Ho, Wo, pt);
-    return idx < 0 ? 0 : expdw_shape_slabs(idx, Ho, Wo);
+int expdw_sum_slabs(const ExpDwGeo& g) {
+    int idx = expdw_default_shape(g);
+    return idx < 0 ? 0 : expdw_shape_slabs(idx, g);
 }
-int expdw_max_slabs(int k, int s, int H, int Ho, int Wo, int pt) {
+int expdw_max_slabs(const ExpDwGeo& g) {
     int mx = 0;
-    for (int i = 0; i < expdw_num_shapes(); i++)
-        if (expdw_shape_fits(i, k, s, H, Ho, Wo, pt)) mx = std::max(mx, expdw_shape_slabs(i, Ho, Wo));
+    for (int i = 0; i < 2 * kNumExpDwShapes; i++)
+        if (expdw_shape_fits(i, g)) mx = std::max(mx, expdw_shape_slabs(i, g));
     return mx;
 }
 // split-bf16 expand weights: [Cp][3][Kp] bf16 in natural k order (a lane reads 8 consecutive k = one 16-byte unit per plane)
@@ -2147,18 +2238,23 @@ bool expdw_supported(int k, int s, int Cin, int Cmid) {
 }
 void launch_expand_dw(const float* x, const float* we, const float* be, const float* wd, const float* bd, float* y,
                       float* partial, int B, int H, int W, int Cin, int Cmid, int Ho, int Wo, int k, int s, int pt,
-                      int pl, int act_e, int act_d, int shape, const StemGeom* stem, hipStream_t st, const uint16_t* wep) {
-    if (!expdw_shape_fits(shape, k, s, H, Ho, Wo, pt)) shape = expdw_default_shape(k, s, H, Ho, Wo, pt);
+                      int pl, int act_e, int act_d, int shape, const StemGeom* stem, hipStream_t st, const uint16_t* wep, int prec) {
+    const ExpDwGeo g0{k, s, H, W, Ho, Wo, pt, pl, stem != nullptr};
+    if (!expdw_shape_fits(shape, g0)) shape = expdw_default_shape(g0);
     if (shape < 0) return;                             // the planner only fuses layers some shape accepts
-    const ExpDwShape* sh = &kExpDwShapes[shape];
-    ExpDwParams p{x, we, be, wd, bd, y, partial, B, H, W, Cin, Cmid, Ho, Wo, pt, pl, act_e, act_d,
-                  (Ho + sh->toh - 1) / sh->toh, (Wo + sh->tow - 1) / sh->tow, (Cmid + 31) / 32, expdw_kw(Cin), expdw_cp(Cmid)};
+    const ExpDwShape* sh = &kExpDwShapes[shape % kNumExpDwShapes];
+    const bool tr = shape >= kNumExpDwShapes;
+    const ExpDwGeo g = expdw_oriented(shape, g0);
+    ExpDwParams p{x, we, be, wd, bd, y, partial, B, g.H, g.W, Cin, Cmid, g.Ho, g.Wo, g.pt, g.pl, act_e, act_d,
+                  (g.Ho + sh->toh - 1) / sh->toh, (g.Wo + sh->tow - 1) / sh->tow, (Cmid + 31) / 32, expdw_kw(Cin), expdw_cp(Cmid)};
+    // the kernel's rows are image columns when tr: one kernel row step = one pixel, one kernel column step = an image row
+    p.xsh = tr ? 1 : W; p.xsw = tr ? W : 1; p.ysh = tr ? 1 : Wo; p.ysw = tr ? Wo : 1; p.tr = tr ? 1 : 0;
     unsigned nblk = (unsigned)B * p.tiles_h * p.tiles_w * p.cchunks;
     p.d_bpc = make_fdiv((unsigned)(p.tiles_h * p.tiles_w * p.cchunks));
     p.d_cch = make_fdiv((unsigned)p.cchunks);
     p.d_tw = make_fdiv((unsigned)p.tiles_w);
     const bool bx = wep != nullptr && !stem && expdw_bx_ok(Cin);
-    if (bx) { p.wep = wep; p.Kp = expdw_kp(Cin); }
+    if (bx) { p.wep = wep; p.Kp = expdw_kp(Cin); p.prec = prec; }
     if (stem) {
         p.Hin = stem->Hin; p.Win = stem->Win; p.pts = stem->pt; p.pls = stem->pl; p.Kw = 24;    // 3 rows x 4 columns x 2 channels
 #define ED_STEM(TH_, TW_, TR_)                                                                                \

@@ -14,8 +14,10 @@ def test_bf16x3_plans_weight_images(built_lib, full_blob):
     da, db = a.describe(), b.describe()
     pw = [s for s in db["steps"] if s["kernel"] == "pw_gemm"]
     forced = [s for s in pw if s["wm_full"] == 6]
-    assert len(forced) >= 16 and all(s["C"] % 32 == 0 for s in forced)       # every layer with whole 32-wide K slabs
-    assert all(s["wm_full"] != 6 for s in pw if s["C"] % 32)                 # b1 (K=32 ok) ... K=16/24/40 layers stay fp32
+    # every layer with K >= 16, K % 4 == 0 (a K tail inside the last 32-wide slab is zero weights x zero-filled columns)
+    assert len(forced) >= 16 and all(s["C"] % 4 == 0 and s["C"] >= 16 for s in forced)
+    assert any(s["C"] % 32 for s in forced)
+    assert all(s["wm_full"] != 6 for s in pw if s["C"] % 4 or s["C"] < 16)
     assert db["weight_bytes"] > 2.0 * da["weight_bytes"]                     # + 1.5x image of every eligible layer
     a.close(); b.close()
 

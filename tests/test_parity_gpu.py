@@ -126,7 +126,9 @@ def test_pipeline_depth_gives_identical_results(full_blob):
         # an unsplit (host-pointer) call right after pipelined ones is ordered behind them
         b.predict_device(x.at(0), 4, out.at(0))
         h = b.predict_batch(xh[:4].reshape(-1), 4)
-        assert np.array_equal(h, o[:4])
+        # (the blocking entry launches the squeeze-excite kernel with 1024-thread blocks, a pipelined call with 256-thread
+        # ones - another fixed summation order: equal to rounding, each entry bit-reproducible on its own)
+        assert np.abs(h - o[:4]).max() < 1e-4 and np.array_equal(h, b.predict_batch(xh[:4].reshape(-1), 4))
     finally:
         a.close(); b.close()
         x.free(); ref.free(); out.free()

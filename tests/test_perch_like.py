@@ -103,3 +103,51 @@ def test_perch_size_vs_oracle_and_softmax_topk(gpu):
             assert [t[1] for t in top[r]] == sorted((t[1] for t in top[r]), reverse=True)
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("orient", ["n", "t"])
+def test_expand_dw_both_orientations_vs_oracle(gpu, orient, monkeypatch):
+    """The fused expand+depthwise kernel with rows and columns swapped (tall, narrow images): every fused layer forced to one
+    orientation, on the v2.4-style geometry sweep (wide images, 3x3 / 5x5, stride 1 / 2, asymmetric SAME padding) and on the
+    Perch-style tiny model, vs the oracle."""
+    from test_parity_gpu import _geo_cfg, assert_parity
+    monkeypatch.setenv("BNHIP_EXPDW_ORIENT", orient)
+    for cfg in (_geo_cfg(1), _geo_cfg(4), sm.tiny_perch_config()):
+        blob = sm.build_model(cfg)
+        x = sm.synth_clips(3, cfg.n_samples, cfg.sample_rate)
+        ref = Interpreter(blob).invoke(x)[0]
+        c = host.HipClassifier(blob, max_batch=8)
+        try:
+            got = c.predict_batch(x.reshape(-1), 3)
+            ed = [s for s in c.describe()["steps"] if s["kernel"] == "expand_dw" and not s["name"].startswith("stem")]
+        finally:
+            c.close()
+        assert ed and all((s["shape"] >= 14) == (orient == "t") for s in ed), [(s["name"], s["shape"]) for s in ed]
+        assert_parity(got, ref)
+        assert np.abs(got - ref).max() < 1e-3
+
+
+@pytest.mark.gpu
+def test_bf16_precision_drift_is_bounded(gpu):
+    """"precision":"bf16" (MFMA operands rounded to bf16, fp32 accumulate and storage) on the Perch-size stand-in: top-1
+    unchanged and softmax drift far inside what the reference accepts for reduced-precision Perch (~0.08 on an f16 GPU,
+    internal/inference/openvino_parity_functional_test.go:156-158); the f32 engine on the same clips is the control."""
+    cfg = sm.perch_config()
+    blob = sm.build_model(cfg)
+    x = sm.synth_clips(3, cfg.n_samples, cfg.sample_rate, first=11)
+    ref = Interpreter(blob).invoke(x)[0]
+    out = {}
+    for prec in ("f32", "bf16"):
+        c = host.HipClassifier(blob, max_batch=8, precision=prec)
+        try:
+            assert c.describe()["precision"] == prec
+            out[prec] = c.predict_batch(x.reshape(-1), 3)
+        finally:
+            c.close()
+    d32 = np.abs(softmax64(out["f32"]) - softmax64(ref)).max()
+    d16 = np.abs(softmax64(out["bf16"]) - softmax64(ref)).max()
+    print(f"softmax drift vs oracle: f32 {d32:.2e}, bf16 {d16:.2e}; max |logit| diff bf16 {np.abs(out['bf16'] - ref).max():.3e}")
+    assert d32 <= 1e-4
+    assert (out["bf16"].argmax(1) == ref.argmax(1)).all() and d16 <= 0.02
+    assert d16 > d32            # the option really changes the arithmetic
