@@ -56,7 +56,7 @@ void bnhip_shutdown(void);
  * container is sniffed: "TFL3" at byte 4 = TFLite flatbuffer, otherwise ONNX ModelProto.  The blob is consumed during the
  * call and may be freed afterwards (classifier.go:37).
  * opts_json (nullable): {"device":0,"devices":[0,1,..],"replicate":"auto","max_batch":256,"plan_only":0,"debug_no_reuse":0,
- *                        "autotune":1,"graphs":0,"lanes":2,"frontend_fft":-1,"depth":1,"bf16x3":1}
+ *                        "autotune":1,"graphs":0,"lanes":2,"frontend_fft":-1,"depth":1,"bf16x3":1,"precision":"f32"}
  * "devices": one handle over several GPUs: one engine per listed device, the clips of every host-
  *          pointer call are sharded index-contiguously over them and run concurrently (one worker thread per device, own
  *          streams and pinned-order staging per device).  The frozen weights are uploaded to the first device only and
@@ -72,7 +72,12 @@ void bnhip_shutdown(void);
  * "bf16x3": pointwise / dense layers on the split-bf16 MFMA path (three exact bf16 pieces per fp32 operand, six
  *          v_mfma_f32_16x16x32_bf16 products per k, fp32 accumulation: every product is reproduced to within 2^-23, see
  *          DESIGN.md): 1 (default) = per layer where the create-time autotuner measures it faster, 0 = f32 MFMA only,
- *          2 = every eligible layer (K a multiple of 32).  */
+ *          2 = every eligible layer (K >= 16, K a multiple of 4).
+ * "precision": "f32" (default) keeps every product fp32 (f32 MFMA or the six-product split above).  "bf16" rounds the MFMA
+ *          operands of the pointwise / dense / fused-expand layers to bf16 (one product per k, fp32 accumulation, fp32
+ *          storage; depthwise, squeeze-excite, front-end and head bias stay fp32): the reduced-precision deployment the
+ *          reference runs Perch v2 in (openvino f16 drift ~0.08 accepted, openvino_parity_functional_test.go:156-158;
+ *          BASELINE configs[4]).  Never a default: BirdNET v2.4 is known not to survive f16 (model_openvino.go:99-103).  */
 int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, bnhip_model** out);
 
 /* n_samples: exact input length per clip (tflite/classifier.go:100-104); n_classes: size of the logits
