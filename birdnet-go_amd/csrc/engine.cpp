@@ -979,7 +979,10 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                     if (slabs > 0) {
                         S = slabs;
                         fused_sum = true;
-                        mp.out = new_val(-1, (size_t)S * C);
+                        // sized for whichever kernel the autotuner ends up with (the LDS-staged form has its own tile counts)
+                        int cap = S;
+                        if (dwconv_lds_supported(dp)) cap = std::max(cap, expdw_max_slabs(ExpDwGeo{d.kh, d.sh, d.H, d.W, d.Ho, d.Wo, d.pt, d.pl}));
+                        mp.out = new_val(-1, (size_t)cap * C);
                         steps.back().out2 = mp.out;
                         steps.back().S = S;
                     }
@@ -1543,7 +1546,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
     HIPCHK(hipMalloc((void**)&d_stage_logits, (size_t)max_batch * n_classes * 4));
     HIPCHK(hipMalloc((void**)&d_post_conf, (size_t)max_batch * n_classes * 4));
     if (emb_dim) HIPCHK(hipMalloc((void**)&d_stage_emb, (size_t)max_batch * emb_dim * 4));
-    if (autotune && !defer_weights) { autotune_pw(); autotune_expdw(); }
+    if (autotune && !defer_weights) { autotune_pw(); autotune_expdw(); autotune_dw(); }
     *code = BNHIP_OK;
     return true;
 }
@@ -1551,7 +1554,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
 void Engine::finish_deferred() {
     if (device < 0) return;
     hipSetDevice(device);
-    if (autotune) { autotune_pw(); autotune_expdw(); }
+    if (autotune) { autotune_pw(); autotune_expdw(); autotune_dw(); }
     defer_weights = false;
 }
 
@@ -1597,6 +1600,55 @@ void Engine::autotune_expdw() {
         s.bx = best_bx;
         if (s.out2 >= 0) {                       // the consumers of the per-tile sums index them by tile count
             s.S = expdw_shape_slabs(best_idx, sg0);
+            for (auto& c : steps) if (&c != &s && c.in0 == s.out2) c.S = s.S;
+        }
+    }
+    hipStreamSynchronize(stream);
+    hipEventDestroy(a); hipEventDestroy(b);
+    (void)hipGetLastError();
+}
+
+// Plain depthwise layers: the register-tiled kernel reads its taps through L1/L2, the LDS-staged form (the fused kernel's
+// second phase on a copied footprint) pays a staging pass instead; which one wins depends on the filter size, the channel
+// count and the image shape, so both are timed per layer - with every tile shape / orientation of the staged form.
+void Engine::autotune_dw() {
+    if (getenv("BNHIP_NO_DW_LDS")) return;
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    const int n = (max_batch + n_lanes - 1) / n_lanes;
+    for (size_t si = 0; si < steps.size(); si++) {
+        Step& s = steps[si];
+        if (s.kind != S_DW) continue;
+        float* in0 = vptr(s.in0, d_stage_in, d_stage_logits, nullptr);
+        float* out = vptr(s.out, d_stage_in, d_stage_logits, nullptr);
+        float* out2 = vptr(s.out2, d_stage_in, d_stage_logits, nullptr);
+        DwParams p{in0, s.w0, s.w1, out, n, s.H, s.W, s.C, s.Ho, s.Wo, s.kh, s.kw, s.sh, s.sw, s.pt, s.pl, s.act};
+        if (!dwconv_lds_supported(p)) continue;
+        if (s.out2 >= 0 && dwconv_sum_slabs(p) == 0) continue;      // (sums planned for the tiled kernel only)
+        const ExpDwGeo g{s.kh, s.sh, s.H, s.W, s.Ho, s.Wo, s.pt, s.pl};
+        auto timeit = [&](auto&& go) {
+            go();
+            hipEventRecord(a, stream);
+            for (int r = 0; r < 3; r++) go();
+            hipEventRecord(b, stream);
+            hipEventSynchronize(b);
+            float ms = 0; hipEventElapsedTime(&ms, a, b);
+            return ms / 3;
+        };
+        float best = timeit([&]() { launch_dwconv(p, out2, stream); });
+        if (getenv("BNHIP_DEBUG")) fprintf(stderr, "[bnhip] tune %-16s dwconv register-tiled: %.1f us\n", s.name.c_str(), best * 1e3);
+        if (getenv("BNHIP_DW_LDS")) best = 1e30f;                   // tests: the staged form wherever it exists
+        int best_idx = -1;
+        for (int idx = 0; idx < expdw_num_shapes(); idx++) {
+            if (!expdw_shape_fits(idx, g)) continue;
+            const float ms = timeit([&]() { launch_dwconv_lds(p, out2, idx, stream); });
+            if (getenv("BNHIP_DEBUG")) fprintf(stderr, "[bnhip] tune %-16s dwconv LDS shape=%d: %.1f us\n", s.name.c_str(), idx, ms * 1e3);
+            if (ms < best * 0.97f) { best = ms; best_idx = idx; }
+        }
+        if (best_idx < 0) continue;
+        s.dwl = 1; s.shape = best_idx;
+        if (s.out2 >= 0) {
+            s.S = expdw_shape_slabs(best_idx, g);
             for (auto& c : steps) if (&c != &s && c.in0 == s.out2) c.S = s.S;
         }
     }
@@ -1860,7 +1912,8 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
             }
             case S_DW: {
                 DwParams p{in0, s.w0, s.w1, out, n, s.H, s.W, s.C, s.Ho, s.Wo, s.kh, s.kw, s.sh, s.sw, s.pt, s.pl, s.act};
-                launch_dwconv(p, out2, stream);
+                if (s.dwl) launch_dwconv_lds(p, out2, s.shape, stream);
+                else launch_dwconv(p, out2, stream);
                 break;
             }
             case S_EXPAND_DW:
@@ -1975,7 +2028,7 @@ std::string Engine::describe() const {
         jesc(os, s.name);
         os << "\",\"H\":" << s.H << ",\"W\":" << s.W << ",\"C\":" << s.C << ",\"Co\":" << s.Co << ",\"k\":" << s.kh
            << ",\"stride\":" << s.sh << ",\"act\":" << s.act << ",\"fused_scale\":" << (s.kind == S_PW && s.in1 >= 0 ? 1 : 0)
-           << ",\"shape\":" << s.shape << ",\"bx\":" << s.bx << ",\"nt\":" << s.nt << ",\"wm\":" << s.wm << ",\"nt_full\":" << s.nt_full << ",\"wm_full\":" << s.wm_full << ",\"fused_res\":" << (s.kind == S_PW && s.in2 >= 0 ? 1 : 0) << ",\"fused_sum\":" << (s.out2 >= 0 ? 1 : 0) << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << ",\"wbytes\":" << s.wbytes << "}";
+           << ",\"shape\":" << s.shape << ",\"dw_lds\":" << s.dwl << ",\"bx\":" << s.bx << ",\"nt\":" << s.nt << ",\"wm\":" << s.wm << ",\"nt_full\":" << s.nt_full << ",\"wm_full\":" << s.wm_full << ",\"fused_res\":" << (s.kind == S_PW && s.in2 >= 0 ? 1 : 0) << ",\"fused_sum\":" << (s.out2 >= 0 ? 1 : 0) << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << ",\"wbytes\":" << s.wbytes << "}";
     }
     os << "]}";
     return os.str();

@@ -35,6 +35,7 @@ struct Step {
     // weights (device pointers into the weight arena)
     const float *w0 = nullptr, *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;
     const uint16_t* wbx = nullptr;   // S_PW / S_EXPAND_DW: split-bf16 weight image (pw_bx3_image / expdw_bx_image) of a bf16x3 engine
+    int dwl = 0;                     // S_DW: 1 = LDS-staged kernel (launch_dwconv_lds, tile shape in `shape`), chosen by the autotuner
     int bx = 0;                      // S_EXPAND_DW: 1 = phase 1 on the split-bf16 MFMA (autotuned per layer; bf16x3 = 2 forces it)
     // geometry per clip
     int H = 0, W = 0, C = 0, Ho = 0, Wo = 0, Co = 0, kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0;
@@ -103,6 +104,7 @@ class Engine {
     bool use_graphs = false;            // opt-in: replay the plan as a hipGraph once a (pointers, n) combination repeats (measured: no gain on ROCm 7.2)
     void drop_graphs();
     void autotune_expdw();
+    void autotune_dw();                 // S_DW: register-tiled k_dwconv_t vs the LDS-staged form, per layer
     // Pipelining across calls ("depth" option, bnhip_predict_device only): call i runs on context i % depth (own stream,
     // own activation arena), so the tail of one batch overlaps the head of the next.  Completion is then signalled by
     // synchronize(), not by the caller's stream.

@@ -135,6 +135,10 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
                       const StemGeom* stem /* non-null: x is the raw image and the expand is the 3x3/2 stem (see kernels.hip) */,
                       hipStream_t st, const uint16_t* wep = nullptr /* non-null: phase 1 on the split-bf16 MFMA (expdw_bx_image) */,
                       int prec = 0 /* with wep: 1 = plain bf16 operands (one product) */);
+// plain depthwise convolution through the same kernel (COPY mode: LDS-staged taps); shape as for launch_expand_dw, partial
+// (nullable) [B, expdw_shape_slabs(shape, geo), C]
+bool dwconv_lds_supported(const DwParams& p);
+void launch_dwconv_lds(const DwParams& p, float* partial, int shape, hipStream_t st);
 bool expdw_bx_ok(int Cin);
 int expdw_kp(int Cin);
 std::vector<uint16_t> expdw_bx_image(const float* We /*[Cmid][Cin]*/, int Cmid, int Cin);

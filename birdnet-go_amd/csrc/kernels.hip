@@ -1790,7 +1790,10 @@ constexpr int expdw_min_waves(int K, int S, int TOW, int TRH) {
     const int tiw = (TOW - 1) * S + K, jt = (TRH * tiw + 15) / 16, jtw = (jt + 3) / 4;
     return jtw <= 4 ? 4 : (jtw == 5 ? 3 : 2);
 }
-template <int K, int S, int TOH, int TOW, int TRH, bool STEM = false, bool H8 = STEM, bool BX = false>
+// COPY: no expand at all - phase 1 only stages the tile's input footprint (32 channels of x itself) in LDS and phase 2 runs
+// as above: a plain depthwise convolution whose taps read LDS instead of L1/L2 (k_dwconv_t re-reads every input value
+// (TIH x TIW) / (TH x TW) = 6x for a 5 x 5 filter), with the fused kernel's tile shapes, orientations and per-tile sums.
+template <int K, int S, int TOH, int TOW, int TRH, bool STEM = false, bool H8 = STEM, bool BX = false, bool COPY = false>
 __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void k_expand_dw(ExpDwParams p, unsigned nblk) {
     constexpr int TIH = (TOH - 1) * S + K, TIW = (TOW - 1) * S + K;
     static_assert(TRH <= TIH, "TRH is a cap on the footprint rows");
@@ -1828,13 +1831,33 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
     const int pl = ed_perm(PERM, lane);                  // logical lane: tx * 8 + c4
     const int c4 = pl & 7, tt = (wave << 3) | (pl >> 3);
     float4 wdreg = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < K * K * 8) {
+    // (COPY: the tap table and bias are the graph's own unpadded tensors - row stride Cp = C, loads guarded)
+    if (tid < K * K * 8 && (!COPY || n_base + 4 * (tid & 7) < p.Cmid)) {
         const int tap = tid >> 3, tsrc = p.tr ? (tap % K) * K + tap / K : tap;
         wdreg = *reinterpret_cast<const float4*>(p.wd + (size_t)tsrc * p.Cp + n_base + 4 * (tid & 7));
     }
-    const float4 bq0 = *reinterpret_cast<const float4*>(p.be + n_base + 4 * kq);
-    const float4 bq1 = *reinterpret_cast<const float4*>(p.be + n_base + 16 + 4 * kq);
-    const float4 bv = *reinterpret_cast<const float4*>(p.bd + n_base + 4 * c4);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bq0 = COPY ? zero4 : *reinterpret_cast<const float4*>(p.be + n_base + 4 * kq);
+    const float4 bq1 = COPY ? zero4 : *reinterpret_cast<const float4*>(p.be + n_base + 16 + 4 * kq);
+    const float4 bv = (COPY && (!p.bd || n_base + 4 * c4 >= p.Cmid)) ? zero4 : *reinterpret_cast<const float4*>(p.bd + n_base + 4 * c4);
+
+    if constexpr (COPY) {
+        // ---- phase 1 (COPY): E[j][0..31] = x[pixel j][n_base ..], zero outside the image; 8 lanes x 16 bytes per pixel
+        const float4* x4 = reinterpret_cast<const float4*>(p.x);
+        const int C4 = p.Cmid >> 2, q4 = (n_base >> 2) + (tid & 7);
+        const bool cin = q4 < C4;
+        const size_t img = (size_t)b * p.H * p.W;
+#pragma unroll 4
+        for (int j = tid >> 3; j < nvalid; j += 32) {
+            const int r = j / TIW, c = j - r * TIW;
+            const int iw = iw0 + c, ih = ih0 + vr0 + r;
+            float4 v = zero4;
+            if (cin && iw >= 0 && iw < p.W) v = x4[(img + (size_t)ih * p.xsh + (size_t)iw * p.xsw) * C4 + q4];
+            *reinterpret_cast<float4*>(&E[j * ED_ES + 4 * (tid & 7)]) = v;
+        }
+        if (tid < K * K * 8) wds[tid] = wdreg;
+        __syncthreads();
+    } else {
 
     // this lane's pixel per owned tile (a): clamped global offset + validity
     int xoff[JTW];               // STEM: top input row of the pixel's 3x4 window, and (scol) its left input column
@@ -2044,6 +2067,7 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
     }
     if (tid < K * K * 8) wds[tid] = wdreg;
     __syncthreads();
+    }   // !COPY
 
     // ---- depthwise from LDS
     const int ty = tt >> 3, tx = tt & 7;                 // ty == wave: row tests below are wave-uniform
@@ -2278,6 +2302,36 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
     ED_CASE(3, 2, 4, 8, 9) ED_CASE(3, 2, 8, 8, 12) ED_CASE(3, 2, 8, 8, 17)
     ED_CASE(5, 2, 4, 8, 11) ED_CASE(5, 2, 4, 16, 6) ED_CASE(5, 2, 8, 8, 19)
 #undef ED_CASE
+}
+
+// plain depthwise conv staged through LDS: the fused kernel in COPY mode (its phase 2 alone), same shape indices as above
+bool dwconv_lds_supported(const DwParams& p) {
+    return (p.C & 3) == 0 && p.kh == p.kw && p.sh == p.sw && (p.kh == 3 || p.kh == 5) && (p.sh == 1 || p.sh == 2);
+}
+void launch_dwconv_lds(const DwParams& q, float* partial, int shape, hipStream_t st) {
+    const ExpDwGeo g0{q.kh, q.sh, q.H, q.W, q.Ho, q.Wo, q.pt, q.pl, false};
+    if (!expdw_shape_fits(shape, g0)) shape = expdw_default_shape(g0);
+    if (shape < 0) return;
+    const ExpDwShape* sh = &kExpDwShapes[shape % kNumExpDwShapes];
+    const bool tr = shape >= kNumExpDwShapes;
+    const ExpDwGeo g = expdw_oriented(shape, g0);
+    ExpDwParams p{q.in, nullptr, nullptr, q.w, q.bias, q.out, partial, q.B, g.H, g.W, q.C, q.C, g.Ho, g.Wo, g.pt, g.pl, ACT_NONE, q.act,
+                  (g.Ho + sh->toh - 1) / sh->toh, (g.Wo + sh->tow - 1) / sh->tow, (q.C + 31) / 32, 0, q.C};
+    p.xsh = tr ? 1 : q.W; p.xsw = tr ? q.W : 1; p.ysh = tr ? 1 : q.Wo; p.ysw = tr ? q.Wo : 1; p.tr = tr ? 1 : 0;
+    unsigned nblk = (unsigned)q.B * p.tiles_h * p.tiles_w * p.cchunks;
+    p.d_bpc = make_fdiv((unsigned)(p.tiles_h * p.tiles_w * p.cchunks));
+    p.d_cch = make_fdiv((unsigned)p.cchunks);
+    p.d_tw = make_fdiv((unsigned)p.tiles_w);
+#define DL_CASE(K_, S_, TH_, TW_, TR_)                                                                        \
+    if (sh->k == K_ && sh->s == S_ && sh->toh == TH_ && sh->tow == TW_ && sh->trh == TR_) {                   \
+        hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, false, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        return;                                                                                               \
+    }
+    DL_CASE(3, 1, 8, 16, 10) DL_CASE(3, 1, 4, 16, 6) DL_CASE(3, 1, 8, 32, 6) DL_CASE(3, 1, 8, 32, 10)
+    DL_CASE(5, 1, 8, 16, 12) DL_CASE(5, 1, 4, 16, 8) DL_CASE(5, 1, 8, 32, 6) DL_CASE(5, 1, 12, 16, 12)
+    DL_CASE(3, 2, 4, 8, 9) DL_CASE(3, 2, 8, 8, 12) DL_CASE(3, 2, 8, 8, 17)
+    DL_CASE(5, 2, 4, 8, 11) DL_CASE(5, 2, 4, 16, 6) DL_CASE(5, 2, 8, 8, 19)
+#undef DL_CASE
 }
 
 // ------------------------------------------------------------------------------------------ spatial mean

@@ -151,3 +151,28 @@ def test_bf16_precision_drift_is_bounded(gpu):
     assert d32 <= 1e-4
     assert (out["bf16"].argmax(1) == ref.argmax(1)).all() and d16 <= 0.02
     assert d16 > d32            # the option really changes the arithmetic
+
+
+@pytest.mark.gpu
+def test_lds_staged_depthwise_vs_oracle(gpu, monkeypatch):
+    """Plain depthwise layers forced onto the LDS-staged kernel (the fused kernel's second phase on a copied footprint:
+    3x3 / 5x5, stride 1 / 2, channel counts that are not multiples of 32, fused squeeze-excite sums) vs the oracle, on the
+    Perch-style tiny model (b1/b2 are expansion-free blocks) and a v2.4-style one with fusion switched off."""
+    from test_parity_gpu import _geo_cfg, assert_parity
+    monkeypatch.setenv("BNHIP_DW_LDS", "1")
+    for cfg, nofuse in ((sm.tiny_perch_config(), False), (_geo_cfg(2), True), (_geo_cfg(5), True)):
+        if nofuse:
+            monkeypatch.setenv("BNHIP_NO_FUSE_EXPDW", "1")
+        blob = sm.build_model(cfg)
+        x = sm.synth_clips(3, cfg.n_samples, cfg.sample_rate)
+        ref = Interpreter(blob).invoke(x)[0]
+        c = host.HipClassifier(blob, max_batch=8)
+        try:
+            got = c.predict_batch(x.reshape(-1), 3)
+            dw = [s for s in c.describe()["steps"] if s["kernel"] == "dwconv"]
+        finally:
+            c.close()
+            monkeypatch.delenv("BNHIP_NO_FUSE_EXPDW", raising=False)
+        assert dw and all(s["dw_lds"] == 1 for s in dw), [(s["name"], s["dw_lds"]) for s in dw]
+        assert_parity(got, ref)
+        assert np.abs(got - ref).max() < 1e-3
