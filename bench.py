@@ -20,6 +20,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF headline is 2:1 sparse)
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_F64_MFMA_TFLOPS = 78.6       # f64 MFMA: half the f32-input rate (v_mfma_f64_16x16x4_f64, 64 cycles)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
@@ -51,12 +52,13 @@ def parse():
     return ap.parse_args()
 
 
-def pmc_traffic(kclass):
+def pmc_traffic(kclass, workload="birdnet"):
     """HBM bytes per launch of a kernel class from the newest committed PMC pass (profiles/rNN_traffic.json, produced by
     tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same bench; FETCH_SIZE
     doubled per the gfx950 correction in MI355X_MICROARCH.md).  PMC cannot be collected inside the timed run itself."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))
+                   if ("perch" in os.path.basename(f)) == (workload == "perch"))
     if not files:
         return None
     names = {"expand_dw": "k_expand_dw", "pw_gemm": "k_pw_gemm", "frontend": "k_frontend", "dwconv": "k_dwconv",
@@ -404,6 +406,8 @@ def main():
             # roofline side of the dominant kernel class: algorithmic intensity vs the machine balance of the pipe it
             # computes on (the mel front-end runs on the f64 MFMA, everything else on the f32-input MFMA)
             peak_tf = PEAK_F64_MFMA_TFLOPS if dom["kernel"] == "frontend" else PEAK_F32_MFMA_TFLOPS
+            if args.precision == "bf16" and dom["kernel"] in ("pw_gemm", "expand_dw"):
+                peak_tf = PEAK_BF16_MFMA_TFLOPS          # one bf16 product per MAC: priced against the dense bf16 peak
             intensity = dom["flops"] / max(dom["bytes"], 1.0)
             if intensity > peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9):
                 ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
@@ -414,7 +418,7 @@ def main():
                 roof = {"kernel": dom["kernel"], "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS,
                         "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None}
             roof["flop_per_byte"] = intensity
-            tr = pmc_traffic(dom["kernel"])
+            tr = pmc_traffic(dom["kernel"], args.workload)
             if tr:
                 roof["traffic"] = tr["bytes_per_launch"]
                 roof["traffic_source"] = tr["source"]

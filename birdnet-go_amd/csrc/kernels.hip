@@ -554,6 +554,13 @@ void launch_conv_direct(const ConvParams& p, hipStream_t s) {
         hipLaunchKernelGGL((k_conv_direct_px<3, 3, 2, 2, PX>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p, wgroups);
         return;
     }
+    if (p.kh == 3 && p.kw == 3 && p.Cin == 1 && p.sh == 2 && p.sw == 2 && (p.Cout & 3) == 0) {      // one-channel image (log-mel stem)
+        constexpr int PX = 4;
+        int wgroups = (p.Wo + PX - 1) / PX;
+        size_t tot = (size_t)p.B * p.Ho * wgroups * (p.Cout >> 2);
+        hipLaunchKernelGGL((k_conv_direct_px<3, 3, 1, 2, PX>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p, wgroups);
+        return;
+    }
     size_t total = (size_t)p.B * p.Ho * p.Wo * (p.Cout >> 2);
     dim3 grid((unsigned)((total + 255) / 256));
     if (p.kh == 3 && p.kw == 3 && p.Cin == 2) hipLaunchKernelGGL((k_conv_direct_t<3, 3, 2>), grid, dim3(256), 0, s, p);

@@ -15,7 +15,7 @@ from collections import defaultdict
 
 def short(name):
     name = re.sub(r"\(.*\)$", "", name)
-    return name.replace("void ", "").replace("bnhip::", "")[:48]
+    return name.replace("void ", "").replace("bnhip::", "")[:72]
 
 
 WINDOW = None
