@@ -1,8 +1,10 @@
 #include "model_onnx.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <set>
 
 #include "../../include/bnhip.h"
 
@@ -332,6 +334,70 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
         m.ops.push_back(std::move(o));
         return m.ops.back();
     };
+    // ---- image tensors.  ONNX convolutions are NCHW; the engine's kernels are NHWC.  A rank-4 value produced by a Conv / pool
+    // (and everything elementwise downstream of it) is kept channels-last: its IR tensor has shape [N, H, W, C] while the
+    // ONNX value it stands for is [N, C, H, W] (`chl`).  Axis attributes and per-channel constants are permuted on the way in;
+    // a value only changes memory layout (TRANSPOSE) where the graph really depends on the element order: a Flatten /
+    // Reshape of an image with H*W > 1 and C > 1, an unusual Transpose, or a graph output.
+    std::set<int> chl;
+    auto onnx_shape = [&](int t) -> std::vector<int> {
+        const auto& sh = m.tensors[t].shape;
+        if (!chl.count(t)) return sh;
+        return {sh[0], sh[3], sh[1], sh[2]};
+    };
+    int tmp_id = 0;
+    // NCHW-ordered copy of a channels-last value (no-op when only one of C, H*W exceeds 1: same element order)
+    auto to_nchw = [&](int t) -> int {
+        if (!chl.count(t)) return t;
+        const auto sh = m.tensors[t].shape;           // [N, H, W, C]
+        const std::vector<int> osh = {sh[0], sh[3], sh[1], sh[2]};
+        const std::string nm = m.tensors[t].name + "/nchw" + std::to_string(tmp_id++);
+        TflTensor nt; nt.name = nm; nt.shape = osh; nt.type = TT_FLOAT32;
+        m.tensors.push_back(std::move(nt));
+        const int o = (int)m.tensors.size() - 1;
+        if (sh[3] == 1 || sh[1] * sh[2] == 1) add_op(OP_RESHAPE, {t}, o).new_shape = osh;
+        else add_op(OP_TRANSPOSE, {t, m.add_const_i32(nm + "/perm", {4}, {0, 3, 1, 2})}, o);
+        return o;
+    };
+    // channels-last copy of a plain NCHW-ordered rank-4 value
+    auto to_chl = [&](int t) -> int {
+        if (chl.count(t)) return t;
+        const auto sh = m.tensors[t].shape;           // [N, C, H, W]
+        const std::vector<int> osh = {sh[0], sh[2], sh[3], sh[1]};
+        const std::string nm = m.tensors[t].name + "/nhwc" + std::to_string(tmp_id++);
+        TflTensor nt; nt.name = nm; nt.shape = osh; nt.type = TT_FLOAT32;
+        m.tensors.push_back(std::move(nt));
+        const int o = (int)m.tensors.size() - 1;
+        if (sh[1] == 1 || sh[2] * sh[3] == 1) add_op(OP_RESHAPE, {t}, o).new_shape = osh;
+        else add_op(OP_TRANSPOSE, {t, m.add_const_i32(nm + "/perm", {4}, {0, 2, 3, 1})}, o);
+        chl.insert(o);
+        return o;
+    };
+    static const int kAxisToChl[4] = {0, 3, 1, 2};       // ONNX axis (N, C, H, W) -> axis of the channels-last tensor
+    // conv / pool geometry: ONNX pads [top, left, bottom, right] (or auto_pad) -> output size and explicit top / left pads
+    auto window_geom = [&](const ONode& nd, int H, int W, int kh, int kw, int sh_, int sw_, int dh, int dw, int* Ho, int* Wo, int* pt, int* pl,
+                           std::string* why) -> bool {
+        std::string ap = "NOTSET";
+        if (const OAttr* a = nd.attr("auto_pad")) ap = a->s;
+        int pb = 0, pr = 0; *pt = 0; *pl = 0;
+        const int eh = dh * (kh - 1) + 1, ew = dw * (kw - 1) + 1;
+        if (ap == "NOTSET" || ap.empty()) {
+            if (const OAttr* a = nd.attr("pads")) {
+                if (a->ints.size() != 4) { *why = "pads must have 4 entries"; return false; }
+                *pt = (int)a->ints[0]; *pl = (int)a->ints[1]; pb = (int)a->ints[2]; pr = (int)a->ints[3];
+            }
+        } else if (ap == "SAME_UPPER" || ap == "SAME_LOWER") {
+            const int oh = (H + sh_ - 1) / sh_, ow = (W + sw_ - 1) / sw_;
+            const int th = std::max((oh - 1) * sh_ + eh - H, 0), tw = std::max((ow - 1) * sw_ + ew - W, 0);
+            *pt = ap == "SAME_UPPER" ? th / 2 : th - th / 2; pb = th - *pt;
+            *pl = ap == "SAME_UPPER" ? tw / 2 : tw - tw / 2; pr = tw - *pl;
+        } else if (ap != "VALID") { *why = "auto_pad " + ap; return false; }
+        if (*pt < 0 || *pl < 0 || pb < 0 || pr < 0 || *pt >= eh || *pl >= ew || pb >= eh || pr >= ew) { *why = "padding out of range"; return false; }
+        if (nd.ai("ceil_mode", 0) != 0) { *why = "ceil_mode"; return false; }
+        *Ho = (H + *pt + pb - eh) / sh_ + 1; *Wo = (W + *pl + pr - ew) / sw_ + 1;
+        if (H + *pt + pb < eh || W + *pl + pr < ew || *Ho < 1 || *Wo < 1) { *why = "window larger than the padded image"; return false; }
+        return true;
+    };
     for (const ONode& nd : nodes) {
         const std::string where = nd.op + " (" + (nd.name.empty() ? (nd.out.empty() ? "?" : nd.out[0]) : nd.name) + ")";
         if (!nd.domain.empty() && nd.domain != "ai.onnx") return fail("ONNX: operator from unsupported domain " + nd.domain + ": " + where);
@@ -340,8 +406,9 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
         const std::string& oname = nd.out[0];
         auto in_act = [&](size_t k) -> int { if (k >= nd.in.size()) return -1; auto it = tid.find(nd.in[k]); return it == tid.end() || m.tensors[it->second].data ? -1 : it->second; };
         if (nd.op == "Gemm" || nd.op == "MatMul") {
-            const int a = in_act(0);
+            int a = in_act(0);
             if (a < 0 || nd.in.size() < 2) return fail("ONNX: " + where + ": first operand must be an activation");
+            a = to_nchw(a);
             std::vector<float> B; std::vector<int64_t> bd;
             if (!const_f(nd.in[1], &B, &bd) || bd.size() != 2) return fail("ONNX: " + where + ": second operand must be a constant float matrix");
             const bool gemm = nd.op == "Gemm";
@@ -368,13 +435,34 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
             add_op(OP_FULLY_CONNECTED, ins, new_act(oname, osh)).keep_num_dims = true;
         } else if (nd.op == "Add" || nd.op == "Sub" || nd.op == "Mul" || nd.op == "Div" || nd.op == "Pow" || nd.op == "Max" || nd.op == "Min") {
             if (nd.in.size() != 2) return fail("ONNX: " + where + ": exactly two operands are supported");
-            const int a = operand(nd.in[0]), b = operand(nd.in[1]);
+            int a = -1, b = -1;
+            const int ia = in_act(0), ib = in_act(1);
+            const bool img = (ia >= 0 && chl.count(ia)) || (ib >= 0 && chl.count(ib));
+            if (img) {
+                // image arithmetic: the other side is an image too, or a constant that broadcasts over [N, C, H, W]
+                auto side = [&](size_t k, int act) -> int {
+                    if (act >= 0) return m.tensors[act].shape.size() == 4 ? to_chl(act) : -2;
+                    std::vector<float> v; std::vector<int64_t> dims;
+                    if (!const_f(nd.in[k], &v, &dims) || dims.size() > 4) return -1;
+                    std::vector<int64_t> d4(4, 1);
+                    for (size_t q = 0; q < dims.size(); q++) d4[4 - dims.size() + q] = dims[q];
+                    std::vector<float> w(v.size());                  // [n][c][h][w] -> [n][h][w][c]
+                    size_t at = 0;
+                    for (int64_t n = 0; n < d4[0]; n++) for (int64_t c = 0; c < d4[1]; c++) for (int64_t h = 0; h < d4[2]; h++) for (int64_t x = 0; x < d4[3]; x++)
+                        w[(((size_t)n * d4[2] + h) * d4[3] + x) * d4[1] + c] = v[at++];
+                    return m.add_const_f32(nd.in[k] + "/nhwc" + std::to_string(tmp_id++), {(int)d4[0], (int)d4[2], (int)d4[3], (int)d4[1]}, w);
+                };
+                a = side(0, ia); b = side(1, ib);
+                if (a == -2 || b == -2) return fail("ONNX: " + where + ": an image and a non-image activation cannot be combined");
+            } else { a = operand(nd.in[0]); b = operand(nd.in[1]); }
             if (a < 0 || b < 0) return fail("ONNX: " + where + ": operand is neither an activation nor a float constant");
             std::vector<int> z;
             if (!bshape(m.tensors[a].shape, m.tensors[b].shape, &z)) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": shapes do not broadcast"); }
             const int opc = nd.op == "Add" ? OP_ADD : nd.op == "Sub" ? OP_SUB : nd.op == "Mul" ? OP_MUL : nd.op == "Div" ? OP_DIV :
                             nd.op == "Pow" ? OP_POW : nd.op == "Max" ? OP_MAXIMUM : OP_MINIMUM;
-            add_op(opc, {a, b}, new_act(oname, z));
+            const int zo = new_act(oname, z);
+            add_op(opc, {a, b}, zo);
+            if (img) chl.insert(zo);
         } else if (nd.op == "Relu" || nd.op == "Sigmoid" || nd.op == "Tanh" || nd.op == "Exp" || nd.op == "Log" || nd.op == "Sqrt" ||
                    nd.op == "Abs" || nd.op == "Neg" || nd.op == "Floor" || nd.op == "Ceil" || nd.op == "HardSwish" || nd.op == "LeakyRelu" ||
                    nd.op == "Elu" || nd.op == "Gelu" || nd.op == "Sin" || nd.op == "Cos") {
@@ -385,7 +473,9 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
                             nd.op == "Floor" ? OP_FLOOR : nd.op == "Ceil" ? OP_CEIL : nd.op == "HardSwish" ? OP_HARD_SWISH :
                             nd.op == "LeakyRelu" ? OP_LEAKY_RELU : nd.op == "Elu" ? OP_ELU : nd.op == "Gelu" ? OP_GELU : nd.op == "Sin" ? OP_SIN : OP_COS;
             if (nd.op == "Elu" && nd.af("alpha", 1.0f) != 1.0f) return fail("ONNX: " + where + ": alpha != 1 is not supported");
-            TflOp& o = add_op(opc, {a}, new_act(oname, m.tensors[a].shape));
+            const int uo = new_act(oname, m.tensors[a].shape);
+            if (chl.count(a)) chl.insert(uo);
+            TflOp& o = add_op(opc, {a}, uo);
             if (nd.op == "LeakyRelu") o.alpha = nd.af("alpha", 0.01f);
             if (nd.op == "Gelu") { const OAttr* ap = nd.attr("approximate"); o.approximate = ap && ap->s == "tanh"; }
         } else if (nd.op == "Clip") {
@@ -398,18 +488,21 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
             if (nd.in.size() > 1 && !nd.in[1].empty()) { if (!const_f(nd.in[1], &cv, nullptr) || cv.size() != 1) return fail("ONNX: " + where + ": min must be a constant scalar"); lo = cv[0]; }
             if (nd.in.size() > 2 && !nd.in[2].empty()) { if (!const_f(nd.in[2], &cv, nullptr) || cv.size() != 1) return fail("ONNX: " + where + ": max must be a constant scalar"); hi = cv[0]; }
             const auto sh = m.tensors[a].shape;
+            const bool cimg = chl.count(a) != 0;
+            struct TagOnExit { std::set<int>& c; std::map<std::string, int>& t; const std::string& n; bool on; ~TagOnExit() { auto it = t.find(n); if (on && it != t.end()) c.insert(it->second); } } tag_clip{chl, tid, oname, cimg};
             if (lo == 0.0f && hi == 6.0f) add_op(OP_RELU6, {a}, new_act(oname, sh));
             else if (lo == 0.0f && std::isinf(hi)) add_op(OP_RELU, {a}, new_act(oname, sh));
             else if (lo == -1.0f && hi == 1.0f) add_op(OP_RELU_N1_TO_1, {a}, new_act(oname, sh));
             else {
                 int cur = a;
-                if (!std::isinf(lo)) { int c = m.add_const_f32(oname + "/min", {1}, {lo}); int t = std::isinf(hi) ? new_act(oname, sh) : new_act(oname + "/lo", sh); add_op(OP_MAXIMUM, {cur, c}, t); cur = t; }
+                if (!std::isinf(lo)) { int c = m.add_const_f32(oname + "/min", {1}, {lo}); int t = std::isinf(hi) ? new_act(oname, sh) : new_act(oname + "/lo", sh); add_op(OP_MAXIMUM, {cur, c}, t); cur = t; if (cimg) chl.insert(t); }
                 if (!std::isinf(hi)) { int c = m.add_const_f32(oname + "/max", {1}, {hi}); add_op(OP_MINIMUM, {cur, c}, new_act(oname, sh)); }
                 if (std::isinf(lo) && std::isinf(hi)) tid[oname] = a;
             }
         } else if (nd.op == "Softmax") {
-            const int a = in_act(0);
+            int a = in_act(0);
             if (a < 0) return fail("ONNX: " + where + ": operand must be an activation");
+            a = to_nchw(a);
             const int rank = (int)m.tensors[a].shape.size();
             int64_t ax = nd.ai("axis", -1);
             if (ax < 0) ax += rank;
@@ -421,8 +514,9 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
             if (nd.op == "Cast" && nd.ai("to", 1) != 1) return fail("ONNX: " + where + ": only casts to float32 are supported");
             tid[oname] = a;                                   // inference-time no-op
         } else if (nd.op == "Flatten" || nd.op == "Reshape" || nd.op == "Squeeze" || nd.op == "Unsqueeze") {
-            const int a = in_act(0);
+            int a = in_act(0);
             if (a < 0) return fail("ONNX: " + where + ": operand must be an activation");
+            a = to_nchw(a);                                   // element order as the graph sees it (free for 1 x 1 images)
             const auto& ish = m.tensors[a].shape;
             const size_t total = m.tensors[a].numel();
             std::vector<int> osh;
@@ -462,23 +556,199 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
             if (a < 0 || nd.in.size() < 5 || !const_f(nd.in[1], &sc, nullptr) || !const_f(nd.in[2], &bi, nullptr) || !const_f(nd.in[3], &mu, nullptr) || !const_f(nd.in[4], &va, nullptr))
                 return fail("ONNX: " + where + ": scale / bias / mean / var must be constants");
             const auto sh = m.tensors[a].shape;
-            if (sh.size() != 2 || (int)sc.size() != sh[1] || bi.size() != sc.size() || mu.size() != sc.size() || va.size() != sc.size())
-                return fail("ONNX: " + where + ": only [batch, channels] inputs are supported");
+            const bool bimg = sh.size() == 4 && chl.count(a);     // channels are the last axis either way: [C] constants broadcast
+            if (!(sh.size() == 2 || bimg) || (int)sc.size() != sh.back() || bi.size() != sc.size() || mu.size() != sc.size() || va.size() != sc.size())
+                return fail("ONNX: " + where + ": only [batch, channels] inputs and convolution outputs are supported");
             const float eps = nd.af("epsilon", 1e-5f);
             std::vector<float> A(sc.size()), Bv(sc.size());
             for (size_t k = 0; k < sc.size(); k++) { A[k] = sc[k] / std::sqrt(va[k] + eps); Bv[k] = bi[k] - mu[k] * A[k]; }
             const int t1 = new_act(oname + "/scaled", sh);
             add_op(OP_MUL, {a, m.add_const_f32(oname + "/a", {(int)sc.size()}, A)}, t1);
-            add_op(OP_ADD, {t1, m.add_const_f32(oname + "/b", {(int)sc.size()}, Bv)}, new_act(oname, sh));
+            const int t2 = new_act(oname, sh);
+            add_op(OP_ADD, {t1, m.add_const_f32(oname + "/b", {(int)sc.size()}, Bv)}, t2);
+            if (bimg) { chl.insert(t1); chl.insert(t2); }
         } else if (nd.op == "Concat") {
             std::vector<int> ins;
-            for (auto& nm : nd.in) { int t = operand(nm); if (t < 0) return fail("ONNX: " + where + ": operand has no value"); ins.push_back(t); }
+            bool cimg = false;
+            for (size_t k = 0; k < nd.in.size(); k++) { int t = in_act(k); if (t >= 0 && chl.count(t)) cimg = true; }
+            for (size_t k = 0; k < nd.in.size(); k++) {
+                int t = cimg ? in_act(k) : operand(nd.in[k]);
+                if (t < 0) return fail("ONNX: " + where + (cimg ? ": every operand of an image concatenation must be an activation" : ": operand has no value"));
+                if (cimg) { if (m.tensors[t].shape.size() != 4) return fail("ONNX: " + where + ": rank mismatch"); t = to_chl(t); }
+                ins.push_back(t);
+            }
             std::vector<int> osh = m.tensors[ins[0]].shape;
             int64_t ax = nd.ai("axis", 1); if (ax < 0) ax += (int64_t)osh.size();
             if (ax < 1 || ax >= (int64_t)osh.size()) return fail("ONNX: " + where + ": axis out of range");
+            if (cimg) ax = kAxisToChl[ax];
             osh[ax] = 0;
             for (int t : ins) { if (m.tensors[t].shape.size() != osh.size()) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": rank mismatch"); } osh[ax] += m.tensors[t].shape[ax]; }
-            add_op(OP_CONCATENATION, ins, new_act(oname, osh)).axis = (int)ax;
+            const int co = new_act(oname, osh);
+            add_op(OP_CONCATENATION, ins, co).axis = (int)ax;
+            if (cimg) chl.insert(co);
+        } else if (nd.op == "Conv") {
+            int a = in_act(0);
+            if (a < 0 || nd.in.size() < 2 || m.tensors[a].shape.size() != 4) return fail("ONNX: " + where + ": input must be a rank-4 activation (2-D convolution)");
+            a = to_chl(a);
+            const auto ish = m.tensors[a].shape;              // [1, H, W, C]
+            std::vector<float> Wv; std::vector<int64_t> wd;
+            if (!const_f(nd.in[1], &Wv, &wd) || wd.size() != 4) return fail("ONNX: " + where + ": weights must be a constant [M, C/group, kh, kw] tensor");
+            const int M = (int)wd[0], Cg = (int)wd[1], kh = (int)wd[2], kw = (int)wd[3], C = ish[3];
+            const int64_t group = nd.ai("group", 1);
+            auto two = [&](const char* key, int dflt, int* x, int* y) -> bool {
+                *x = *y = dflt;
+                if (const OAttr* p = nd.attr(key)) { if (p->ints.size() != 2) return false; *x = (int)p->ints[0]; *y = (int)p->ints[1]; }
+                return *x >= 1 && *y >= 1;
+            };
+            int sh_, sw_, dh, dw;
+            if (!two("strides", 1, &sh_, &sw_) || !two("dilations", 1, &dh, &dw)) return fail("ONNX: " + where + ": strides / dilations must have two positive entries");
+            if (const OAttr* p = nd.attr("kernel_shape")) if (p->ints.size() != 2 || p->ints[0] != kh || p->ints[1] != kw) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": kernel_shape disagrees with the weights"); }
+            if (M < 1 || kh < 1 || kw < 1 || group < 1 || (int64_t)Cg * group != C || M % group) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": weight shape disagrees with the input channels / group"); }
+            int Ho, Wo, pt, pl; std::string why;
+            if (!window_geom(nd, ish[1], ish[2], kh, kw, sh_, sw_, dh, dw, &Ho, &Wo, &pt, &pl, &why)) return fail("ONNX: " + where + ": " + why);
+            std::vector<int> ins = {a};
+            int opc;
+            int mult = 1;
+            if (group == 1) {                                 // OIHW -> OHWI
+                std::vector<float> w((size_t)M * kh * kw * C);
+                for (int o = 0; o < M; o++) for (int c = 0; c < C; c++) for (int i = 0; i < kh; i++) for (int j = 0; j < kw; j++)
+                    w[(((size_t)o * kh + i) * kw + j) * C + c] = Wv[(((size_t)o * C + c) * kh + i) * kw + j];
+                ins.push_back(m.add_const_f32(nd.in[1] + "/ohwi", {M, kh, kw, C}, w));
+                opc = OP_CONV_2D;
+            } else if (group == C && Cg == 1) {               // depthwise (channel multiplier M / C): [M,1,kh,kw] -> [1,kh,kw,M]
+                std::vector<float> w((size_t)kh * kw * M);
+                for (int o = 0; o < M; o++) for (int i = 0; i < kh; i++) for (int j = 0; j < kw; j++)
+                    w[((size_t)i * kw + j) * M + o] = Wv[((size_t)o * kh + i) * kw + j];
+                ins.push_back(m.add_const_f32(nd.in[1] + "/1hwm", {1, kh, kw, M}, w));
+                opc = OP_DEPTHWISE_CONV_2D; mult = M / C;
+            } else return fail("ONNX: " + where + ": grouped convolutions other than depthwise are not supported");
+            if (nd.in.size() > 2 && !nd.in[2].empty()) {
+                std::vector<float> bv;
+                if (!const_f(nd.in[2], &bv, nullptr) || (int)bv.size() != M) return fail("ONNX: " + where + ": bias must be a constant [M] tensor");
+                ins.push_back(m.add_const_f32(nd.in[2] + "/b", {M}, bv));
+            }
+            const int co = new_act(oname, {1, Ho, Wo, M});
+            TflOp& o = add_op(opc, ins, co);
+            o.stride_h = sh_; o.stride_w = sw_; o.dil_h = dh; o.dil_w = dw; o.depth_multiplier = mult;
+            // padding: VALID / TF-SAME where the pads say exactly that (the planner's fused patterns key on them), explicit otherwise
+            const int same_h = (ish[1] + sh_ - 1) / sh_, same_w = (ish[2] + sw_ - 1) / sw_;
+            const int spt = std::max((same_h - 1) * sh_ + dh * (kh - 1) + 1 - ish[1], 0) / 2, spl = std::max((same_w - 1) * sw_ + dw * (kw - 1) + 1 - ish[2], 0) / 2;
+            if (pt == 0 && pl == 0 && Ho == (ish[1] - (dh * (kh - 1) + 1)) / sh_ + 1 && Wo == (ish[2] - (dw * (kw - 1) + 1)) / sw_ + 1) o.padding = 1;
+            else if (Ho == same_h && Wo == same_w && pt == spt && pl == spl) o.padding = 0;
+            else {
+                o.padding = 1; o.explicit_pad = true; o.pad_t = pt; o.pad_l = pl;      // bottom / right follow from the output size
+                o.pad_b = std::max((Ho - 1) * sh_ + dh * (kh - 1) + 1 - ish[1] - pt, 0); o.pad_r = std::max((Wo - 1) * sw_ + dw * (kw - 1) + 1 - ish[2] - pl, 0);
+            }
+            chl.insert(co);
+        } else if (nd.op == "GlobalAveragePool" || nd.op == "ReduceMean") {
+            int a = in_act(0);
+            if (a < 0) return fail("ONNX: " + where + ": operand must be an activation");
+            const bool img = chl.count(a) != 0;
+            const int rank = (int)m.tensors[a].shape.size();
+            std::vector<int64_t> axes; bool keep = true;
+            if (nd.op == "GlobalAveragePool") { if (rank != 4) return fail("ONNX: " + where + ": input must be rank 4"); if (!img) a = to_chl(a); axes = {2, 3}; }
+            else {
+                keep = nd.ai("keepdims", 1) != 0;
+                if (const OAttr* p = nd.attr("axes")) axes = p->ints;
+                else if (nd.in.size() > 1 && !nd.in[1].empty()) { if (!const_i(nd.in[1], &axes)) return fail("ONNX: " + where + ": axes must be constant"); }
+                else return fail("ONNX: " + where + ": reduction over all axes is not supported");
+            }
+            const bool cl = chl.count(a) != 0;
+            std::vector<int32_t> ax32; std::vector<char> red(rank, 0);
+            for (auto ax : axes) { if (ax < 0) ax += rank; if (ax < 1 || ax >= rank || red[ax]) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": bad reduction axis"); } red[ax] = 1; ax32.push_back((int32_t)(cl ? kAxisToChl[ax] : ax)); }
+            std::sort(ax32.begin(), ax32.end());
+            std::vector<int> osh; const auto ish = m.tensors[a].shape;
+            for (int k = 0; k < rank; k++) { const bool r = std::find(ax32.begin(), ax32.end(), k) != ax32.end(); if (r) { if (keep) osh.push_back(1); } else osh.push_back(ish[k]); }
+            // without keepdims the result has lower rank: it stays in the graph's element order only when the kept image axes are
+            // not mixed, i.e. (for an image) both spatial axes are reduced -> [N, C]
+            if (cl && !keep && !(red[2] && red[3] && !red[1])) return fail("ONNX: " + where + ": this reduction of an image without keepdims is not supported");
+            const int ro = new_act(oname, osh);
+            add_op(OP_MEAN, {a, m.add_const_i32(oname + "/axes", {(int)ax32.size()}, ax32)}, ro).keep_dims = keep;
+            if (cl && keep) chl.insert(ro);
+        } else if (nd.op == "MaxPool" || nd.op == "AveragePool") {
+            int a = in_act(0);
+            if (a < 0 || m.tensors[a].shape.size() != 4) return fail("ONNX: " + where + ": input must be a rank-4 activation");
+            a = to_chl(a);
+            const auto ish = m.tensors[a].shape;
+            const OAttr* ks = nd.attr("kernel_shape");
+            if (!ks || ks->ints.size() != 2) return fail("ONNX: " + where + ": kernel_shape must have two entries");
+            int sh_ = 1, sw_ = 1;
+            if (const OAttr* p = nd.attr("strides")) { if (p->ints.size() != 2) return fail("ONNX: " + where + ": strides"); sh_ = (int)p->ints[0]; sw_ = (int)p->ints[1]; }
+            if (const OAttr* p = nd.attr("dilations")) for (auto dv : p->ints) if (dv != 1) return fail("ONNX: " + where + ": dilated pooling is not supported");
+            if (nd.op == "AveragePool" && nd.ai("count_include_pad", 0) != 0) return fail("ONNX: " + where + ": count_include_pad is not supported");
+            const int kh = (int)ks->ints[0], kw = (int)ks->ints[1];
+            int Ho, Wo, pt, pl; std::string why;
+            if (kh < 1 || kw < 1 || sh_ < 1 || sw_ < 1 || !window_geom(nd, ish[1], ish[2], kh, kw, sh_, sw_, 1, 1, &Ho, &Wo, &pt, &pl, &why)) return fail("ONNX: " + where + ": " + why);
+            // the pooling kernels know VALID and TF-SAME padding (excluded from the average, as ONNX does by default)
+            const int same_h = (ish[1] + sh_ - 1) / sh_, same_w = (ish[2] + sw_ - 1) / sw_;
+            const int spt = std::max((same_h - 1) * sh_ + kh - ish[1], 0) / 2, spl = std::max((same_w - 1) * sw_ + kw - ish[2], 0) / 2;
+            int padding;
+            if (pt == 0 && pl == 0 && Ho == (ish[1] - kh) / sh_ + 1 && Wo == (ish[2] - kw) / sw_ + 1) padding = 1;
+            else if (Ho == same_h && Wo == same_w && pt == spt && pl == spl) padding = 0;
+            else return fail("ONNX: " + where + ": only VALID and SAME_UPPER-equivalent pooling padding is supported");
+            const int po = new_act(oname, {1, Ho, Wo, ish[3]});
+            TflOp& o = add_op(nd.op == "MaxPool" ? OP_MAX_POOL_2D : OP_AVERAGE_POOL_2D, {a}, po);
+            o.filter_h = kh; o.filter_w = kw; o.stride_h = sh_; o.stride_w = sw_; o.padding = padding;
+            chl.insert(po);
+        } else if (nd.op == "Transpose") {
+            const int a = in_act(0);
+            if (a < 0) return fail("ONNX: " + where + ": operand must be an activation");
+            const int rank = (int)m.tensors[a].shape.size();
+            std::vector<int64_t> perm;
+            if (const OAttr* p = nd.attr("perm")) perm = p->ints; else for (int k = rank - 1; k >= 0; k--) perm.push_back(k);
+            if ((int)perm.size() != rank) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": perm length != rank"); }
+            const bool to_cf = rank == 4 && perm == std::vector<int64_t>{0, 3, 1, 2};     // NHWC data -> NCHW value
+            const bool to_cl = rank == 4 && perm == std::vector<int64_t>{0, 2, 3, 1};     // NCHW value -> NHWC data
+            if (to_cf && !chl.count(a)) {
+                // the result is an NCHW value whose channels-last form is exactly this tensor: no data movement, an alias tensor
+                // carries the tag (the source may still be used as a plain tensor elsewhere)
+                const int t = new_act(oname, m.tensors[a].shape);
+                add_op(OP_RESHAPE, {a}, t).new_shape = m.tensors[a].shape;
+                chl.insert(t);
+            } else if (to_cl && chl.count(a)) {
+                const int t = new_act(oname, m.tensors[a].shape);
+                add_op(OP_RESHAPE, {a}, t).new_shape = m.tensors[a].shape;
+            } else {
+                const int src = to_nchw(a);
+                std::vector<int> osh; std::vector<int32_t> p32;
+                for (auto pk : perm) { if (pk < 0 || pk >= rank) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": bad permutation"); } osh.push_back(m.tensors[src].shape[pk]); p32.push_back((int32_t)pk); }
+                if (perm[0] != 0) return fail("ONNX: " + where + ": the batch axis cannot move");
+                add_op(OP_TRANSPOSE, {src, m.add_const_i32(oname + "/perm", {rank}, p32)}, new_act(oname, osh));
+            }
+        } else if (nd.op == "HardSigmoid") {
+            const int a = in_act(0);
+            if (a < 0) return fail("ONNX: " + where + ": operand must be an activation");
+            const float al = nd.af("alpha", 0.2f), be = nd.af("beta", 0.5f);
+            const auto sh = m.tensors[a].shape; const bool img = chl.count(a) != 0;
+            const int t1 = new_act(oname + "/ax", sh), t2 = new_act(oname + "/axb", sh), t3 = new_act(oname + "/lo", sh), t4 = new_act(oname, sh);
+            add_op(OP_MUL, {a, m.add_const_f32(oname + "/alpha", {1}, {al})}, t1);
+            add_op(OP_ADD, {t1, m.add_const_f32(oname + "/beta", {1}, {be})}, t2);
+            add_op(OP_MAXIMUM, {t2, m.add_const_f32(oname + "/zero", {1}, {0.0f})}, t3);
+            add_op(OP_MINIMUM, {t3, m.add_const_f32(oname + "/one", {1}, {1.0f})}, t4);
+            if (img) for (int t : {t1, t2, t3, t4}) chl.insert(t);
+        } else if (nd.op == "Pad") {
+            int a = in_act(0);
+            if (a < 0) return fail("ONNX: " + where + ": operand must be an activation");
+            const OAttr* md = nd.attr("mode");
+            if (md && !md->s.empty() && md->s != "constant") return fail("ONNX: " + where + ": only constant padding is supported");
+            const int rank = (int)m.tensors[a].shape.size();
+            std::vector<int64_t> pads;
+            if (const OAttr* p = nd.attr("pads")) pads = p->ints;
+            else if (nd.in.size() < 2 || !const_i(nd.in[1], &pads)) return fail("ONNX: " + where + ": pads must be constant");
+            if ((int)pads.size() != 2 * rank) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": pads length != 2 * rank"); }
+            if (nd.in.size() > 2 && !nd.in[2].empty()) { std::vector<float> cv; if (!const_f(nd.in[2], &cv, nullptr) || cv.size() != 1 || cv[0] != 0.0f) return fail("ONNX: " + where + ": only zero padding is supported"); }
+            if (nd.af("value", 0.0f) != 0.0f) return fail("ONNX: " + where + ": only zero padding is supported");
+            const bool img = chl.count(a) != 0;
+            std::vector<int32_t> pv(2 * rank, 0); std::vector<int> osh = m.tensors[a].shape;
+            for (int k = 0; k < rank; k++) {
+                const int64_t lo = pads[k], hi = pads[rank + k];
+                if (lo < 0 || hi < 0 || lo > (1 << 24) || hi > (1 << 24) || (k == 0 && (lo || hi))) return fail("ONNX: " + where + ": negative or batch padding is not supported");
+                const int q = img ? kAxisToChl[k] : k;
+                pv[2 * q] = (int32_t)lo; pv[2 * q + 1] = (int32_t)hi; osh[q] += (int)(lo + hi);
+            }
+            const int po = new_act(oname, osh);
+            add_op(OP_PAD, {a, m.add_const_i32(oname + "/pads", {rank, 2}, pv)}, po);
+            if (img) chl.insert(po);
         } else {
             return fail("ONNX: unsupported operator " + where);
         }
@@ -486,7 +756,7 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
     for (auto& vi : g_out) {
         auto it = tid.find(vi.name);
         if (it == tid.end()) { *code = BNHIP_E_MODEL; return fail("ONNX: graph output is not produced by any node: " + vi.name); }
-        m.outputs.push_back(it->second);
+        m.outputs.push_back(to_nchw(it->second));             // an image output leaves in the graph's own (NCHW) order
     }
     *code = BNHIP_OK;
     return true;

@@ -45,6 +45,17 @@ int TflModel::add_const_f32(const std::string& name, const std::vector<int>& sha
     return (int)tensors.size() - 1;
 }
 
+int TflModel::add_const_i32(const std::string& name, const std::vector<int>& shape, const std::vector<int32_t>& v) {
+    auto buf = std::make_shared<std::vector<uint8_t>>(v.size() * sizeof(int32_t));
+    if (!v.empty()) memcpy(buf->data(), v.data(), buf->size());
+    owned.push_back(buf);
+    TflTensor t;
+    t.name = name; t.shape = shape; t.type = TT_INT32;
+    t.data = buf->data(); t.nbytes = buf->size();
+    tensors.push_back(std::move(t));
+    return (int)tensors.size() - 1;
+}
+
 namespace {
 
 // Bounds-checked flatbuffer cursor. Any violation sets ok=false; accessors then return zeros.

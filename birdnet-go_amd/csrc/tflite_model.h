@@ -69,6 +69,7 @@ struct TflModel {
     std::vector<std::shared_ptr<std::vector<uint8_t>>> owned;
     // adds a float32 constant tensor owning a copy of `v`; returns its index
     int add_const_f32(const std::string& name, const std::vector<int>& shape, const std::vector<float>& v);
+    int add_const_i32(const std::string& name, const std::vector<int>& shape, const std::vector<int32_t>& v);
 };
 
 // Parses `blob`; returns false and fills `err` on malformed input. Never reads out of bounds.

@@ -153,3 +153,71 @@ def build_dense_head(dims, style="gemm", hidden_act="Relu", final=None, seed=11,
     t = b.node("Identity", [t])
     b.output(t, [batch_dim, dims[-1]])
     return b.finish(), ws
+
+
+def build_cnn(in_shape=(1, 40, 56), stem=16, blocks=((1, 3, 1, 8), (4, 3, 2, 16), (4, 5, 1, 16), (6, 3, 2, 24)), top=48, n_classes=21,
+              style="torch", seed=5, emit_embedding=False, nhwc_input=False):
+    """Convolutional classifier on an image-like input (a spectrogram), in the NCHW vocabulary exporters emit:
+    Conv (+bias), Sigmoid * Mul (swish), depthwise Conv (group = C), squeeze-excite as GlobalAveragePool -> Conv 1x1 ->
+    swish -> Conv 1x1 -> Sigmoid -> Mul, residual Add, then GlobalAveragePool -> Flatten -> Gemm.
+    style "torch": explicit symmetric pads, Flatten + Gemm;  "tf": auto_pad SAME_UPPER, ReduceMean(axes 2,3, keepdims 0) +
+    MatMul + Add, BatchNormalization left unfolded after the stem, HardSigmoid in the last block's gate, an AveragePool.
+    nhwc_input: the graph input is [N, H, W, C] followed by the Transpose tf2onnx puts in front of the first Conv.
+    -> bytes"""
+    rng = np.random.default_rng(seed)
+    b = OnnxBuilder()
+    C, H, W = in_shape
+    if nhwc_input:
+        t = b.input("spectrogram", ["N", H, W, C])
+        t = b.node("Transpose", [t], perm=[0, 3, 1, 2])
+    else:
+        t = b.input("spectrogram", ["N", C, H, W])
+    tf = style == "tf"
+
+    def conv(t, cin, cout, k, s, groups=1, gain=1.4, bias=True):
+        w = (rng.standard_normal((cout, cin // groups, k, k)) * gain / np.sqrt(k * k * cin / groups)).astype(np.float32)
+        ins = [t, b.init(w)]
+        if bias:
+            ins.append(b.init((rng.standard_normal(cout) * 0.1).astype(np.float32)))
+        if tf:
+            return b.node("Conv", ins, kernel_shape=[k, k], strides=[s, s], group=groups, auto_pad="SAME_UPPER")
+        return b.node("Conv", ins, kernel_shape=[k, k], strides=[s, s], group=groups, pads=[k // 2] * 4, dilations=[1, 1])
+
+    def swish(t):
+        return b.node("Mul", [t, b.node("Sigmoid", [t])])
+
+    t = conv(t, C, stem, 3, 2, bias=not tf)
+    if tf:                                               # unfolded batch norm after the stem
+        p = [rng.uniform(0.5, 1.5, stem), rng.standard_normal(stem) * 0.1, rng.standard_normal(stem) * 0.1, rng.uniform(0.5, 1.5, stem)]
+        t = b.node("BatchNormalization", [t] + [b.init(v.astype(np.float32)) for v in p], epsilon=1e-3)
+    t = swish(t)
+    cin = stem
+    for bi, (er, k, s, cout) in enumerate(blocks):
+        inp, mid = t, cin * er
+        if er != 1:
+            t = swish(conv(t, cin, mid, 1, 1, gain=1.6))
+        t = swish(conv(t, mid, mid, k, s, groups=mid, gain=1.6))
+        cse = max(1, cin // 4)
+        g_ = b.node("GlobalAveragePool", [t])
+        g_ = swish(conv(g_, mid, cse, 1, 1, gain=1.0))
+        g_ = conv(g_, cse, mid, 1, 1, gain=1.0)
+        g_ = b.node("HardSigmoid", [g_], alpha=0.2, beta=0.5) if (tf and bi == len(blocks) - 1) else b.node("Sigmoid", [g_])
+        t = b.node("Mul", [t, g_])
+        t = conv(t, mid, cout, 1, 1)
+        if s == 1 and cin == cout:
+            t = b.node("Add", [t, inp])
+        cin = cout
+    t = swish(conv(t, cin, top, 1, 1, gain=1.6))
+    if tf:
+        t = b.node("AveragePool", [t], kernel_shape=[2, 2], strides=[2, 2])
+        emb = b.node("ReduceMean", [t], axes=[2, 3], keepdims=0)
+        wh = (rng.standard_normal((top, n_classes)) * 2.0 / np.sqrt(top)).astype(np.float32)
+        t = b.node("Add", [b.node("MatMul", [emb, b.init(wh)]), b.init((rng.standard_normal(n_classes) * 0.5).astype(np.float32))])
+    else:
+        emb = b.node("Flatten", [b.node("GlobalAveragePool", [t])], axis=1)
+        wh = (rng.standard_normal((n_classes, top)) * 2.0 / np.sqrt(top)).astype(np.float32)
+        t = b.node("Gemm", [emb, b.init(wh), b.init((rng.standard_normal(n_classes) * 0.5).astype(np.float32))], alpha=1.0, beta=1.0, transB=1)
+    b.output(t, ["N", n_classes])
+    if emit_embedding:
+        b.output(emb, ["N", top])
+    return b.finish()

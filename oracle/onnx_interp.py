@@ -2,7 +2,8 @@
 
 Independent reader + numpy executor for the ONNX graphs the reference runs through ONNX Runtime 1.25.1
 (`github.com/yalue/onnxruntime_go v1.30.1`, third-party, absent from /root/reference): secondary dense heads
-(`internal/inference/onnx/custom_classifier.go:148-174` CustomClassifier.PredictRaw; `internal/classifier/bat_onnx.go:252-282`).
+(`internal/inference/onnx/custom_classifier.go:148-174` CustomClassifier.PredictRaw; `internal/classifier/bat_onnx.go:252-282`)
+and convolutional classifiers (`internal/inference/onnx/classifier.go:268-430`: NCHW Conv / pooling / reductions).
 Each operator restates the ONNX operator specification (Gemm: Y = alpha*A'*B' + beta*C; MatMul; BatchNormalization
 inference form; Softmax over `axis`; elementwise ops with numpy broadcasting).  PARITY UNPINNED against ONNX Runtime itself
 (no runtime and no real head files exist here); what this pins is engine-vs-specification on files both readers parse.
@@ -164,6 +165,72 @@ class OnnxModel:
         self.runtime_inputs = [n for n in self.inputs if n not in self.inits]
 
 
+def _window_pads(at, H, W, kh, kw, sh, sw, dh, dw):
+    """ONNX padding attributes -> (top, left, bottom, right)."""
+    ap = at.get("auto_pad") or "NOTSET"
+    eh, ew = dh * (kh - 1) + 1, dw * (kw - 1) + 1
+    if ap == "NOTSET":
+        p = at.get("pads") or [0, 0, 0, 0]
+        return p[0], p[1], p[2], p[3]
+    if ap == "VALID":
+        return 0, 0, 0, 0
+    th = max((-(-H // sh) - 1) * sh + eh - H, 0)
+    tw = max((-(-W // sw) - 1) * sw + ew - W, 0)
+    if ap == "SAME_UPPER":
+        return th // 2, tw // 2, th - th // 2, tw - tw // 2
+    return th - th // 2, tw - tw // 2, th // 2, tw // 2
+
+
+def _conv(x, w, b, at, fdt):
+    """Conv (2-D, NCHW, OIHW weights, group 1 or depthwise-style groups): direct sum over the kernel window."""
+    N, C, H, W = x.shape
+    M, Cg, kh, kw = w.shape
+    g = int(at.get("group", 1))
+    sh, sw = at.get("strides") or [1, 1]
+    dh, dw = at.get("dilations") or [1, 1]
+    pt, pl, pb, pr = _window_pads(at, H, W, kh, kw, sh, sw, dh, dw)
+    xp = np.pad(x, [(0, 0), (0, 0), (pt, pb), (pl, pr)])
+    Ho = (H + pt + pb - (dh * (kh - 1) + 1)) // sh + 1
+    Wo = (W + pl + pr - (dw * (kw - 1) + 1)) // sw + 1
+    y = np.zeros((N, M, Ho, Wo), fdt)
+    mg = M // g
+    for i in range(kh):
+        for j in range(kw):
+            patch = xp[:, :, i * dh:i * dh + (Ho - 1) * sh + 1:sh, j * dw:j * dw + (Wo - 1) * sw + 1:sw]     # [N, C, Ho, Wo]
+            if g == 1:
+                y += np.einsum("nchw,mc->nmhw", patch, w[:, :, i, j], optimize=True)
+            else:
+                for q in range(g):
+                    y[:, q * mg:(q + 1) * mg] += np.einsum("nchw,mc->nmhw", patch[:, q * Cg:(q + 1) * Cg], w[q * mg:(q + 1) * mg, :, i, j],
+                                                          optimize=True)
+    if b is not None:
+        y += b.reshape(1, -1, 1, 1)
+    return y
+
+
+def _pool(x, at, is_max, fdt):
+    N, C, H, W = x.shape
+    kh, kw = at["kernel_shape"]
+    sh, sw = at.get("strides") or [1, 1]
+    pt, pl, pb, pr = _window_pads(at, H, W, kh, kw, sh, sw, 1, 1)
+    fill = -np.inf if is_max else 0.0
+    xp = np.pad(x, [(0, 0), (0, 0), (pt, pb), (pl, pr)], constant_values=fill)
+    cnt = np.pad(np.ones((1, 1, H, W), fdt), [(0, 0), (0, 0), (pt, pb), (pl, pr)])
+    Ho = (H + pt + pb - kh) // sh + 1
+    Wo = (W + pl + pr - kw) // sw + 1
+    y = np.full((N, C, Ho, Wo), fill, fdt)
+    n = np.zeros((1, 1, Ho, Wo), fdt)
+    for i in range(kh):
+        for j in range(kw):
+            patch = xp[:, :, i:i + (Ho - 1) * sh + 1:sh, j:j + (Wo - 1) * sw + 1:sw]
+            if is_max:
+                y = np.maximum(y, patch)
+            else:
+                y = y + patch
+                n = n + cnt[:, :, i:i + (Ho - 1) * sh + 1:sh, j:j + (Wo - 1) * sw + 1:sw]
+    return y if is_max else y / n           # count_include_pad = 0 (the default)
+
+
 def run(blob, x, precision="f32"):
     """x [B, dim] -> list of outputs (float32)."""
     m = blob if isinstance(blob, OnnxModel) else OnnxModel(blob)
@@ -198,6 +265,8 @@ def run(blob, x, precision="f32"):
             y = e / e.sum(axis=ax, keepdims=True)
         elif op == "BatchNormalization":
             x_, sc, bi, mu, va = a[:5]
+            if x_.ndim == 4:                     # per-channel parameters of an NCHW image
+                sc, bi, mu, va = (v.reshape(1, -1, 1, 1) for v in (sc, bi, mu, va))
             y = (x_ - mu) / np.sqrt(va + np.asarray(at.get("epsilon", 1e-5), fdt)) * sc + bi
         elif op in ("Identity", "Dropout"):
             y = a[0]
@@ -209,6 +278,46 @@ def run(blob, x, precision="f32"):
             y = np.clip(a[0], lo, hi)
         elif op == "Concat":
             y = np.concatenate(a, axis=at.get("axis", 1))
+        elif op == "Conv":
+            y = _conv(a[0], a[1], a[2] if len(a) > 2 else None, at, fdt)
+        elif op in ("MaxPool", "AveragePool"):
+            y = _pool(a[0], at, op == "MaxPool", fdt)
+        elif op == "GlobalAveragePool":
+            y = a[0].mean(axis=(2, 3), keepdims=True, dtype=fdt)
+        elif op == "ReduceMean":
+            axes = at.get("axes")
+            if axes is None and len(a) > 1 and a[1] is not None:
+                axes = [int(v) for v in a[1]]
+            y = a[0].mean(axis=tuple(axes), keepdims=bool(at.get("keepdims", 1)), dtype=fdt)
+        elif op == "Transpose":
+            y = np.transpose(a[0], at.get("perm") or list(range(a[0].ndim))[::-1])
+        elif op == "Reshape":
+            shp = [int(v) for v in a[1]]
+            shp = [a[0].shape[i] if v == 0 else v for i, v in enumerate(shp)]
+            shp[0] = a[0].shape[0] if shp[0] != -1 else -1       # the file says batch 1; the oracle runs any batch
+            y = a[0].reshape(shp)
+        elif op == "Squeeze":
+            axes = at.get("axes")
+            if axes is None and len(a) > 1 and a[1] is not None:
+                axes = [int(v) for v in a[1]]
+            y = np.squeeze(a[0], axis=tuple(axes) if axes is not None else tuple(i for i in range(1, a[0].ndim) if a[0].shape[i] == 1))
+        elif op == "Unsqueeze":
+            axes = at.get("axes")
+            if axes is None:
+                axes = [int(v) for v in a[1]]
+            y = a[0]
+            for ax in sorted(ax_ % (a[0].ndim + len(axes)) for ax_ in axes):
+                y = np.expand_dims(y, ax)
+        elif op == "HardSigmoid":
+            y = np.clip(np.asarray(at.get("alpha", 0.2), fdt) * a[0] + np.asarray(at.get("beta", 0.5), fdt), 0, 1)
+        elif op == "HardSwish":
+            y = a[0] * np.clip(a[0] / np.asarray(6.0, fdt) + np.asarray(0.5, fdt), 0, 1)
+        elif op == "Pad":
+            pads = at.get("pads")
+            if pads is None:
+                pads = [int(v) for v in a[1]]
+            r = a[0].ndim
+            y = np.pad(a[0], [(pads[k], pads[r + k]) for k in range(r)])
         else:
             raise ValueError(f"oracle: unsupported ONNX op {op}")
         vals[outs[0]] = np.asarray(y, fdt)

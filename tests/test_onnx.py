@@ -7,6 +7,7 @@ import pytest
 import birdnet_go_amd  # noqa: F401
 from birdnet_go_amd import host, onnx_build as ob, synth_model as sm
 from oracle import gofuncs as G, onnx_interp
+from oracle import onnx_interp as oi
 
 STYLES = [("gemm", "Relu", None), ("matmul", "Relu", "Sigmoid"), ("bn", "Tanh", None), ("matmul", "LeakyRelu", "Softmax"),
           ("gemm", "Sigmoid", None)]
@@ -91,3 +92,94 @@ def test_bat_pipeline_with_onnx_head(gpu, tiny_cfg):
         assert [g[0] for g in got] == [w[0] for w in want]
         assert np.allclose([g[1] for g in got], [w[1] for w in want], atol=1e-5)
     backbone.close(); head.close()
+
+
+# ------------------------------------------------------------------------------------------------ convolutional ONNX graphs
+CNN_VARIANTS = [("torch", False), ("torch", True), ("tf", False), ("tf", True)]
+
+
+@pytest.mark.parametrize("style,nhwc", CNN_VARIANTS)
+def test_onnx_cnn_plans_onto_the_fused_kernels(built_lib, style, nhwc):
+    """NCHW Conv graphs (a8: `internal/inference/onnx/classifier.go:268-430` runs convolutional classifiers through ORT) are
+    lowered channels-last: the MBConv / squeeze-excite / residual patterns land on the same fused kernels as the TFLite form,
+    the second output is recognised as the embedding, and nothing but the tf-style extras needs the generic tier."""
+    blob = ob.build_cnn(style=style, nhwc_input=nhwc, emit_embedding=True)
+    c = host.HipClassifier(blob, plan_only=True)
+    try:
+        assert (c.n_samples, c.num_species(), c.emb_dim) == (40 * 56, 21, 48)
+        kinds = [s["kernel"] for s in c.describe()["steps"]]
+        assert kinds.count("expand_dw") == 3 and kinds.count("se") >= 3 and "conv_generic" not in kinds
+        assert not any(k.startswith("generic_copy") or k == "transpose" for k in kinds), kinds     # no layout copies at all
+    finally:
+        c.close()
+
+
+def test_onnx_cnn_reader_reports_what_it_cannot_lower(built_lib):
+    def graph(mut):
+        b = ob.OnnxBuilder()
+        x = b.input("x", ["N", 4, 8, 8])
+        w = np.zeros((6, 4, 3, 3), np.float32)
+        y = mut(b, x, w)
+        b.output(y, ["N", 6, 8, 8])
+        return b.finish()
+    cases = {
+        "group": lambda b, x, w: b.node("Conv", [x, b.init(w[:, :2])], kernel_shape=[3, 3], group=2, pads=[1, 1, 1, 1]),
+        "weight shape": lambda b, x, w: b.node("Conv", [x, b.init(w[:, :3])], kernel_shape=[3, 3], pads=[1, 1, 1, 1]),
+        "kernel_shape": lambda b, x, w: b.node("Conv", [x, b.init(w)], kernel_shape=[5, 5], pads=[1, 1, 1, 1]),
+        "padding": lambda b, x, w: b.node("Conv", [x, b.init(w)], kernel_shape=[3, 3], pads=[3, 3, 3, 3]),
+        "auto_pad": lambda b, x, w: b.node("Conv", [x, b.init(w)], kernel_shape=[3, 3], auto_pad="SAME_SIDEWAYS"),
+        "count_include_pad": lambda b, x, w: b.node("AveragePool", [x], kernel_shape=[2, 2], count_include_pad=1),
+        "ceil_mode": lambda b, x, w: b.node("MaxPool", [x], kernel_shape=[2, 2], strides=[2, 2], ceil_mode=1),
+    }
+    for key, mut in cases.items():
+        with pytest.raises(host.HipError, match=key) as e:
+            host.HipClassifier(graph(mut), plan_only=True)
+        assert e.value.code in (host.E_MODEL, host.E_UNSUPPORTED), key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("style,nhwc", CNN_VARIANTS)
+def test_onnx_cnn_hip_vs_oracle(gpu, style, nhwc):
+    """HIP (ONNX reader -> channels-last IR -> fused kernels) vs the oracle's NCHW numpy execution of the same file: explicit
+    pads and auto_pad, depthwise groups, squeeze-excite through GlobalAveragePool, HardSigmoid, unfolded BatchNormalization,
+    AveragePool, ReduceMean without keepdims, NHWC input behind a Transpose, two outputs."""
+    blob = ob.build_cnn(style=style, nhwc_input=nhwc, emit_embedding=True, seed=9)
+    x = np.random.default_rng(4).standard_normal((5, 40, 56, 1) if nhwc else (5, 1, 40, 56)).astype(np.float32)
+    ref = oi.run(blob, x)
+    c = host.HipClassifier(blob, max_batch=8)
+    try:
+        got, emb = c.predict_batch(x.reshape(-1), 5, want_embeddings=True)
+    finally:
+        c.close()
+    assert np.abs(got - ref[0]).max() < 1e-4 * max(1.0, np.abs(ref[0]).max()) and np.abs(emb - ref[1]).max() < 1e-4
+    assert (got.argmax(1) == ref[0].argmax(1)).all()
+
+
+@pytest.mark.gpu
+def test_onnx_cnn_multichannel_image_and_image_output(gpu):
+    """A 3-channel NCHW input (real layout change in front of the first Conv), odd sizes with asymmetric SAME padding, MaxPool,
+    channel Concat, a per-channel constant [1,C,1,1] and an image-shaped graph output (leaves in NCHW order)."""
+    rng = np.random.default_rng(12)
+    b = ob.OnnxBuilder()
+    x = b.input("img", ["N", 3, 19, 23])
+    w1 = (rng.standard_normal((8, 3, 3, 3)) * 0.3).astype(np.float32)
+    t = b.node("Conv", [x, b.init(w1), b.init(rng.standard_normal(8).astype(np.float32) * 0.1)], kernel_shape=[3, 3], strides=[2, 2], auto_pad="SAME_UPPER")
+    t = b.node("Relu", [t])
+    p = b.node("MaxPool", [t], kernel_shape=[2, 2], strides=[2, 2])
+    q = b.node("AveragePool", [t], kernel_shape=[2, 2], strides=[2, 2])
+    t = b.node("Concat", [p, q], axis=1)
+    t = b.node("Mul", [t, b.init(rng.uniform(0.5, 1.5, (1, 16, 1, 1)).astype(np.float32))])
+    w2 = (rng.standard_normal((4, 16, 1, 1)) * 0.3).astype(np.float32)
+    t = b.node("Conv", [t, b.init(w2)], kernel_shape=[1, 1])
+    b.output(t, ["N", 4, 5, 6])
+    blob = b.finish()
+    xv = rng.standard_normal((3, 3, 19, 23)).astype(np.float32)
+    ref = oi.run(blob, xv)[0]
+    assert ref.shape == (3, 4, 5, 6)
+    c = host.HipClassifier(blob, max_batch=4)
+    try:
+        assert c.num_species() == 4 * 5 * 6
+        got = c.predict_batch(xv.reshape(-1), 3).reshape(3, 4, 5, 6)
+    finally:
+        c.close()
+    assert np.abs(got - ref).max() < 1e-5

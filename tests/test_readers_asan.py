@@ -56,6 +56,11 @@ def test_readers_never_read_out_of_bounds(fuzz_bin, tmp_path, tiny_blob):
         ox, _ = ob.build_dense_head([16, 8, 4], style=style, final="Softmax")
         corpus.append(ox)
         corpus += _mutations(ox, rng, 300)
+    for style, nhwc in (("torch", False), ("tf", True)):           # convolutional ONNX graphs: Conv / pools / layout propagation
+        ox = ob.build_cnn(in_shape=(1, 12, 16), stem=8, blocks=((1, 3, 1, 8), (4, 5, 2, 8)), top=16, n_classes=5, style=style,
+                          nhwc_input=nhwc, emit_embedding=True)
+        corpus.append(ox)
+        corpus += _mutations(ox, rng, 400)
     path = tmp_path / "corpus.bin"
     with open(path, "wb") as f:
         for b in corpus:
@@ -64,4 +69,4 @@ def test_readers_never_read_out_of_bounds(fuzz_bin, tmp_path, tiny_blob):
     r = subprocess.run([fuzz_bin, str(path)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-6000:])
     n, acc = [int(v) for v in r.stdout.split()[1::2]]
-    assert n == len(corpus) and acc >= len(seeds) + 3          # the unmutated files are all accepted
+    assert n == len(corpus) and acc >= len(seeds) + 5          # the unmutated files are all accepted
