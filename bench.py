@@ -363,7 +363,7 @@ def main():
     oracle_rows = sorted({0, B // 2 - 1 if B > 1 else 0, B - 1})
     if rank == 0 and not args.no_oracle_check:
         from oracle.interp import Interpreter
-        ref = Interpreter(blob, conv_backend="torch").invoke(x_host[oracle_rows])[0]
+        ref = Interpreter(blob, conv_backend="torch").invoke(x_host[oracle_rows])[3 if perch else 0]     # Perch v2: logits are output 3
         got = logits[oracle_rows].float().cpu().numpy()
         sg = lambda v: 1.0 / (1.0 + np.exp(-v.astype(np.float64)))
         if perch:                                   # Perch scores are a softmax over the 14795 logits (perch_onnx.go:315-335)

@@ -595,6 +595,8 @@ int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, 
         // default 1: per layer where the create-time autotuner measures the split-bf16 kernel faster (fp32-equivalent
         // products; tests/test_bf16x3.py holds the error comparison against the float64 arbiter that decided the default)
         e->bf16x3 = (int)json_int(opts_json, "bf16x3", benv ? atoi(benv) : 1);
+        e->logits_output = (int)json_int(opts_json, "logits_output", -1);
+        e->embedding_output = (int)json_int(opts_json, "embedding_output", -2);       // -1: no embedding; -2: the family rule
         {
             // "precision": "f32" (default) | "bf16": MFMA operands rounded to bf16, fp32 accumulate and storage (BASELINE
             // configs[4] asks for this on Perch; never the default: v2.4 in reduced precision is known to fail, model_openvino.go:99-103)

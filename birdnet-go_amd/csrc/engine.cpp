@@ -362,6 +362,26 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
     // graph rewrites first (float16 constants behind DEQUANTIZE, unfolded batch norm, PAD + VALID convolutions): the
     // patterns below then see one canonical form whatever the exporter emitted
     if (!run_graph_passes(&m, err)) { *code = BNHIP_E_UNSUPPORTED; return false; }
+    // Which graph outputs are the logits and the embedding: the reference decides by model family from the input length and
+    // the number / size of the outputs (internal/inference/onnx/detection.go:24-112: v2.4 logits 0 [+ embedding 1]; BirdNET v3.0
+    // (160000 samples, 2 outputs) the 1280-wide port is the embedding, the other the predictions; Perch v2 (160000 samples, 4
+    // outputs: embedding, spatial embedding, spectrogram, logits) logits 3, embedding 0).  Explicit options win.  The boundary
+    // returns logits + embedding only, so every other output is dropped here and never computed.
+    if (!m.inputs.empty() && !m.outputs.empty()) {
+        const size_t n_in = m.tensors[m.inputs[0]].numel();
+        const int n_out = (int)m.outputs.size();
+        auto last_dim = [&](int oi) { const auto& sh = m.tensors[m.outputs[oi]].shape; return sh.empty() ? 0 : sh.back(); };
+        int li = 0, ei = n_out > 1 ? 1 : -1;
+        if (n_in == 160000 && n_out == 4) { li = 3; ei = 0; }
+        else if (n_in == 160000 && n_out == 2) { if (last_dim(0) == 1280) { ei = 0; li = 1; } else { ei = 1; li = 0; } }
+        if (logits_output >= 0) li = logits_output;
+        if (embedding_output != -2) ei = embedding_output;
+        if (li < 0 || li >= n_out || ei >= n_out || ei == li) { *code = BNHIP_E_INVALID; *err = "logits_output / embedding_output do not name two distinct graph outputs"; return false; }
+        std::vector<int> keep = {m.outputs[li]};
+        if (ei >= 0) keep.push_back(m.outputs[ei]);
+        logits_output = li; embedding_output = ei;
+        m.outputs = keep;
+    }
     Planner P(m);
 
     const TflTensor& tin = m.tensors[m.inputs[0]];
@@ -2013,7 +2033,7 @@ static void jesc(std::ostringstream& os, const std::string& s) {
 std::string Engine::describe() const {
     std::ostringstream os;
     os << "{\"n_samples\":" << n_samples << ",\"n_classes\":" << n_classes << ",\"emb_dim\":" << emb_dim
-       << ",\"max_batch\":" << max_batch << ",\"precision\":\"" << (precision ? "bf16" : "f32") << "\",\"lanes\":" << n_lanes << ",\"lane_min_batch\":" << dual_lane_min << ",\"act_arena_bytes\":" << act_bytes << ",\"weight_bytes\":" << w_bytes
+       << ",\"max_batch\":" << max_batch << ",\"logits_output\":" << logits_output << ",\"embedding_output\":" << embedding_output << ",\"precision\":\"" << (precision ? "bf16" : "f32") << "\",\"lanes\":" << n_lanes << ",\"lane_min_batch\":" << dual_lane_min << ",\"act_arena_bytes\":" << act_bytes << ",\"weight_bytes\":" << w_bytes
        << ",\"specs\":[";
     for (size_t i = 0; i < specs.size(); i++) {
         const FrontSpec& f = specs[i];

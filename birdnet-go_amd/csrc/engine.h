@@ -97,6 +97,7 @@ class Engine {
     char* weights_ptr() const { return w_arena; }
     size_t weights_bytes() const { return w_bytes; }
     int frontend_fft = -1;              // -1 / 1: FFT path where the frame length is supported (512/1024/2048), 0: folded-GEMM kernel for real-part graphs
+    int logits_output = -1, embedding_output = -2;   // graph output indices (options; -1 / -2 = the reference's per-family rule, see build())
     int precision = 0;                  // 0: fp32 products everywhere (f32 MFMA or the six-product split); 1 ("precision":"bf16"): the MFMA
                                         // layers round their operands to bf16 (one product, fp32 accumulate) - Perch-style deployments
     int bf16x3 = 0;                     // split-bf16 MFMA path for pointwise / dense layers (k_pw_bx3): 0 off, 1 per layer where the

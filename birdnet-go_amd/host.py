@@ -102,7 +102,7 @@ class HipClassifier:
 
     def __init__(self, model_bytes: bytes, device=0, max_batch=256, plan_only=False, debug_no_reuse=False,
                  graphs=None, frontend_fft=None, depth=None, lanes=None, autotune=None, devices=None, replicate=None,
-                 bf16x3=None, precision=None):
+                 bf16x3=None, precision=None, logits_output=None, embedding_output=None):
         self._lib = load_library()
         self._h = C.c_void_p()
         o = {"device": device, "max_batch": max_batch, "plan_only": int(plan_only), "debug_no_reuse": int(debug_no_reuse)}
@@ -112,6 +112,10 @@ class HipClassifier:
             o["replicate"] = str(replicate)
         if bf16x3 is not None:
             o["bf16x3"] = int(bf16x3)
+        if logits_output is not None:    # graph output indices (default: the reference's per-family rule, bnhip.h)
+            o["logits_output"] = int(logits_output)
+        if embedding_output is not None:
+            o["embedding_output"] = int(embedding_output)
         if precision is not None:        # "f32" (default) | "bf16": MFMA operands rounded to bf16, fp32 accumulate (Perch-style)
             o["precision"] = str(precision)
         if graphs is not None:

@@ -60,6 +60,7 @@ class SynthConfig:
     top: int = 1024
     n_classes: int = 6522
     emit_embeddings: bool = False    # second graph output = 1024-d embedding (bat / Perch-style)
+    perch_outputs: bool = False      # four outputs in Perch v2's order: embedding, spatial embedding, spectrogram, logits
     seed: int = 2024
     head_bias: float = -4.0
     name: str = "birdnet_v24_synth"
@@ -88,7 +89,8 @@ def perch_config(**kw):
                 complex_mode="abs", normalize=False, pad=(160, 160), compress="log", time_major=True, stem=40,
                 blocks=((1, 3, 1, 24, 2), (6, 3, 2, 32, 3), (6, 5, 2, 48, 3), (6, 3, 2, 96, 5), (6, 5, 1, 136, 5),
                         (6, 5, 2, 232, 6), (6, 3, 1, 384, 2)),
-                top=1536, n_classes=14795, emit_embeddings=True, head_bias=0.0, seed=2025, name="perch_v2_like_synth")
+                top=1536, n_classes=14795, emit_embeddings=True, perch_outputs=True, head_bias=0.0, seed=2025,
+                name="perch_v2_like_synth")
     base.update(kw)
     return SynthConfig(**base)
 
@@ -273,6 +275,10 @@ def build_model(cfg: SynthConfig = None) -> bytes:
     logits = g.op("FULLY_CONNECTED", [emb4, g.const(wh, "head/w"), g.const(bh, "head/b")],
                   [1, cfg.n_classes], dict(fused_activation_function=S.ACT_NONE), name="CLASS_DENSE_LAYER")
     outs = [logits, emb4] if cfg.emit_embeddings else [logits]
+    if cfg.perch_outputs:            # internal/inference/onnx/classifier.go:495-505: [B,1536], [B,16,4,1536], [B,500,128], [B,14795]
+        assert len(chans) == 1
+        spec3 = g.op("RESHAPE", [chans[0], g.const(i32([1, F0, cfg.n_mels]))], [1, F0, cfg.n_mels], dict(new_shape=[1, F0, cfg.n_mels]))
+        outs = [emb4, t, spec3, logits]
     return g.finish([x], outs)
 
 

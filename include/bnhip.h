@@ -56,7 +56,8 @@ void bnhip_shutdown(void);
  * container is sniffed: "TFL3" at byte 4 = TFLite flatbuffer, otherwise ONNX ModelProto.  The blob is consumed during the
  * call and may be freed afterwards (classifier.go:37).
  * opts_json (nullable): {"device":0,"devices":[0,1,..],"replicate":"auto","max_batch":256,"plan_only":0,"debug_no_reuse":0,
- *                        "autotune":1,"graphs":0,"lanes":2,"frontend_fft":-1,"depth":1,"bf16x3":1,"precision":"f32"}
+ *                        "autotune":1,"graphs":0,"lanes":2,"frontend_fft":-1,"depth":1,"bf16x3":1,"precision":"f32",
+ *                        "logits_output":0,"embedding_output":1}
  * "devices": one handle over several GPUs: one engine per listed device, the clips of every host-
  *          pointer call are sharded index-contiguously over them and run concurrently (one worker thread per device, own
  *          streams and pinned-order staging per device).  The frozen weights are uploaded to the first device only and
@@ -73,6 +74,10 @@ void bnhip_shutdown(void);
  *          v_mfma_f32_16x16x32_bf16 products per k, fp32 accumulation: every product is reproduced to within 2^-23, see
  *          DESIGN.md): 1 (default) = per layer where the create-time autotuner measures it faster, 0 = f32 MFMA only,
  *          2 = every eligible layer (K >= 16, K a multiple of 4).
+ * "logits_output" / "embedding_output": indices of the graph outputs returned as logits / embedding.  Default: the reference's
+ *          per-family rule (internal/inference/onnx/detection.go:24-112): output 0 (+ 1 as embedding); 160000-sample graphs
+ *          with 4 outputs (Perch v2) logits 3 / embedding 0; with 2 outputs (BirdNET v3.0) the 1280-wide one is the embedding.
+ *          Other outputs are not computed.  "embedding_output": -1 = none.
  * "precision": "f32" (default) keeps every product fp32 (f32 MFMA or the six-product split above).  "bf16" rounds the MFMA
  *          operands of the pointwise / dense / fused-expand layers to bf16 (one product per k, fp32 accumulation, fp32
  *          storage; depthwise, squeeze-excite, front-end and head bias stay fp32): the reduced-precision deployment the

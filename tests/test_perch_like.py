@@ -11,6 +11,13 @@ from oracle import gofuncs as G
 from oracle.interp import Interpreter
 
 
+def oracle_logits_emb(blob, x):
+    """(logits, embedding) of the oracle in the graph's own output order: Perch v2 lists embedding first and logits fourth
+    (internal/inference/onnx/classifier.go:495-505, perch_onnx.go:28), two-output graphs logits first."""
+    outs = Interpreter(blob).invoke(x)
+    return (outs[3], outs[0]) if len(outs) == 4 else (outs[0], outs[1] if len(outs) > 1 else None)
+
+
 def softmax64(v):
     z = np.asarray(v, np.float64)
     e = np.exp(z - z.max(axis=-1, keepdims=True))
@@ -24,6 +31,9 @@ def test_perch_like_plans_with_log_mel_front_end(built_lib):
         c = host.HipClassifier(sm.build_model(cfg), plan_only=True)
         try:
             assert (c.n_samples, c.num_species(), c.emb_dim) == shape
+            if cfg.perch_outputs:                                    # detection.go:107-111: logits are output 3, the embedding output 0
+                d = c.describe()
+                assert (d["logits_output"], d["embedding_output"]) == (3, 0)
             kinds = [s["kernel"] for s in c.describe()["steps"]]
             assert kinds[:2] == ["stft", "frontend"] and "clip_minmax" not in kinds      # raw samples: no min/max pass
             assert "elementwise" not in kinds and not any(k.startswith("generic") for k in kinds)
@@ -35,8 +45,8 @@ def test_perch_like_oracle_shapes():
     """CPU: the stand-in's tensors have the shapes the reference lists for Perch v2's outputs."""
     from oracle.tflite_reader import read_model
     m = read_model(sm.build_model(sm.perch_config()))
-    shapes = {tuple(int(d) for d in t.shape) for t in m.tensors}
-    assert (1, 500, 128, 1) in shapes and (1, 16, 4, 1536) in shapes and (1, 1536) in shapes and (1, 14795) in shapes
+    # the four outputs, in Perch v2's order (internal/inference/onnx/classifier.go:495-505)
+    assert [tuple(int(d) for d in m.tensors[t].shape) for t in m.outputs] == [(1, 1536), (1, 16, 4, 1536), (1, 500, 128), (1, 14795)]
 
 
 def test_front_end_variant_rejects_what_it_cannot_do(built_lib):
@@ -54,18 +64,22 @@ def test_front_end_variant_rejects_what_it_cannot_do(built_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["tiny", "tiny_two_lanes", "tiny_fft1024"])
+@pytest.mark.parametrize("variant", ["tiny", "tiny_two_lanes", "tiny_fft1024", "tiny_perch_order"])
 def test_tiny_perch_like_vs_oracle(gpu, variant):
     cfg = sm.tiny_perch_config()
     if variant == "tiny_fft1024":
         cfg = sm.tiny_perch_config(specs=(sm.SpecConfig(640, 320, 60.0, 16000.0, 1024),), n_samples=16000, pad=(160, 160), n_mels=128)
+    kw = {}
+    if variant == "tiny_perch_order":                            # four outputs in Perch's order, picked by explicit option
+        cfg = sm.tiny_perch_config(perch_outputs=True)
+        kw = dict(logits_output=3, embedding_output=0)
     blob = sm.build_model(cfg)
     n = 37 if variant == "tiny_two_lanes" else 5
     x = sm.synth_clips(n, cfg.n_samples, cfg.sample_rate)
     x[1] = 0.0                                                   # silence: every band sits on the log floor
     x[2, : cfg.n_samples // 2] = 0.0
-    ref = Interpreter(blob).invoke(x)
-    c = host.HipClassifier(blob, max_batch=64)
+    ref = oracle_logits_emb(blob, x)
+    c = host.HipClassifier(blob, max_batch=64, **kw)
     try:
         got, emb = c.predict_batch(x.reshape(-1), n, want_embeddings=True)
         assert np.isfinite(got).all()
@@ -87,7 +101,7 @@ def test_perch_size_vs_oracle_and_softmax_topk(gpu):
     blob = sm.build_model(cfg)
     x = sm.synth_clips(3, cfg.n_samples, cfg.sample_rate)
     x[2] = 0.0
-    ref = Interpreter(blob).invoke(x)
+    ref = oracle_logits_emb(blob, x)
     c = host.HipClassifier(blob, max_batch=8)
     try:
         got, emb = c.predict_batch(x.reshape(-1), 3, want_embeddings=True)
@@ -116,7 +130,7 @@ def test_expand_dw_both_orientations_vs_oracle(gpu, orient, monkeypatch):
     for cfg in (_geo_cfg(1), _geo_cfg(4), sm.tiny_perch_config()):
         blob = sm.build_model(cfg)
         x = sm.synth_clips(3, cfg.n_samples, cfg.sample_rate)
-        ref = Interpreter(blob).invoke(x)[0]
+        ref = oracle_logits_emb(blob, x)[0]
         c = host.HipClassifier(blob, max_batch=8)
         try:
             got = c.predict_batch(x.reshape(-1), 3)
@@ -136,7 +150,7 @@ def test_bf16_precision_drift_is_bounded(gpu):
     cfg = sm.perch_config()
     blob = sm.build_model(cfg)
     x = sm.synth_clips(3, cfg.n_samples, cfg.sample_rate, first=11)
-    ref = Interpreter(blob).invoke(x)[0]
+    ref = oracle_logits_emb(blob, x)[0]
     out = {}
     for prec in ("f32", "bf16"):
         c = host.HipClassifier(blob, max_batch=8, precision=prec)
@@ -165,7 +179,7 @@ def test_lds_staged_depthwise_vs_oracle(gpu, monkeypatch):
             monkeypatch.setenv("BNHIP_NO_FUSE_EXPDW", "1")
         blob = sm.build_model(cfg)
         x = sm.synth_clips(3, cfg.n_samples, cfg.sample_rate)
-        ref = Interpreter(blob).invoke(x)[0]
+        ref = oracle_logits_emb(blob, x)[0]
         c = host.HipClassifier(blob, max_batch=8)
         try:
             got = c.predict_batch(x.reshape(-1), 3)
