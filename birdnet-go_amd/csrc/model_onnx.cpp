@@ -551,7 +551,8 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
             if (chk != total || osh.empty() || osh[0] != 1) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": reshape changes the element count or the batch dimension"); }
             add_op(OP_RESHAPE, {a}, new_act(oname, osh)).new_shape = osh;
         } else if (nd.op == "BatchNormalization") {
-            const int a = in_act(0);
+            int a = in_act(0);
+            if (a >= 0 && m.tensors[a].shape.size() == 4) a = to_chl(a);      // channels = axis 1 of the ONNX value = last axis here
             std::vector<float> sc, bi, mu, va;
             if (a < 0 || nd.in.size() < 5 || !const_f(nd.in[1], &sc, nullptr) || !const_f(nd.in[2], &bi, nullptr) || !const_f(nd.in[3], &mu, nullptr) || !const_f(nd.in[4], &va, nullptr))
                 return fail("ONNX: " + where + ": scale / bias / mean / var must be constants");

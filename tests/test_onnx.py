@@ -183,3 +183,35 @@ def test_onnx_cnn_multichannel_image_and_image_output(gpu):
     finally:
         c.close()
     assert np.abs(got - ref).max() < 1e-5
+
+
+SEEDS = list(range(40))
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_onnx_cnn_plans_and_oracle_runs(built_lib, seed):
+    """CPU: every seeded random NCHW graph is executed by the oracle and accepted by the reader + planner (no GPU needed)."""
+    from onnxgen import random_cnn, random_image
+    blob, in_shape, n_cls = random_cnn(seed)
+    y = oi.run(blob, random_image(seed, in_shape, 2))[0]
+    assert y.shape == (2, n_cls) and np.isfinite(y).all()
+    c = host.HipClassifier(blob, plan_only=True)
+    try:
+        assert c.num_species() == n_cls and c.n_samples == int(np.prod(in_shape))
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_onnx_cnn_hip_vs_oracle(gpu, seed):
+    from onnxgen import random_cnn, random_image
+    blob, in_shape, n_cls = random_cnn(seed)
+    x = random_image(seed, in_shape, 3)
+    ref = oi.run(blob, x)[0]
+    c = host.HipClassifier(blob, max_batch=4)
+    try:
+        got = c.predict_batch(x.reshape(-1), 3)
+    finally:
+        c.close()
+    assert np.abs(got - ref).max() <= 2e-5 * max(1.0, float(np.abs(ref).max())), (seed, np.abs(got - ref).max())
