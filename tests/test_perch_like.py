@@ -190,3 +190,51 @@ def test_lds_staged_depthwise_vs_oracle(gpu, monkeypatch):
         assert dw and all(s["dw_lds"] == 1 for s in dw), [(s["name"], s["dw_lds"]) for s in dw]
         assert_parity(got, ref)
         assert np.abs(got - ref).max() < 1e-3
+
+
+def _fe_cfg(i):
+    """Seeded log-mel front-end geometries: frame / transform / hop / padding / band-count combinations the Perch-size model
+    does not have (frame = transform, odd hops, one-sided padding, frames that end exactly at the clip end)."""
+    rng = np.random.default_rng(500 + i)
+    lfft = int(rng.choice([512, 1024, 2048]))
+    L = int(rng.choice([lfft, lfft, lfft // 2, lfft * 5 // 8, lfft - 2]))
+    hop = int(rng.choice([L // 2, L // 4, 94, 160, 278]))
+    pad = [(0, 0), (L // 4, L // 4), (hop, 0), (0, L // 2), (7, 13)][int(rng.integers(0, 5))]
+    frames = int(rng.integers(9, 40))
+    from math import gcd
+    sub = gcd(L, hop)                                     # tf.signal.frame reshapes the (padded) clip into sub-frames of gcd(L, hop)
+    n_samples = L + hop * (frames - 1) - pad[0] - pad[1] + sub * int(rng.integers(0, max(hop // sub, 1)))   # + a tail the framing ignores
+    n_mels = int(rng.choice([16, 40, 64, 96, 128]))
+    fmax = 7000.0 if lfft == 2048 else 16000.0           # the STFT kernel keeps at most 512 needed bins (8 per lane)
+    return sm.tiny_perch_config(n_samples=n_samples, sample_rate=32000, specs=(sm.SpecConfig(L, hop, 60.0, fmax, lfft),),
+                                n_mels=n_mels, pad=pad, log_floor=float(rng.choice([1e-3, 1e-2, 0.5])), log_scale=float(rng.choice([0.1, 1.0])),
+                                normalize=bool(rng.integers(0, 3) == 0), compress=str(rng.choice(["log", "log", "pow"])),
+                                time_major=bool(rng.integers(0, 4) != 0), seed=900 + i)
+
+
+@pytest.mark.parametrize("i", range(10))
+def test_front_end_geometry_sweep_plans(built_lib, i):
+    cfg = _fe_cfg(i)
+    c = host.HipClassifier(sm.build_model(cfg), plan_only=True)
+    try:
+        kinds = [s["kernel"] for s in c.describe()["steps"]]
+        assert "stft" in kinds and ("clip_minmax" in kinds) == cfg.normalize
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(10))
+def test_front_end_geometry_sweep_vs_oracle(gpu, i):
+    cfg = _fe_cfg(i)
+    blob = sm.build_model(cfg)
+    x = sm.synth_clips(4, cfg.n_samples, cfg.sample_rate, first=7 * i)
+    x[3] = 0.0
+    ref, ref_emb = oracle_logits_emb(blob, x)
+    c = host.HipClassifier(blob, max_batch=8)
+    try:
+        got, emb = c.predict_batch(x.reshape(-1), 4, want_embeddings=True)
+    finally:
+        c.close()
+    assert (got.argmax(1) == ref.argmax(1)).all()
+    assert np.abs(softmax64(got) - softmax64(ref)).max() <= 1e-4 and np.abs(got - ref).max() < 1e-3 and np.abs(emb - ref_emb).max() < 1e-3
