@@ -527,14 +527,14 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
             const bool can_fft = stft_supported(fm.Lfft, (int)bins.size()) && !bins.empty();
             if (fm.magnitude && !can_fft) {
                 *code = BNHIP_E_UNSUPPORTED;
-                *err = "front-end: magnitude STFT (COMPLEX_ABS) is only implemented for fft_length 512 / 1024 / 2048 with at most 512 DFT bins under the mel matrix";
+                *err = "front-end: magnitude STFT (COMPLEX_ABS) is only implemented for fft_length 512 / 1024 / 2048";
                 return false;
             }
             // the folded-GEMM kernel only knows the v2.4 layer (normalised clip, power compression, [mel, time] image)
             const bool variant = !fm.normalize || fm.log_compress || fm.time_major || fm.pad_left || fm.pad_right;
             if (variant && !can_fft) {
                 *code = BNHIP_E_UNSUPPORTED;
-                *err = "front-end: log-mel / unnormalised / padded front-ends are only implemented for fft_length 512 / 1024 / 2048 with at most 512 DFT bins under the mel matrix";
+                *err = "front-end: log-mel / unnormalised / padded front-ends are only implemented for fft_length 512 / 1024 / 2048";
                 return false;
             }
             fs.fft = fm.magnitude || variant || (frontend_fft != 0 && can_fft);     // measured faster than the folded GEMM (0.95 vs 1.05 ms)

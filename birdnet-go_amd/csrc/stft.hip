@@ -250,6 +250,27 @@ __global__ __launch_bounds__(64 * W) void k_stft_bins(StftParams p) {
             }
             orow[idx] = o;
         }
+        // more than 512 needed bins (a 2048-point transform under a wide mel bank): the rest take their bin index and twiddle
+        // from the plan-time image each frame instead of from registers
+        for (int idx = lane + 64 * NBL; idx < p.nbp; idx += 64) {
+            float o = 0.f;
+            if (idx < p.nb) {
+                const int k = p.bins[idx];
+                const int ka = k % N2, kb = (N2 - k % N2) % N2;
+                const double zr = wre[ka], zi = wim[ka], mr = wre[kb], mi = -wim[kb];
+                const double er = 0.5 * (zr + mr), ei = 0.5 * (zi + mi);
+                const double dr = zr - mr, di = zi - mi;
+                const double or_ = 0.5 * di, oi = -0.5 * dr;
+                const double c = p.tw[NTAB + idx], s = p.tw[NTAB + p.nb_cap + idx];
+                const double xr = er + fma(or_, c, -(oi * s));
+                if (p.mode == 0) o = (float)xr;
+                else {
+                    const double xi = ei + fma(or_, s, oi * c);
+                    o = hypotf((float)xr, (float)xi);
+                }
+            }
+            orow[idx] = o;
+        }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
     }
@@ -290,7 +311,7 @@ size_t stft_lds_bytes(int P, int nb_cap) {
 bool stft_supported(int Lfft, int nb) {
     if (Lfft != 2048 && Lfft != 1024 && Lfft != 512) return false;
     int P = Lfft / 128, cap = (nb + 63) / 64 * 64;
-    return nb <= 512 && stft_lds_bytes(P, cap) <= 160 * 1024;      // 8 bins per lane are held in registers
+    return nb <= Lfft / 2 + 1 && stft_lds_bytes(P, cap) <= 160 * 1024;      // (the first 512 bins' twiddles live in registers)
 }
 void launch_stft_bins(const StftParams& p0, hipStream_t s) {
     StftParams p = p0;

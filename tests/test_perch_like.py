@@ -205,7 +205,7 @@ def _fe_cfg(i):
     sub = gcd(L, hop)                                     # tf.signal.frame reshapes the (padded) clip into sub-frames of gcd(L, hop)
     n_samples = L + hop * (frames - 1) - pad[0] - pad[1] + sub * int(rng.integers(0, max(hop // sub, 1)))   # + a tail the framing ignores
     n_mels = int(rng.choice([16, 40, 64, 96, 128]))
-    fmax = 7000.0 if lfft == 2048 else 16000.0           # the STFT kernel keeps at most 512 needed bins (8 per lane)
+    fmax = 7000.0 if (lfft == 2048 and i % 2) else 16000.0       # 2048-point transforms under a narrow and under a full-band (1020-bin) mel bank
     return sm.tiny_perch_config(n_samples=n_samples, sample_rate=32000, specs=(sm.SpecConfig(L, hop, 60.0, fmax, lfft),),
                                 n_mels=n_mels, pad=pad, log_floor=float(rng.choice([1e-3, 1e-2, 0.5])), log_scale=float(rng.choice([0.1, 1.0])),
                                 normalize=bool(rng.integers(0, 3) == 0), compress=str(rng.choice(["log", "log", "pow"])),
