@@ -188,9 +188,11 @@ bool match_frontend(Planner& P, int ri, FrontendMatch* fm) {
         if (n2 < 0) return P.fail("front-end: normalisation MUL needs a scalar constant");
         int p_sub = P.producer[n2];
         bool rhs = false;
-        if (p_sub < 0 || m.ops[p_sub].code != OP_SUB) return P.fail("front-end: normalisation (SUB c) not found");
+        // (x - c), or the (x + (-c)) a converter may rewrite it to
+        if (p_sub < 0 || (m.ops[p_sub].code != OP_SUB && m.ops[p_sub].code != OP_ADD)) return P.fail("front-end: normalisation (SUB c) not found");
         int nm = P.bin_const(m.ops[p_sub], &fm->norm_sub, &rhs);
-        if (nm < 0 || !rhs) return P.fail("front-end: normalisation SUB needs a scalar constant rhs");
+        if (nm < 0 || (m.ops[p_sub].code == OP_SUB && !rhs)) return P.fail("front-end: normalisation SUB needs a scalar constant rhs");
+        if (m.ops[p_sub].code == OP_ADD) fm->norm_sub = -fm->norm_sub;
         int p_div = P.producer[nm];
         if (p_div < 0 || m.ops[p_div].code != OP_DIV) return P.fail("front-end: normalisation (DIV) not found");
         int s1 = m.ops[p_div].inputs[0], dn = m.ops[p_div].inputs[1];
@@ -220,16 +222,29 @@ bool match_frontend(Planner& P, int ri, FrontendMatch* fm) {
     P.absorbed[ci] = 1;
     t = P.skip_down(m.ops[ci].outputs[0]);
     ci = P.only_consumer(t);
-    if (ci < 0 || m.ops[ci].code != OP_FULLY_CONNECTED) return P.fail("front-end: mel projection (FULLY_CONNECTED) not found");
+    if (ci < 0 || (m.ops[ci].code != OP_FULLY_CONNECTED && m.ops[ci].code != OP_BATCH_MATMUL))
+        return P.fail("front-end: mel projection (FULLY_CONNECTED / BATCH_MATMUL) not found");
     {
         const TflOp& fc = m.ops[ci];
         if (!P.is_const(fc.inputs[1]) || (fc.inputs.size() > 2 && fc.inputs[2] >= 0))
             return P.fail("front-end: mel projection must have constant weights and no bias");
         const TflTensor& w = P.T(fc.inputs[1]);
-        if (w.shape.size() != 2 || w.shape[1] != fm->Lfft / 2 + 1 || w.type != TT_FLOAT32)
+        const int nbins = fm->Lfft / 2 + 1;
+        // FULLY_CONNECTED keeps [n_mels, bins]; tf.tensordot may also arrive as BATCH_MATMUL with the [bins, n_mels] matrix
+        // (or its transpose with adj_y) on the right
+        const bool bmm = fc.code == OP_BATCH_MATMUL;
+        if (bmm && fc.adj_x) return P.fail("front-end: mel BATCH_MATMUL with adj_x is not supported");
+        const bool rows_are_mels = !bmm || fc.adj_y;
+        if (w.shape.size() != 2 || w.shape[rows_are_mels ? 1 : 0] != nbins || w.type != TT_FLOAT32)
             return P.fail("front-end: mel matrix shape mismatch");
-        fm->mel_tensor = fc.inputs[1];
-        fm->n_mels = w.shape[0];
+        fm->n_mels = w.shape[rows_are_mels ? 0 : 1];
+        if (rows_are_mels) fm->mel_tensor = fc.inputs[1];
+        else {                                              // re-lay [bins, n_mels] -> [n_mels, bins]
+            std::vector<float> wt((size_t)fm->n_mels * nbins);
+            for (int k = 0; k < nbins; k++)
+                for (int mm = 0; mm < fm->n_mels; mm++) wt[(size_t)mm * nbins + k] = w.f32()[(size_t)k * fm->n_mels + mm];
+            fm->mel_tensor = const_cast<TflModel&>(m).add_const_f32(w.name + "/T", {fm->n_mels, nbins}, wt);
+        }
         P.absorbed[ci] = 1;
         t = P.skip_down(fc.outputs[0]);
     }
@@ -252,6 +267,18 @@ bool match_frontend(Planner& P, int ri, FrontendMatch* fm) {
         } else fm->log_scale = 1.f;
     }
     int npow = 0;
+    // the square may arrive as POW(x, 2), SQUARE(x) or MUL(x, x)
+    if (!fm->log_compress) {
+        ci = P.only_consumer(t);
+        const bool mul_self = ci < 0 && P.consumers[t].size() == 2 && P.consumers[t][0] == P.consumers[t][1] &&
+                              m.ops[P.consumers[t][0]].code == OP_MUL && m.ops[P.consumers[t][0]].inputs[0] == t && m.ops[P.consumers[t][0]].inputs[1] == t;
+        if (mul_self) ci = P.consumers[t][0];
+        if (ci >= 0 && (m.ops[ci].code == OP_SQUARE || mul_self)) {
+            fm->p1 = 2.0f; npow = 1;
+            P.absorbed[ci] = 1;
+            t = P.skip_down(m.ops[ci].outputs[0]);
+        }
+    }
     while (!fm->log_compress && (ci = P.only_consumer(t)) >= 0 && m.ops[ci].code == OP_POW && npow < 2) {
         float e;
         if (!P.const_scalar(m.ops[ci].inputs[1], &e)) return P.fail("front-end: POW exponent must be a scalar constant");

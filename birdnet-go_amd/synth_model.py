@@ -52,6 +52,9 @@ class SynthConfig:
     log_floor: float = 1e-2
     log_scale: float = 0.1
     time_major: bool = False         # True: spectrogram image is [1, frames, mel, 1] (no REVERSE / TRANSPOSE), Perch-style
+    fe_forms: tuple = ()             # alternative op forms a converter may emit for the same front-end arithmetic:
+                                     # "add_neg" (x + (-0.5) for x - 0.5), "bmm" (BATCH_MATMUL with the [bins, mel] matrix),
+                                     # "bmm_adj" (BATCH_MATMUL, [mel, bins] matrix with adj_y), "square" (SQUARE for POW 2), "mul_self" (MUL(x, x))
     stem: int = 32
     # (expand_ratio, kernel, stride, out_channels, repeats)
     blocks: tuple = ((1, 3, 1, 16, 1), (6, 3, 2, 24, 2), (6, 5, 2, 40, 2), (6, 3, 2, 80, 3),
@@ -158,7 +161,10 @@ def build_model(cfg: SynthConfig = None) -> bytes:
             mx = g.op("REDUCE_MAX", [s1, ax1], [1, 1], dict(keep_dims=1))
             dn = g.op("ADD", [mx, g.const(f32(1e-6))], [1, 1], {})
             nm = g.op("DIV", [s1, dn], [1, cfg.n_samples], {})
-            n2 = g.op("SUB", [nm, g.const(f32(0.5))], [1, cfg.n_samples], {})
+            if "add_neg" in cfg.fe_forms:
+                n2 = g.op("ADD", [nm, g.const(f32(-0.5))], [1, cfg.n_samples], {})
+            else:
+                n2 = g.op("SUB", [nm, g.const(f32(0.5))], [1, cfg.n_samples], {})
             xn = g.op("MUL", [n2, g.const(f32(2.0))], [1, cfg.n_samples], {})
         else:
             xn = x
@@ -188,12 +194,22 @@ def build_model(cfg: SynthConfig = None) -> bytes:
             re = g.op("COMPLEX_ABS", [sq], [1, F, nb], {})
         r2 = g.op("RESHAPE", [re, g.const(i32([F, nb]))], [F, nb], dict(new_shape=[F, nb]))
         mel = mel_weight_matrix(cfg.n_mels, nb, cfg.sample_rate, sp.fmin, sp.fmax)
-        mm = g.op("FULLY_CONNECTED", [r2, g.const(np.ascontiguousarray(mel.T), pre + "mel"), -1],
-                  [F, cfg.n_mels], dict(fused_activation_function=S.ACT_NONE))
+        if "bmm" in cfg.fe_forms:
+            mm = g.op("BATCH_MATMUL", [r2, g.const(np.ascontiguousarray(mel), pre + "mel")], [F, cfg.n_mels], dict(adj_x=0, adj_y=0))
+        elif "bmm_adj" in cfg.fe_forms:
+            mm = g.op("BATCH_MATMUL", [r2, g.const(np.ascontiguousarray(mel.T), pre + "mel")], [F, cfg.n_mels], dict(adj_x=0, adj_y=1))
+        else:
+            mm = g.op("FULLY_CONNECTED", [r2, g.const(np.ascontiguousarray(mel.T), pre + "mel"), -1],
+                      [F, cfg.n_mels], dict(fused_activation_function=S.ACT_NONE))
         r3 = g.op("RESHAPE", [mm, g.const(i32([1, F, cfg.n_mels]))], [1, F, cfg.n_mels],
                   dict(new_shape=[1, F, cfg.n_mels]))
         if cfg.compress == "pow":
-            p1 = g.op("POW", [r3, g.const(f32(2.0))], [1, F, cfg.n_mels], {})
+            if "square" in cfg.fe_forms:
+                p1 = g.op("SQUARE", [r3], [1, F, cfg.n_mels], {})
+            elif "mul_self" in cfg.fe_forms:
+                p1 = g.op("MUL", [r3, r3], [1, F, cfg.n_mels], {})
+            else:
+                p1 = g.op("POW", [r3, g.const(f32(2.0))], [1, F, cfg.n_mels], {})
             expo = 1.0 / (1.0 + np.exp(cfg.mag_scale))
             cz = g.op("POW", [p1, g.const(f32(expo), pre + "mag_exponent")], [1, F, cfg.n_mels], {})
         else:
