@@ -1041,22 +1041,45 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                 bool se = false;
                 int mt = o.outputs[0];
                 do {
+                    // MEAN -> FC(Cr) + act -> FC(C) + act -> MUL with the MEAN's input, each FC a 1x1 CONV_2D or a FULLY_CONNECTED,
+                    // with any pure reshapes in between (Keras: GlobalAveragePooling2D -> Reshape(1,1,C) -> Conv2D ... -> Multiply)
                     if (P.uses[mt] != 1) break;
-                    int c1 = P.only_consumer(mt);
-                    if (c1 < 0 || m.ops[c1].code != OP_CONV_2D || !P.is_const(m.ops[c1].inputs[1])) break;
-                    const TflTensor& w1 = m.tensors[m.ops[c1].inputs[1]];
-                    if (w1.shape.size() != 4 || w1.shape[1] != 1 || w1.shape[2] != 1 || w1.shape[3] != C || m.ops[c1].act != 0) break;
-                    int y1 = m.ops[c1].outputs[0];
-                    // peek activation without absorbing yet
                     std::vector<char> save = P.absorbed;
+                    auto fc_like = [&](int oi, int K, int* N) -> bool {      // op oi: [*, K] -> [*, N] with constant weights
+                        if (oi < 0 || P.absorbed[oi]) return false;
+                        const TflOp& f = m.ops[oi];
+                        if ((f.code != OP_CONV_2D && f.code != OP_FULLY_CONNECTED) || f.inputs.size() < 2 || !P.is_const(f.inputs[1])) return false;
+                        const TflTensor& w = m.tensors[f.inputs[1]];
+                        if (w.type != TT_FLOAT32) return false;
+                        if (f.code == OP_CONV_2D) {
+                            if (w.shape.size() != 4 || w.shape[1] != 1 || w.shape[2] != 1 || w.shape[3] != K || f.stride_h != 1 || f.stride_w != 1) return false;
+                        } else if (w.shape.size() != 2 || w.shape[1] != K) return false;
+                        if (f.inputs.size() > 2 && f.inputs[2] >= 0 && (!P.is_const(f.inputs[2]) || (int)m.tensors[f.inputs[2]].numel() != w.shape[0])) return false;
+                        *N = w.shape[0];
+                        return true;
+                    };
+                    auto fused_or_trailing = [&](int oi, int* act) -> int {  // activation of FC op oi; returns the tensor after it
+                        *act = map_act(m.ops[oi].act);
+                        if (*act < 0) return -1;
+                        int y = m.ops[oi].outputs[0];
+                        if (*act == ACT_NONE) y = trailing_act(y, act);
+                        return y;
+                    };
+                    int c1 = P.only_consumer(P.skip_down(mt));
+                    int Cr = 0, Cb = 0;
+                    if (!fc_like(c1, C, &Cr)) { P.absorbed = save; break; }
                     int act1 = ACT_NONE, act2 = ACT_NONE;
-                    int r = trailing_act(y1, &act1);
+                    int r = fused_or_trailing(c1, &act1);
+                    if (r < 0) { P.absorbed = save; break; }
+                    r = P.skip_down(r);
                     int c2 = P.uses[r] == 1 ? P.only_consumer(r) : -1;
-                    if (c2 < 0 || m.ops[c2].code != OP_CONV_2D || !P.is_const(m.ops[c2].inputs[1]) || m.ops[c2].act != 0) { P.absorbed = save; break; }
+                    if (!fc_like(c2, Cr, &Cb) || Cb != C) { P.absorbed = save; break; }
+                    const TflTensor& w1 = m.tensors[m.ops[c1].inputs[1]];
                     const TflTensor& w2 = m.tensors[m.ops[c2].inputs[1]];
-                    int Cr = w1.shape[0];
-                    if (w2.shape.size() != 4 || w2.shape[1] != 1 || w2.shape[2] != 1 || w2.shape[3] != Cr || w2.shape[0] != C) { P.absorbed = save; break; }
-                    int e = trailing_act(m.ops[c2].outputs[0], &act2);
+                    (void)w1;
+                    int e = fused_or_trailing(c2, &act2);
+                    if (e < 0) { P.absorbed = save; break; }
+                    e = P.skip_down(e);
                     int mu = P.uses[e] == 1 ? P.only_consumer(e) : -1;
                     if (mu < 0 || m.ops[mu].code != OP_MUL || m.ops[mu].act != 0) { P.absorbed = save; break; }
                     int other = m.ops[mu].inputs[0] == e ? m.ops[mu].inputs[1] : m.ops[mu].inputs[0];

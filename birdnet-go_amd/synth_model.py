@@ -52,6 +52,9 @@ class SynthConfig:
     log_floor: float = 1e-2
     log_scale: float = 0.1
     time_major: bool = False         # True: spectrogram image is [1, frames, mel, 1] (no REVERSE / TRANSPOSE), Perch-style
+    se_form: str = "conv"            # squeeze-excite spelling: "conv" (MEAN keep_dims -> 1x1 CONV_2Ds), "keras" (MEAN -> RESHAPE [1,1,1,C] ->
+                                     # CONV_2Ds, what GlobalAveragePooling2D + Reshape converts to), "dense" (MEAN -> FULLY_CONNECTED with fused
+                                     # RELU -> FULLY_CONNECTED -> LOGISTIC -> RESHAPE [1,1,1,C])
     fe_forms: tuple = ()             # alternative op forms a converter may emit for the same front-end arithmetic:
                                      # "add_neg" (x + (-0.5) for x - 0.5), "bmm" (BATCH_MATMUL with the [bins, mel] matrix),
                                      # "bmm_adj" (BATCH_MATMUL, [mel, bins] matrix with adj_y), "square" (SQUARE for POW 2), "mul_self" (MUL(x, x))
@@ -276,9 +279,25 @@ def build_model(cfg: SynthConfig = None) -> bytes:
             t, H, W = dwconv(t, mid, k, stride, 1.6, H, W, name + "/dw")
             # squeeze-excite
             cse = max(1, int(cin * cfg.se_ratio))
-            m = g.op("MEAN", [t, g.const(i32([1, 2]))], [1, 1, 1, mid], dict(keep_dims=1))
-            m, _, _ = conv(m, mid, cse, 1, 1, "swish", 1.0, 1, 1, name + "/se_reduce")
-            m, _, _ = conv(m, cse, mid, 1, 1, "sigmoid", 1.0, 1, 1, name + "/se_expand")
+            if cfg.se_form == "conv":
+                m = g.op("MEAN", [t, g.const(i32([1, 2]))], [1, 1, 1, mid], dict(keep_dims=1))
+                m, _, _ = conv(m, mid, cse, 1, 1, "swish", 1.0, 1, 1, name + "/se_reduce")
+                m, _, _ = conv(m, cse, mid, 1, 1, "sigmoid", 1.0, 1, 1, name + "/se_expand")
+            elif cfg.se_form == "keras":
+                m = g.op("MEAN", [t, g.const(i32([1, 2]))], [1, mid], dict(keep_dims=0))
+                m = g.op("RESHAPE", [m, g.const(i32([1, 1, 1, mid]))], [1, 1, 1, mid], dict(new_shape=[1, 1, 1, mid]))
+                m, _, _ = conv(m, mid, cse, 1, 1, "swish", 1.0, 1, 1, name + "/se_reduce")
+                m, _, _ = conv(m, cse, mid, 1, 1, "sigmoid", 1.0, 1, 1, name + "/se_expand")
+            else:
+                m = g.op("MEAN", [t, g.const(i32([1, 2]))], [1, mid], dict(keep_dims=0))
+                w1 = (rng.standard_normal((cse, mid)) / np.sqrt(mid)).astype(np.float32)
+                w2 = (rng.standard_normal((mid, cse)) / np.sqrt(cse)).astype(np.float32)
+                m = g.op("FULLY_CONNECTED", [m, g.const(w1, name + "/se_fc1/w"), g.const((rng.standard_normal(cse) * 0.1).astype(np.float32))],
+                         [1, cse], dict(fused_activation_function=S.ACT_RELU))
+                m = g.op("FULLY_CONNECTED", [m, g.const(w2, name + "/se_fc2/w"), g.const((rng.standard_normal(mid) * 0.1).astype(np.float32))],
+                         [1, mid], dict(fused_activation_function=S.ACT_NONE))
+                m = g.op("LOGISTIC", [m], [1, mid])
+                m = g.op("RESHAPE", [m, g.const(i32([1, 1, 1, mid]))], [1, 1, 1, mid], dict(new_shape=[1, 1, 1, mid]))
             t = g.op("MUL", [t, m], [1, H, W, mid], {})
             t, H, W = conv(t, mid, cout, 1, 1, None, 1.4, H, W, name + "/project")
             if stride == 1 and cin == cout:

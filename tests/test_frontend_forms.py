@@ -42,3 +42,41 @@ def test_front_end_op_forms_vs_oracle(gpu, forms):
             c.close()
         assert (outs[f].argmax(1) == ref.argmax(1)).all() and np.abs(outs[f] - ref).max() < 1e-3
     assert np.array_equal(outs[()], outs[forms])
+
+
+SE_FORMS = ["keras", "dense"]
+
+
+@pytest.mark.parametrize("form", SE_FORMS)
+def test_squeeze_excite_spellings_fuse(built_lib, form):
+    """GlobalAveragePooling2D + Reshape(1,1,C) in front of the 1x1 convolutions (Keras), or Dense layers with a fused RELU and a
+    RESHAPE in front of the MUL (MobileNet-style): both must land on the fused squeeze-excite kernel, scale folded into the
+    projection's operand load, exactly like the canonical MEAN(keep_dims) -> CONV_2D form."""
+    ref_kinds = None
+    for f in ("conv", form):
+        c = host.HipClassifier(sm.build_model(sm.tiny_config(se_form=f)), plan_only=True)
+        try:
+            st = c.describe()["steps"]
+            kinds = [s["kernel"] for s in st]
+            assert kinds.count("se") == 5 and "elementwise" not in kinds and not any(k.startswith("generic") for k in kinds)
+            assert sum(s["fused_scale"] for s in st if s["kernel"] == "pw_gemm") == 5
+            ref_kinds = ref_kinds or kinds
+            assert kinds == ref_kinds
+        finally:
+            c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", SE_FORMS)
+def test_squeeze_excite_spellings_vs_oracle(gpu, form):
+    cfg = sm.tiny_config(se_form=form)
+    blob = sm.build_model(cfg)
+    x = sm.synth_clips(5, cfg.n_samples, cfg.sample_rate)
+    ref = Interpreter(blob).invoke(x)[0]
+    for kw in (dict(), dict(autotune=False, lanes=1)):
+        c = host.HipClassifier(blob, max_batch=8, **kw)
+        try:
+            got = c.predict_batch(x.reshape(-1), 5)
+        finally:
+            c.close()
+        assert (got.argmax(1) == ref.argmax(1)).all() and np.abs(got - ref).max() < 1e-3
