@@ -866,6 +866,18 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                     s.bytes = 4.0 * ((double)H * W * C + (double)H * W * Co * (s.in2 >= 0 ? 2 : 1));
                     s.wbytes = 4.0 * C * Co;
                     emit(s, outt, (size_t)Ho * Wo * Co, post, wconst(o.inputs[1]), boff);
+                } else if (conv_igemm_supported(C, Co, kh, kw) && scaled.find(in_t) == scaled.end() && !getenv("BNHIP_NO_CONV_IGEMM") &&
+                           (double)max_batch * Ho * Wo * std::max(Ho * Wo, C) < 1.0e12) {
+                    // a real convolution (kh x kw over >= 4 input channels): implicit GEMM on the f32 MFMA, weights as in the file
+                    s.kind = S_CONV_IGEMM; s.kclass = "conv_igemm";
+                    s.in0 = need_val(in_t);
+                    if (s.in0 < 0) { *err = "CONV_2D: input has no value: " + oname; return false; }
+                    s.kh = kh; s.kw = kw; s.sh = o.stride_h; s.sw = o.stride_w; s.g.dh = o.dil_h; s.g.dw = o.dil_w;
+                    conv_pads(o, H, W, Ho, Wo, kh, kw, &s.pt, &s.pl);
+                    s.flops = 2.0 * Ho * Wo * Co * kh * kw * C;
+                    s.bytes = 4.0 * ((double)H * W * C + (double)Ho * Wo * Co);
+                    s.wbytes = 4.0 * kh * kw * C * Co;
+                    emit(s, outt, (size_t)Ho * Wo * Co, post, wconst(o.inputs[1]), boff);
                 } else if (o.dil_h != 1 || o.dil_w != 1 || (Co & 3)) {
                     // dilated convolutions and channel counts the vectorised kernels do not cover: generic kernel, weights as
                     // in the file (OHWI)
@@ -1972,6 +1984,10 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
                 else launch_conv_direct(p, stream);
                 break;
             }
+            case S_CONV_IGEMM:
+                launch_conv_igemm(in0, s.w0, s.w1, out, n, s.H, s.W, s.C, s.Ho, s.Wo, s.Co, s.kh, s.kw, s.sh, s.sw, s.g.dh, s.g.dw, s.pt, s.pl,
+                                  s.act, 0, 0, stream);
+                break;
             case S_PW: {
                 PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, nl > 1 ? s.nt : s.nt_full,
                            nl > 1 ? s.wm : s.wm_full};

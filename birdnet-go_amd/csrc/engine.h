@@ -13,7 +13,8 @@ namespace bnhip {
 
 enum StepKind { S_MINMAX, S_FRONTEND, S_NORMALIZE, S_STFT, S_MELFIN, S_MELBAND, S_CONV_DIRECT, S_PW, S_DW, S_EXPAND_DW, S_MEAN_PARTIAL, S_MEAN_FINISH, S_SE, S_UNARY, S_BINARY,
                 // generic tier (generic.hip): any float op the fused plan does not absorb
-                S_EW_UNARY, S_EW_BINARY, S_POOL, S_COPY, S_SOFTMAX, S_REDUCE, S_CONV_GENERIC };
+                S_EW_UNARY, S_EW_BINARY, S_POOL, S_COPY, S_SOFTMAX, S_REDUCE, S_CONV_GENERIC,
+                S_CONV_IGEMM };   // general convolution as an implicit GEMM on the f32 MFMA (k_pw_gemm<IM>)
 
 struct GenGeom {             // per-clip 4-D view geometry of a generic step (see kernels.h BcastParams / CopyParams)
     int d[4] = {1, 1, 1, 1};

@@ -79,6 +79,11 @@ struct ConvParams {       // direct conv, small Cin (stem)
     int B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, pt, pl, act;
 };
 void launch_conv_direct(const ConvParams& p, hipStream_t s);
+// general convolution as an implicit GEMM on the f32 MFMA (weights OHWI as in the file): Cin % 4 == 0, kh * kw * Cin >= 32
+bool conv_igemm_supported(int Cin, int Cout, int kh, int kw);
+void launch_conv_igemm(const float* in, const float* w_ohwi, const float* bias, float* out, int B, int H, int W, int Cin, int Ho, int Wo,
+                       int Cout, int kh, int kw, int sh, int sw, int dh, int dw, int pt, int pl, int act, int nt /*0 = heuristic*/,
+                       int wm /*1 = 64-row tiles, else 128*/, hipStream_t s);
 // MFMA stem: wm = [Cout][32] weights in (row, 4 columns, channel) order with zero pads, bias_p = [Cout] (zeros if absent)
 bool stem_mfma_supported(const ConvParams& p);
 void launch_stem_mfma(const ConvParams& p, const float* wm, const float* bias_p, hipStream_t s);

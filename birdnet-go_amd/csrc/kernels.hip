@@ -785,8 +785,15 @@ __device__ long long* g_pw_trace = nullptr;      // [64 blocks][4 waves][PW_TRAC
 #else
 #define PW_T(i) do { } while (0)
 #endif
-template <int NT, bool SC, int WM>
-__global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigned nblk, FDiv dn, FDiv dhw) {
+// IM (implicit GEMM): the same kernel as a general convolution.  A is never materialised: row m is output pixel
+// (b, oh, ow), column k = (i * kw + j) * Cin + ci is input value x[b][oh s - pt + i d][ow s - pl + j d][ci] (zero outside the
+// image), and the file's OHWI weights are already the [N][K] matrix.  Cin % 4 == 0, so a float4 of K never straddles a tap.
+struct ImGeo {
+    int H, W, Cin, kw, sh, sw, dh, dw, pt, pl, Wo;
+    FDiv d_cin, d_kw, d_wo, d_howo;      // k -> tap, tap -> row, pixel -> (oh, ow), m -> clip
+};
+template <int NT, bool SC, int WM, bool IM = false>
+__global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigned nblk, FDiv dn, FDiv dhw, ImGeo g) {
     constexpr int BM = 64 * WM;                  // rows per block: 4 waves x (16*WM) rows
     constexpr int XQ = BM * PW_C4 / 256;         // float4 per thread for the activation tile
     // operand tiles (the epilogue re-uses the array as per-wave output staging).  SC: squeeze-excite scale on A.
@@ -817,6 +824,18 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
             srow[SC ? q : 0] = (int)fdiv((unsigned)(m < p.M ? m : 0), dhw);
         }
     }
+    // IM: top-left input coordinate and image base of each staged row (fixed for the block)
+    int ih0[IM ? XQ : 1], iw0[IM ? XQ : 1]; unsigned ibase[IM ? XQ : 1];
+    if (IM) {
+#pragma unroll
+        for (int q = 0; q < XQ; q++) {
+            const unsigned m = (unsigned)min(m0 + (tid + 256 * q) / PW_C4, p.M - 1);
+            const unsigned b = fdiv(m, g.d_howo), pix = m - b * g.d_howo.d;
+            const unsigned oh = fdiv(pix, g.d_wo), ow = pix - oh * (unsigned)g.Wo;
+            ih0[IM ? q : 0] = (int)oh * g.sh - g.pt; iw0[IM ? q : 0] = (int)ow * g.sw - g.pl;
+            ibase[IM ? q : 0] = b * (unsigned)(g.H * g.W);
+        }
+    }
     // all global loads of a slab are issued back-to-back (scale included); the multiply happens at LDS-store time
     auto gload = [&](int k0) {
 #pragma unroll
@@ -825,7 +844,15 @@ __global__ __launch_bounds__(256) void k_pw_gemm(PwParams p, int nblk_n, unsigne
             int row = idx / PW_C4, c4 = idx % PW_C4;
             int m = m0 + row, k = k0 + 4 * c4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < p.M && k < K) {
+            if (IM) {
+                if (m < p.M && k < K) {
+                    const unsigned tap = fdiv((unsigned)k, g.d_cin), ci = (unsigned)k - tap * (unsigned)g.Cin;
+                    const unsigned ti = fdiv(tap, g.d_kw), tj = tap - ti * (unsigned)g.kw;
+                    const int ih = ih0[IM ? q : 0] + (int)ti * g.dh, iw = iw0[IM ? q : 0] + (int)tj * g.dw;
+                    if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
+                        v = *reinterpret_cast<const float4*>(p.A + ((size_t)ibase[IM ? q : 0] + (size_t)ih * g.W + iw) * g.Cin + ci);
+                }
+            } else if (m < p.M && k < K) {
                 v = *reinterpret_cast<const float4*>(p.A + (size_t)m * K + k);
                 if (SC) sc = *reinterpret_cast<const float4*>(p.ascale + (size_t)srow[SC ? q : 0] * K + k);
             }
@@ -1518,7 +1545,7 @@ void launch_pw_gemm(const PwParams& p, hipStream_t s) {
     dim3 grid(nblk);
     const FDiv dn = make_fdiv((unsigned)nblk_n), dhw = make_fdiv((unsigned)std::max(p.HW, 1));
     const bool sc = p.ascale != nullptr;
-#define PW_LAUNCH(NT_, SC_, WM_) hipLaunchKernelGGL((k_pw_gemm<NT_, SC_, WM_>), grid, dim3(256), 0, s, p, nblk_n, nblk, dn, dhw)
+#define PW_LAUNCH(NT_, SC_, WM_) hipLaunchKernelGGL((k_pw_gemm<NT_, SC_, WM_>), grid, dim3(256), 0, s, p, nblk_n, nblk, dn, dhw, ImGeo{})
 #define PW_CASE(NT_) case NT_: if (sc) { if (wm == 1) PW_LAUNCH(NT_, true, 1); else PW_LAUNCH(NT_, true, 2); } \
                      else { if (wm == 1) PW_LAUNCH(NT_, false, 1); else PW_LAUNCH(NT_, false, 2); } break;
 #define PP_LAUNCH(NT_, SC_, WM_) hipLaunchKernelGGL((k_pw_pipe<NT_, SC_, WM_>), grid, dim3(256), 0, s, p, nblk_n, nblk, dn, dhw)
@@ -1533,6 +1560,35 @@ void launch_pw_gemm(const PwParams& p, hipStream_t s) {
     switch (nt) { PW_CASE(1) PW_CASE(2) PW_CASE(3) PW_CASE(4) PW_CASE(5) PW_CASE(6) PW_CASE(7) default: PW_CASE(8) }
 #undef PW_LAUNCH
 #undef PW_CASE
+}
+
+// General convolution as an implicit GEMM on the f32 MFMA (k_pw_gemm<.., IM = true>): any kernel size, stride, dilation and
+// explicit top / left padding, Cin % 4 == 0.  Weights are the file's OHWI tensor as it is.  Bias, activation and the output
+// burst are the pointwise kernel's epilogue.
+bool conv_igemm_supported(int Cin, int Cout, int kh, int kw) { return (Cin & 3) == 0 && Cin >= 4 && kh * kw * Cin >= 32 && Cout >= 1; }
+void launch_conv_igemm(const float* in, const float* w_ohwi, const float* bias, float* out, int B, int H, int W, int Cin, int Ho, int Wo,
+                       int Cout, int kh, int kw, int sh, int sw, int dh, int dw, int pt, int pl, int act, int nt_req, int wm_req,
+                       hipStream_t s) {
+    PwParams p{in, w_ohwi, bias, nullptr, nullptr, out, B * Ho * Wo, Cout, kh * kw * Cin, Ho * Wo, act, nt_req, wm_req};
+    int nt = (p.nt >= 1 && p.nt <= 8) ? p.nt : pick_nt(p.M, p.N);
+    int wm = p.wm == 1 ? 1 : 2;
+    int bm = 64 * wm;
+    int nblk_n = (p.N + nt * 16 - 1) / (nt * 16);
+    unsigned nblk = (unsigned)((p.M + bm - 1) / bm) * nblk_n;
+    if (nblk < 64 && (nt > 1 || wm > 1)) {
+        nt = 1; wm = 1; bm = 64;
+        nblk_n = (p.N + 15) / 16;
+        nblk = (unsigned)((p.M + bm - 1) / bm) * nblk_n;
+    }
+    ImGeo g{H, W, Cin, kw, sh, sw, dh, dw, pt, pl, Wo, make_fdiv((unsigned)Cin), make_fdiv((unsigned)kw), make_fdiv((unsigned)Wo),
+            make_fdiv((unsigned)(Ho * Wo))};
+    const FDiv dn = make_fdiv((unsigned)nblk_n), dhw = make_fdiv((unsigned)std::max(p.HW, 1));
+    dim3 grid(nblk);
+#define IG_LAUNCH(NT_, WM_) hipLaunchKernelGGL((k_pw_gemm<NT_, false, WM_, true>), grid, dim3(256), 0, s, p, nblk_n, nblk, dn, dhw, g)
+#define IG_CASE(NT_) case NT_: if (wm == 1) IG_LAUNCH(NT_, 1); else IG_LAUNCH(NT_, 2); break;
+    switch (nt) { IG_CASE(1) IG_CASE(2) IG_CASE(3) IG_CASE(4) IG_CASE(5) IG_CASE(6) IG_CASE(7) default: IG_CASE(8) }
+#undef IG_LAUNCH
+#undef IG_CASE
 }
 
 // ------------------------------------------------------------------------------------------ depthwise conv
