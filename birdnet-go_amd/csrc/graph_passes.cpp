@@ -155,12 +155,33 @@ void pass_fold_pad(TflModel* m) {
     }
 }
 
+// AVERAGE_POOL_2D whose window is the whole image (VALID, any stride) is a global average pool: rewritten to the MEAN over
+// (H, W) with keep_dims that Keras' GlobalAveragePooling2D converts to, so that the squeeze-excite and pooling-head patterns
+// of the planner see one spelling
+void pass_global_pool(TflModel* m) {
+    for (auto& o : m->ops) {
+        if (o.code != OP_AVERAGE_POOL_2D || o.inputs.size() != 1 || o.outputs.size() != 1 || o.act != 0) continue;
+        const auto& ish = m->tensors[o.inputs[0]].shape;
+        const auto& osh = m->tensors[o.outputs[0]].shape;
+        if (ish.size() != 4 || osh.size() != 4 || o.filter_h != ish[1] || o.filter_w != ish[2] || osh[1] != 1 || osh[2] != 1) continue;
+        if (o.padding != 1 /*VALID*/ && !(ish[1] == 1 && ish[2] == 1)) {
+            // SAME with a full-size window also yields 1x1 only for stride >= size; partial windows would average fewer pixels
+            if (o.stride_h < ish[1] || o.stride_w < ish[2]) continue;
+        }
+        const int ax = m->add_const_i32(m->tensors[o.outputs[0]].name + "/axes", {2}, {1, 2});
+        o.code = OP_MEAN;
+        o.inputs.push_back(ax);
+        o.keep_dims = true;
+    }
+}
+
 }  // namespace
 
 bool run_graph_passes(TflModel* m, std::string* err) {
     if (!pass_dequantize(m, err)) return false;
     pass_fold_affine(m);
     pass_fold_pad(m);
+    pass_global_pool(m);
     return true;
 }
 

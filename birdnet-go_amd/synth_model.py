@@ -52,7 +52,8 @@ class SynthConfig:
     log_floor: float = 1e-2
     log_scale: float = 0.1
     time_major: bool = False         # True: spectrogram image is [1, frames, mel, 1] (no REVERSE / TRANSPOSE), Perch-style
-    se_form: str = "conv"            # squeeze-excite spelling: "conv" (MEAN keep_dims -> 1x1 CONV_2Ds), "keras" (MEAN -> RESHAPE [1,1,1,C] ->
+    se_form: str = "conv"            # squeeze-excite spelling: "conv" (MEAN keep_dims -> 1x1 CONV_2Ds), "avgpool" (the same with a
+                                     # whole-image AVERAGE_POOL_2D for the MEAN, also in front of the head), "keras" (MEAN -> RESHAPE [1,1,1,C] ->
                                      # CONV_2Ds, what GlobalAveragePooling2D + Reshape converts to), "dense" (MEAN -> FULLY_CONNECTED with fused
                                      # RELU -> FULLY_CONNECTED -> LOGISTIC -> RESHAPE [1,1,1,C])
     fe_forms: tuple = ()             # alternative op forms a converter may emit for the same front-end arithmetic:
@@ -279,8 +280,12 @@ def build_model(cfg: SynthConfig = None) -> bytes:
             t, H, W = dwconv(t, mid, k, stride, 1.6, H, W, name + "/dw")
             # squeeze-excite
             cse = max(1, int(cin * cfg.se_ratio))
-            if cfg.se_form == "conv":
-                m = g.op("MEAN", [t, g.const(i32([1, 2]))], [1, 1, 1, mid], dict(keep_dims=1))
+            if cfg.se_form in ("conv", "avgpool"):
+                if cfg.se_form == "avgpool":
+                    m = g.op("AVERAGE_POOL_2D", [t], [1, 1, 1, mid], dict(padding=S.PAD_VALID, stride_w=W, stride_h=H, filter_width=W,
+                                                                           filter_height=H, fused_activation_function=S.ACT_NONE))
+                else:
+                    m = g.op("MEAN", [t, g.const(i32([1, 2]))], [1, 1, 1, mid], dict(keep_dims=1))
                 m, _, _ = conv(m, mid, cse, 1, 1, "swish", 1.0, 1, 1, name + "/se_reduce")
                 m, _, _ = conv(m, cse, mid, 1, 1, "sigmoid", 1.0, 1, 1, name + "/se_expand")
             elif cfg.se_form == "keras":
@@ -304,7 +309,12 @@ def build_model(cfg: SynthConfig = None) -> bytes:
                 t = g.op("ADD", [t, inp], [1, H, W, cout], dict(fused_activation_function=S.ACT_NONE))
             cin = cout
     t, H, W = conv(t, cin, cfg.top, 1, 1, "swish", 1.6, H, W, "top")
-    emb4 = g.op("MEAN", [t, g.const(i32([1, 2]))], [1, cfg.top], dict(keep_dims=0), name="GLOBAL_AVG_POOL")
+    if cfg.se_form == "avgpool":
+        gp = g.op("AVERAGE_POOL_2D", [t], [1, 1, 1, cfg.top], dict(padding=S.PAD_VALID, stride_w=W, stride_h=H, filter_width=W,
+                                                                    filter_height=H, fused_activation_function=S.ACT_NONE))
+        emb4 = g.op("RESHAPE", [gp, g.const(i32([1, cfg.top]))], [1, cfg.top], dict(new_shape=[1, cfg.top]), name="GLOBAL_AVG_POOL")
+    else:
+        emb4 = g.op("MEAN", [t, g.const(i32([1, 2]))], [1, cfg.top], dict(keep_dims=0), name="GLOBAL_AVG_POOL")
     wh = (rng.standard_normal((cfg.n_classes, cfg.top)) * (2.0 / np.sqrt(cfg.top))).astype(np.float32)
     bh = (cfg.head_bias + rng.standard_normal(cfg.n_classes) * 0.5).astype(np.float32)
     logits = g.op("FULLY_CONNECTED", [emb4, g.const(wh, "head/w"), g.const(bh, "head/b")],

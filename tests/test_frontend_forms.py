@@ -44,7 +44,7 @@ def test_front_end_op_forms_vs_oracle(gpu, forms):
     assert np.array_equal(outs[()], outs[forms])
 
 
-SE_FORMS = ["keras", "dense"]
+SE_FORMS = ["keras", "dense", "avgpool"]
 
 
 @pytest.mark.parametrize("form", SE_FORMS)
