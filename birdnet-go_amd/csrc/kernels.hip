@@ -2724,6 +2724,116 @@ __global__ __launch_bounds__(1024) void k_us_frame_power(const T* __restrict__ s
         powers[(size_t)clip * frames + frame] = sum;
     }
 }
+// 8192-point frames (the reference's default, filter.go:20-66) the fast way.  The frame is real: its even / odd samples are
+// packed into 4096 complex points, transformed by four in-place radix-8 decimation-in-frequency passes (512 threads, one 8-point
+// butterfly per thread and pass, the 8-point DFT in registers: 4 LDS round trips instead of the 13 of the radix-2 kernel above,
+// on half the data), and the spectrum of the real frame is recovered on the fly in the power sum: X[k] = E[k] + W^k O[k] with
+// E, O from Z[k] and conj(Z[4096 - k]).  DIF leaves Z[k] at the base-8 digit-reversed index.  LDS index i lives at i + (i >> 3)
+// (one pad per 8 doubles: the last pass walks the array with stride 8).  73.7 KB of LDS per frame: two frames per CU.
+__device__ __forceinline__ void us_dft8(double (&re)[8], double (&im)[8]) {
+    constexpr double R = 0.70710678118654752440;
+    // stage 1: (m, m + 4), lower half times W8^m
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const double ur = re[m] + re[m + 4], ui = im[m] + im[m + 4], vr = re[m] - re[m + 4], vi = im[m] - im[m + 4];
+        re[m] = ur; im[m] = ui;
+        if (m == 0) { re[4] = vr; im[4] = vi; }
+        else if (m == 1) { re[5] = (vr + vi) * R; im[5] = (vi - vr) * R; }       // (1 - i) / sqrt 2
+        else if (m == 2) { re[6] = vi; im[6] = -vr; }                             // -i
+        else { re[7] = (vi - vr) * R; im[7] = -(vr + vi) * R; }                   // (-1 - i) / sqrt 2
+    }
+    // stage 2: (m, m + 2) inside each half, lower element times W4^m
+#pragma unroll
+    for (int h = 0; h < 8; h += 4)
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const int a = h + m, b = h + m + 2;
+            const double ur = re[a] + re[b], ui = im[a] + im[b], vr = re[a] - re[b], vi = im[a] - im[b];
+            re[a] = ur; im[a] = ui;
+            if (m == 0) { re[b] = vr; im[b] = vi; } else { re[b] = vi; im[b] = -vr; }
+        }
+    // stage 3: (m, m + 1)
+#pragma unroll
+    for (int a = 0; a < 8; a += 2) {
+        const double ur = re[a] + re[a + 1], ui = im[a] + im[a + 1], vr = re[a] - re[a + 1], vi = im[a] - im[a + 1];
+        re[a] = ur; im[a] = ui; re[a + 1] = vr; im[a + 1] = vi;
+    }
+    // outputs sit in bit-reversed order: slot (0..7) holds y[0, 4, 2, 6, 1, 5, 3, 7]
+}
+#define US8_N2 4096
+#define US8_PHYS(i) ((i) + ((i) >> 3))
+template <typename T>
+__global__ __launch_bounds__(512) void k_us_frame_power8(const T* __restrict__ samples, int n, int hop, int frames, int split_bin,
+                                                         const double2* __restrict__ tw /* [4096] (cos, -sin)(2 pi j / 8192), then Hann [8192] */,
+                                                         double* __restrict__ powers) {
+    extern __shared__ __attribute__((aligned(16))) double us8_lds[];
+    double* zr = us8_lds; double* zi = us8_lds + US8_PHYS(US8_N2);
+    __shared__ double red[8];
+    const int tid = threadIdx.x, frame = blockIdx.x, clip = blockIdx.y;
+    const T* x = samples + (size_t)clip * n + (size_t)frame * hop;
+    const double* __restrict__ hann = reinterpret_cast<const double*>(tw + US8_N2);
+    auto sample = [&](int i) -> double { return std::is_same<T, int16_t>::value ? (double)x[i] / 32768.0 : (double)x[i]; };
+    for (int i = tid; i < US8_N2; i += 512) {
+        zr[US8_PHYS(i)] = sample(2 * i) * hann[2 * i];
+        zi[US8_PHYS(i)] = sample(2 * i + 1) * hann[2 * i + 1];
+    }
+    __syncthreads();
+    constexpr int kSlot[8] = {0, 4, 2, 6, 1, 5, 3, 7};                // output q of us_dft8 sits in slot kSlot-inverse: slot s holds y[kSlot[s]]
+#pragma unroll 1
+    for (int st = 0; st < 4; st++) {
+        const int L = US8_N2 >> (3 * st), span = L >> 3;
+        const int j = tid & (span - 1), base = ((tid - j) << 3) + j;  // (tid / span) * L + j
+        double re[8], im[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) { const int i = US8_PHYS(base + m * span); re[m] = zr[i]; im[m] = zi[i]; }
+        us_dft8(re, im);
+        const int tstep = j * (8192 / L);                            // W_L^(j q) = W_8192^(q * tstep)
+#pragma unroll
+        for (int sl = 0; sl < 8; sl++) {
+            const int q = kSlot[sl];
+            double yr = re[sl], yi = im[sl];
+            if (q != 0 && st < 3) {                                  // the last pass has span 1: j = 0, no twiddles
+                int e = q * tstep;                                   // < 7168
+                double2 w = tw[e & 4095];
+                if (e >= 4096) { w.x = -w.x; w.y = -w.y; }
+                const double tr = yr * w.x - yi * w.y, ti = yr * w.y + yi * w.x;
+                yr = tr; yi = ti;
+            }
+            const int i = US8_PHYS(base + q * span);
+            zr[i] = yr; zi[i] = yi;
+        }
+        __syncthreads();
+    }
+    // power above the split bin (filter.go:48-63) from the spectrum of the real frame
+    auto rev = [](int k) { return ((k & 7) << 9) | (((k >> 3) & 7) << 6) | (((k >> 6) & 7) << 3) | ((k >> 9) & 7); };
+    const int nyq = US8_N2;                                          // bin index of the Nyquist frequency (fft / 2)
+    double pw = 0.0;
+    for (int b = split_bin + tid; b <= nyq; b += 512) {
+        double xr, xi;
+        if (b == nyq) { const int i0 = US8_PHYS(0); xr = zr[i0] - zi[i0]; xi = 0.0; }
+        else {
+            const int ia = US8_PHYS(rev(b)), ib = US8_PHYS(rev((US8_N2 - b) & (US8_N2 - 1)));
+            const double ar = zr[ia], ai = zi[ia], br = zr[ib], bi = -zi[ib];      // Z[b], conj(Z[N2 - b])
+            const double er = 0.5 * (ar + br), ei = 0.5 * (ai + bi);
+            const double dr = ar - br, di = ai - bi;
+            const double orr = 0.5 * di, oi = -0.5 * dr;                             // O = -i/2 (Z[b] - conj(Z[N2 - b]))
+            const double2 w = tw[b];                                                 // W_8192^b
+            xr = er + (orr * w.x - oi * w.y); xi = ei + (orr * w.y + oi * w.x);
+        }
+        double q = xr * xr + xi * xi;
+        if (b > 0 && b < nyq) q *= 2.0;
+        pw += q;
+    }
+    for (int o = 32; o > 0; o >>= 1) pw += __shfl_down(pw, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = pw;
+    __syncthreads();
+    if (tid == 0) {
+        double sum = 0.0;
+        for (int w = 0; w < 8; w++) sum += red[w];
+        powers[(size_t)clip * frames + frame] = sum;
+    }
+}
+
 std::vector<double> us_twiddle_table(int fft_size) {
     std::vector<double> t((size_t)2 * fft_size);             // fft/2 (cos, -sin) pairs, then the fft window coefficients
     for (int j = 0; j < fft_size / 2; j++) {
@@ -2737,6 +2847,20 @@ std::vector<double> us_twiddle_table(int fft_size) {
 void launch_us_frame_power(const void* samples, int pcm16, int n_clips, int n, int fft_size, int hop, int frames, int split_bin,
                            const double* d_tw, double* powers, hipStream_t s) {
     const double2* tw = reinterpret_cast<const double2*>(d_tw);
+    static const bool no8 = getenv("BNHIP_US_RADIX2") != nullptr;
+    if (fft_size == 8192 && !no8) {
+        const size_t lds8 = (size_t)2 * US8_PHYS(US8_N2) * sizeof(double);
+        if (pcm16) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_us_frame_power8<int16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            hipLaunchKernelGGL(k_us_frame_power8<int16_t>, dim3(frames, n_clips), dim3(512), lds8, s, static_cast<const int16_t*>(samples), n, hop,
+                               frames, split_bin, tw, powers);
+        } else {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_us_frame_power8<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            hipLaunchKernelGGL(k_us_frame_power8<double>, dim3(frames, n_clips), dim3(512), lds8, s, static_cast<const double*>(samples), n, hop,
+                               frames, split_bin, tw, powers);
+        }
+        return;
+    }
     int log2n = 0; while ((1 << log2n) < fft_size) log2n++;
     size_t lds = (size_t)fft_size * 2 * sizeof(double);
     int threads = fft_size / 2 < 1024 ? (fft_size / 2 < 64 ? 64 : fft_size / 2) : 1024;
