@@ -142,9 +142,27 @@ type Classifier struct {
 // (tflite.NewTFLiteClassifier(modelData []byte, ...), internal/inference/tflite/classifier.go:38).
 // devices: one ordinal = one GPU; several = one handle sharding every batch over them.
 func NewClassifier(modelData []byte, devices ...int) (*Classifier, error) {
+	return NewClassifierWithOptions(modelData, Options{Devices: devices})
+}
+
+// Options are the creation options of include/bnhip.h a host may want to set; zero values keep the library defaults.
+type Options struct {
+	Devices  []int // GPU ordinals (default: device 0)
+	MaxBatch int   // largest PredictBatch the handle accepts (default 256)
+	// Precision "bf16" rounds the MFMA operands to bf16 (fp32 accumulation): only for models that tolerate it
+	// (Perch v2; never BirdNET v2.4, internal/classifier/model_openvino.go:99-103). Default "f32".
+	Precision string
+	// LogitsOutput / EmbeddingOutput name graph outputs explicitly (1-based here so that the zero value means "the
+	// reference's per-family rule", internal/inference/onnx/detection.go:52-112).
+	LogitsOutput, EmbeddingOutput int
+}
+
+// NewClassifierWithOptions is NewClassifier with explicit creation options (e.g. Perch v2 on bf16 operands).
+func NewClassifierWithOptions(modelData []byte, o Options) (*Classifier, error) {
 	if len(modelData) == 0 {
 		return nil, errors.New("hip: empty model data")
 	}
+	devices := o.Devices
 	if len(devices) == 0 {
 		devices = []int{0}
 	}
@@ -155,7 +173,23 @@ func NewClassifier(modelData []byte, devices ...int) (*Classifier, error) {
 		}
 		list += fmt.Sprint(d)
 	}
-	opts := C.CString(fmt.Sprintf(`{"devices":[%s],"max_batch":256}`, list))
+	maxBatch := o.MaxBatch
+	if maxBatch <= 0 {
+		maxBatch = 256
+	}
+	js := fmt.Sprintf(`{"devices":[%s],"max_batch":%d`, list, maxBatch)
+	if o.Precision == "bf16" || o.Precision == "f32" {
+		js += fmt.Sprintf(`,"precision":"%s"`, o.Precision)
+	} else if o.Precision != "" {
+		return nil, fmt.Errorf("hip: unknown precision %q", o.Precision)
+	}
+	if o.LogitsOutput > 0 {
+		js += fmt.Sprintf(`,"logits_output":%d`, o.LogitsOutput-1)
+	}
+	if o.EmbeddingOutput > 0 {
+		js += fmt.Sprintf(`,"embedding_output":%d`, o.EmbeddingOutput-1)
+	}
+	opts := C.CString(js + "}")
 	defer C.free(unsafe.Pointer(opts))
 	runtime.LockOSThread()
 	defer runtime.UnlockOSThread()
