@@ -111,7 +111,7 @@ def test_cgo_preamble_compiles_and_go_call_sequence_cpu(cabi_driver, built_lib, 
 def test_go_shim_pins_the_os_thread_around_error_fetch():
     src = open(GO_SHIM).read()
     # every exported entry that can fail fetches the thread-local error text: each must hold the OS thread
-    for fn in ("func Init(", "func NewClassifier(", "func (c *Classifier) predict(", "func (c *Classifier) PredictBatch(",
+    for fn in ("func Init(", "func NewClassifierWithOptions(", "func (c *Classifier) predict(", "func (c *Classifier) PredictBatch(",
                "func (c *Classifier) PredictTopK("):
         body = src[src.index(fn):]
         body = body[:body.index("\n}\n")]
