@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libbnhip.so")
 SOURCES = ["kernels.hip", "generic.hip", "resample.hip", "stft.hip", "engine.cpp", "graph_passes.cpp", "tflite_model.cpp", "model_onnx.cpp", "api.cpp"]
-HEADERS = ["kernels.h", "engine.h", "tflite_model.h", "model_onnx.h", os.path.join("..", "..", "include", "bnhip.h")]
+HEADERS = ["kernels.h", "engine.h", "tflite_model.h", "model_onnx.h", "fft_r8.h", os.path.join("..", "..", "include", "bnhip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 NO_VGPR_FORM = set()     # sources to compile without the VGPR-form MFMA rewrite (none at present)
 

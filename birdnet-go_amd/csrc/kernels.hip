@@ -6,6 +6,7 @@
 // Layouts: activations NHWC fp32; pointwise/FC weights [N][K] (TFLite OHWI with 1x1 == [Cout][Cin]),
 // depthwise weights [kh][kw][C], stem weights re-laid to [kh][kw][Cin][Cout] at plan time.
 #include "kernels.h"
+#include "fft_r8.h"
 
 #include <algorithm>
 #include <type_traits>
@@ -2730,36 +2731,6 @@ __global__ __launch_bounds__(1024) void k_us_frame_power(const T* __restrict__ s
 // on half the data), and the spectrum of the real frame is recovered on the fly in the power sum: X[k] = E[k] + W^k O[k] with
 // E, O from Z[k] and conj(Z[4096 - k]).  DIF leaves Z[k] at the base-8 digit-reversed index.  LDS index i lives at i + (i >> 3)
 // (one pad per 8 doubles: the last pass walks the array with stride 8).  73.7 KB of LDS per frame: two frames per CU.
-__device__ __forceinline__ void us_dft8(double (&re)[8], double (&im)[8]) {
-    constexpr double R = 0.70710678118654752440;
-    // stage 1: (m, m + 4), lower half times W8^m
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-        const double ur = re[m] + re[m + 4], ui = im[m] + im[m + 4], vr = re[m] - re[m + 4], vi = im[m] - im[m + 4];
-        re[m] = ur; im[m] = ui;
-        if (m == 0) { re[4] = vr; im[4] = vi; }
-        else if (m == 1) { re[5] = (vr + vi) * R; im[5] = (vi - vr) * R; }       // (1 - i) / sqrt 2
-        else if (m == 2) { re[6] = vi; im[6] = -vr; }                             // -i
-        else { re[7] = (vi - vr) * R; im[7] = -(vr + vi) * R; }                   // (-1 - i) / sqrt 2
-    }
-    // stage 2: (m, m + 2) inside each half, lower element times W4^m
-#pragma unroll
-    for (int h = 0; h < 8; h += 4)
-#pragma unroll
-        for (int m = 0; m < 2; m++) {
-            const int a = h + m, b = h + m + 2;
-            const double ur = re[a] + re[b], ui = im[a] + im[b], vr = re[a] - re[b], vi = im[a] - im[b];
-            re[a] = ur; im[a] = ui;
-            if (m == 0) { re[b] = vr; im[b] = vi; } else { re[b] = vi; im[b] = -vr; }
-        }
-    // stage 3: (m, m + 1)
-#pragma unroll
-    for (int a = 0; a < 8; a += 2) {
-        const double ur = re[a] + re[a + 1], ui = im[a] + im[a + 1], vr = re[a] - re[a + 1], vi = im[a] - im[a + 1];
-        re[a] = ur; im[a] = ui; re[a + 1] = vr; im[a + 1] = vi;
-    }
-    // outputs sit in bit-reversed order: slot (0..7) holds y[0, 4, 2, 6, 1, 5, 3, 7]
-}
 #define US8_N2 4096
 #define US8_PHYS(i) ((i) + ((i) >> 3))
 template <typename T>
@@ -2778,7 +2749,6 @@ __global__ __launch_bounds__(512) void k_us_frame_power8(const T* __restrict__ s
         zi[US8_PHYS(i)] = sample(2 * i + 1) * hann[2 * i + 1];
     }
     __syncthreads();
-    constexpr int kSlot[8] = {0, 4, 2, 6, 1, 5, 3, 7};                // output q of us_dft8 sits in slot kSlot-inverse: slot s holds y[kSlot[s]]
 #pragma unroll 1
     for (int st = 0; st < 4; st++) {
         const int L = US8_N2 >> (3 * st), span = L >> 3;
@@ -2786,11 +2756,11 @@ __global__ __launch_bounds__(512) void k_us_frame_power8(const T* __restrict__ s
         double re[8], im[8];
 #pragma unroll
         for (int m = 0; m < 8; m++) { const int i = US8_PHYS(base + m * span); re[m] = zr[i]; im[m] = zi[i]; }
-        us_dft8(re, im);
+        fft_r8_dft8(re, im);
         const int tstep = j * (8192 / L);                            // W_L^(j q) = W_8192^(q * tstep)
 #pragma unroll
         for (int sl = 0; sl < 8; sl++) {
-            const int q = kSlot[sl];
+            const int q = kFftR8Slot[sl];
             double yr = re[sl], yi = im[sl];
             if (q != 0 && st < 3) {                                  // the last pass has span 1: j = 0, no twiddles
                 int e = q * tstep;                                   // < 7168
