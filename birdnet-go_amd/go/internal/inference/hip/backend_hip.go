@@ -268,6 +268,16 @@ func (c *Classifier) PredictBatch(flat []float32, batchSize int) ([]float32, err
 // PredictTopK runs predict + sigmoid(sensitivity) + top-k on the device ((*BirdNET).Predict's
 // post-processing, classifier/analyze.go:113-115,197-253): confidences and label indices, descending.
 func (c *Classifier) PredictTopK(flat []float32, batchSize, k int, sensitivity float64) ([]float32, []int32, error) {
+	return c.predictTopK(flat, batchSize, k, 0, sensitivity)
+}
+
+// PredictTopKSoftmax is the Perch v2 form: softmax over the logits (perchSoftmax, classifier/perch_onnx.go:315-335:
+// max-subtract, exp in float64, float32 running sum) + top-k on the device.
+func (c *Classifier) PredictTopKSoftmax(flat []float32, batchSize, k int) ([]float32, []int32, error) {
+	return c.predictTopK(flat, batchSize, k, 1, 1.0)
+}
+
+func (c *Classifier) predictTopK(flat []float32, batchSize, k, activation int, sensitivity float64) ([]float32, []int32, error) {
 	if c.h == nil {
 		return nil, nil, errors.New("hip: classifier is closed")
 	}
@@ -281,7 +291,7 @@ func (c *Classifier) PredictTopK(flat []float32, batchSize, k int, sensitivity f
 	idx := make([]int32, batchSize*k)
 	runtime.LockOSThread()
 	defer runtime.UnlockOSThread()
-	if rc := C.bnbind_predict_topk(c.h, (*C.float)(unsafe.Pointer(&flat[0])), C.int(batchSize), 0, C.double(sensitivity),
+	if rc := C.bnbind_predict_topk(c.h, (*C.float)(unsafe.Pointer(&flat[0])), C.int(batchSize), C.int(activation), C.double(sensitivity),
 		C.int(k), (*C.float)(unsafe.Pointer(&conf[0])), (*C.int32_t)(unsafe.Pointer(&idx[0]))); rc != 0 {
 		return nil, nil, fmt.Errorf("hip: predict_topk failed (%d): %s", int(rc), lastError())
 	}

@@ -112,7 +112,7 @@ def test_go_shim_pins_the_os_thread_around_error_fetch():
     src = open(GO_SHIM).read()
     # every exported entry that can fail fetches the thread-local error text: each must hold the OS thread
     for fn in ("func Init(", "func NewClassifierWithOptions(", "func (c *Classifier) predict(", "func (c *Classifier) PredictBatch(",
-               "func (c *Classifier) PredictTopK("):
+               "func (c *Classifier) predictTopK("):
         body = src[src.index(fn):]
         body = body[:body.index("\n}\n")]
         assert "runtime.LockOSThread()" in body and "defer runtime.UnlockOSThread()" in body, fn
