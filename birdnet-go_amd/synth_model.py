@@ -68,6 +68,7 @@ class SynthConfig:
     n_classes: int = 6522
     emit_embeddings: bool = False    # second graph output = 1024-d embedding (bat / Perch-style)
     perch_outputs: bool = False      # four outputs in Perch v2's order: embedding, spatial embedding, spectrogram, logits
+    emb_first: bool = False          # two outputs with the embedding FIRST (one of the two orders BirdNET v3.0 exports come in)
     seed: int = 2024
     head_bias: float = -4.0
     name: str = "birdnet_v24_synth"
@@ -320,6 +321,8 @@ def build_model(cfg: SynthConfig = None) -> bytes:
     logits = g.op("FULLY_CONNECTED", [emb4, g.const(wh, "head/w"), g.const(bh, "head/b")],
                   [1, cfg.n_classes], dict(fused_activation_function=S.ACT_NONE), name="CLASS_DENSE_LAYER")
     outs = [logits, emb4] if cfg.emit_embeddings else [logits]
+    if cfg.emit_embeddings and cfg.emb_first:
+        outs = [emb4, logits]
     if cfg.perch_outputs:            # internal/inference/onnx/classifier.go:495-505: [B,1536], [B,16,4,1536], [B,500,128], [B,14795]
         assert len(chans) == 1
         spec3 = g.op("RESHAPE", [chans[0], g.const(i32([1, F0, cfg.n_mels]))], [1, F0, cfg.n_mels], dict(new_shape=[1, F0, cfg.n_mels]))

@@ -238,3 +238,35 @@ def test_front_end_geometry_sweep_vs_oracle(gpu, i):
         c.close()
     assert (got.argmax(1) == ref.argmax(1)).all()
     assert np.abs(softmax64(got) - softmax64(ref)).max() <= 1e-4 and np.abs(got - ref).max() < 1e-3 and np.abs(emb - ref_emb).max() < 1e-3
+
+
+@pytest.mark.parametrize("emb_first", [False, True])
+def test_birdnet_v3_output_rule(built_lib, emb_first):
+    """BirdNET v3.0 graphs (160000 samples, two outputs) come with the 1280-wide embedding port first or second depending on
+    the export; the reference picks it by size (internal/inference/onnx/detection.go:91-106).  A 160000-sample stand-in with a
+    1280-d embedding in either order must bind logits / embedding the same way, and the oracle agrees on the GPU."""
+    cfg = sm.tiny_perch_config(n_samples=160000, specs=(sm.SpecConfig(1024, 2048, 60.0, 16000.0, 1024),), pad=(0, 0), n_mels=32,
+                               top=1280, n_classes=40, emb_first=emb_first)
+    c = host.HipClassifier(sm.build_model(cfg), plan_only=True)
+    try:
+        d = c.describe()
+        assert (c.num_species(), c.emb_dim) == (40, 1280)
+        assert (d["logits_output"], d["embedding_output"]) == ((1, 0) if emb_first else (0, 1))
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
+def test_birdnet_v3_output_rule_vs_oracle(gpu):
+    cfg = sm.tiny_perch_config(n_samples=160000, specs=(sm.SpecConfig(1024, 2048, 60.0, 16000.0, 1024),), pad=(0, 0), n_mels=32,
+                               top=1280, n_classes=40, emb_first=True)
+    blob = sm.build_model(cfg)
+    x = sm.synth_clips(3, cfg.n_samples, cfg.sample_rate)
+    outs = Interpreter(blob).invoke(x)                       # graph order: embedding, logits
+    c = host.HipClassifier(blob, max_batch=4)
+    try:
+        got, emb = c.predict_batch(x.reshape(-1), 3, want_embeddings=True)
+    finally:
+        c.close()
+    assert got.shape == (3, 40) and emb.shape == (3, 1280)
+    assert np.abs(got - outs[1]).max() < 1e-3 and np.abs(emb - outs[0]).max() < 1e-3
