@@ -245,7 +245,7 @@ def test_birdnet_v3_output_rule(built_lib, emb_first):
     """BirdNET v3.0 graphs (160000 samples, two outputs) come with the 1280-wide embedding port first or second depending on
     the export; the reference picks it by size (internal/inference/onnx/detection.go:91-106).  A 160000-sample stand-in with a
     1280-d embedding in either order must bind logits / embedding the same way, and the oracle agrees on the GPU."""
-    cfg = sm.tiny_perch_config(n_samples=160000, specs=(sm.SpecConfig(1024, 2048, 60.0, 16000.0, 1024),), pad=(0, 0), n_mels=32,
+    cfg = sm.tiny_perch_config(n_samples=160000, specs=(sm.SpecConfig(640, 1280, 60.0, 16000.0, 1024),), pad=(0, 0), n_mels=32,
                                top=1280, n_classes=40, emb_first=emb_first)
     c = host.HipClassifier(sm.build_model(cfg), plan_only=True)
     try:
@@ -258,7 +258,7 @@ def test_birdnet_v3_output_rule(built_lib, emb_first):
 
 @pytest.mark.gpu
 def test_birdnet_v3_output_rule_vs_oracle(gpu):
-    cfg = sm.tiny_perch_config(n_samples=160000, specs=(sm.SpecConfig(1024, 2048, 60.0, 16000.0, 1024),), pad=(0, 0), n_mels=32,
+    cfg = sm.tiny_perch_config(n_samples=160000, specs=(sm.SpecConfig(640, 1280, 60.0, 16000.0, 1024),), pad=(0, 0), n_mels=32,
                                top=1280, n_classes=40, emb_first=True)
     blob = sm.build_model(cfg)
     x = sm.synth_clips(3, cfg.n_samples, cfg.sample_rate)
