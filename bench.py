@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-oracle-check", action="store_true", help="skip the max-abs probability diff vs the oracle (3 rows, outside the timed region)")
     ap.add_argument("--cpu-clips", type=int, default=0, help="clips in the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-profile", action="store_true", help="disable per-kernel HIP-event timing")
+    ap.add_argument("--no-host-pointer", action="store_true", help="skip the host_pointer leg (rates through the blocking host-pointer entries)")
     ap.add_argument("--detail", action="store_true", help="print a per-launch table to stderr")
     ap.add_argument("--depth", type=int, default=2, help="engine pipeline depth: successive batches run on alternating "
                     "contexts (own stream + activation arena) so one batch's tail overlaps the next one's head; 1 = off "
@@ -139,6 +140,44 @@ def cpu_baseline(blob, n_samples, sample_rate, n_clips_hint):
                       f"{workers} processes x {threads} BLAS threads ({workers * threads} of {cores} host cores), "
                       f"{busy:.1f} s compute ({wall:.1f} s incl. start-up); restatement baseline - NOT TFLite "
                       "(no TFLite runtime or real weights exist in this environment)"}
+
+
+def host_pointer_rates(clf, x, reps_small=100, reps_mid=12, reps_big=5):
+    """PCIe-inclusive rates through the BLOCKING host-pointer entries - what the reference's callers use
+    (internal/analysis/process.go:280-295 one clip per Predict; internal/inference/onnx/classifier.go:372-430 PredictBatch):
+    pageable caller memory in, logits in caller memory on return.  Median wall time per call.  x: [256, n_samples] float32."""
+    def t(fn, reps):
+        fn(); fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2]
+    res = {}
+    ncls = clf.num_species()
+    pcm = (np.clip(x, -1, 1) * 32767).astype(np.int16)
+    out256 = np.zeros((256, ncls), np.float32)
+    out2048 = np.zeros((2048, ncls), np.float32)
+    dt = t(lambda: clf.predict_batch(x[:1].reshape(-1), 1), reps_small)
+    res["f32_1"] = {"ms": dt * 1e3, "clips_per_s": 1 / dt}
+    dt = t(lambda: clf.predict_topk(x[:1].reshape(-1), 1, 10, 0, 1.0), reps_small)
+    res["f32_1_topk"] = {"ms": dt * 1e3, "clips_per_s": 1 / dt}
+    dt = t(lambda: clf.predict_batch(x[:8].reshape(-1), 8), reps_small)
+    res["f32_8"] = {"ms": dt * 1e3, "clips_per_s": 8 / dt}
+    dt = t(lambda: clf.predict_batch(x.reshape(-1), 256, out=out256), reps_mid)
+    res["f32_256"] = {"ms": dt * 1e3, "clips_per_s": 256 / dt}
+    dt = t(lambda: clf.predict_pcm16(pcm.reshape(-1), 256, out=out256), reps_mid)
+    res["pcm16_256"] = {"ms": dt * 1e3, "clips_per_s": 256 / dt}
+    bigp = np.tile(pcm, (8, 1))
+    dt = t(lambda: clf.predict_pcm16(bigp.reshape(-1), 2048, out=out2048), reps_big)
+    res["pcm16_2048"] = {"ms": dt * 1e3, "clips_per_s": 2048 / dt}
+    del bigp
+    big = np.tile(x, (8, 1))
+    dt = t(lambda: clf.predict_batch(big.reshape(-1), 2048, out=out2048), reps_big)
+    res["f32_2048"] = {"ms": dt * 1e3, "clips_per_s": 2048 / dt}
+    res["note"] = ("blocking C-ABI entries bnhip_predict / bnhip_predict_pcm16 on pageable numpy memory, outputs complete on return; "
+                   "calls of >= 128 clips run as chunks on two contexts fed from pinned staging (csrc/hostpipe.cpp); median of the calls")
+    return res
 
 
 def bat_chirps(n, n_samples=144000, rate=256000, first=0):
@@ -476,6 +515,11 @@ def main():
             torch.cuda.synchronize(dev)
             dt0 = time.perf_counter() - t1
             out["fp32_mfma_only"] = {"value": B * args.steps / dt0, "unit": "clips/s", "ms_per_step": dt0 / args.steps * 1e3}
+        if world == 1 and not perch and not args.no_host_pointer and B == 256:
+            # the product boundary: the same model through the blocking host-pointer entries (own engine: default options)
+            clf.close()
+            clf = host.HipClassifier(blob, device=local_rank, max_batch=B, bf16x3=args.bf16x3, precision=args.precision)
+            out["host_pointer"] = host_pointer_rates(clf, x_host)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob, cfg.n_samples, cfg.sample_rate, args.cpu_clips)
         print(json.dumps(out))

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "engine.h"
+#include "hostpipe.h"
 #include "model_onnx.h"
 #include "tflite_model.h"
 
@@ -291,123 +292,9 @@ int shard_run(bnhip_model* m, int n_clips, F f) {
 }
 
 // ---------------------------------------------------------------------------------------------- one engine, one shard
-// pcm_bits: 0 = float32 samples, 16 / 24 / 32 = little-endian PCM converted on the device
-int predict_host_one(Engine& e, const void* src, int pcm_bits, int n_clips, float* logits, float* emb, std::string& err) {
-    if (hipSetDevice(e.device) != hipSuccess) { err = "hipSetDevice failed"; return BNHIP_E_RUNTIME; }
-    const bool pcm = pcm_bits != 0;
-    const size_t bps = (size_t)pcm_bits / 8;
-    // chunk = max_batch for calls larger than it; a single large batch (>= 128 clips) is split too, so that the pageable
-    // H2D copy of its second part overlaps the compute of the first (PCIe-inclusive rate of a 256-clip call: +25 %)
-    static const int split_env = getenv("BNHIP_HOST_SPLIT") ? atoi(getenv("BNHIP_HOST_SPLIT")) : 2;
-    int ck = e.max_batch;
-    if (n_clips <= e.max_batch && n_clips >= 128 && split_env > 1) ck = (n_clips + split_env - 1) / split_env;
-    const int nchunks = (n_clips + ck - 1) / ck;
-    const bool pipelined = nchunks > 1;
-    // PCM staging: one buffer, or two (one per in-flight chunk) when the call is pipelined
-    const size_t pcm_half = (size_t)e.max_batch * e.n_samples * bps, pcm_need = pcm_half * (pipelined ? 2 : 1);
-    if (pcm && e.stage_pcm_bytes < pcm_need) {
-        if (e.d_stage_pcm) { hipStreamSynchronize(e.stream); hipFree(e.d_stage_pcm); e.d_stage_pcm = nullptr; e.stage_pcm_bytes = 0; }
-        if (hipMalloc((void**)&e.d_stage_pcm, pcm_need) != hipSuccess) { err = "device allocation failed (pcm staging)"; return BNHIP_E_NOMEM; }
-        e.stage_pcm_bytes = pcm_need;
-    }
-    if (pipelined && !e.staging2_ready) {       // second staging set, created on first use; committed only when complete
-        float *in2 = nullptr, *lg2 = nullptr, *em2 = nullptr;
-        hipStream_t cs = nullptr;
-        hipEvent_t evc[2] = {nullptr, nullptr}, evd[2] = {nullptr, nullptr};
-        hipError_t he = hipMalloc((void**)&in2, (size_t)e.max_batch * e.n_samples * 4);
-        if (he == hipSuccess) he = hipMalloc((void**)&lg2, (size_t)e.max_batch * e.n_classes * 4);
-        if (he == hipSuccess && e.emb_dim) he = hipMalloc((void**)&em2, (size_t)e.max_batch * e.emb_dim * 4);
-        if (he == hipSuccess) he = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
-        for (int i = 0; i < 2 && he == hipSuccess; i++) {
-            he = hipEventCreateWithFlags(&evc[i], hipEventDisableTiming);
-            if (he == hipSuccess) he = hipEventCreateWithFlags(&evd[i], hipEventDisableTiming);
-        }
-        if (he != hipSuccess) {
-            if (in2) hipFree(in2);
-            if (lg2) hipFree(lg2);
-            if (em2) hipFree(em2);
-            if (cs) hipStreamDestroy(cs);
-            for (int i = 0; i < 2; i++) { if (evc[i]) hipEventDestroy(evc[i]); if (evd[i]) hipEventDestroy(evd[i]); }
-            (void)hipGetLastError();
-            err = std::string("staging allocation failed: ") + hipGetErrorString(he);
-            return BNHIP_E_NOMEM;
-        }
-        e.d_stage_in2 = in2; e.d_stage_logits2 = lg2; e.d_stage_emb2 = em2; e.copy_stream = cs;
-        for (int i = 0; i < 2; i++) { e.ev_copied[i] = evc[i]; e.ev_done[i] = evd[i]; }
-        e.staging2_ready = true;
-    }
-    if (!pipelined) {
-        for (int off = 0; off < n_clips; off += e.max_batch) {
-            int n = std::min(e.max_batch, n_clips - off);
-            size_t cnt = (size_t)n * e.n_samples;
-            hipError_t he;
-            if (pcm) {
-                he = hipMemcpyAsync(e.d_stage_pcm, (const char*)src + (size_t)off * e.n_samples * bps, cnt * bps,
-                                    hipMemcpyHostToDevice, e.stream);
-                if (he == hipSuccess) launch_pcm_to_f32(e.d_stage_pcm, pcm_bits, e.d_stage_in, cnt, e.stream);
-            } else {
-                he = hipMemcpyAsync(e.d_stage_in, (const float*)src + (size_t)off * e.n_samples, cnt * 4,
-                                    hipMemcpyHostToDevice, e.stream);
-            }
-            if (he != hipSuccess) { err = std::string("H2D copy: ") + hipGetErrorString(he); return BNHIP_E_RUNTIME; }
-            if (!e.run(e.d_stage_in, n, e.d_stage_logits, emb ? e.d_stage_emb : nullptr, &err)) return BNHIP_E_RUNTIME;
-            he = hipMemcpyAsync(logits + (size_t)off * e.n_classes, e.d_stage_logits, (size_t)n * e.n_classes * 4,
-                                hipMemcpyDeviceToHost, e.stream);
-            if (he == hipSuccess && emb)
-                he = hipMemcpyAsync(emb + (size_t)off * e.emb_dim, e.d_stage_emb, (size_t)n * e.emb_dim * 4,
-                                    hipMemcpyDeviceToHost, e.stream);
-            if (he == hipSuccess) he = hipStreamSynchronize(e.stream);
-            if (he != hipSuccess) { err = std::string("D2H copy/sync: ") + hipGetErrorString(he); return BNHIP_E_RUNTIME; }
-        }
-        return BNHIP_OK;
-    }
-    // ---- pipelined: the (host-blocking) pageable H2D of chunk i+1 runs on the copy stream while the compute stream is
-    // busy with chunk i; the D2H of chunk i-1 is issued after chunk i's kernels are queued.
-    float* din[2] = {e.d_stage_in, e.d_stage_in2};
-    float* dlog[2] = {e.d_stage_logits, e.d_stage_logits2};
-    float* demb[2] = {e.d_stage_emb, e.d_stage_emb2};
-    auto fail = [&](const std::string& what, hipError_t he) {
-        hipStreamSynchronize(e.stream); hipStreamSynchronize(e.copy_stream);
-        err = what + ": " + hipGetErrorString(he);
-        return BNHIP_E_RUNTIME;
-    };
-    auto drain = [&](int c) -> hipError_t {      // copy chunk c's results to the caller (waits for its compute)
-        int off = c * ck, n = std::min(ck, n_clips - off), b = c & 1;
-        hipError_t he = hipStreamWaitEvent(e.copy_stream, e.ev_done[b], 0);
-        if (he == hipSuccess) he = hipMemcpyAsync(logits + (size_t)off * e.n_classes, dlog[b], (size_t)n * e.n_classes * 4,
-                                                  hipMemcpyDeviceToHost, e.copy_stream);
-        if (he == hipSuccess && emb)
-            he = hipMemcpyAsync(emb + (size_t)off * e.emb_dim, demb[b], (size_t)n * e.emb_dim * 4, hipMemcpyDeviceToHost,
-                                e.copy_stream);
-        if (he == hipSuccess) he = hipStreamSynchronize(e.copy_stream);     // buffer b is free again afterwards
-        return he;
-    };
-    for (int c = 0; c < nchunks; c++) {
-        int off = c * ck, n = std::min(ck, n_clips - off), b = c & 1;
-        hipError_t he;
-        if (pcm) {      // raw PCM over PCIe (a half or a quarter of the float bytes), converted on the copy stream
-            char* dp = reinterpret_cast<char*>(e.d_stage_pcm) + (size_t)b * pcm_half;
-            he = hipMemcpyAsync(dp, (const char*)src + (size_t)off * e.n_samples * bps, (size_t)n * e.n_samples * bps,
-                                hipMemcpyHostToDevice, e.copy_stream);
-            if (he == hipSuccess) launch_pcm_to_f32(dp, pcm_bits, din[b], (size_t)n * e.n_samples, e.copy_stream);
-        } else {
-            he = hipMemcpyAsync(din[b], (const float*)src + (size_t)off * e.n_samples, (size_t)n * e.n_samples * 4,
-                                hipMemcpyHostToDevice, e.copy_stream);
-        }
-        if (he == hipSuccess) he = hipEventRecord(e.ev_copied[b], e.copy_stream);
-        if (he == hipSuccess) he = hipStreamWaitEvent(e.stream, e.ev_copied[b], 0);
-        if (he != hipSuccess) return fail("H2D copy", he);
-        if (!e.run(din[b], n, dlog[b], emb ? demb[b] : nullptr, &err)) { hipStreamSynchronize(e.stream); return BNHIP_E_RUNTIME; }
-        he = hipEventRecord(e.ev_done[b], e.stream);
-        if (he != hipSuccess) return fail("event record", he);
-        if (c >= 1) { he = drain(c - 1); if (he != hipSuccess) return fail("D2H copy", he); }
-    }
-    hipError_t he = drain(nchunks - 1);
-    if (he == hipSuccess) he = hipStreamSynchronize(e.stream);
-    if (he != hipSuccess) return fail("D2H copy/sync", he);
-    return BNHIP_OK;
-}
-
+// pcm_bits: 0 = float32 samples, 16 / 24 / 32 = little-endian PCM converted on the device.  The work itself - small calls
+// straight through the engine, calls of >= 128 clips as chunks on alternating contexts fed from pinned staging - is
+// hostpipe.cpp's host_run.
 int predict_host(bnhip_model* m, const void* src, int pcm_bits, int n_clips, float* logits, float* emb) {
     if (!m || !src || !logits) return set_err(BNHIP_E_INVALID, "NULL argument");
     if (n_clips <= 0) return set_err(BNHIP_E_INVALID, "n_clips must be positive");
@@ -417,8 +304,10 @@ int predict_host(bnhip_model* m, const void* src, int pcm_bits, int n_clips, flo
     const size_t in_stride = (size_t)e0.n_samples * (pcm_bits ? (size_t)pcm_bits / 8 : 4);
     const int nc = e0.n_classes, ed = e0.emb_dim;
     return shard_run(m, n_clips, [=](Engine& e, int off, int cnt, std::string& err) {
-        return predict_host_one(e, (const char*)src + (size_t)off * in_stride, pcm_bits, cnt, logits + (size_t)off * nc,
-                                emb ? emb + (size_t)off * ed : nullptr, err);
+        HostJob j;
+        j.src = (const char*)src + (size_t)off * in_stride; j.pcm_bits = pcm_bits; j.n_clips = cnt;
+        j.logits = logits + (size_t)off * nc; j.emb = emb ? emb + (size_t)off * ed : nullptr;
+        return host_run(e, j, err);
     });
 }
 
@@ -437,9 +326,9 @@ int ensure_topk(Engine& e, int k, std::string& err) {
     return BNHIP_OK;
 }
 
-// samples != nullptr: predict first; else `logits` (host) are the input
-int topk_one(Engine& e, const float* samples, const float* logits, int n_clips, int activation, double sensitivity, int k,
-             float* out_conf, int32_t* out_idx, std::string& err) {
+// activation + top-k of logits that are already on the host (bnhip_postprocess_topk)
+int post_topk_one(Engine& e, const float* logits, int n_clips, int activation, double sensitivity, int k, float* out_conf,
+                  int32_t* out_idx, std::string& err) {
     if (hipSetDevice(e.device) != hipSuccess) { err = "hipSetDevice failed"; return BNHIP_E_RUNTIME; }
     const int n_classes = e.n_classes;
     int kk = std::min(k, n_classes);
@@ -447,17 +336,9 @@ int topk_one(Engine& e, const float* samples, const float* logits, int n_clips, 
     if (rc) return rc;
     for (int off = 0; off < n_clips; off += e.max_batch) {
         int n = std::min(e.max_batch, n_clips - off);
-        hipError_t he;
-        if (samples) {
-            he = hipMemcpyAsync(e.d_stage_in, samples + (size_t)off * e.n_samples, (size_t)n * e.n_samples * 4,
-                                hipMemcpyHostToDevice, e.stream);
-            if (he != hipSuccess) { err = std::string("H2D copy: ") + hipGetErrorString(he); return BNHIP_E_RUNTIME; }
-            if (!e.run(e.d_stage_in, n, e.d_stage_logits, nullptr, &err)) return BNHIP_E_RUNTIME;
-        } else {
-            he = hipMemcpyAsync(e.d_stage_logits, logits + (size_t)off * n_classes, (size_t)n * n_classes * 4,
-                                hipMemcpyHostToDevice, e.stream);
-            if (he != hipSuccess) { err = std::string("H2D copy: ") + hipGetErrorString(he); return BNHIP_E_RUNTIME; }
-        }
+        hipError_t he = hipMemcpyAsync(e.d_stage_logits, logits + (size_t)off * n_classes, (size_t)n * n_classes * 4,
+                                       hipMemcpyHostToDevice, e.stream);
+        if (he != hipSuccess) { err = std::string("H2D copy: ") + hipGetErrorString(he); return BNHIP_E_RUNTIME; }
         launch_activation(e.d_stage_logits, e.d_post_conf, n, n_classes, activation, sensitivity, e.stream);
         launch_topk(e.d_post_conf, n, n_classes, kk, e.d_topk_conf, e.d_topk_idx, e.stream);
         hipMemcpyAsync(out_conf + (size_t)off * kk, e.d_topk_conf, (size_t)n * kk * 4, hipMemcpyDeviceToHost, e.stream);
@@ -590,6 +471,10 @@ int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, 
         e->autotune = json_int(opts_json, "autotune", 1) != 0;
         e->n_lanes = (int)json_int(opts_json, "lanes", lenv ? atoi(lenv) : 2);
         e->depth = (int)json_int(opts_json, "depth", denv ? atoi(denv) : 1);
+        {
+            const char* henv = getenv("BNHIP_HOST_DEPTH");
+            e->host_depth = (int)json_int(opts_json, "host_depth", henv ? atoi(henv) : 2);
+        }
         e->frontend_fft = (int)json_int(opts_json, "frontend_fft", fenv ? atoi(fenv) : -1);
         e->use_graphs = json_int(opts_json, "graphs", genv ? atoi(genv) : 0) != 0;
         // default 1: per layer where the create-time autotuner measures the split-bf16 kernel faster (fp32-equivalent
@@ -753,8 +638,8 @@ int bnhip_postprocess_topk(bnhip_model* m, const float* logits, int n_clips, int
     if ((size_t)n_classes * 4 > 150 * 1024) return set_err(BNHIP_E_UNSUPPORTED, "too many classes for the LDS top-k");
     const int kk = std::min(k, n_classes);
     return shard_run(m, n_clips, [=](Engine& en, int off, int cnt, std::string& err) {
-        return topk_one(en, nullptr, logits + (size_t)off * n_classes, cnt, activation, sensitivity, k,
-                        out_conf + (size_t)off * kk, out_idx + (size_t)off * kk, err);
+        return post_topk_one(en, logits + (size_t)off * n_classes, cnt, activation, sensitivity, k,
+                             out_conf + (size_t)off * kk, out_idx + (size_t)off * kk, err);
     });
     BN_GUARD_END((void)0)
 }
@@ -770,8 +655,10 @@ int bnhip_predict_topk(bnhip_model* m, const float* samples, int n_clips, int ac
     if (e.device < 0) return set_err(BNHIP_E_INVALID, "plan-only model cannot run");
     const int kk = std::min(k, e.n_classes), ns = e.n_samples;
     return shard_run(m, n_clips, [=](Engine& en, int off, int cnt, std::string& err) {
-        return topk_one(en, samples + (size_t)off * ns, nullptr, cnt, activation, sensitivity, k, out_conf + (size_t)off * kk,
-                        out_idx + (size_t)off * kk, err);
+        HostJob j;
+        j.src = samples + (size_t)off * ns; j.n_clips = cnt; j.topk = k; j.activation = activation; j.sensitivity = sensitivity;
+        j.out_conf = out_conf + (size_t)off * kk; j.out_idx = out_idx + (size_t)off * kk;
+        return host_run(en, j, err);
     });
     BN_GUARD_END((void)0)
 }
@@ -803,9 +690,12 @@ int bnhip_us_frame_cv(int device, const double* samples, int n_clips, int n, int
     if (he == hipSuccess) {
         const double* d_tw = us_twiddles(device, fft_size);
         if (!d_tw) he = hipErrorOutOfMemory;
-        else launch_us_frame_power(d_s, 0, n_clips, n, fft_size, hop, frames, split_bin, d_tw, d_p, nullptr);
-        launch_us_cv(d_p, n_clips, frames, d_cv, nullptr);
-        he = hipMemcpy(cv, d_cv, (size_t)n_clips * 8, hipMemcpyDeviceToHost);
+        else {
+            launch_us_frame_power(d_s, 0, n_clips, n, fft_size, hop, frames, split_bin, d_tw, d_p, nullptr);
+            launch_us_cv(d_p, n_clips, frames, d_cv, nullptr);
+            he = hipGetLastError();
+            if (he == hipSuccess) he = hipMemcpy(cv, d_cv, (size_t)n_clips * 8, hipMemcpyDeviceToHost);
+        }
     }
     if (d_s) hipFree(d_s);
     if (d_p) hipFree(d_p);
@@ -847,15 +737,24 @@ int bnhip_debug_fetch(bnhip_model* m, int tensor_index, int n_clips, float* out,
     if (!m || !out || m->eng().device < 0) return set_err(BNHIP_E_INVALID, "NULL argument or plan-only model");
     BN_GUARD_BEGIN
     Engine& e = m->eng();
-    auto it = e.tensor_value.find(tensor_index);
-    if (it == e.tensor_value.end()) return set_err(BNHIP_E_INVALID, "tensor is not materialised by the plan (fused away)");
-    const Value& v = e.vals[it->second];
+    // tensor_index <= -2 names a plan value directly (value id = -tensor_index - 2: the "out_v" / "out2_v" of a describe()
+    // step, which also covers internal scratch such as the squeeze-excite partial sums)
+    int vid = -1;
+    if (tensor_index <= -2) {
+        vid = -tensor_index - 2;
+        if (vid >= (int)e.vals.size()) return set_err(BNHIP_E_INVALID, "value id out of range");
+    } else {
+        auto it = e.tensor_value.find(tensor_index);
+        if (it == e.tensor_value.end()) return set_err(BNHIP_E_INVALID, "tensor is not materialised by the plan (fused away)");
+        vid = it->second;
+    }
+    const Value& v = e.vals[vid];
     if (v.external) return set_err(BNHIP_E_INVALID, "tensor is bound externally (graph input/logits)");
     size_t n = v.elems * (size_t)n_clips;
     if (n > cap_floats || n_clips > e.max_batch) return set_err(BNHIP_E_INVALID, "buffer too small");
     hipSetDevice(e.device);
     hipStreamSynchronize(e.stream);
-    if (hipMemcpy(out, e.value_ptr(it->second), n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+    if (hipMemcpy(out, e.value_ptr(vid), n * 4, hipMemcpyDeviceToHost) != hipSuccess)
         return set_err(BNHIP_E_RUNTIME, "debug fetch copy failed");
     return (int)v.elems;
     BN_GUARD_END((void)0)
@@ -989,28 +888,41 @@ static int resampler_run(bnhip_resampler* r, const void* in, bool pcm16, int n_i
     hipSetDevice(r->device);
     const size_t esz = pcm16 ? 2 : 4;
     const size_t need = (size_t)r->n_hist + (size_t)n_in;
+    const int n_work = r->n_hist + n_in;
+    // what the next call still needs: the inputs from n0(i_end) - (T-1) on.  Computed up front so that every allocation
+    // (including the staging the history compaction moves through) happens BEFORE any work is queued: a failure below
+    // leaves n_total / i_next / n_hist / n_base exactly as they were ("fails before the state advances", resample.go:137-144).
+    long long keep_from = (i_end * r->M + r->half) / r->L - (r->T - 1);
+    if (keep_from < r->n_base) keep_from = r->n_base;
+    if (keep_from > n_after) keep_from = n_after;
+    const int drop = flush ? 0 : (int)(keep_from - r->n_base), keep = flush ? 0 : n_work - drop;
     if (need > r->work_cap) {
         size_t cap = std::max<size_t>(need * 2, 4096);
         float* nw = nullptr;
-        if (hipMalloc((void**)&nw, cap * 4) != hipSuccess) return set_err(BNHIP_E_NOMEM, "device allocation failed (resampler work buffer)");
-        if (r->n_hist) hipMemcpyAsync(nw, r->d_work, (size_t)r->n_hist * 4, hipMemcpyDeviceToDevice, r->stream);
-        hipStreamSynchronize(r->stream);
+        if (hipMalloc((void**)&nw, cap * 4) != hipSuccess) { (void)hipGetLastError(); return set_err(BNHIP_E_NOMEM, "device allocation failed (resampler work buffer)"); }
+        hipError_t hc = hipSuccess;
+        if (r->n_hist) hc = hipMemcpyAsync(nw, r->d_work, (size_t)r->n_hist * 4, hipMemcpyDeviceToDevice, r->stream);
+        if (hc == hipSuccess) hc = hipStreamSynchronize(r->stream);
+        if (hc != hipSuccess) { hipFree(nw); return set_err(BNHIP_E_RUNTIME, std::string("resampler: ") + hipGetErrorString(hc)); }
         if (r->d_work) hipFree(r->d_work);
         r->d_work = nw; r->work_cap = cap;
     }
-    if ((size_t)n_in * esz > r->in_cap) {
-        if (r->d_in) hipFree(r->d_in);
-        r->d_in = nullptr; r->in_cap = 0;
-        size_t cap = std::max<size_t>((size_t)n_in * esz * 2, 8192);
-        if (hipMalloc(&r->d_in, cap) != hipSuccess) return set_err(BNHIP_E_NOMEM, "device allocation failed (resampler input)");
-        r->in_cap = cap;
+    {   // input staging; doubles as the bounce buffer of the (overlapping) history move, so it is sized for both
+        const size_t in_need = std::max((size_t)n_in * esz, drop > 0 && keep > 0 ? (size_t)keep * 4 : (size_t)0);
+        if (in_need > r->in_cap) {
+            size_t cap = std::max<size_t>(in_need * 2, 8192);
+            void* ni = nullptr;
+            if (hipMalloc(&ni, cap) != hipSuccess) { (void)hipGetLastError(); return set_err(BNHIP_E_NOMEM, "device allocation failed (resampler input)"); }
+            if (r->d_in) hipFree(r->d_in);
+            r->d_in = ni; r->in_cap = cap;
+        }
     }
     if (cnt > 0 && (size_t)cnt * esz > r->out_cap) {
-        if (r->d_out) hipFree(r->d_out);
-        r->d_out = nullptr; r->out_cap = 0;
         size_t cap = std::max<size_t>((size_t)cnt * esz * 2, 8192);
-        if (hipMalloc(&r->d_out, cap) != hipSuccess) return set_err(BNHIP_E_NOMEM, "device allocation failed (resampler output)");
-        r->out_cap = cap;
+        void* no = nullptr;
+        if (hipMalloc(&no, cap) != hipSuccess) { (void)hipGetLastError(); return set_err(BNHIP_E_NOMEM, "device allocation failed (resampler output)"); }
+        if (r->d_out) hipFree(r->d_out);
+        r->d_out = no; r->out_cap = cap;
     }
     hipError_t he = hipSuccess;
     if (n_in > 0) {
@@ -1021,41 +933,27 @@ static int resampler_run(bnhip_resampler* r, const void* in, bool pcm16, int n_i
             he = hipMemcpyAsync(r->d_work + r->n_hist, in, (size_t)n_in * 4, hipMemcpyHostToDevice, r->stream);
         }
     }
-    const int n_work = r->n_hist + n_in;
     if (he == hipSuccess && cnt > 0) {
         int lrc = launch_resample(r->d_work, r->d_out, r->d_table, 0, pcm16 ? 1 : 0, 1, n_work, (int)cnt, r->L, r->M, r->T, r->half,
                                   r->i_next, r->n_base, r->stream);
-        if (lrc) return set_err(BNHIP_E_UNSUPPORTED, "resample ratio needs a phase table larger than LDS");
+        if (lrc) { hipStreamSynchronize(r->stream); return set_err(BNHIP_E_UNSUPPORTED, "resample ratio needs a phase table larger than LDS"); }
         he = hipMemcpyAsync(out, r->d_out, (size_t)cnt * esz, hipMemcpyDeviceToHost, r->stream);
     }
+    // history compaction (an overlapping move inside one buffer, bounced through the now idle input staging), queued behind
+    // the resample kernel that still reads the old layout
+    if (he == hipSuccess && drop > 0 && keep > 0) {
+        he = hipMemcpyAsync(r->d_in, r->d_work + drop, (size_t)keep * 4, hipMemcpyDeviceToDevice, r->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(r->d_work, r->d_in, (size_t)keep * 4, hipMemcpyDeviceToDevice, r->stream);
+    }
     if (he == hipSuccess) he = hipStreamSynchronize(r->stream);
-    if (he != hipSuccess) return set_err(BNHIP_E_RUNTIME, std::string("resampler: ") + hipGetErrorString(he));
+    if (he != hipSuccess) { (void)hipGetLastError(); return set_err(BNHIP_E_RUNTIME, std::string("resampler: ") + hipGetErrorString(he)); }
+    // ---- commit: everything above succeeded
     if (n_out) *n_out = (int)cnt;
     if (flush) {                                          // back to the initial state: the next call starts a new stream
         r->n_total = 0; r->i_next = 0; r->n_base = 0; r->n_hist = 0;
         return BNHIP_OK;
     }
-    // keep the inputs the next output still needs: from n0(i_end) - (T-1) on
     r->n_total = n_after; r->i_next = i_end;
-    long long keep_from = (i_end * r->M + r->half) / r->L - (r->T - 1);
-    if (keep_from < r->n_base) keep_from = r->n_base;
-    if (keep_from > n_after) keep_from = n_after;
-    const int drop = (int)(keep_from - r->n_base), keep = n_work - drop;
-    if (drop > 0 && keep > 0) {
-        // overlapping move inside one buffer: stage through the (idle) input buffer when it is large enough, else two-step
-        if ((size_t)keep * 4 <= r->in_cap) {
-            hipMemcpyAsync(r->d_in, r->d_work + drop, (size_t)keep * 4, hipMemcpyDeviceToDevice, r->stream);
-            hipMemcpyAsync(r->d_work, r->d_in, (size_t)keep * 4, hipMemcpyDeviceToDevice, r->stream);
-        } else {
-            float* tmp = nullptr;
-            if (hipMalloc((void**)&tmp, (size_t)keep * 4) != hipSuccess) return set_err(BNHIP_E_NOMEM, "device allocation failed (resampler history)");
-            hipMemcpyAsync(tmp, r->d_work + drop, (size_t)keep * 4, hipMemcpyDeviceToDevice, r->stream);
-            hipMemcpyAsync(r->d_work, tmp, (size_t)keep * 4, hipMemcpyDeviceToDevice, r->stream);
-            hipStreamSynchronize(r->stream);
-            hipFree(tmp);
-        }
-        hipStreamSynchronize(r->stream);
-    }
     r->n_hist = keep > 0 ? keep : 0;
     r->n_base = keep_from;
     return BNHIP_OK;

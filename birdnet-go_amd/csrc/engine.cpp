@@ -8,6 +8,7 @@
 #include <sstream>
 
 #include "../../include/bnhip.h"
+#include "hostpipe.h"
 
 namespace bnhip {
 
@@ -363,17 +364,15 @@ Engine::~Engine() {
     for (auto& e : prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto e : ev_pool) hipEventDestroy(e);
     for (void* p : {(void*)act_arena, (void*)w_arena, (void*)d_stage_in, (void*)d_stage_logits, (void*)d_stage_emb,
-                    (void*)d_stage_pcm, (void*)d_post_conf, (void*)d_topk_conf, (void*)d_topk_idx, (void*)d_stage_in2,
-                    (void*)d_stage_logits2, (void*)d_stage_emb2})
+                    (void*)d_stage_pcm, (void*)d_post_conf, (void*)d_topk_conf, (void*)d_topk_idx})
         if (p) hipFree(p);
-    for (int i = 0; i < 2; i++) { if (ev_copied[i]) hipEventDestroy(ev_copied[i]); if (ev_done[i]) hipEventDestroy(ev_done[i]); }
+    hostpipe_free(hostpipe);
     for (int c = 0; c < kMaxDepth; c++) {
         if (ctx_stream[c]) { hipStreamSynchronize(ctx_stream[c]); hipStreamDestroy(ctx_stream[c]); }
         if (c > 0 && ctx_arena[c]) hipFree(ctx_arena[c]);
         if (ev_ctx_done[c]) hipEventDestroy(ev_ctx_done[c]);
     }
     if (ev_ctx_fork) hipEventDestroy(ev_ctx_fork);
-    if (copy_stream) hipStreamDestroy(copy_stream);
     for (int i = 0; i < kMaxLanes - 1; i++) {
         if (lane_stream[i]) { hipStreamSynchronize(lane_stream[i]); hipStreamDestroy(lane_stream[i]); }
         if (ev_join[i]) hipEventDestroy(ev_join[i]);
@@ -1598,15 +1597,8 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
     if (!defer_weights) HIPCHK(hipMemcpy(w_arena, wimg.data(), w_bytes, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&act_arena, std::max<size_t>(act_bytes, 256)));
     depth = std::max(1, std::min(depth, kMaxDepth));
-    if (depth > 1) {
-        HIPCHK(hipEventCreateWithFlags(&ev_ctx_fork, hipEventDisableTiming));
-        for (int c = 0; c < depth; c++) {
-            HIPCHK(hipStreamCreateWithFlags(&ctx_stream[c], hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&ev_ctx_done[c], hipEventDisableTiming));
-            if (c == 0) ctx_arena[c] = act_arena;
-            else HIPCHK(hipMalloc((void**)&ctx_arena[c], std::max<size_t>(act_bytes, 256)));
-        }
-    }
+    host_depth = std::max(1, std::min(host_depth, kMaxDepth));
+    if (depth > 1 && !ensure_contexts(depth, err)) return false;
     for (size_t si = 0; si < steps.size(); si++) {
         const float** slots[4] = {&steps[si].w0, &steps[si].w1, &steps[si].w2, &steps[si].w3};
         for (int k = 0; k < 4; k++)
@@ -1630,6 +1622,23 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
     if (emb_dim) HIPCHK(hipMalloc((void**)&d_stage_emb, (size_t)max_batch * emb_dim * 4));
     if (autotune && !defer_weights) { autotune_pw(); autotune_expdw(); autotune_dw(); }
     *code = BNHIP_OK;
+    return true;
+}
+
+// Contexts 0..d-1 (stream, completion event, activation arena; context 0 shares the engine's own arena).  Idempotent.
+bool Engine::ensure_contexts(int d, std::string* err) {
+    d = std::max(1, std::min(d, kMaxDepth));
+    if (device < 0) { *err = "plan-only model has no contexts"; return false; }
+    hipSetDevice(device);
+    if (!ev_ctx_fork) HIPCHK(hipEventCreateWithFlags(&ev_ctx_fork, hipEventDisableTiming));
+    for (int c = 0; c < d; c++) {
+        if (!ctx_stream[c]) HIPCHK(hipStreamCreateWithFlags(&ctx_stream[c], hipStreamNonBlocking));
+        if (!ev_ctx_done[c]) HIPCHK(hipEventCreateWithFlags(&ev_ctx_done[c], hipEventDisableTiming));
+        if (!ctx_arena[c]) {
+            if (c == 0) ctx_arena[c] = act_arena;
+            else HIPCHK(hipMalloc((void**)&ctx_arena[c], std::max<size_t>(act_bytes, 256)));
+        }
+    }
     return true;
 }
 
@@ -1760,7 +1769,9 @@ void Engine::autotune_pw() {
             // context fills every stall - so there the candidate with the least padded MFMA work wins and time only breaks
             // ties: N = 80 / 112 take exact 80- / 112-column tiles although 48- / 64-column ones are 10-45 % faster alone
             // (measured: +1.2 % on the pipelined bench).
-            const bool by_work = depth > 1 && !getenv("BNHIP_TUNE_BY_TIME");
+            // The full-batch tuning (pass 1) is what a context runs, and the host-pointer pipeline (host_depth > 1) runs its
+            // chunks on contexts too; the lane tuning (pass 0) serves serial calls of a depth-1 engine and stays by time.
+            const bool by_work = (depth > 1 || (pass == 1 && host_depth > 1)) && !getenv("BNHIP_TUNE_BY_TIME");
             for (int wm = 4; wm >= 1; wm--) {
                 for (int nt = 1; nt <= 8; nt++) {
                     const long M_ = (long)n * s.H * s.W, bm = (wm == 1 || wm == 3) ? 64 : 128;
@@ -1853,16 +1864,30 @@ bool Engine::run_pipelined(const float* d_in, int n, float* d_logits, float* d_e
     cur_stream = nullptr;
     return ok;
 }
+// One chunk of a host-pointer call on context c (hostpipe.cpp orders the context's stream behind the chunk's copy and
+// records its completion): the whole plan, unsplit, on that context's stream and arena.
+bool Engine::run_on_context(int c, const float* d_in, int n, float* d_logits, float* d_emb, std::string* err) {
+    if (n <= 0 || n > max_batch) { *err = "batch size out of range"; return false; }
+    if (c < 0 || c >= kMaxDepth || !ctx_stream[c] || !ctx_arena[c]) { *err = "context does not exist"; return false; }
+    call_idx++;                                  // a later unsplit run() orders itself behind the contexts
+    cur_arena = ctx_arena[c];
+    cur_stream = ctx_stream[c];
+    bool ok = run_eager(d_in, n, d_logits, d_emb, err);
+    cur_arena = nullptr;
+    cur_stream = nullptr;
+    return ok;
+}
 void Engine::sync_contexts() {
     for (int c = 0; c < kMaxDepth; c++) if (ctx_stream[c]) hipStreamSynchronize(ctx_stream[c]);
 }
 
 bool Engine::run(const float* d_in, int n, float* d_logits, float* d_emb, std::string* err) {
     if (n <= 0 || n > max_batch) { *err = "batch size out of range"; return false; }
-    if (depth > 1 && call_idx) {
+    if (call_idx) {
         // an unsplit call after pipelined ones: order it (on the GPU) behind whatever the contexts still have queued -
         // context 0 shares this call's arena
-        for (int c = 0; c < depth; c++) { hipEventRecord(ev_ctx_done[c], ctx_stream[c]); hipStreamWaitEvent(stream, ev_ctx_done[c], 0); }
+        for (int c = 0; c < kMaxDepth; c++)
+            if (ctx_stream[c]) { hipEventRecord(ev_ctx_done[c], ctx_stream[c]); hipStreamWaitEvent(stream, ev_ctx_done[c], 0); }
     }
     if (!use_graphs || profiling) return run_eager(d_in, n, d_logits, d_emb, err);
     GraphEntry* ge = nullptr;
@@ -2114,7 +2139,8 @@ std::string Engine::describe() const {
         jesc(os, s.name);
         os << "\",\"H\":" << s.H << ",\"W\":" << s.W << ",\"C\":" << s.C << ",\"Co\":" << s.Co << ",\"k\":" << s.kh
            << ",\"stride\":" << s.sh << ",\"act\":" << s.act << ",\"fused_scale\":" << (s.kind == S_PW && s.in1 >= 0 ? 1 : 0)
-           << ",\"shape\":" << s.shape << ",\"dw_lds\":" << s.dwl << ",\"bx\":" << s.bx << ",\"nt\":" << s.nt << ",\"wm\":" << s.wm << ",\"nt_full\":" << s.nt_full << ",\"wm_full\":" << s.wm_full << ",\"fused_res\":" << (s.kind == S_PW && s.in2 >= 0 ? 1 : 0) << ",\"fused_sum\":" << (s.out2 >= 0 ? 1 : 0) << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << ",\"wbytes\":" << s.wbytes << "}";
+           << ",\"shape\":" << s.shape << ",\"dw_lds\":" << s.dwl << ",\"bx\":" << s.bx << ",\"nt\":" << s.nt << ",\"wm\":" << s.wm << ",\"nt_full\":" << s.nt_full << ",\"wm_full\":" << s.wm_full << ",\"fused_res\":" << (s.kind == S_PW && s.in2 >= 0 ? 1 : 0) << ",\"fused_sum\":" << (s.out2 >= 0 ? 1 : 0) << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << ",\"wbytes\":" << s.wbytes
+           << ",\"out_v\":" << s.out << ",\"out2_v\":" << s.out2 << "}";
     }
     os << "]}";
     return os.str();

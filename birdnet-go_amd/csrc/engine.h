@@ -118,6 +118,14 @@ class Engine {
     unsigned call_idx = 0;
     bool run_pipelined(const float* d_in, int n, float* d_logits, float* d_emb, std::string* err);
     void sync_contexts();
+    // Host-pointer pipeline (hostpipe.cpp): the blocking bnhip_predict* entries run calls of >= 128 clips as chunks on
+    // alternating contexts ("host_depth", default 2), fed from a ring of pinned staging slots, so that chunk i+1's copy
+    // and front half overlap chunk i's back half exactly as successive bnhip_predict_device calls do.  The contexts are
+    // created on first use (ensure_contexts) when the engine was built with depth 1.
+    int host_depth = 2;
+    bool ensure_contexts(int d, std::string* err);
+    bool run_on_context(int c, const float* d_in, int n, float* d_logits, float* d_emb, std::string* err);
+    struct HostPipe* hostpipe = nullptr;
     static constexpr int kMaxLanes = 4;
     int n_lanes = 2;                    // batches of >= dual_lane_min clips are split over this many streams (see run_eager)
     int dual_lane_min = 32;
@@ -141,12 +149,6 @@ class Engine {
     float* d_stage_in = nullptr;      // [max_batch, n_samples]
     float* d_stage_logits = nullptr;  // [max_batch, n_classes]
     float* d_stage_emb = nullptr;     // [max_batch, emb_dim]
-    // second staging set + copy stream: host-pointer calls with more than max_batch clips overlap the H2D copy of
-    // chunk i+1 with the compute of chunk i
-    float* d_stage_in2 = nullptr; float* d_stage_logits2 = nullptr; float* d_stage_emb2 = nullptr;
-    bool staging2_ready = false;      // set only when the whole second set (buffers, copy stream, events) exists
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     int16_t* d_stage_pcm = nullptr;      // PCM staging of the bnhip_predict_pcm* entries (16/24/32-bit: sized in bytes)
     size_t stage_pcm_bytes = 0;
     float* d_post_conf = nullptr;     // [max_batch, n_classes]

@@ -1,0 +1,372 @@
+// Host-pointer pipeline: see hostpipe.h.  Replaces the reference's blocking backend call for batches
+// (internal/inference/onnx/classifier.go:372-430 PredictBatch; internal/analysis/process.go:280-295 for the ownership rule:
+// the caller's slice is only read before the entry returns).
+#include "hostpipe.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "../../include/bnhip.h"
+#include "engine.h"
+
+namespace bnhip {
+
+// ------------------------------------------------------------------------------------------------ copy pool
+// Pageable caller memory -> pinned staging.  One thread moves ~10 GB/s; a 256-clip int16 chunk is 74 MB and has to be
+// staged in well under the 3.6 ms the GPU needs for it, so the copy is cut into 2 MB pieces served by a few threads (the
+// calling thread helps).  Process-wide, shared by every engine and every worker thread of a multi-device handle.
+namespace {
+
+struct Ticket {
+    std::atomic<int> remaining{0};
+    std::mutex mu;
+    std::condition_variable cv;
+};
+
+class CopyPool {
+  public:
+    struct Task { char* dst; const char* src; size_t n; Ticket* t; };
+    CopyPool() {
+        int n = 0;
+        if (const char* e = getenv("BNHIP_COPY_THREADS")) n = atoi(e);
+        else {
+            unsigned hw = std::thread::hardware_concurrency();
+            n = (int)std::min(8u, std::max(1u, hw / 4));
+        }
+        n = std::max(0, std::min(n, 64));
+        for (int i = 0; i < n; i++) th_.emplace_back([this] { loop(); });
+    }
+    ~CopyPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : th_) if (t.joinable()) t.join();
+    }
+    int threads() const { return (int)th_.size(); }
+    // enqueue the copy; the ticket reaches zero when every piece has landed
+    void submit(void* dst, const void* src, size_t bytes, Ticket* t) {
+        const size_t piece = 2u << 20;
+        const int np = (int)std::max<size_t>(1, (bytes + piece - 1) / piece);
+        t->remaining.store(np, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (int i = 0; i < np; i++) {
+                size_t off = (size_t)i * piece, n = std::min(piece, bytes - off);
+                q_.push_back(Task{(char*)dst + off, (const char*)src + off, n, t});
+            }
+        }
+        cv_.notify_all();
+    }
+    // the caller works on queued pieces (its own or anybody's) until its ticket is done
+    void wait(Ticket* t) {
+        for (;;) {
+            if (t->remaining.load(std::memory_order_acquire) == 0) return;
+            Task k;
+            bool got = false;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (!q_.empty()) { k = q_.front(); q_.pop_front(); got = true; }
+            }
+            if (got) { run(k); continue; }
+            std::unique_lock<std::mutex> lk(t->mu);
+            t->cv.wait(lk, [t] { return t->remaining.load(std::memory_order_acquire) == 0; });
+            return;
+        }
+    }
+
+  private:
+    static void run(const Task& k) {
+        if (k.n) memcpy(k.dst, k.src, k.n);
+        if (k.t->remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+            std::lock_guard<std::mutex> lk(k.t->mu);
+            k.t->cv.notify_all();
+        }
+    }
+    void loop() {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+            if (stop_) return;
+            Task k = q_.front(); q_.pop_front();
+            lk.unlock();
+            run(k);
+            lk.lock();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<Task> q_;
+    bool stop_ = false;
+};
+
+CopyPool& pool() {
+    static CopyPool* p = new CopyPool();     // never destroyed: a Go host exits without static destructors anyway, and a
+    return *p;                               // destructor joining threads at dlclose time can deadlock under a loader lock
+}
+
+}  // namespace
+
+void parallel_copy(void* dst, const void* src, size_t bytes) {
+    if (bytes < (4u << 20)) { if (bytes) memcpy(dst, src, bytes); return; }
+    Ticket t;
+    pool().submit(dst, src, bytes, &t);
+    pool().wait(&t);
+}
+int copy_pool_threads() { return pool().threads(); }
+
+// ------------------------------------------------------------------------------------------------ staging ring
+struct HostPipe {
+    static constexpr int K = 4;              // slots: chunk c may be staged while c-1, c-2 are in flight and c-3 drains
+    struct Slot {
+        char* h_in = nullptr; size_t h_in_cap = 0;         // pinned, raw caller bytes of one chunk
+        char* d_raw = nullptr;                             // device PCM bytes (only for the PCM entries)
+        float* d_in = nullptr;                             // device float32 [max_batch, n_samples]
+        float* d_logits = nullptr; float* h_logits = nullptr;
+        float* d_emb = nullptr; float* h_emb = nullptr;
+        float* d_conf = nullptr;                           // [max_batch, n_classes] activation output (top-k jobs)
+        float* d_tkc = nullptr; int32_t* d_tki = nullptr; float* h_tkc = nullptr; int32_t* h_tki = nullptr; int tk_cap = 0;
+        hipEvent_t ev_h2d = nullptr, ev_done = nullptr;
+        Ticket fill;
+        int chunk = -1;                                    // chunk index in flight, -1 = idle
+    };
+    Slot s[K];
+    hipStream_t h2d = nullptr;
+};
+
+void hostpipe_free(HostPipe* hp) {
+    if (!hp) return;
+    for (auto& s : hp->s) {
+        for (void* p : {(void*)s.d_raw, (void*)s.d_in, (void*)s.d_logits, (void*)s.d_emb, (void*)s.d_conf, (void*)s.d_tkc, (void*)s.d_tki})
+            if (p) hipFree(p);
+        for (void* p : {(void*)s.h_in, (void*)s.h_logits, (void*)s.h_emb, (void*)s.h_tkc, (void*)s.h_tki})
+            if (p) hipHostFree(p);
+        if (s.ev_h2d) hipEventDestroy(s.ev_h2d);
+        if (s.ev_done) hipEventDestroy(s.ev_done);
+    }
+    if (hp->h2d) { hipStreamSynchronize(hp->h2d); hipStreamDestroy(hp->h2d); }
+    delete hp;
+}
+
+namespace {
+
+#define HP_TRY(call, what)                                                                 \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            (void)hipGetLastError();                                                       \
+            err = std::string(what) + ": " + hipGetErrorString(e_);                        \
+            return e_ == hipErrorOutOfMemory ? BNHIP_E_NOMEM : BNHIP_E_RUNTIME;            \
+        }                                                                                  \
+    } while (0)
+
+// everything a job of this shape needs in every slot; idempotent, grows only
+int ensure_pipe(Engine& e, const HostJob& j, size_t chunk_bytes, std::string& err) {
+    if (!e.hostpipe) e.hostpipe = new HostPipe();
+    HostPipe& hp = *e.hostpipe;
+    if (!hp.h2d) HP_TRY(hipStreamCreateWithFlags(&hp.h2d, hipStreamNonBlocking), "copy stream");
+    const size_t mb = (size_t)e.max_batch;
+    for (auto& s : hp.s) {
+        if (!s.ev_h2d) HP_TRY(hipEventCreateWithFlags(&s.ev_h2d, hipEventDisableTiming), "event");
+        if (!s.ev_done) HP_TRY(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming), "event");
+        if (s.h_in_cap < chunk_bytes) {
+            if (s.h_in) { hipHostFree(s.h_in); s.h_in = nullptr; s.h_in_cap = 0; }
+            HP_TRY(hipHostMalloc((void**)&s.h_in, chunk_bytes, hipHostMallocDefault), "pinned staging allocation");
+            s.h_in_cap = chunk_bytes;
+        }
+        if (!s.d_in) HP_TRY(hipMalloc((void**)&s.d_in, mb * e.n_samples * 4), "device staging allocation");
+        if (j.pcm_bits && !s.d_raw) HP_TRY(hipMalloc((void**)&s.d_raw, mb * e.n_samples * 4), "device PCM staging allocation");
+        if (!s.d_logits) HP_TRY(hipMalloc((void**)&s.d_logits, mb * e.n_classes * 4), "device logits staging allocation");
+        if (j.logits && !s.h_logits) HP_TRY(hipHostMalloc((void**)&s.h_logits, mb * e.n_classes * 4, hipHostMallocDefault), "pinned logits staging allocation");
+        if (j.emb && !s.d_emb) HP_TRY(hipMalloc((void**)&s.d_emb, mb * e.emb_dim * 4), "device embedding staging allocation");
+        if (j.emb && !s.h_emb) HP_TRY(hipHostMalloc((void**)&s.h_emb, mb * e.emb_dim * 4, hipHostMallocDefault), "pinned embedding staging allocation");
+        if (j.topk > 0) {
+            if (!s.d_conf) HP_TRY(hipMalloc((void**)&s.d_conf, mb * e.n_classes * 4), "device confidence allocation");
+            if (s.tk_cap < j.topk) {
+                for (void* p : {(void*)s.d_tkc, (void*)s.d_tki}) if (p) hipFree(p);
+                for (void* p : {(void*)s.h_tkc, (void*)s.h_tki}) if (p) hipHostFree(p);
+                s.d_tkc = nullptr; s.d_tki = nullptr; s.h_tkc = nullptr; s.h_tki = nullptr; s.tk_cap = 0;
+                HP_TRY(hipMalloc((void**)&s.d_tkc, mb * j.topk * 4), "device top-k allocation");
+                HP_TRY(hipMalloc((void**)&s.d_tki, mb * j.topk * 4), "device top-k allocation");
+                HP_TRY(hipHostMalloc((void**)&s.h_tkc, mb * j.topk * 4, hipHostMallocDefault), "pinned top-k allocation");
+                HP_TRY(hipHostMalloc((void**)&s.h_tki, mb * j.topk * 4, hipHostMallocDefault), "pinned top-k allocation");
+                s.tk_cap = j.topk;
+            }
+        }
+    }
+    return BNHIP_OK;
+}
+
+int ensure_small_topk(Engine& e, int k, std::string& err) {
+    if (k <= e.topk_cap) return BNHIP_OK;
+    if (e.d_topk_conf) hipFree(e.d_topk_conf);
+    if (e.d_topk_idx) hipFree(e.d_topk_idx);
+    e.d_topk_conf = nullptr; e.d_topk_idx = nullptr; e.topk_cap = 0;
+    HP_TRY(hipMalloc((void**)&e.d_topk_conf, (size_t)e.max_batch * k * 4), "device top-k allocation");
+    HP_TRY(hipMalloc((void**)&e.d_topk_idx, (size_t)e.max_batch * k * 4), "device top-k allocation");
+    e.topk_cap = k;
+    return BNHIP_OK;
+}
+
+// Calls below the pipelining threshold (the product's own pattern is ONE clip per Predict, analyze.go:60): straight
+// through the engine's staging buffers on its main stream; the plan's two lanes split batches of >= 32 clips.
+int small_run(Engine& e, const HostJob& j, std::string& err) {
+    const size_t bps = j.pcm_bits ? (size_t)j.pcm_bits / 8 : 4;
+    const int kk = j.topk > 0 ? std::min(j.topk, e.n_classes) : 0;
+    if (kk) { int rc = ensure_small_topk(e, kk, err); if (rc) return rc; }
+    if (j.pcm_bits) {
+        const size_t need = (size_t)e.max_batch * e.n_samples * bps;
+        if (e.stage_pcm_bytes < need) {
+            if (e.d_stage_pcm) { hipStreamSynchronize(e.stream); hipFree(e.d_stage_pcm); e.d_stage_pcm = nullptr; e.stage_pcm_bytes = 0; }
+            HP_TRY(hipMalloc((void**)&e.d_stage_pcm, need), "device PCM staging allocation");
+            e.stage_pcm_bytes = need;
+        }
+    }
+    for (int off = 0; off < j.n_clips; off += e.max_batch) {
+        const int n = std::min(e.max_batch, j.n_clips - off);
+        const size_t cnt = (size_t)n * e.n_samples;
+        const char* src = (const char*)j.src + (size_t)off * e.n_samples * bps;
+        if (j.pcm_bits) {
+            HP_TRY(hipMemcpyAsync(e.d_stage_pcm, src, cnt * bps, hipMemcpyHostToDevice, e.stream), "H2D copy");
+            launch_pcm_to_f32(e.d_stage_pcm, j.pcm_bits, e.d_stage_in, cnt, e.stream);
+        } else {
+            HP_TRY(hipMemcpyAsync(e.d_stage_in, src, cnt * 4, hipMemcpyHostToDevice, e.stream), "H2D copy");
+        }
+        if (!e.run(e.d_stage_in, n, e.d_stage_logits, j.emb ? e.d_stage_emb : nullptr, &err)) { hipStreamSynchronize(e.stream); return BNHIP_E_RUNTIME; }
+        if (kk) {
+            launch_activation(e.d_stage_logits, e.d_post_conf, n, e.n_classes, j.activation, j.sensitivity, e.stream);
+            launch_topk(e.d_post_conf, n, e.n_classes, kk, e.d_topk_conf, e.d_topk_idx, e.stream);
+            HP_TRY(hipMemcpyAsync(j.out_conf + (size_t)off * kk, e.d_topk_conf, (size_t)n * kk * 4, hipMemcpyDeviceToHost, e.stream), "D2H copy");
+            HP_TRY(hipMemcpyAsync(j.out_idx + (size_t)off * kk, e.d_topk_idx, (size_t)n * kk * 4, hipMemcpyDeviceToHost, e.stream), "D2H copy");
+        }
+        if (j.logits)
+            HP_TRY(hipMemcpyAsync(j.logits + (size_t)off * e.n_classes, e.d_stage_logits, (size_t)n * e.n_classes * 4, hipMemcpyDeviceToHost, e.stream), "D2H copy");
+        if (j.emb)
+            HP_TRY(hipMemcpyAsync(j.emb + (size_t)off * e.emb_dim, e.d_stage_emb, (size_t)n * e.emb_dim * 4, hipMemcpyDeviceToHost, e.stream), "D2H copy");
+        HP_TRY(hipStreamSynchronize(e.stream), "synchronize");
+    }
+    return BNHIP_OK;
+}
+
+}  // namespace
+
+int host_run(Engine& e, const HostJob& j, std::string& err) {
+    if (hipSetDevice(e.device) != hipSuccess) { err = "hipSetDevice failed"; return BNHIP_E_RUNTIME; }
+    static const int min_pipe = getenv("BNHIP_HOST_PIPE_MIN") ? atoi(getenv("BNHIP_HOST_PIPE_MIN")) : 128;
+    const int D = std::max(1, std::min(e.host_depth, Engine::kMaxDepth));
+    if (j.n_clips < std::max(2, min_pipe) || D < 1) return small_run(e, j, err);
+
+    // chunks: max_batch clips each; a call that fits one batch is still cut in two so its second half's copy overlaps the
+    // first half's compute
+    int nch = (j.n_clips + e.max_batch - 1) / e.max_batch;
+    if (nch == 1) nch = 2;
+    const int ck = (j.n_clips + nch - 1) / nch;
+    nch = (j.n_clips + ck - 1) / ck;
+    const size_t bps = j.pcm_bits ? (size_t)j.pcm_bits / 8 : 4;
+    const size_t clip_bytes = (size_t)e.n_samples * bps;
+    const int kk = j.topk > 0 ? std::min(j.topk, e.n_classes) : 0;
+    HostJob jj = j; jj.topk = kk;
+    int rc = ensure_pipe(e, jj, (size_t)e.max_batch * clip_bytes, err);
+    if (rc) return rc;
+    if (!e.ensure_contexts(D, &err)) return BNHIP_E_NOMEM;
+    HostPipe& hp = *e.hostpipe;
+    constexpr int K = HostPipe::K;
+
+    auto chunk_n = [&](int c) { return std::min(ck, j.n_clips - c * ck); };
+    auto abort_all = [&]() {
+        for (auto& s : hp.s) { pool().wait(&s.fill); s.chunk = -1; }
+        hipStreamSynchronize(hp.h2d);
+        e.sync_contexts();
+        (void)hipGetLastError();
+    };
+    // results of the chunk a slot holds -> the caller's buffers (blocks until the chunk is done on the GPU)
+    auto finish = [&](HostPipe::Slot& s) -> hipError_t {
+        if (s.chunk < 0) return hipSuccess;
+        hipError_t he = hipEventSynchronize(s.ev_done);
+        if (he != hipSuccess) return he;
+        const size_t off = (size_t)s.chunk * ck, n = (size_t)chunk_n(s.chunk);
+        if (j.logits) parallel_copy(j.logits + off * e.n_classes, s.h_logits, n * e.n_classes * 4);
+        if (j.emb) memcpy(j.emb + off * e.emb_dim, s.h_emb, n * e.emb_dim * 4);
+        if (kk) {
+            memcpy(j.out_conf + off * kk, s.h_tkc, n * kk * 4);
+            memcpy(j.out_idx + off * kk, s.h_tki, n * kk * 4);
+        }
+        s.chunk = -1;
+        return hipSuccess;
+    };
+    auto start_fill = [&](int c) -> hipError_t {
+        HostPipe::Slot& s = hp.s[c % K];
+        hipError_t he = finish(s);                       // the slot's previous chunk (c - K) must have left it
+        if (he != hipSuccess) return he;
+        s.chunk = c;
+        pool().submit(s.h_in, (const char*)j.src + (size_t)c * ck * clip_bytes, (size_t)chunk_n(c) * clip_bytes, &s.fill);
+        return hipSuccess;
+    };
+#define HP_PIPE(call, what)                                                                \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            abort_all();                                                                   \
+            err = std::string(what) + ": " + hipGetErrorString(e_);                        \
+            return BNHIP_E_RUNTIME;                                                        \
+        }                                                                                  \
+    } while (0)
+
+    static const bool trace = getenv("BNHIP_HOST_TRACE") != nullptr;
+    const bool serial = getenv("BNHIP_HOST_SERIAL") != nullptr;      // diagnostics: one chunk at a time (read per call)
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_call = now_ms();
+    std::vector<double> tr;
+    HP_PIPE(start_fill(0), "staging");
+    for (int c = 0; c < nch; c++) {
+        if (trace) tr.push_back(now_ms() - t_call);
+        HostPipe::Slot& s = hp.s[c % K];
+        const int n = chunk_n(c), ctx = c % D;
+        const size_t cnt = (size_t)n * e.n_samples;
+        hipStream_t cs = e.ctx_stream[ctx];
+        pool().wait(&s.fill);
+        if (trace) tr.push_back(now_ms() - t_call);
+        HP_PIPE(hipMemcpyAsync(j.pcm_bits ? (void*)s.d_raw : (void*)s.d_in, s.h_in, cnt * bps, hipMemcpyHostToDevice, hp.h2d), "H2D copy");
+        HP_PIPE(hipEventRecord(s.ev_h2d, hp.h2d), "event record");
+        HP_PIPE(hipStreamWaitEvent(cs, s.ev_h2d, 0), "stream wait");
+        if (j.pcm_bits) launch_pcm_to_f32(s.d_raw, j.pcm_bits, s.d_in, cnt, cs);      // a1: PCM -> float32 on the device
+        if (!e.run_on_context(ctx, s.d_in, n, s.d_logits, j.emb ? s.d_emb : nullptr, &err)) { abort_all(); return BNHIP_E_RUNTIME; }
+        if (kk) {
+            launch_activation(s.d_logits, s.d_conf, n, e.n_classes, j.activation, j.sensitivity, cs);
+            launch_topk(s.d_conf, n, e.n_classes, kk, s.d_tkc, s.d_tki, cs);
+            HP_PIPE(hipMemcpyAsync(s.h_tkc, s.d_tkc, (size_t)n * kk * 4, hipMemcpyDeviceToHost, cs), "D2H copy");
+            HP_PIPE(hipMemcpyAsync(s.h_tki, s.d_tki, (size_t)n * kk * 4, hipMemcpyDeviceToHost, cs), "D2H copy");
+        }
+        if (j.logits) HP_PIPE(hipMemcpyAsync(s.h_logits, s.d_logits, (size_t)n * e.n_classes * 4, hipMemcpyDeviceToHost, cs), "D2H copy");
+        if (j.emb) HP_PIPE(hipMemcpyAsync(s.h_emb, s.d_emb, (size_t)n * e.emb_dim * 4, hipMemcpyDeviceToHost, cs), "D2H copy");
+        HP_PIPE(hipEventRecord(s.ev_done, cs), "event record");
+        if (serial) HP_PIPE(hipStreamSynchronize(cs), "synchronize");
+        if (trace) tr.push_back(now_ms() - t_call);
+        // stage the next chunk while this one and its predecessor are on the GPU
+        if (c + 1 < nch) HP_PIPE(start_fill(c + 1), "staging");
+        if (trace) tr.push_back(now_ms() - t_call);
+    }
+    for (int c = std::max(0, nch - K); c < nch; c++) {
+        HP_PIPE(finish(hp.s[c % K]), "D2H copy/sync");
+        if (trace) fprintf(stderr, "[bnhip] host trace: chunk %d results delivered at %.3f ms\n", c, now_ms() - t_call);
+    }
+    if (trace)
+        for (int c = 0; c < nch; c++)
+            fprintf(stderr, "[bnhip] host trace: chunk %d: loop %.3f, filled %.3f, enqueued %.3f, next fill started %.3f ms\n", c,
+                    tr[4 * c], tr[4 * c + 1], tr[4 * c + 2], tr[4 * c + 3]);
+#undef HP_PIPE
+    return BNHIP_OK;
+}
+
+}  // namespace bnhip

@@ -96,7 +96,17 @@ bool parse_tensor(const uint8_t* b, size_t n, OTensor* t) {
             default: break;
         }
     }
-    return pb.ok;
+    if (!pb.ok) return false;
+    // Dimensions are indexed with int arithmetic downstream: every one must be in [0, INT_MAX] and the element count must
+    // not overflow (a negative or wrapped dim would let a tensor whose payload is empty claim any shape).
+    if (t->dims.size() > 8) return false;
+    uint64_t cnt = 1;
+    for (int64_t dv : t->dims) {
+        if (dv < 0 || dv > 0x7fffffffLL) return false;
+        cnt *= (uint64_t)dv;
+        if (cnt > (1ull << 31)) return false;
+    }
+    return true;
 }
 
 bool parse_attr(const uint8_t* b, size_t n, OAttr* a) {
@@ -184,7 +194,16 @@ float half_to_float(uint16_t h) {
     float f; memcpy(&f, &bits, 4); return f;
 }
 
-size_t numel(const std::vector<int64_t>& d) { size_t n = 1; for (auto v : d) n *= (size_t)std::max<int64_t>(v, 0); return n; }
+// element count of validated dims (parse_tensor bounds them); anything out of range maps to a count no payload can match
+size_t numel(const std::vector<int64_t>& d) {
+    uint64_t n = 1;
+    for (auto v : d) {
+        if (v < 0 || v > 0x7fffffffLL) return SIZE_MAX / 16;
+        n *= (uint64_t)v;
+        if (n > (1ull << 31)) return SIZE_MAX / 16;
+    }
+    return (size_t)n;
+}
 
 // initializer -> float vector (FLOAT, FLOAT16, DOUBLE) ; false when the dtype is not a float type or sizes disagree
 bool tensor_floats(const OTensor& t, std::vector<float>* out) {
@@ -543,8 +562,20 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
                 else if (nd.in.size() > 1 && !const_i(nd.in[1], &axes)) return fail("ONNX: " + where + ": axes must be constant");
                 const int rank_out = nd.op == "Unsqueeze" ? (int)(ish.size() + axes.size()) : (int)ish.size();
                 std::vector<char> mark(std::max(rank_out, 1), 0);
-                for (auto ax : axes) { if (ax < 0) ax += rank_out; if (ax < 0 || ax >= rank_out) return fail("ONNX: " + where + ": axis out of range"); mark[ax] = 1; }
-                if (nd.op == "Unsqueeze") { size_t q = 0; for (int k = 0; k < rank_out; k++) osh.push_back(mark[k] ? 1 : ish[q++]); }
+                for (auto ax : axes) {
+                    if (ax < 0) ax += rank_out;
+                    if (ax < 0 || ax >= rank_out) return fail("ONNX: " + where + ": axis out of range");
+                    if (mark[ax]) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": duplicate axis"); }
+                    mark[ax] = 1;
+                }
+                if (nd.op == "Unsqueeze") {
+                    size_t q = 0;
+                    for (int k = 0; k < rank_out; k++) {
+                        if (mark[k]) { osh.push_back(1); continue; }
+                        if (q >= ish.size()) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": axes do not fit the input rank"); }
+                        osh.push_back(ish[q++]);
+                    }
+                }
                 else for (size_t k = 0; k < ish.size(); k++) { if (axes.empty() ? (ish[k] == 1 && k > 0) : mark[k]) { if (ish[k] != 1) return fail("ONNX: " + where + ": squeezed dimension is not 1"); } else osh.push_back(ish[k]); }
             }
             size_t chk = 1; for (int dv : osh) chk *= (size_t)dv;
@@ -698,6 +729,13 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
             std::vector<int64_t> perm;
             if (const OAttr* p = nd.attr("perm")) perm = p->ints; else for (int k = rank - 1; k >= 0; k--) perm.push_back(k);
             if ((int)perm.size() != rank) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": perm length != rank"); }
+            {
+                std::vector<char> seen(rank, 0);
+                for (auto pk : perm) {
+                    if (pk < 0 || pk >= rank || seen[pk]) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": perm is not a permutation"); }
+                    seen[pk] = 1;
+                }
+            }
             const bool to_cf = rank == 4 && perm == std::vector<int64_t>{0, 3, 1, 2};     // NHWC data -> NCHW value
             const bool to_cl = rank == 4 && perm == std::vector<int64_t>{0, 2, 3, 1};     // NCHW value -> NHWC data
             if (to_cf && !chl.count(a)) {

@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void k_mel_finish(MelFinParams p) {
 // the wide read is the lever.  Products are added in ascending k with fmaf (the GEMM summed them in its slab order).
 // Bands are dealt to waves in order (wave w: bands 32 w ..), so the wide top bands do not set the trip count of every wave.
 #define MSP_F 16
-template <int C>
+template <int C, int VAR = 0>
 __global__ __launch_bounds__(256) void k_mel_banded(MelBandParams p) {
     extern __shared__ __attribute__((aligned(16))) float msm[];
     float* rows[2];
@@ -449,6 +449,13 @@ __global__ __launch_bounds__(256) void k_mel_banded(MelBandParams p) {
 #pragma unroll
                         for (int i = 0; i < MSP_F / 2; i++) {
                             const float4 x4 = *reinterpret_cast<const float4*>(L + (size_t)i * ld + 4 * (k4 + j));
+                            if (VAR == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            if (VAR == 1) {
+                                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[i]) : "v"(x4.x), "v"(w4[j].x));
+                                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[i]) : "v"(x4.y), "v"(w4[j].y));
+                                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[i]) : "v"(x4.z), "v"(w4[j].z));
+                                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[i]) : "v"(x4.w), "v"(w4[j].w));
+                            } else
                             acc[i] = fmaf(x4.w, w4[j].w, fmaf(x4.z, w4[j].z, fmaf(x4.y, w4[j].y, fmaf(x4.x, w4[j].x, acc[i]))));
                         }
                     }
@@ -488,7 +495,10 @@ void launch_mel_banded(const MelBandParams& p, int nch, int n_clips, hipStream_t
     size_t lds = (size_t)MSP_F * (p.nbp[0] + (nch == 2 ? p.nbp[1] : 0)) * 4 + (size_t)nch * MSP_F * (p.n_mels + 1) * 4;
     dim3 grid((p.F + MSP_F - 1) / MSP_F, n_clips);
     const dim3 block(p.n_mels <= 96 ? 192 : 256);        // two frame groups of 8 per band
-    if (nch == 2) hipLaunchKernelGGL((k_mel_banded<2>), grid, block, lds, s, p);
+    static const int var = getenv("BNHIP_MEL_VARIANT") ? atoi(getenv("BNHIP_MEL_VARIANT")) : 0;
+    if (nch == 2 && var == 1) hipLaunchKernelGGL((k_mel_banded<2, 1>), grid, block, lds, s, p);
+    else if (nch == 2 && var == 2) hipLaunchKernelGGL((k_mel_banded<2, 2>), grid, block, lds, s, p);
+    else if (nch == 2) hipLaunchKernelGGL((k_mel_banded<2>), grid, block, lds, s, p);
     else hipLaunchKernelGGL((k_mel_banded<1>), grid, block, lds, s, p);
 }
 

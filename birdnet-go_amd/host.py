@@ -102,7 +102,7 @@ class HipClassifier:
 
     def __init__(self, model_bytes: bytes, device=0, max_batch=256, plan_only=False, debug_no_reuse=False,
                  graphs=None, frontend_fft=None, depth=None, lanes=None, autotune=None, devices=None, replicate=None,
-                 bf16x3=None, precision=None, logits_output=None, embedding_output=None):
+                 bf16x3=None, precision=None, logits_output=None, embedding_output=None, host_depth=None):
         self._lib = load_library()
         self._h = C.c_void_p()
         o = {"device": device, "max_batch": max_batch, "plan_only": int(plan_only), "debug_no_reuse": int(debug_no_reuse)}
@@ -124,6 +124,8 @@ class HipClassifier:
             o["frontend_fft"] = int(frontend_fft)
         if depth is not None:
             o["depth"] = int(depth)
+        if host_depth is not None:       # contexts the blocking host-pointer entries pipeline their chunks over (default 2)
+            o["host_depth"] = int(host_depth)
         if lanes is not None:
             o["lanes"] = int(lanes)
         if autotune is not None:
@@ -163,23 +165,32 @@ class HipClassifier:
         return lg[0], em[0]
 
     # ---- onnx.Classifier.PredictBatch shape: flat [B*N] in, [B, classes] out
-    def predict_batch(self, flat, batch_size, want_embeddings=False):
+    def predict_batch(self, flat, batch_size, want_embeddings=False, out=None):
+        """`out`: optional preallocated float32 [batch_size, classes] result array (a serving loop reuses it; a fresh
+        numpy array costs a page fault per 4 KB on its first write)."""
         self._alive()
         x = np.ascontiguousarray(flat, np.float32).reshape(-1)
         if batch_size <= 0 or x.size != batch_size * self.n_samples:
             raise HipError(E_INVALID, f"input size mismatch: expected {batch_size * self.n_samples} samples, got {x.size}")
-        logits = np.empty((batch_size, self._n_classes), np.float32)
+        logits = self._out(out, batch_size)
         emb = np.empty((batch_size, self.emb_dim), np.float32) if (want_embeddings and self.emb_dim) else None
         _check(self._lib, self._lib.bnhip_predict(self._h, x.ctypes.data, batch_size, logits.ctypes.data,
                                                   emb.ctypes.data if emb is not None else None))
         return (logits, emb) if want_embeddings else logits
 
-    def predict_pcm16(self, pcm, batch_size):
+    def _out(self, out, batch_size):
+        if out is None:
+            return np.empty((batch_size, self._n_classes), np.float32)
+        if out.dtype != np.float32 or not out.flags.c_contiguous or out.size != batch_size * self._n_classes:
+            raise HipError(E_INVALID, "out must be a C-contiguous float32 array of batch_size * classes elements")
+        return out.reshape(batch_size, self._n_classes)
+
+    def predict_pcm16(self, pcm, batch_size, out=None):
         self._alive()
         x = np.ascontiguousarray(pcm, np.int16).reshape(-1)
         if x.size != batch_size * self.n_samples:
             raise HipError(E_INVALID, f"input size mismatch: expected {batch_size * self.n_samples} samples, got {x.size}")
-        logits = np.empty((batch_size, self._n_classes), np.float32)
+        logits = self._out(out, batch_size)
         _check(self._lib, self._lib.bnhip_predict_pcm16(self._h, x.ctypes.data, batch_size, logits.ctypes.data, None))
         return logits
 

@@ -1,29 +1,24 @@
-import sys, time, os
+"""PCIe-inclusive rates of the blocking host-pointer entries (what a cgo caller gets): pageable numpy memory in,
+logits back in caller memory on return.  `python tools/hostrate.py [--json out.json]` (the same leg bench.py attaches
+as `host_pointer`)."""
+import json
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-import numpy as np
-import birdnet_go_amd
+import birdnet_go_amd  # noqa: F401
 from birdnet_go_amd import host, synth_model as sm
-blob = sm.build_model()
-clf = host.HipClassifier(blob, max_batch=256)
-x = sm.synth_clips(256)
-def t(fn, reps):
-    fn(); fn()
-    t0 = time.perf_counter()
-    for _ in range(reps): fn()
-    return (time.perf_counter() - t0) / reps
-for n, reps in ((1, 300), (8, 200), (256, 20)):
-    dt = t(lambda: clf.predict_batch(x[:n].reshape(-1), n), reps)
-    print(f"fp32 n={n}: {dt*1e3:.3f} ms  {n/dt:.0f} clips/s")
-pcm = (np.clip(x, -1, 1) * 32767).astype(np.int16)
-dt = t(lambda: clf.predict_pcm16(pcm.reshape(-1), 256), 20)
-print(f"pcm16 n=256: {dt*1e3:.3f} ms  {256/dt:.0f} clips/s")
-bigp = np.tile(pcm, (8, 1))
-dt = t(lambda: clf.predict_pcm16(bigp.reshape(-1), 2048), 5)
-print(f"pcm16 n=2048 (8 chunks): {dt*1e3:.3f} ms  {2048/dt:.0f} clips/s")
-big = np.tile(x, (8, 1))
-dt = t(lambda: clf.predict_batch(big.reshape(-1), 2048), 5)
-print(f"fp32 n=2048 (8 chunks): {dt*1e3:.3f} ms  {2048/dt:.0f} clips/s")
-dt = t(lambda: clf.predict_topk(x[:1].reshape(-1), 1, 10, 0, 1.0), 300)
-print(f"predict_topk n=1: {dt*1e3:.3f} ms")
-clf.close()
+from bench import host_pointer_rates
+
+if __name__ == "__main__":
+    blob = sm.build_model()
+    clf = host.HipClassifier(blob, max_batch=256)
+    x = sm.synth_clips(256)
+    res = host_pointer_rates(clf, x, reps_small=200, reps_mid=20, reps_big=8)
+    for k, v in res.items():
+        if isinstance(v, dict):
+            print(f"{k:12s} {v['ms']:9.3f} ms  {v['clips_per_s']:9.0f} clips/s")
+    if "--json" in sys.argv:
+        with open(sys.argv[sys.argv.index("--json") + 1], "w") as fh:
+            json.dump(res, fh, indent=1)
+    clf.close()
