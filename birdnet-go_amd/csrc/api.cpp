@@ -564,7 +564,7 @@ int bnhip_set_stream(bnhip_model* m, void* hip_stream) {
     hipSetDevice(e.device);
     e.drop_graphs();                                    // captured on the old stream
     e.sync_contexts();
-    if (e.own_stream && e.stream) { hipStreamSynchronize(e.stream); hipStreamDestroy(e.stream); }
+    if (e.stream) hipStreamSynchronize(e.stream);       // (the engine keeps its own streams: contexts and lanes run on them)
     e.stream = reinterpret_cast<hipStream_t>(hip_stream);
     e.own_stream = false;
     return BNHIP_OK;

@@ -367,18 +367,15 @@ Engine::~Engine() {
                     (void*)d_stage_pcm, (void*)d_post_conf, (void*)d_topk_conf, (void*)d_topk_idx})
         if (p) hipFree(p);
     hostpipe_free(hostpipe);
+    for (int i = 0; i < kMaxKStreams; i++) if (kstream[i]) hipStreamSynchronize(kstream[i]);
     for (int c = 0; c < kMaxDepth; c++) {
-        if (ctx_stream[c]) { hipStreamSynchronize(ctx_stream[c]); hipStreamDestroy(ctx_stream[c]); }
         if (c > 0 && ctx_arena[c]) hipFree(ctx_arena[c]);
         if (ev_ctx_done[c]) hipEventDestroy(ev_ctx_done[c]);
     }
     if (ev_ctx_fork) hipEventDestroy(ev_ctx_fork);
-    for (int i = 0; i < kMaxLanes - 1; i++) {
-        if (lane_stream[i]) { hipStreamSynchronize(lane_stream[i]); hipStreamDestroy(lane_stream[i]); }
-        if (ev_join[i]) hipEventDestroy(ev_join[i]);
-    }
+    for (int i = 0; i < kMaxLanes - 1; i++) if (ev_join[i]) hipEventDestroy(ev_join[i]);
     if (ev_fork) hipEventDestroy(ev_fork);
-    if (own_stream && stream) hipStreamDestroy(stream);
+    for (int i = 0; i < kMaxKStreams; i++) if (kstream[i]) hipStreamDestroy(kstream[i]);
 }
 
 bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* err, int* code) {
@@ -1583,12 +1580,14 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
     if (plan_only) { device = -1; *code = BNHIP_OK; return true; }   // CPU-side planning only (tests, describe)
     *code = BNHIP_E_RUNTIME;
     HIPCHK(hipSetDevice(device));
-    HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    stream = kernel_stream(0);
+    if (!stream) { *err = "hipStreamCreate failed"; return false; }
     n_lanes = std::max(1, std::min(n_lanes, kMaxLanes));
     if (n_lanes > 1) {
         HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         for (int i = 0; i < n_lanes - 1; i++) {
-            HIPCHK(hipStreamCreateWithFlags(&lane_stream[i], hipStreamNonBlocking));
+            lane_stream[i] = kernel_stream(1 + i);
+            if (!lane_stream[i]) { *err = "hipStreamCreate failed"; return false; }
             HIPCHK(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
         }
     }
@@ -1625,15 +1624,23 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
     return true;
 }
 
+hipStream_t Engine::kernel_stream(int i) {
+    if (i < 0 || i >= kMaxKStreams) return nullptr;
+    if (!kstream[i] && hipStreamCreateWithFlags(&kstream[i], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); kstream[i] = nullptr; }
+    return kstream[i];
+}
+
 // Contexts 0..d-1 (stream, completion event, activation arena; context 0 shares the engine's own arena).  Idempotent.
-bool Engine::ensure_contexts(int d, std::string* err) {
+bool Engine::ensure_contexts(int d, std::string* err, bool with_streams) {
     d = std::max(1, std::min(d, kMaxDepth));
     if (device < 0) { *err = "plan-only model has no contexts"; return false; }
     hipSetDevice(device);
-    if (!ev_ctx_fork) HIPCHK(hipEventCreateWithFlags(&ev_ctx_fork, hipEventDisableTiming));
+    if (with_streams && !ev_ctx_fork) HIPCHK(hipEventCreateWithFlags(&ev_ctx_fork, hipEventDisableTiming));
     for (int c = 0; c < d; c++) {
-        if (!ctx_stream[c]) HIPCHK(hipStreamCreateWithFlags(&ctx_stream[c], hipStreamNonBlocking));
-        if (!ev_ctx_done[c]) HIPCHK(hipEventCreateWithFlags(&ev_ctx_done[c], hipEventDisableTiming));
+        if (with_streams) {
+            if (!ctx_stream[c]) { ctx_stream[c] = kernel_stream(1 + c); if (!ctx_stream[c]) { *err = "hipStreamCreate failed"; return false; } }
+            if (!ev_ctx_done[c]) HIPCHK(hipEventCreateWithFlags(&ev_ctx_done[c], hipEventDisableTiming));
+        }
         if (!ctx_arena[c]) {
             if (c == 0) ctx_arena[c] = act_arena;
             else HIPCHK(hipMalloc((void**)&ctx_arena[c], std::max<size_t>(act_bytes, 256)));
@@ -1855,8 +1862,10 @@ bool Engine::run_pipelined(const float* d_in, int n, float* d_logits, float* d_e
     if (n <= 0 || n > max_batch) { *err = "batch size out of range"; return false; }
     if (depth <= 1 || (profiling && profile_filter.empty())) return run(d_in, n, d_logits, d_emb, err);
     const int c = (int)(call_idx++ % (unsigned)depth);
-    hipEventRecord(ev_ctx_fork, stream);
-    hipStreamWaitEvent(ctx_stream[c], ev_ctx_fork, 0);
+    if (ctx_stream[c] != stream) {              // (context 0 IS the main stream until the caller hands in its own)
+        hipEventRecord(ev_ctx_fork, stream);
+        hipStreamWaitEvent(ctx_stream[c], ev_ctx_fork, 0);
+    }
     cur_arena = ctx_arena[c];
     cur_stream = ctx_stream[c];
     bool ok = run_eager(d_in, n, d_logits, d_emb, err);
@@ -1864,21 +1873,21 @@ bool Engine::run_pipelined(const float* d_in, int n, float* d_logits, float* d_e
     cur_stream = nullptr;
     return ok;
 }
-// One chunk of a host-pointer call on context c (hostpipe.cpp orders the context's stream behind the chunk's copy and
-// records its completion): the whole plan, unsplit, on that context's stream and arena.
-bool Engine::run_on_context(int c, const float* d_in, int n, float* d_logits, float* d_emb, std::string* err) {
+// One chunk of a host-pointer call in context c's arena on stream st (hostpipe.cpp orders st behind the chunk's copy and
+// records its completion): the whole plan, unsplit.
+bool Engine::run_on_context(int c, hipStream_t st, const float* d_in, int n, float* d_logits, float* d_emb, std::string* err) {
     if (n <= 0 || n > max_batch) { *err = "batch size out of range"; return false; }
-    if (c < 0 || c >= kMaxDepth || !ctx_stream[c] || !ctx_arena[c]) { *err = "context does not exist"; return false; }
+    if (c < 0 || c >= kMaxDepth || !st || !ctx_arena[c]) { *err = "context does not exist"; return false; }
     call_idx++;                                  // a later unsplit run() orders itself behind the contexts
     cur_arena = ctx_arena[c];
-    cur_stream = ctx_stream[c];
+    cur_stream = st;
     bool ok = run_eager(d_in, n, d_logits, d_emb, err);
     cur_arena = nullptr;
     cur_stream = nullptr;
     return ok;
 }
 void Engine::sync_contexts() {
-    for (int c = 0; c < kMaxDepth; c++) if (ctx_stream[c]) hipStreamSynchronize(ctx_stream[c]);
+    for (int i = 0; i < kMaxKStreams; i++) if (kstream[i]) hipStreamSynchronize(kstream[i]);
 }
 
 bool Engine::run(const float* d_in, int n, float* d_logits, float* d_emb, std::string* err) {
@@ -1887,7 +1896,8 @@ bool Engine::run(const float* d_in, int n, float* d_logits, float* d_emb, std::s
         // an unsplit call after pipelined ones: order it (on the GPU) behind whatever the contexts still have queued -
         // context 0 shares this call's arena
         for (int c = 0; c < kMaxDepth; c++)
-            if (ctx_stream[c]) { hipEventRecord(ev_ctx_done[c], ctx_stream[c]); hipStreamWaitEvent(stream, ev_ctx_done[c], 0); }
+            if (ctx_stream[c] && ctx_stream[c] != stream) { hipEventRecord(ev_ctx_done[c], ctx_stream[c]); hipStreamWaitEvent(stream, ev_ctx_done[c], 0); }
+        if (kstream[0] && kstream[0] != stream) hipStreamSynchronize(kstream[0]);      // (caller-owned main stream: the engine's own may still hold a chunk)
     }
     if (!use_graphs || profiling) return run_eager(d_in, n, d_logits, d_emb, err);
     GraphEntry* ge = nullptr;

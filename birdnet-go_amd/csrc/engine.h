@@ -123,8 +123,8 @@ class Engine {
     // and front half overlap chunk i's back half exactly as successive bnhip_predict_device calls do.  The contexts are
     // created on first use (ensure_contexts) when the engine was built with depth 1.
     int host_depth = 2;
-    bool ensure_contexts(int d, std::string* err);
-    bool run_on_context(int c, const float* d_in, int n, float* d_logits, float* d_emb, std::string* err);
+    bool ensure_contexts(int d, std::string* err, bool with_streams = true);   // host pipeline: arenas only (it runs on kstream[0..1])
+    bool run_on_context(int c, hipStream_t st, const float* d_in, int n, float* d_logits, float* d_emb, std::string* err);
     struct HostPipe* hostpipe = nullptr;
     static constexpr int kMaxLanes = 4;
     int n_lanes = 2;                    // batches of >= dual_lane_min clips are split over this many streams (see run_eager)
@@ -135,8 +135,15 @@ class Engine {
     std::map<int, int> tensor_value;    // tflite tensor index -> value id (diagnostics)
     const float* value_ptr(int v) const { return reinterpret_cast<const float*>(act_arena + vals[v].offset); }
     int n_samples = 0, n_classes = 0, emb_dim = 0, C_spec = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // main stream: kstream[0] until bnhip_set_stream hands in the caller's
     bool own_stream = false;
+    // Kernel streams of the engine.  HIP maps the streams of one priority onto at most four hardware queues
+    // (GPU_MAX_HW_QUEUES) and two streams that share one serialise each other's kernels - so lanes and contexts, which never run at
+    // the same time, draw from ONE small pool: lane i = kstream[i] (lane 0 = the main stream), context c = kstream[1 + c] (never the
+    // main stream: a pipelined call forks from whatever the main stream has queued, which must not include the previous call).
+    static constexpr int kMaxKStreams = 4;
+    hipStream_t kstream[kMaxKStreams] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t kernel_stream(int i);   // created on first use; nullptr on failure
     bool profiling = false;
     std::string profile_filter;      // non-empty: only launches of this kernel class are bracketed by events
 

@@ -137,12 +137,12 @@ struct HostPipe {
         float* d_emb = nullptr; float* h_emb = nullptr;
         float* d_conf = nullptr;                           // [max_batch, n_classes] activation output (top-k jobs)
         float* d_tkc = nullptr; int32_t* d_tki = nullptr; float* h_tkc = nullptr; int32_t* h_tki = nullptr; int tk_cap = 0;
-        hipEvent_t ev_h2d = nullptr, ev_done = nullptr;
+        hipEvent_t ev_h2d = nullptr, ev_comp = nullptr, ev_done = nullptr;   // input landed / kernels done / results in pinned memory
         Ticket fill;
         int chunk = -1;                                    // chunk index in flight, -1 = idle
     };
     Slot s[K];
-    hipStream_t h2d = nullptr;
+    hipStream_t xfer = nullptr;              // the one copy stream, both directions (see ensure_pipe)
 };
 
 void hostpipe_free(HostPipe* hp) {
@@ -154,8 +154,9 @@ void hostpipe_free(HostPipe* hp) {
             if (p) hipHostFree(p);
         if (s.ev_h2d) hipEventDestroy(s.ev_h2d);
         if (s.ev_done) hipEventDestroy(s.ev_done);
+        if (s.ev_comp) hipEventDestroy(s.ev_comp);
     }
-    if (hp->h2d) { hipStreamSynchronize(hp->h2d); hipStreamDestroy(hp->h2d); }
+    if (hp->xfer) { hipStreamSynchronize(hp->xfer); hipStreamDestroy(hp->xfer); }
     delete hp;
 }
 
@@ -175,11 +176,24 @@ namespace {
 int ensure_pipe(Engine& e, const HostJob& j, size_t chunk_bytes, std::string& err) {
     if (!e.hostpipe) e.hostpipe = new HostPipe();
     HostPipe& hp = *e.hostpipe;
-    if (!hp.h2d) HP_TRY(hipStreamCreateWithFlags(&hp.h2d, hipStreamNonBlocking), "copy stream");
+    if (!hp.xfer) {
+        // Streams are a scarce resource here: HIP maps ALL streams of a process onto at most four hardware queues
+        // (GPU_MAX_HW_QUEUES; measured on ROCm 7.2: a fifth active stream lands on a queue another one uses, whatever its
+        // priority), and two streams on one queue serialise - a copy marker behind a context's kernels stalls the next
+        // chunk, two contexts on one queue stop overlapping altogether (both seen in BNHIP_HOST_TRACE timelines).  So the
+        // pipeline runs on exactly three: the engine's two kernel streams (the main stream and the lane stream, idle during
+        // a pipelined call) as the two contexts, and ONE copy stream that carries both directions in an order that never
+        // blocks a prefetch: ... H2D(c+1), D2H(c-2), H2D(c+2), D2H(c-1) ... (a copy-out waits for its chunk's kernels, which
+        // are done long before the input issued behind it is needed).
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        HP_TRY(hipStreamCreateWithPriority(&hp.xfer, hipStreamNonBlocking, greatest), "copy stream");
+    }
     const size_t mb = (size_t)e.max_batch;
     for (auto& s : hp.s) {
         if (!s.ev_h2d) HP_TRY(hipEventCreateWithFlags(&s.ev_h2d, hipEventDisableTiming), "event");
         if (!s.ev_done) HP_TRY(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming), "event");
+        if (!s.ev_comp) HP_TRY(hipEventCreateWithFlags(&s.ev_comp, hipEventDisableTiming), "event");
         if (s.h_in_cap < chunk_bytes) {
             if (s.h_in) { hipHostFree(s.h_in); s.h_in = nullptr; s.h_in_cap = 0; }
             HP_TRY(hipHostMalloc((void**)&s.h_in, chunk_bytes, hipHostMallocDefault), "pinned staging allocation");
@@ -267,27 +281,52 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
     const int D = std::max(1, std::min(e.host_depth, Engine::kMaxDepth));
     if (j.n_clips < std::max(2, min_pipe) || D < 1) return small_run(e, j, err);
 
-    // chunks: max_batch clips each; a call that fits one batch is still cut in two so its second half's copy overlaps the
-    // first half's compute
-    int nch = (j.n_clips + e.max_batch - 1) / e.max_batch;
-    if (nch == 1) nch = 2;
-    const int ck = (j.n_clips + nch - 1) / nch;
-    nch = (j.n_clips + ck - 1) / ck;
+    // Chunk schedule.  The call is blocking, so its first chunk starts on an idle GPU only after its own staging + H2D, and
+    // its last chunk ends alone on one context: both cost the more the bigger those chunks are.  Hence a ramp: u, 2u, then
+    // chunks of up to max_batch, then 5u/2, u/2 (u = max_batch / 4; measured within 1.5 % of each other: 64/128..128/64,
+    // 64/128..160/32, 64/160..160/48 - the schedule stopped being the lever once the streams stopped sharing queues).  Calls too small for the full ramp are cut into u-sized
+    // chunks (a call that fits one batch still overlaps its later parts' copies with the earlier parts' compute).
+    static const int ramp_env = getenv("BNHIP_HOST_RAMP") ? atoi(getenv("BNHIP_HOST_RAMP")) : -1;
+    const int unit = ramp_env >= 0 ? ramp_env : std::max(8, e.max_batch / 4);
+    std::vector<int> csize;
+    if (unit <= 0 || unit * 2 > e.max_batch) {
+        int nc = (j.n_clips + e.max_batch - 1) / e.max_batch;
+        if (nc == 1) nc = 2;
+        const int ck = (j.n_clips + nc - 1) / nc;
+        for (int left = j.n_clips; left > 0; left -= ck) csize.push_back(std::min(ck, left));
+    } else if (j.n_clips < 6 * unit + e.max_batch) {
+        const int nc = std::max(2, (j.n_clips + unit - 1) / unit);
+        const int ck = (j.n_clips + nc - 1) / nc;
+        for (int left = j.n_clips; left > 0; left -= ck) csize.push_back(std::min(ck, left));
+    } else {
+        int h1 = unit, h2 = 2 * unit, t1 = 5 * unit / 2, t2 = std::max(1, unit / 2);   // (the context that frees first takes the larger last piece)
+        if (const char* sc = getenv("BNHIP_HOST_SCHED")) sscanf(sc, "%d,%d,%d,%d", &h1, &h2, &t1, &t2);   // experiments
+        h1 = std::max(1, std::min(h1, e.max_batch)); h2 = std::max(1, std::min(h2, e.max_batch));
+        t1 = std::max(1, std::min(t1, e.max_batch)); t2 = std::max(1, std::min(t2, e.max_batch));
+        const int mid = j.n_clips - (h1 + h2 + t1 + t2), nm = (mid + e.max_batch - 1) / e.max_batch;
+        csize.push_back(h1); csize.push_back(h2);
+        for (int k = 0, left = mid; k < nm; k++) { const int c = (left + (nm - k) - 1) / (nm - k); csize.push_back(c); left -= c; }
+        csize.push_back(t1); csize.push_back(t2);
+    }
+    const int nch = (int)csize.size();
+    std::vector<int> cfirst(nch + 1, 0);
+    for (int c = 0; c < nch; c++) cfirst[c + 1] = cfirst[c] + csize[c];
     const size_t bps = j.pcm_bits ? (size_t)j.pcm_bits / 8 : 4;
     const size_t clip_bytes = (size_t)e.n_samples * bps;
     const int kk = j.topk > 0 ? std::min(j.topk, e.n_classes) : 0;
     HostJob jj = j; jj.topk = kk;
     int rc = ensure_pipe(e, jj, (size_t)e.max_batch * clip_bytes, err);
     if (rc) return rc;
-    if (!e.ensure_contexts(D, &err)) return BNHIP_E_NOMEM;
+    if (!e.ensure_contexts(D, &err, false)) return BNHIP_E_NOMEM;
     HostPipe& hp = *e.hostpipe;
     constexpr int K = HostPipe::K;
 
-    auto chunk_n = [&](int c) { return std::min(ck, j.n_clips - c * ck); };
+    auto chunk_n = [&](int c) { return csize[c]; };
     auto abort_all = [&]() {
         for (auto& s : hp.s) { pool().wait(&s.fill); s.chunk = -1; }
-        hipStreamSynchronize(hp.h2d);
-        e.sync_contexts();
+        hipStreamSynchronize(hp.xfer);
+        for (int c = 0; c < D; c++) if (e.kstream[c]) hipStreamSynchronize(e.kstream[c]);
+        hipStreamSynchronize(hp.xfer);
         (void)hipGetLastError();
     };
     // results of the chunk a slot holds -> the caller's buffers (blocks until the chunk is done on the GPU)
@@ -295,7 +334,7 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
         if (s.chunk < 0) return hipSuccess;
         hipError_t he = hipEventSynchronize(s.ev_done);
         if (he != hipSuccess) return he;
-        const size_t off = (size_t)s.chunk * ck, n = (size_t)chunk_n(s.chunk);
+        const size_t off = (size_t)cfirst[s.chunk], n = (size_t)chunk_n(s.chunk);
         if (j.logits) parallel_copy(j.logits + off * e.n_classes, s.h_logits, n * e.n_classes * 4);
         if (j.emb) memcpy(j.emb + off * e.emb_dim, s.h_emb, n * e.emb_dim * 4);
         if (kk) {
@@ -310,7 +349,7 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
         hipError_t he = finish(s);                       // the slot's previous chunk (c - K) must have left it
         if (he != hipSuccess) return he;
         s.chunk = c;
-        pool().submit(s.h_in, (const char*)j.src + (size_t)c * ck * clip_bytes, (size_t)chunk_n(c) * clip_bytes, &s.fill);
+        pool().submit(s.h_in, (const char*)j.src + (size_t)cfirst[c] * clip_bytes, (size_t)chunk_n(c) * clip_bytes, &s.fill);
         return hipSuccess;
     };
 #define HP_PIPE(call, what)                                                                \
@@ -324,42 +363,71 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
     } while (0)
 
     static const bool trace = getenv("BNHIP_HOST_TRACE") != nullptr;
+    std::vector<hipEvent_t> tev;                          // trace: [base][per chunk: h2d done, compute start, done]
+    if (trace) {
+        tev.resize(1 + 3 * (size_t)nch);
+        for (auto& ev : tev) hipEventCreate(&ev);
+        hipEventRecord(tev[0], hp.xfer);
+    }
     const bool serial = getenv("BNHIP_HOST_SERIAL") != nullptr;      // diagnostics: one chunk at a time (read per call)
     auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_call = now_ms();
     std::vector<double> tr;
+    // copy-out of chunk c on the copy stream, behind its kernels
+    auto issue_d2h = [&](int c) -> hipError_t {
+        HostPipe::Slot& s = hp.s[c % K];
+        const int n = chunk_n(c);
+        hipError_t he = hipStreamWaitEvent(hp.xfer, s.ev_comp, 0);
+        if (he == hipSuccess && kk) he = hipMemcpyAsync(s.h_tkc, s.d_tkc, (size_t)n * kk * 4, hipMemcpyDeviceToHost, hp.xfer);
+        if (he == hipSuccess && kk) he = hipMemcpyAsync(s.h_tki, s.d_tki, (size_t)n * kk * 4, hipMemcpyDeviceToHost, hp.xfer);
+        if (he == hipSuccess && j.logits) he = hipMemcpyAsync(s.h_logits, s.d_logits, (size_t)n * e.n_classes * 4, hipMemcpyDeviceToHost, hp.xfer);
+        if (he == hipSuccess && j.emb) he = hipMemcpyAsync(s.h_emb, s.d_emb, (size_t)n * e.emb_dim * 4, hipMemcpyDeviceToHost, hp.xfer);
+        if (he == hipSuccess) he = hipEventRecord(s.ev_done, hp.xfer);
+        return he;
+    };
+    constexpr int LAG = 2;                                 // D2H(c) is issued after H2D(c + LAG): LAG < K - 1
     HP_PIPE(start_fill(0), "staging");
     for (int c = 0; c < nch; c++) {
         if (trace) tr.push_back(now_ms() - t_call);
         HostPipe::Slot& s = hp.s[c % K];
         const int n = chunk_n(c), ctx = c % D;
         const size_t cnt = (size_t)n * e.n_samples;
-        hipStream_t cs = e.ctx_stream[ctx];
+        hipStream_t cs = e.kernel_stream(ctx);
+        if (!cs) { abort_all(); err = "hipStreamCreate failed"; return BNHIP_E_RUNTIME; }
         pool().wait(&s.fill);
         if (trace) tr.push_back(now_ms() - t_call);
-        HP_PIPE(hipMemcpyAsync(j.pcm_bits ? (void*)s.d_raw : (void*)s.d_in, s.h_in, cnt * bps, hipMemcpyHostToDevice, hp.h2d), "H2D copy");
-        HP_PIPE(hipEventRecord(s.ev_h2d, hp.h2d), "event record");
+        HP_PIPE(hipMemcpyAsync(j.pcm_bits ? (void*)s.d_raw : (void*)s.d_in, s.h_in, cnt * bps, hipMemcpyHostToDevice, hp.xfer), "H2D copy");
+        HP_PIPE(hipEventRecord(s.ev_h2d, hp.xfer), "event record");
+        if (trace) hipEventRecord(tev[1 + 3 * c], hp.xfer);
+        if (c >= LAG) HP_PIPE(issue_d2h(c - LAG), "D2H copy");
         HP_PIPE(hipStreamWaitEvent(cs, s.ev_h2d, 0), "stream wait");
+        if (trace) hipEventRecord(tev[2 + 3 * c], cs);
         if (j.pcm_bits) launch_pcm_to_f32(s.d_raw, j.pcm_bits, s.d_in, cnt, cs);      // a1: PCM -> float32 on the device
-        if (!e.run_on_context(ctx, s.d_in, n, s.d_logits, j.emb ? s.d_emb : nullptr, &err)) { abort_all(); return BNHIP_E_RUNTIME; }
+        if (!e.run_on_context(ctx, cs, s.d_in, n, s.d_logits, j.emb ? s.d_emb : nullptr, &err)) { abort_all(); return BNHIP_E_RUNTIME; }
         if (kk) {
             launch_activation(s.d_logits, s.d_conf, n, e.n_classes, j.activation, j.sensitivity, cs);
             launch_topk(s.d_conf, n, e.n_classes, kk, s.d_tkc, s.d_tki, cs);
-            HP_PIPE(hipMemcpyAsync(s.h_tkc, s.d_tkc, (size_t)n * kk * 4, hipMemcpyDeviceToHost, cs), "D2H copy");
-            HP_PIPE(hipMemcpyAsync(s.h_tki, s.d_tki, (size_t)n * kk * 4, hipMemcpyDeviceToHost, cs), "D2H copy");
         }
-        if (j.logits) HP_PIPE(hipMemcpyAsync(s.h_logits, s.d_logits, (size_t)n * e.n_classes * 4, hipMemcpyDeviceToHost, cs), "D2H copy");
-        if (j.emb) HP_PIPE(hipMemcpyAsync(s.h_emb, s.d_emb, (size_t)n * e.emb_dim * 4, hipMemcpyDeviceToHost, cs), "D2H copy");
-        HP_PIPE(hipEventRecord(s.ev_done, cs), "event record");
+        HP_PIPE(hipEventRecord(s.ev_comp, cs), "event record");
+        if (trace) hipEventRecord(tev[3 + 3 * c], cs);
         if (serial) HP_PIPE(hipStreamSynchronize(cs), "synchronize");
         if (trace) tr.push_back(now_ms() - t_call);
         // stage the next chunk while this one and its predecessor are on the GPU
         if (c + 1 < nch) HP_PIPE(start_fill(c + 1), "staging");
         if (trace) tr.push_back(now_ms() - t_call);
     }
+    for (int c = std::max(0, nch - LAG); c < nch; c++) HP_PIPE(issue_d2h(c), "D2H copy");
     for (int c = std::max(0, nch - K); c < nch; c++) {
         HP_PIPE(finish(hp.s[c % K]), "D2H copy/sync");
         if (trace) fprintf(stderr, "[bnhip] host trace: chunk %d results delivered at %.3f ms\n", c, now_ms() - t_call);
+    }
+    if (trace) {
+        for (int c = 0; c < nch; c++) {
+            float a = 0, b = 0, d = 0;
+            hipEventElapsedTime(&a, tev[0], tev[1 + 3 * c]); hipEventElapsedTime(&b, tev[0], tev[2 + 3 * c]); hipEventElapsedTime(&d, tev[0], tev[3 + 3 * c]);
+            fprintf(stderr, "[bnhip] host trace: chunk %d (%d clips, ctx %d) GPU: h2d done %.3f, compute start %.3f, done %.3f ms\n", c, csize[c], c % D, a, b, d);
+        }
+        for (auto& ev : tev) hipEventDestroy(ev);
     }
     if (trace)
         for (int c = 0; c < nch; c++)

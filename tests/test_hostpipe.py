@@ -105,3 +105,39 @@ def test_two_engine_handle_shards_through_the_pipeline(gpu, tiny_blob):
         assert np.abs(a - b).max() < 1e-4 and (a.argmax(1) == b.argmax(1)).all()
     finally:
         one.close(); two.close()
+
+
+@pytest.mark.gpu
+def test_two_contexts_with_different_data_equal_the_serial_results(gpu, full_blob):
+    """Regression for the round-3 finding: with two contexts in flight on DIFFERENT clips, 2-4 % of the clips came out
+    slightly wrong (k_mel_banded's band sums, compiled by the SLP vectorizer into dependent v_pk_fma_f32 chains, lost low
+    halves whenever another stream's kernels shared the CU; never when run alone - so every earlier test, which fed both
+    contexts the same batch or ran one at a time, stayed green).  Device-pointer entry, depth 2, eight distinct batches
+    queued back to back, against the same engine run one call at a time: bit-identical."""
+    from test_parity_gpu import _DevBuf
+    B, NB = 256, 8
+    x256 = sm.synth_clips(B, 144000, 48000)
+    xs = [np.roll(x256, 31 * c, axis=0).copy() for c in range(NB)]
+    clf = host.HipClassifier(full_blob, max_batch=B, depth=2, lanes=1)
+    xd = [_DevBuf(x.nbytes) for x in xs]
+    o = _DevBuf(NB * B * 6522 * 4)
+    try:
+        for d, x in zip(xd, xs):
+            d.upload(x)
+        for c in range(NB):                                        # one call at a time: nothing overlaps
+            clf.predict_device(xd[c].at(0), B, o.at(c * B * 6522 * 4))
+            clf.synchronize()
+        ref = o.download((NB, B, 6522)).copy()
+        for c in range(1, NB):                                     # (and the clips do not care where in a batch they sit)
+            assert np.array_equal(ref[c], np.roll(ref[0], 31 * c, axis=0))
+        for rep in range(4):
+            for c in range(NB):
+                clf.predict_device(xd[c].at(0), B, o.at(c * B * 6522 * 4))
+            clf.synchronize()
+            got = o.download((NB, B, 6522))
+            bad = int((np.abs(got - ref).max(2) > 0).sum())
+            assert bad == 0, f"{bad} clips differ between overlapped and serial execution (rep {rep})"
+    finally:
+        clf.close(); o.free()
+        for d in xd:
+            d.free()
