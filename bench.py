@@ -43,8 +43,10 @@ def parse():
                          "material (ultrasonic frame-CV gate + backbone embeddings + ONNX regional head), an extra line")
     ap.add_argument("--no-fp32-run", action="store_true", help="skip the secondary (untimed-by-contract) run with bf16x3 = 0")
     ap.add_argument("--no-oracle-check", action="store_true", help="skip the max-abs probability diff vs the oracle (3 rows, outside the timed region)")
-    ap.add_argument("--cpu-clips", type=int, default=0, help="clips in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="duration of the CPU baseline's throughput loop")
     ap.add_argument("--no-profile", action="store_true", help="disable per-kernel HIP-event timing")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the bat / Perch legs attached to the headline line as `secondary`")
+    ap.add_argument("--no-distribution", action="store_true", help="skip the per-step distribution run (>= 40 extra steps)")
     ap.add_argument("--no-host-pointer", action="store_true", help="skip the host_pointer leg (rates through the blocking host-pointer entries)")
     ap.add_argument("--detail", action="store_true", help="print a per-launch table to stderr")
     ap.add_argument("--depth", type=int, default=2, help="engine pipeline depth: successive batches run on alternating "
@@ -79,67 +81,132 @@ def pmc_traffic(kclass, workload="birdnet"):
 
 
 def cpu_worker_main(argv):
-    """`bench.py --cpu-worker <blob> <n_samples> <rate> <first> <count>`: one oracle process timing its share."""
-    blob_path, n_samples, sample_rate, first, count = argv[0], int(argv[1]), int(argv[2]), int(argv[3]), int(argv[4])
+    """`bench.py --cpu-worker <blob> <n_samples> <rate> <seconds> <procs>`: the CPU baseline, run in a process of its own
+    (no GPU runtime in it, so it may fork).  Throughput mode = what the reference's own benchmark loop does
+    (cmd/benchmark/benchmark.go:99-133: one clip per Predict for a fixed duration), once per host core: `procs` forked
+    single-thread workers, each pinned to its core, each running whole-model batch-1 forward passes of the torch-CPU
+    restatement (oracle/torch_cpu.py: oneDNN convolutions, channels-last, fused SiLU) for `seconds`; the rate is clips
+    completed / seconds, summed.  Latency mode = one process, batch 1, with 1 thread and with nproc - 1 threads (the
+    reference's rule, internal/inference/tflite/classifier.go:48-58, threads.go:13-30)."""
+    blob_path, n_samples, sample_rate, seconds, procs = argv[0], int(argv[1]), int(argv[2]), float(argv[3]), int(argv[4])
+    os.environ["OMP_NUM_THREADS"] = "1"
     import birdnet_go_amd  # noqa: F401
     from birdnet_go_amd import synth_model as sm
-    from oracle.interp import Interpreter
     import torch
-    torch.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "1")))
-    # same op-by-op restatement as the parity oracle; the two convolution ops go through torch's CPU (oneDNN) kernels,
-    # which is 2-3x faster than the numpy tap loops and a fairer picture of what the host cores can do
-    it = Interpreter(open(blob_path, "rb").read(), conv_backend="torch")
-    x = sm.synth_clips(count, n_samples, sample_rate, first=first)
-    it.invoke(x[:1])                                    # warm-up
-    t0 = time.time()
-    for i in range(0, count, 2):
-        it.invoke(x[i:i + 2])
-    print(f"CPU_WORKER_SECONDS {time.time() - t0:.6f}")
+    torch.set_num_threads(1)
+    from oracle.torch_cpu import TorchCPU
+    model = TorchCPU(open(blob_path, "rb").read())
+    x = sm.synth_clips(4, n_samples, sample_rate, first=100000)
+    cores = sorted(os.sched_getaffinity(0))
+    # two passes: one worker per logical CPU, then one per two (a 256-thread host is 128 cores x SMT, and 256 workers of ~20 MB
+    # working set each are DRAM-bound); the better total is the baseline, both are printed
+    for procs_now in ([procs, max(1, procs // 2)] if procs >= 16 else [procs]):
+        _cpu_throughput_pass(model, x, cores, procs_now, seconds / (2 if procs >= 16 else 1))
+    _cpu_latency(model, x, cores, torch)
 
 
-def cpu_baseline(blob, n_samples, sample_rate, n_clips_hint):
-    """Oracle restatement ("port") timed on the host cores: a bounded sample of the same workload, run as several
-    oracle processes x BLAS threads so the whole socket is used (a single numpy process cannot use 100+ cores)."""
+def _cpu_throughput_pass(model, x, cores, procs, seconds):
+    step = max(1, len(cores) // procs)
+    rd, wr = os.pipe()
+    pids = []
+    for w in range(procs):
+        pid = os.fork()
+        if pid == 0:
+            try:
+                os.close(rd)
+                try:
+                    os.sched_setaffinity(0, {cores[(w * step) % len(cores)]})
+                except OSError:
+                    pass
+                model.invoke(x[:1])                                  # warm-up (weight re-layout, oneDNN primitive cache)
+                n, t0 = 0, time.time()
+                while time.time() - t0 < seconds:
+                    model.invoke(x[n % 4:n % 4 + 1])
+                    n += 1
+                os.write(wr, f"{n} {time.time() - t0:.6f}\n".encode())
+            finally:
+                os._exit(0)
+        pids.append(pid)
+    os.close(wr)
+    buf = b""
+    while True:
+        chunk = os.read(rd, 65536)
+        if not chunk:
+            break
+        buf += chunk
+    for pid in pids:
+        os.waitpid(pid, 0)
+    rows = [ln.split() for ln in buf.decode().splitlines() if ln.strip()]
+    rate = sum(int(r[0]) / float(r[1]) for r in rows)
+    print(f"CPU_THROUGHPUT {len(rows)} {sum(int(r[0]) for r in rows)} {rate:.3f}", flush=True)
+
+
+def _cpu_latency(model, x, cores, torch):
+    # latency mode (after the children are gone: the whole box is free)
+    def lat(threads, reps):
+        torch.set_num_threads(threads)
+        model.invoke(x[:1])
+        ts = []
+        for i in range(reps):
+            t0 = time.time(); model.invoke(x[i % 4:i % 4 + 1]); ts.append(time.time() - t0)
+        ts.sort()
+        return ts[len(ts) // 2] * 1e3
+    print(f"CPU_LATENCY_1T {lat(1, 10):.3f}")
+    # the reference would hand XNNPACK nproc - 1 threads; torch's OpenMP pool on a 256-core host turns that into seconds per
+    # clip (measured: 22 s), which says nothing about the reference - 8 threads is the figure reported beside the 1-thread one
+    nthr = max(1, min(8, len(cores) - 1))
+    print(f"CPU_LATENCY_ALLT {nthr} {lat(nthr, 5):.3f}")
+
+
+def cpu_baseline(blob, n_samples, sample_rate, seconds):
+    """CPU restatement ("port") timed on the host cores beside the GPU run: see cpu_worker_main."""
     import subprocess
     import tempfile
 
-    cores = os.cpu_count() or 1
-    workers = max(1, min(32, cores // 4))
-    threads = max(1, cores // workers)
-    per_worker = max(2, (n_clips_hint or 24 * workers) // workers)     # ~15 s of host compute on the bench box
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    seconds = seconds or 12.0
     tmp = tempfile.NamedTemporaryFile(suffix=".tflite", delete=False)
     tmp.write(blob)
     tmp.close()
-    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OPENBLAS_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    env = dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     t0 = time.time()
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", tmp.name, str(n_samples),
-                               str(sample_rate), str(100000 + w * per_worker), str(per_worker)],
-                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True)
-             for w in range(workers)]
-    times = []
+    res = {"value": None, "unit": "clips/s", "cores": cores, "kind": "port", "sample": "cpu baseline worker failed"}
     try:
-        for pr in procs:
-            out, _ = pr.communicate(timeout=300)
-            for line in out.splitlines():
-                if line.startswith("CPU_WORKER_SECONDS"):
-                    times.append(float(line.split()[1]))
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", tmp.name, str(n_samples), str(sample_rate),
+                              str(seconds), str(cores)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True,
+                             timeout=seconds * 4 + 240).stdout
+        thr = lat1 = latn = None
+        passes = []
+        for line in out.splitlines():
+            f = line.split()
+            if f and f[0] == "CPU_THROUGHPUT":
+                passes.append((int(f[1]), int(f[2]), float(f[3])))
+                if thr is None or float(f[3]) > thr[2]:
+                    thr = passes[-1]
+            elif f and f[0] == "CPU_LATENCY_1T":
+                lat1 = float(f[1])
+            elif f and f[0] == "CPU_LATENCY_ALLT":
+                latn = (int(f[1]), float(f[2]))
+        if thr:
+            res = {"value": thr[2], "unit": "clips/s", "cores": cores, "kind": "port",
+                   "clips_per_s_per_core": thr[2] / cores, "worker_processes": thr[0],
+                   "passes": [{"processes": q[0], "clips": q[1], "clips_per_s": q[2]} for q in passes],
+                   "clips_per_s_one_core_alone": 1e3 / lat1 if lat1 else None,
+                   "latency_ms_batch1": {"threads_1": lat1, f"threads_{latn[0]}" if latn else "threads_all": latn[1] if latn else None},
+                   "sample": f"{thr[1]} clips of the config-2 generator in {seconds / (2 if cores >= 16 else 1):.0f} s: {thr[0]} single-thread processes (pinned, of {cores} host CPUs; the better of the passes), "
+                             "each looping whole-model batch-1 forward passes like the reference's own benchmark loop "
+                             "(cmd/benchmark/benchmark.go:99-133) through the torch-CPU restatement of the graph (oracle/torch_cpu.py: oneDNN "
+                             f"convolutions, channels-last, fused SiLU; pinned to the parity oracle in tests/test_torch_cpu.py); {time.time() - t0:.0f} s incl. "
+                             "start-up; latency = one process, batch 1, median.  RESTATEMENT baseline - NOT TFLite/XNNPACK (no TFLite "
+                             "runtime or real weights exist in this environment); the reference documents ~11 clips/s on a 4-core "
+                             "Raspberry Pi 5 (doc/wiki/faq.md:192)"}
+    except Exception as ex:                                   # noqa: BLE001  (the baseline must never take the bench line down)
+        res["sample"] = f"cpu baseline failed: {type(ex).__name__}"
     finally:
-        for pr in procs:
-            if pr.poll() is None:
-                pr.kill()
         os.unlink(tmp.name)
-    wall = time.time() - t0
-    if len(times) != workers:
-        return {"value": None, "unit": "clips/s", "cores": cores, "kind": "port", "sample": "cpu baseline workers failed"}
-    n = workers * per_worker
-    busy = max(times)                                   # steady-state compute time (excludes process start-up/import)
-    return {"value": n / busy, "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"{n} clips of the config-2 generator through the fp32 oracle restatement (numpy + torch-CPU/oneDNN convolutions): "
-                      f"{workers} processes x {threads} BLAS threads ({workers * threads} of {cores} host cores), "
-                      f"{busy:.1f} s compute ({wall:.1f} s incl. start-up); restatement baseline - NOT TFLite "
-                      "(no TFLite runtime or real weights exist in this environment)"}
+    return res
 
 
 def host_pointer_rates(clf, x, reps_small=100, reps_mid=12, reps_big=5):
@@ -275,14 +342,22 @@ def main_bat(args):
            "us_frame_cv": {"frames_per_clip": frames, "gflops_f64": fft_flops / 1e9,
                            "tflops_f64": fft_flops / (stage_ms[0] * 1e-3) / 1e12, "input_gbs": B * cfg.n_samples * 2 / (stage_ms[0] * 1e-3) / 1e9},
            "max_rel_cv_diff_vs_go_restatement": cv_err, "max_abs_score_diff_vs_oracle": sc_err}
-    print(json.dumps(out))
     backbone.close(); head.close()
+    return out
 
 
 def main():
     args = parse()
     if args.workload == "bat":
-        return main_bat(args)
+        print(json.dumps(main_bat(args)))
+        return
+    out = run_model(args)
+    if out is not None:
+        print(json.dumps(out))
+
+
+def run_model(args):
+    """One model workload (birdnet = the contract's line, perch = BASELINE configs[4]); returns the JSON object on rank 0."""
     import torch
     import torch.distributed as dist
     import birdnet_go_amd  # noqa: F401
@@ -376,6 +451,32 @@ def main():
                   f"{r['flops'] / r['launches'] / (ms * 1e-3) / 1e12:6.1f} TF  {r['bytes'] / r['launches'] / (ms * 1e-3) / 1e9:7.0f} GB/s",
                   file=sys.stderr)
     clf.profile_enable(False)
+    # per-step distribution (>= 30 batches, median + p95, like cmd/perch-benchmark/main.go:31-32,354-391): a second,
+    # untimed-by-contract run of >= 40 steps with ONE event pair per step on the stream the step runs on.  With two contexts
+    # in flight the steps overlap, so two figures: the interval between consecutive completions (what throughput is made of)
+    # and each step's own start-to-end latency.
+    dist_stats = None
+    if rank == 0 and not args.no_distribution:
+        nd = max(40, args.steps)
+        clf.profile_steps(True)
+        for _ in range(nd):
+            step()
+        clf.synchronize()
+        torch.cuda.synchronize(dev)
+        st_ms, en_ms = clf.profile_steps_read()
+        clf.profile_steps(False)
+        if len(en_ms) >= 8:
+            done = np.sort(en_ms)
+            # with `depth` contexts the steps complete in bursts of `depth`; the time per step is the spacing of completions
+            # `depth` apart, divided by `depth` (the first `depth` steps start on an empty GPU and are left out)
+            iv = ((done[depth:] - done[:-depth]) / depth)[depth:]
+            lat = (en_ms - st_ms)[depth:]
+            pct = lambda v, q: float(np.percentile(v, q))
+            dist_stats = {"steps": int(len(en_ms)), "completion_interval_ms": {"p50": pct(iv, 50), "p95": pct(iv, 95), "max": float(iv.max())},
+                          "step_latency_ms": {"p50": pct(lat, 50), "p95": pct(lat, 95)},
+                          "clips_per_s_at_p50_interval": B / (pct(iv, 50) * 1e-3),
+                          "method": "one HIP event pair per step on the step's own stream; interval = spacing of step completions "
+                                    "`pipeline_depth` apart / pipeline_depth (steps on alternating contexts overlap and finish in bursts)"}
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -438,6 +539,8 @@ def main():
                        "pipeline_depth": depth, "input_sets": NSETS},
             "finite_outputs": ok, "max_abs_logit_diff_vs_small_batch": consist, "consistent": bool(consist <= 1e-3),
         }
+        if dist_stats:
+            out["step_distribution"] = dist_stats
         if prof:
             prof = sorted(prof, key=lambda r: -r["ms"])
             dom = prof[0]
@@ -448,7 +551,11 @@ def main():
             if args.precision == "bf16" and dom["kernel"] in ("pw_gemm", "expand_dw"):
                 peak_tf = PEAK_BF16_MFMA_TFLOPS          # one bf16 product per MAC: priced against the dense bf16 peak
             intensity = dom["flops"] / max(dom["bytes"], 1.0)
-            if intensity > peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9):
+            # a contraction class whose intensity is above the f32 machine balance is priced against the matrix pipe it issues
+            # on even when that pipe (bf16: 312 flop/B balance) would in theory leave it HBM-bound: its measured HBM traffic
+            # is the algorithmic minimum at a fraction of the HBM rate, so "hbm" would misname what limits it
+            mfma_class = dom["kernel"] in ("pw_gemm", "expand_dw", "frontend", "conv_igemm")
+            if intensity > peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9) or (mfma_class and intensity > PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)):
                 ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
                 roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": ach, "peak": peak_tf,
                         "unit": "TFLOP/s", "frac": ach / peak_tf, "traffic": None}
@@ -493,7 +600,11 @@ def main():
                                            "tflops": r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] else 0.0,
                                            "gbs": r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] else 0.0}
                                           for r in sorted(warm_prof, key=lambda r: -r["ms"])]
-        desc_steps = clf.describe()["steps"]
+        dsc = clf.describe()
+        desc_steps = dsc["steps"]
+        out["weights"] = {"model_file_bytes": len(blob), "device_weight_image_bytes": dsc.get("weight_bytes"), "note": ("stand-in; the real perch_v2_no_dft_fp32.onnx is 413.4 MB "
+                          "(internal/classifier/model_catalog.go:311)") if perch else
+                          "stand-in; the real BirdNET_v2.4_fp32_dfttrunc.onnx is 54.07 MB (model_catalog.go:426)"}
         out["arithmetic"] = {
             "bf16x3": args.bf16x3 if args.bf16x3 is not None else 1,
             "layers_on_split_bf16_mfma": sum(1 for s_ in desc_steps if s_["kernel"] == "pw_gemm" and s_["wm_full"] >= 5),
@@ -521,11 +632,33 @@ def main():
             clf = host.HipClassifier(blob, device=local_rank, max_batch=B, bf16x3=args.bf16x3, precision=args.precision)
             out["host_pointer"] = host_pointer_rates(clf, x_host)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(blob, cfg.n_samples, cfg.sample_rate, args.cpu_clips)
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(blob, cfg.n_samples, cfg.sample_rate, args.cpu_seconds)
     clf.close()
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0 and world == 1 and not use_dist and not perch and not args.no_secondary and args.precision != "bf16":
+        # BASELINE configs[3] / configs[4] next to the headline, at reduced step counts, so that they pass through the same
+        # driver-observed run; each leg is the same code `--workload bat|perch` runs on its own
+        import copy
+        sec = {}
+        for name, kw in (("bat", {"workload": "bat", "steps": 10, "warmup": 2}),
+                         ("perch_f32", {"workload": "perch", "steps": 8, "warmup": 2, "precision": None}),
+                         ("perch_bf16", {"workload": "perch", "steps": 8, "warmup": 2, "precision": "bf16"})):
+            a2 = copy.copy(args)
+            a2.batch = 0; a2.no_cpu_baseline = True; a2.no_fp32_run = True; a2.no_host_pointer = True; a2.no_secondary = True
+            a2.no_distribution = True; a2.detail = False
+            for k, v in kw.items():
+                setattr(a2, k, v)
+            try:
+                leg = main_bat(a2) if name == "bat" else run_model(a2)
+                keep = ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "data", "config", "max_abs_prob_diff_vs_oracle",
+                        "top1_identical_vs_oracle", "stages_ms", "max_rel_cv_diff_vs_go_restatement", "max_abs_score_diff_vs_oracle",
+                        "roofline", "consistent", "weights")
+                sec[name] = {k: leg[k] for k in keep if k in leg}
+            except Exception as ex:                         # noqa: BLE001  (a secondary leg must not take the headline down)
+                sec[name] = {"error": f"{type(ex).__name__}: {ex}"}
+        out["secondary"] = sec
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":

@@ -1006,6 +1006,21 @@ int bnhip_profile_read(bnhip_model* m, char* buf, size_t cap) {
     BN_GUARD_END((void)0)
 }
 
+int bnhip_profile_steps(bnhip_model* m, int on) {
+    if (!m) return set_err(BNHIP_E_INVALID, "model is NULL");
+    m->eng().step_timing = on != 0;
+    return BNHIP_OK;
+}
+
+int bnhip_profile_steps_read(bnhip_model* m, double* start_ms, double* end_ms, int cap) {
+    if (!m || m->eng().device < 0) return set_err(BNHIP_E_INVALID, "model is NULL or plan-only");
+    if (cap < 0) return set_err(BNHIP_E_INVALID, "negative capacity");
+    BN_GUARD_BEGIN
+    hipSetDevice(m->eng().device);
+    return m->eng().steps_read(start_ms, end_ms, cap);
+    BN_GUARD_END((void)0)
+}
+
 int bnhip_model_describe(const bnhip_model* m, char* buf, size_t cap) {
     if (!m) return set_err(BNHIP_E_INVALID, "model is NULL");
     BN_GUARD_BEGIN

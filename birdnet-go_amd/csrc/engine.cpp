@@ -363,6 +363,7 @@ Engine::~Engine() {
     drop_graphs();
     for (auto& e : prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto e : ev_pool) hipEventDestroy(e);
+    for (auto& p : step_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (void* p : {(void*)act_arena, (void*)w_arena, (void*)d_stage_in, (void*)d_stage_logits, (void*)d_stage_emb,
                     (void*)d_stage_pcm, (void*)d_post_conf, (void*)d_topk_conf, (void*)d_topk_idx})
         if (p) hipFree(p);
@@ -494,7 +495,15 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
             std::vector<float> asf((img.size() + 1) / 2);
             memcpy(asf.data(), img.data(), img.size() * 2);
             obx = wpush(asf.data(), asf.size());
-            if (bf16x3 >= 2) steps.back().wm = steps.back().wm_full = 6;      // forced: 128-row tiles (the autotuner refines)
+            // WHICH arithmetic a layer runs is decided here, by shape, never by a timing (with a create-time race
+            // between the two kernels the same clip could get different logits on different devices of one handle, and
+            // from process to process): the split-bf16 kernel where the layer is compute-bound - algorithmic intensity at
+            // max_batch >= 12 flop/B; measured at batch 256 the split wins every layer above that line by 19-32 % and ties
+            // (+-4 %) the HBM-bound early projections below it (b1-b3: 5-10 flop/B) - everywhere with bf16x3 = 2 or
+            // "precision":"bf16".  The autotuner then only picks the TILE inside that kernel family.
+            const double Mr = (double)maxb * s.H * s.W, Nr = s.Co, Kr = s.C;
+            const double intensity = 2.0 * Mr * Nr * Kr / (4.0 * (Mr * Kr + Mr * Nr + Nr * Kr));
+            if (bf16x3 >= 2 || precision == 1 || intensity >= 12.0) { steps.back().bx = 1; steps.back().wm = steps.back().wm_full = 6; }
         }
         step_bx.push_back(obx);
     };
@@ -834,7 +843,9 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                                 std::vector<float> asf((img.size() + 1) / 2);
                                 memcpy(asf.data(), img.data(), img.size() * 2);
                                 step_bx.back() = wpush(asf.data(), asf.size());
-                                if (bf16x3 >= 2) steps.back().bx = 1;
+                                // (arithmetic by rule, not by timing: the split-bf16 phase 1 measured +0-0.5 % at best, so it is
+                                // used only where asked for)
+                                if (bf16x3 >= 2 || precision == 1) steps.back().bx = 1;
                             }
                             break;
                         }
@@ -1674,10 +1685,11 @@ void Engine::autotune_expdw() {
         float* out2 = vptr(s.out2, d_stage_in, d_stage_logits, nullptr);
         float best = 1e30f; int best_idx = -1, best_bx = 0;
         const bool can_bx = s.wbx != nullptr && s.mode != 1 && bf16x3;
+        const int bx_fixed = (can_bx && s.bx) ? 1 : 0;      // arithmetic is the planner's decision (shape rule); only the tile is timed
         const ExpDwGeo sg0{s.kh, s.sh, s.H, s.W, s.Ho, s.Wo, s.pt, s.pl, s.mode == 1};
         for (int idx = 0; idx < expdw_num_shapes(); idx++) {
             if (!expdw_shape_fits(idx, sg0)) continue;
-            for (int bx = (can_bx && bf16x3 >= 2) ? 1 : 0; bx <= (can_bx ? 1 : 0); bx++) {
+            for (int bx = bx_fixed; bx <= bx_fixed; bx++) {
                 auto go = [&]() {
                     StemGeom sg{s.H2, s.W2, s.pt2, s.pl2};
                     launch_expand_dw(in0, s.w0, s.w1, s.w2, s.w3, out, out2, n, s.H, s.W, s.C, s.Co, s.Ho, s.Wo, s.kh, s.sh, s.pt, s.pl,
@@ -1779,7 +1791,8 @@ void Engine::autotune_pw() {
             // The full-batch tuning (pass 1) is what a context runs, and the host-pointer pipeline (host_depth > 1) runs its
             // chunks on contexts too; the lane tuning (pass 0) serves serial calls of a depth-1 engine and stays by time.
             const bool by_work = (depth > 1 || (pass == 1 && host_depth > 1)) && !getenv("BNHIP_TUNE_BY_TIME");
-            for (int wm = 4; wm >= 1; wm--) {
+            const bool arith_bx = s.bx && s.wbx && bf16x3;        // the planner's shape rule: which kernel family computes this layer
+            for (int wm = arith_bx ? 0 : 4; wm >= 1; wm--) {
                 for (int nt = 1; nt <= 8; nt++) {
                     const long M_ = (long)n * s.H * s.W, bm = (wm == 1 || wm == 3) ? 64 : 128;
                     long cols = (long)((s.Co + nt * 16 - 1) / (nt * 16)) * nt * 16;
@@ -1800,9 +1813,8 @@ void Engine::autotune_pw() {
                     if (less_work || ms < best * 0.98f) { best = ms; best_nt = nt; best_wm = wm; best_work = std::min(best_work, work); }
                 }
             }
-            if (s.wbx && bf16x3) {
-                // split-bf16 candidates (wm 5 / 6 = 64- / 128-row tiles): taken where measured faster than the best fp32 tile
-                // (bf16x3 = 2: always, by their own best time)
+            if (arith_bx) {
+                // split-bf16 candidates (wm 5 / 6 = 64- / 128-row tiles, 7 / 8 the software-pipelined form): the fastest tile
                 float bbest = 1e30f; int bnt = 0, bwm = 0;
                 for (int wm = 8; wm >= 5; wm--)
                     for (int nt = 1; nt <= 8; nt++) {
@@ -1820,7 +1832,7 @@ void Engine::autotune_pw() {
                         if (getenv("BNHIP_DEBUG")) fprintf(stderr, "[bnhip] tune %-16s n=%d M=%d N=%d K=%d nt=%d wm=%d (bf16x3): %.1f us (%.1f TF fp32-equivalent)\n", s.name.c_str(), n, n * s.H * s.W, s.Co, s.C, nt, wm, ms / 3 * 1e3, 2.0 * n * s.H * s.W * s.Co * s.C / (ms / 3 * 1e-3) / 1e12);
                         if (ms < bbest * 0.98f) { bbest = ms; bnt = nt; bwm = wm; }
                     }
-                if (bnt && (bf16x3 >= 2 || bbest < best * (precision ? 1.0f : 0.97f))) { best_nt = bnt; best_wm = bwm; }
+                if (bnt) { best_nt = bnt; best_wm = bwm; } else { best_nt = 0; best_wm = 6; }
             }
             if (pass == 0) { s.nt = best_nt; s.wm = best_wm; } else { s.nt_full = best_nt; s.wm_full = best_wm; }
         }
@@ -1954,6 +1966,8 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
                          d_emb_all ? d_emb_all + (size_t)c0 * emb_dim : nullptr, li == 0 ? main_stream : lane_stream[li - 1], c0};
         c0 += cnt;
     }
+    hipEvent_t st_a = nullptr, st_b = nullptr;
+    if (step_timing) { hipEventCreate(&st_a); hipEventCreate(&st_b); hipEventRecord(st_a, main_stream); }
     if (nl > 1) {
         hipEventRecord(ev_fork, main_stream);
         for (int li = 1; li < nl; li++) hipStreamWaitEvent(lanes[li].st, ev_fork, 0);
@@ -2121,9 +2135,26 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
         hipEventRecord(ev_join[li - 1], lanes[li].st);
         hipStreamWaitEvent(main_stream, ev_join[li - 1], 0);
     }
+    if (step_timing) { hipEventRecord(st_b, main_stream); step_ev.emplace_back(st_a, st_b); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { *err = std::string("kernel launch: ") + hipGetErrorString(e); return false; }
     return true;
+}
+
+int Engine::steps_read(double* start_ms, double* end_ms, int cap) {
+    sync_contexts();
+    if (stream) hipStreamSynchronize(stream);
+    const int n = (int)step_ev.size();
+    for (int i = 0; i < n; i++) {
+        float a = 0, b = 0;
+        hipEventElapsedTime(&a, step_ev[0].first, step_ev[i].first);
+        hipEventElapsedTime(&b, step_ev[0].first, step_ev[i].second);
+        if (i < cap) { if (start_ms) start_ms[i] = a; if (end_ms) end_ms[i] = b; }
+    }
+    for (auto& p : step_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    step_ev.clear();
+    (void)hipGetLastError();
+    return n;
 }
 
 // ================================================================================================ describe / profile

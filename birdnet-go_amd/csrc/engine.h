@@ -165,6 +165,13 @@ class Engine {
 
     std::string describe() const;
     std::string profile_read();
+    // Whole-call timing (bnhip_profile_steps): one event pair around the plan of every call, on the stream the call runs on -
+    // two kernel boundaries per call instead of 2 x 61, so it can stay on inside a timed region.  The per-step distribution
+    // the reference's benchmarks report (median / p95 over >= 30 batches, cmd/perch-benchmark/main.go:31-32,354-391) comes
+    // from here.
+    bool step_timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> step_ev;
+    int steps_read(double* start_ms, double* end_ms, int cap);     // relative to the first call's start; clears
 
   private:
     struct GraphEntry { const float* in; float* logits; float* emb; int n; int seen; hipGraphExec_t exec; };

@@ -31,7 +31,7 @@ SYMBOLS = ["bnhip_init", "bnhip_shutdown", "bnhip_model_create", "bnhip_model_in
            "bnhip_resample_f32", "bnhip_resample_pcm16", "bnhip_model_devices", "bnhip_last_error_copy",
            "bnhip_resampler_create", "bnhip_resampler_estimate", "bnhip_resampler_process_pcm16",
            "bnhip_resampler_process_f32", "bnhip_resampler_flush_pcm16", "bnhip_resampler_flush_f32",
-           "bnhip_resampler_destroy", "bnhip_us_frame_cv_device"]
+           "bnhip_resampler_destroy", "bnhip_us_frame_cv_device", "bnhip_profile_steps", "bnhip_profile_steps_read"]
 
 
 class HipError(RuntimeError):
@@ -256,6 +256,20 @@ class HipClassifier:
         rows = json.loads(buf.value.decode())
         classes = [r for r in rows if "step" not in r]
         return (classes, [r for r in rows if "step" in r]) if per_step else classes
+
+    def profile_steps(self, on=True):
+        _check(self._lib, self._lib.bnhip_profile_steps(self._h, int(on)))
+
+    def profile_steps_read(self, cap=4096):
+        """(start_ms, end_ms) of every call since the last read, relative to the first call's start."""
+        a, b = np.zeros(cap, np.float64), np.zeros(cap, np.float64)
+        lib = self._lib
+        lib.bnhip_profile_steps_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        n = lib.bnhip_profile_steps_read(self._h, a.ctypes.data, b.ctypes.data, cap)
+        if n < 0:
+            _check(lib, n)
+        n = min(n, cap)
+        return a[:n].copy(), b[:n].copy()
 
     def describe(self):
         need = self._lib.bnhip_model_describe(self._h, None, 0)

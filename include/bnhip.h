@@ -183,6 +183,14 @@ int bnhip_profile_enable(bnhip_model* m, int on);
 int bnhip_profile_filter(bnhip_model* m, const char* kernel_class);
 int bnhip_profile_read(bnhip_model* m, char* buf, size_t cap);
 
+/* Whole-call timing: when enabled, every call's plan is bracketed by ONE event pair on the stream it runs on (two kernel
+ * boundaries per call, cheap enough for a timed region).  bnhip_profile_steps_read synchronises, writes up to cap calls'
+ * start / end times in milliseconds relative to the first call's start (either array may be NULL), clears the record and
+ * returns the number of calls recorded.  Source of the per-batch median / p95 the reference's benchmarks report
+ * (cmd/perch-benchmark/main.go:31-32,354-391).  Single-device handles (engine 0 of a multi-device one). */
+int bnhip_profile_steps(bnhip_model* m, int on);
+int bnhip_profile_steps_read(bnhip_model* m, double* start_ms, double* end_ms, int cap);
+
 /* Plan description (JSON) for diagnostics/DESIGN tables: one entry per launch with shapes,
  * algorithmic flops and bytes. Returns bytes needed. */
 int bnhip_model_describe(const bnhip_model* m, char* buf, size_t cap);
