@@ -456,6 +456,25 @@ int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, 
         int ocode = BNHIP_E_MODEL;
         if (!parse_onnx(blob, n_bytes, &tm, &err, &ocode)) return set_err(ocode, err);
     }
+    if (getenv("BNHIP_DUMP_IR")) {                      // diagnostics: the operator list the planner will see
+        for (size_t oi = 0; oi < tm.ops.size(); oi++) {
+            const TflOp& o = tm.ops[oi];
+            fprintf(stderr, "[bnhip] ir %3zu %-18s", oi, op_name(o.code));
+            for (int t : o.inputs) {
+                if (t < 0) { fprintf(stderr, " -"); continue; }
+                fprintf(stderr, " %s%d[", tm.tensors[t].data ? "c" : "t", t);
+                for (size_t k = 0; k < tm.tensors[t].shape.size(); k++) fprintf(stderr, "%s%d", k ? "," : "", tm.tensors[t].shape[k]);
+                fprintf(stderr, "]");
+            }
+            fprintf(stderr, " ->");
+            for (int t : o.outputs) {
+                fprintf(stderr, " t%d[", t);
+                for (size_t k = 0; k < tm.tensors[t].shape.size(); k++) fprintf(stderr, "%s%d", k ? "," : "", tm.tensors[t].shape[k]);
+                fprintf(stderr, "]");
+            }
+            fprintf(stderr, "\n");
+        }
+    }
     if (!validate_graph(tm, &err)) return set_err(BNHIP_E_MODEL, err);
 
     m = new bnhip_model();

@@ -1399,6 +1399,44 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                 add_step(s);
                 break;
             }
+            case OP_GATHER: {
+                // GATHER of an activation with a CONSTANT selector that is affine in its (<= 2) indices - tf.signal.frame's
+                // sliding window idx[f][q] = f * step + q, a strided pick idx[i] = i0 + i * a, a single element - is a strided
+                // view of the input: one copy kernel.  (Inside a recognised audio front-end the framing never runs: the STFT
+                // kernel fetches its frames from the clip; this is the literal path for graphs the recogniser does not take.)
+                int vin = need_val(o.inputs[0]);
+                const auto& ish = m.tensors[o.inputs[0]].shape;
+                const int rank = (int)ish.size();
+                if (vin < 0 || o.inputs.size() != 2 || !P.is_const(o.inputs[1]) || m.tensors[o.inputs[1]].type != TT_INT32 || o.batch_dims != 0) { *err = "GATHER: needs an activation and a constant int32 selector at " + oname; return false; }
+                const TflTensor& sel = m.tensors[o.inputs[1]];
+                int ax = o.axis < 0 ? o.axis + rank : o.axis;
+                if (ax < 1 || ax >= rank || sel.shape.size() > 2 || sel.numel() < 1) { *err = "GATHER: unsupported axis / selector rank at " + oname; return false; }
+                const int n0 = sel.shape.empty() ? 1 : sel.shape[0], n1 = sel.shape.size() == 2 ? sel.shape[1] : 1;
+                const int32_t* sv = sel.i32();
+                const long i0 = sv[0], a0 = n0 > 1 ? (long)sv[n1] - sv[0] : 0, a1 = n1 > 1 ? (long)sv[1] - sv[0] : 0;
+                for (int f = 0; f < n0; f++)
+                    for (int q = 0; q < n1; q++) {
+                        const long want = i0 + f * a0 + q * a1;
+                        if (sv[(size_t)f * n1 + q] != want || want < 0 || want >= ish[ax]) { *err = "GATHER: the constant selector is not affine (or out of range) at " + oname; return false; }
+                    }
+                long pre = 1, post = 1;
+                for (int k = 1; k < ax; k++) pre *= ish[k];
+                for (int k = ax + 1; k < rank; k++) post *= ish[k];
+                if (ish[0] != 1) { *err = "GATHER: batch dimension must be 1 at " + oname; return false; }
+                Step s; s.kind = S_COPY; s.kclass = "copy"; s.name = oname; s.in0 = vin;
+                // view [pre, n0, n1, post] of the input [pre, ish[ax], post]
+                const long din[4] = {pre, n0, n1, post};
+                const long sin_[4] = {(long)ish[ax] * post, a0 * post, a1 * post, 1};
+                long so = 1;
+                for (int k = 3; k >= 0; k--) { s.g.d[k] = (int)din[k]; s.g.sa[k] = sin_[k]; s.g.so[k] = so; so *= din[k]; }
+                s.g.offa = i0 * post;
+                const size_t elems = m.tensors[o.outputs[0]].numel();
+                if ((size_t)(pre * n0 * n1 * post) != elems) { *err = "GATHER: output shape mismatch at " + oname; return false; }
+                s.out = new_val(o.outputs[0], elems); tv[o.outputs[0]] = s.out;
+                s.bytes = 8.0 * elems;
+                add_step(s);
+                break;
+            }
             case OP_PAD: case OP_PADV2: {
                 int vin = need_val(o.inputs[0]);
                 const auto& ish = m.tensors[o.inputs[0]].shape;

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <set>
 
@@ -242,6 +243,104 @@ bool tensor_ints(const OTensor& t, std::vector<int64_t>* out) {
     return false;
 }
 
+// ---------------------------------------------------------------------------------------------- in-graph audio front-ends
+// Every ONNX classifier the reference ships computes its spectrogram inside the graph (internal/classifier/model_catalog.go:
+// 412-426 BirdNET v2.4 "dfttrunc", :490-501 the BattyBirdNET backbone, :273-311 Perch v2 "with in-graph DFT",
+// internal/classifier/birdnet_v3_onnx.go:44-48 "its mel front-end is a Conv1d").  The transform arrives in one of four
+// forms - a MatMul with a constant (truncated) DFT basis, a strided Conv1d whose filters are window x DFT rows, the opset-17
+// STFT operator, the opset-17 DFT operator - and the reader keeps such a value SYMBOLIC (SpecH) until it sees how it is
+// used: real part or magnitude into a constant mel MatMul followed by the canonical tail becomes the TFLite-shaped chain
+// (GATHER framing, window MUL, RFFT2D, CAST / COMPLEX_ABS, FULLY_CONNECTED) that the engine's front-end recogniser turns into
+// the fp64 FFT + banded-mel kernels; any other use materialises the value as the dense fp32 GEMM the file literally asks for.
+struct SpecH {
+    int frames = -1;            // IR tensor [1, F, Lfft]: windowed, zero-padded frames
+    int Lfft = 0, F = 0;
+    std::vector<int> bins;      // DFT bin of every column (row)
+    // 0 real, 1 imaginary, 2 real^2, 3 imaginary^2, 4 power, 5 magnitude, 6 [re rows | im rows] (Conv1d), 7 [.., K, 2] (STFT / DFT),
+    // 8 = 7 squared elementwise
+    int part = 0;
+    bool bins_major = false;    // the ONNX value is [N, K, F] (Conv1d) rather than [N, F, K]
+    bool last1 = false;         // a trailing axis of 1 is still attached (Slice [0:1] of a [.., K, 2] value before its Squeeze)
+};
+
+// B [rows n = 0..N-1][K columns]: every column j equal to cos(2 pi n k_j / N) (kind 0) or -sin(2 pi n k_j / N) (kind 1)?
+bool dft_columns(const std::vector<float>& B, int N, int K, int* kind, std::vector<int>* bins) {
+    if (N < 4 || K < 1 || (size_t)N * K != B.size()) return false;
+    std::vector<double> ct(N), st(N);
+    for (int i = 0; i < N; i++) { ct[i] = std::cos(2.0 * M_PI * i / N); st[i] = std::sin(2.0 * M_PI * i / N); }
+    for (int kd = 0; kd < 2; kd++) {
+        bins->assign(K, 0);
+        bool ok = true;
+        for (int j = 0; j < K && ok; j++) {
+            int k;
+            if (kd == 0) {
+                double c1 = std::min(1.0, std::max(-1.0, (double)B[(size_t)1 * K + j]));
+                k = (int)std::lround(std::acos(c1) * N / (2.0 * M_PI));
+            } else {
+                double s1 = -(double)B[(size_t)1 * K + j], s2 = -(double)B[(size_t)2 * K + j];
+                double c = std::fabs(s1) > 1e-9 ? s2 / (2.0 * s1) : 1.0;
+                k = (int)std::lround(std::atan2(s1, c) * N / (2.0 * M_PI));
+            }
+            if (k < 0 || k > N / 2) { ok = false; break; }
+            for (int n = 0; n < N; n++) {
+                const long ph = ((long)n * k) % N;
+                const double want = kd == 0 ? ct[ph] : -st[ph];
+                if (std::fabs((double)B[(size_t)n * K + j] - want) > 1e-5) { ok = false; break; }
+            }
+            (*bins)[j] = k;
+        }
+        if (ok) { *kind = kd; return true; }
+    }
+    return false;
+}
+
+// Conv1d filters W [2K rows][L taps]: rows 0..K-1 = w[n] cos(2 pi k_j n / N), rows K..2K-1 = -w[n] sin(2 pi k_j n / N)?
+// Recovers the window, the transform length N >= L and the bins.
+bool dft_conv_rows(const std::vector<float>& W, int R, int L, std::vector<float>* window, int* Nfft, std::vector<int>* bins) {
+    if (R < 2 || (R & 1) || L < 8 || (size_t)R * L != W.size()) return false;
+    const int K = R / 2;
+    window->assign(L, 0.f);
+    // the window from the row pair with the largest energy (every pair carries the same one)
+    for (int n = 0; n < L; n++) (*window)[n] = std::hypot(W[(size_t)0 * L + n], W[(size_t)K * L + n]);
+    int n0 = 0; float wmax = 0.f;
+    for (int n = 0; n + 1 < L; n++) { float v = std::min((*window)[n], (*window)[n + 1]); if (v > wmax) { wmax = v; n0 = n; } }
+    if (!(wmax > 0.f)) return false;
+    std::vector<double> om(K);
+    for (int j = 0; j < K; j++) {
+        const double a0 = std::atan2(-(double)W[(size_t)(K + j) * L + n0], (double)W[(size_t)j * L + n0]);
+        const double a1 = std::atan2(-(double)W[(size_t)(K + j) * L + n0 + 1], (double)W[(size_t)j * L + n0 + 1]);
+        double d = a1 - a0;
+        while (d < 0) d += 2.0 * M_PI;
+        while (d >= 2.0 * M_PI) d -= 2.0 * M_PI;
+        if (d > M_PI + 1e-6) return false;
+        om[j] = d;
+    }
+    int N = L;
+    if (K >= 2) {
+        double dmin = 1e30;
+        for (int j = 0; j + 1 < K; j++) { double d = std::fabs(om[j + 1] - om[j]); if (d > 1e-9) dmin = std::min(dmin, d); }
+        if (dmin > 1e29) return false;
+        N = (int)std::lround(2.0 * M_PI / dmin);
+    }
+    if (N < L || N > (1 << 16) || (N & 1)) return false;
+    bins->assign(K, 0);
+    double werr = 0;
+    for (int j = 0; j < K; j++) {
+        const int k = (int)std::lround(om[j] * N / (2.0 * M_PI));
+        if (k < 0 || k > N / 2) return false;
+        (*bins)[j] = k;
+        for (int n = 0; n < L; n++) {
+            const double ph = 2.0 * M_PI * (double)(((long)n * k) % N) / N, w = (*window)[n];
+            werr = std::max(werr, std::fabs((double)W[(size_t)j * L + n] - w * std::cos(ph)));
+            werr = std::max(werr, std::fabs((double)W[(size_t)(K + j) * L + n] + w * std::sin(ph)));
+        }
+    }
+    *Nfft = N;
+    return werr <= 2e-5 * std::max(1.0f, wmax);
+}
+
+int igcd_(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
 }  // namespace
 
 bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err, int* code) {
@@ -417,15 +516,361 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
         if (H + *pt + pb < eh || W + *pl + pr < ew || *Ho < 1 || *Wo < 1) { *why = "window larger than the padded image"; return false; }
         return true;
     };
-    for (const ONode& nd : nodes) {
+    // ---- symbolic spectra (see SpecH) and the lazy [N, K, F] <-> [1, F, K] transposition of Conv1d-style tensors
+    std::map<std::string, std::vector<int>> users;            // ONNX value -> consuming node indices
+    for (size_t ni = 0; ni < nodes.size(); ni++) for (auto& nm : nodes[ni].in) if (!nm.empty()) users[nm].push_back((int)ni);
+    std::set<std::string> graph_outs;
+    for (auto& vi : g_out) graph_outs.insert(vi.name);
+    std::set<int> tr3;                                        // IR tensor [1, F, K] standing for the ONNX value [N, K, F]
+    std::map<std::string, SpecH> spec;                        // symbolic values (no IR tensor yet)
+    std::map<std::string, std::vector<int>> spec_pending;     // ... and the nodes that must be lowered literally to materialise them
+    std::set<int> lowered;                                    // node indices already lowered literally
+    auto new_t = [&](const std::string& name, const std::vector<int>& shape, int type) {
+        TflTensor t; t.name = name; t.shape = shape; t.type = type;
+        m.tensors.push_back(std::move(t));
+        return (int)m.tensors.size() - 1;
+    };
+    // plain [1, K, F] copy of a lazily transposed value
+    auto untr3 = [&](int t) -> int {
+        if (!tr3.count(t)) return t;
+        const auto sh = m.tensors[t].shape;               // [1, F, K]
+        const int o = new_t(m.tensors[t].name + "/kf" + std::to_string(tmp_id++), {sh[0], sh[2], sh[1]}, TT_FLOAT32);
+        add_op(OP_TRANSPOSE, {t, m.add_const_i32(m.tensors[o].name + "/perm", {3}, {0, 2, 1})}, o);
+        return o;
+    };
+    auto as_tr3 = [&](int t) -> int {                      // [1, F, K] form of a rank-3 value
+        if (tr3.count(t)) return t;
+        const auto sh = m.tensors[t].shape;               // [1, K, F]
+        const int o = new_t(m.tensors[t].name + "/fk" + std::to_string(tmp_id++), {sh[0], sh[2], sh[1]}, TT_FLOAT32);
+        if (sh[1] == 1 || sh[2] == 1) add_op(OP_RESHAPE, {t}, o).new_shape = m.tensors[o].shape;
+        else add_op(OP_TRANSPOSE, {t, m.add_const_i32(m.tensors[o].name + "/perm", {3}, {0, 2, 1})}, o);
+        tr3.insert(o);
+        return o;
+    };
+    // the one consumer of an ONNX value that is not a graph output, or nullptr
+    auto only_user = [&](const std::string& nm) -> const ONode* {
+        auto it = users.find(nm);
+        if (it == users.end() || it->second.size() != 1 || graph_outs.count(nm)) return nullptr;
+        return &nodes[it->second[0]];
+    };
+    auto scalar_const = [&](const std::string& nm, float* v) -> bool {
+        std::vector<float> c;
+        if (!const_f(nm, &c, nullptr) || c.size() != 1) return false;
+        *v = c[0];
+        return true;
+    };
+    // Does the chain behind the mel MatMul output `nm` (mel axis = ONNX axis `mel_ax` of a rank-3 value) have the shape the
+    // engine's recogniser fuses?  (Pow, Pow | Mul self, Pow | Max, Log, Mul) -> [reverse Slice over the mel axis] -> [Transpose 0 2 1]
+    // -> Unsqueeze / Reshape to a rank-4 image
+    auto tail_ok = [&](std::string nm, int mel_ax) -> bool {
+        int npow = 0; bool logc = false;
+        for (int guard = 0; guard < 12; guard++) {
+            const ONode* u = only_user(nm);
+            float v;
+            if (!u || u->out.empty()) return false;
+            if (u->op == "Pow" && npow < 2 && !logc && u->in.size() == 2 && u->in[0] == nm && scalar_const(u->in[1], &v)) { npow++; nm = u->out[0]; continue; }
+            if (u->op == "Mul" && npow == 0 && !logc && u->in.size() == 2 && u->in[0] == nm && u->in[1] == nm) { npow = 1; nm = u->out[0]; continue; }
+            if (u->op == "Max" && npow == 0 && !logc && u->in.size() == 2 && u->in[0] == nm && scalar_const(u->in[1], &v) && v > 0.f) {
+                const ONode* lg = only_user(u->out[0]);
+                if (!lg || lg->op != "Log") return false;
+                logc = true; nm = lg->out[0];
+                const ONode* mu = only_user(nm);
+                if (mu && mu->op == "Mul" && mu->in.size() == 2 && mu->in[0] == nm && scalar_const(mu->in[1], &v)) nm = mu->out[0];
+                continue;
+            }
+            if (u->op == "Slice" && u->in.size() >= 5) {
+                std::vector<int64_t> st, en, ax, sp;
+                if (!const_i(u->in[1], &st) || !const_i(u->in[2], &en) || !const_i(u->in[3], &ax) || !const_i(u->in[4], &sp)) return false;
+                if (st.size() != 1 || sp[0] != -1 || st[0] != -1 || (ax[0] != mel_ax && ax[0] != mel_ax - 3)) return false;
+                nm = u->out[0];
+                u = only_user(nm);
+                if (!u) return false;
+            }
+            if (u->op == "Transpose") {
+                const OAttr* pa = u->attr("perm");
+                if (!pa || pa->ints != std::vector<int64_t>{0, 2, 1}) return false;
+                nm = u->out[0];
+                u = only_user(nm);
+                if (!u) return false;
+            }
+            return u->op == "Unsqueeze" || u->op == "Reshape";
+        }
+        return false;
+    };
+    // IR side: is `t` ([1, F, Lfft]) produced by [PAD of the last axis] <- MUL(constant window) <- RESHAPE <- GATHER(constant
+    // sliding-window selector), the framing the engine's recogniser walks?
+    auto frames_canonical = [&](int t) -> bool {
+        std::vector<int> prod(m.tensors.size(), -1);
+        for (size_t oi = 0; oi < m.ops.size(); oi++) for (int o : m.ops[oi].outputs) prod[o] = (int)oi;
+        auto skip = [&](int x) { while (prod[x] >= 0 && m.ops[prod[x]].code == OP_RESHAPE) x = m.ops[prod[x]].inputs[0]; return x; };
+        t = skip(t);
+        if (prod[t] >= 0 && m.ops[prod[t]].code == OP_PAD) t = skip(m.ops[prod[t]].inputs[0]);
+        if (prod[t] >= 0 && m.ops[prod[t]].code == OP_MUL) {
+            const TflOp& mu = m.ops[prod[t]];
+            const int wc = m.tensors[mu.inputs[1]].data ? 1 : (m.tensors[mu.inputs[0]].data ? 0 : -1);
+            if (wc < 0) return false;
+            t = skip(mu.inputs[1 - wc]);
+        }
+        return prod[t] >= 0 && m.ops[prod[t]].code == OP_GATHER && m.tensors[m.ops[prod[t]].inputs[1]].data != nullptr;
+    };
+    // framing of a [1, T] signal into windowed, zero-padded frames [1, F, Lfft], written the way tf.signal.frame converts
+    auto emit_frames = [&](int sig, int T, int L, int hop, int Lfft, const std::vector<float>& window, const std::string& base, int* F_out) -> int {
+        const int F = (T - L) / hop + 1;
+        int sub = igcd_(igcd_(L, hop), T);
+        const int nsub = T / sub, Q = L / sub, step = hop / sub;
+        const int r1 = new_t(base + "/subframes", {1, nsub, sub}, TT_FLOAT32);
+        add_op(OP_RESHAPE, {sig}, r1).new_shape = {1, nsub, sub};
+        std::vector<int32_t> sel((size_t)F * Q);
+        for (int f = 0; f < F; f++) for (int q = 0; q < Q; q++) sel[(size_t)f * Q + q] = f * step + q;
+        const int ga = new_t(base + "/gather", {1, F, Q, sub}, TT_FLOAT32);
+        { TflOp& g = add_op(OP_GATHER, {r1, m.add_const_i32(base + "/frame_selector", {F, Q}, sel)}, ga); g.axis = 1; g.batch_dims = 0; }
+        const int fr = new_t(base + "/frames", {1, F, L}, TT_FLOAT32);
+        add_op(OP_RESHAPE, {ga}, fr).new_shape = {1, F, L};
+        int wn = new_t(base + "/windowed", {1, F, L}, TT_FLOAT32);
+        add_op(OP_MUL, {fr, m.add_const_f32(base + "/window", {L}, window)}, wn);
+        if (Lfft != L) {
+            const int pd = new_t(base + "/padded", {1, F, Lfft}, TT_FLOAT32);
+            add_op(OP_PAD, {wn, m.add_const_i32(base + "/frame_pad", {3, 2}, {0, 0, 0, 0, 0, Lfft - L})}, pd);
+            wn = pd;
+        }
+        *F_out = F;
+        return wn;
+    };
+    std::function<bool(const ONode&, bool)> lower_node;
+    // materialise symbolic inputs: lower, literally, every node that was skipped to keep them symbolic
+    auto materialise = [&](const std::string& nm) -> bool {
+        auto it = spec_pending.find(nm);
+        if (it == spec_pending.end()) return true;
+        std::vector<int> todo = it->second;
+        std::sort(todo.begin(), todo.end());
+        todo.erase(std::unique(todo.begin(), todo.end()), todo.end());
+        for (int ni : todo) {
+            if (lowered.count(ni)) continue;
+            lowered.insert(ni);
+            for (auto& o : nodes[ni].out) { spec.erase(o); }
+            if (!lower_node(nodes[ni], false)) return false;
+        }
+        for (int ni : todo) for (auto& o : nodes[ni].out) spec_pending.erase(o);
+        return true;
+    };
+    auto make_spec = [&](const ONode& nd, int ni, const SpecH& h, std::initializer_list<std::string> from) {
+        spec[nd.out[0]] = h;
+        std::vector<int> pend;
+        for (auto& f : from) { auto it = spec_pending.find(f); if (it != spec_pending.end()) pend.insert(pend.end(), it->second.begin(), it->second.end()); }
+        pend.push_back(ni);
+        spec_pending[nd.out[0]] = pend;
+    };
+    // RFFT2D chain + mel projection for a real-part / magnitude spectrum; returns the [1, F, n_mels] tensor
+    auto emit_fused = [&](const SpecH& h, const std::vector<float>& mel_km /*[K][n_mels]*/, int n_mels, const std::string& base) -> int {
+        const int nb = h.Lfft / 2 + 1;
+        const int e1 = new_t(base + "/fft_in", {1, h.F, 1, h.Lfft}, TT_FLOAT32);
+        add_op(OP_RESHAPE, {h.frames}, e1).new_shape = {1, h.F, 1, h.Lfft};
+        const int ft = new_t(base + "/rfft", {1, h.F, 1, nb}, TT_COMPLEX64);
+        add_op(OP_RFFT2D, {e1, m.add_const_i32(base + "/fft_length", {2}, {1, h.Lfft})}, ft);
+        const int sq = new_t(base + "/bins_c", {1, h.F, nb}, TT_COMPLEX64);
+        add_op(OP_RESHAPE, {ft}, sq).new_shape = {1, h.F, nb};
+        const int re = new_t(base + (h.part == 5 ? "/magnitude" : "/real"), {1, h.F, nb}, TT_FLOAT32);
+        if (h.part == 5) add_op(OP_COMPLEX_ABS, {sq}, re);
+        else { TflOp& c = add_op(OP_CAST, {sq}, re); c.in_type = TT_COMPLEX64; c.out_type = TT_FLOAT32; }
+        const int r2 = new_t(base + "/bins2d", {h.F, nb}, TT_FLOAT32);
+        add_op(OP_RESHAPE, {re}, r2).new_shape = {h.F, nb};
+        std::vector<float> wfull((size_t)n_mels * nb, 0.f);               // [n_mels][nb]: the file's columns scattered to their bins
+        for (size_t j = 0; j < h.bins.size(); j++)
+            for (int mm = 0; mm < n_mels; mm++) wfull[(size_t)mm * nb + h.bins[j]] += mel_km[j * (size_t)n_mels + mm];
+        const int mm2 = new_t(base + "/mel2d", {h.F, n_mels}, TT_FLOAT32);
+        add_op(OP_FULLY_CONNECTED, {r2, m.add_const_f32(base + "/mel", {n_mels, nb}, wfull), -1}, mm2);
+        const int r3 = new_t(base + "/mel", {1, h.F, n_mels}, TT_FLOAT32);
+        add_op(OP_RESHAPE, {mm2}, r3).new_shape = {1, h.F, n_mels};
+        return r3;
+    };
+    int node_index = -1;
+    // Recognised producers / consumers of symbolic spectra.  Returns 1: the node is handled (its output is symbolic or was
+    // emitted in fused form); 0: lower it literally (symbolic inputs have been materialised); -1: error (err set).
+    auto try_symbolic = [&](const ONode& nd, int ni) -> int {
+        if (nd.out.empty()) return 0;
+        const std::string& oname = nd.out[0];
+        auto act_of = [&](const std::string& nm) -> int { auto it = tid.find(nm); return it == tid.end() || m.tensors[it->second].data ? -1 : it->second; };
+        auto H = [&](size_t k) -> const SpecH* { if (k >= nd.in.size()) return nullptr; auto it = spec.find(nd.in[k]); return it == spec.end() ? nullptr : &it->second; };
+        bool any = false;
+        for (auto& nm : nd.in) if (spec.count(nm)) any = true;
+        // ---- producers
+        if (!any && nd.op == "MatMul" && nd.in.size() == 2) {
+            const int a = act_of(nd.in[0]);
+            std::vector<float> B; std::vector<int64_t> bd;
+            if (a >= 0 && !chl.count(a) && !tr3.count(a) && m.tensors[a].shape.size() == 3 && const_f(nd.in[1], &B, &bd) && bd.size() == 2 &&
+                bd[0] == m.tensors[a].shape[2] && bd[0] >= 64 && frames_canonical(a)) {
+                SpecH h; int kind = 0;
+                if (dft_columns(B, (int)bd[0], (int)bd[1], &kind, &h.bins)) {
+                    h.frames = a; h.Lfft = (int)bd[0]; h.F = m.tensors[a].shape[1]; h.part = kind;
+                    make_spec(nd, ni, h, {});
+                    return 1;
+                }
+            }
+            return 0;
+        }
+        if (!any && nd.op == "Conv" && nd.in.size() == 2) {
+            const int a = act_of(nd.in[0]);
+            std::vector<float> Wv; std::vector<int64_t> wd;
+            if (a >= 0 && !chl.count(a) && m.tensors[a].shape.size() == 3 && !tr3.count(a) && m.tensors[a].shape[1] == 1 && const_f(nd.in[1], &Wv, &wd) &&
+                wd.size() == 3 && wd[1] == 1 && nd.ai("group", 1) == 1) {
+                const OAttr* st = nd.attr("strides"); const OAttr* pd = nd.attr("pads"); const OAttr* dl = nd.attr("dilations"); const OAttr* ap = nd.attr("auto_pad");
+                const int hop = st && st->ints.size() == 1 ? (int)st->ints[0] : 1;
+                bool plain = (!pd || (pd->ints.size() == 2 && pd->ints[0] == 0 && pd->ints[1] == 0)) && (!dl || (dl->ints.size() == 1 && dl->ints[0] == 1)) &&
+                             (!ap || ap->s.empty() || ap->s == "NOTSET" || ap->s == "VALID");
+                SpecH h; std::vector<float> window; int Nfft = 0;
+                const int T = m.tensors[a].shape[2], L = (int)wd[2];
+                if (plain && hop >= 1 && L <= T && dft_conv_rows(Wv, (int)wd[0], L, &window, &Nfft, &h.bins)) {
+                    const int sig = new_t(oname + "/signal", {1, T}, TT_FLOAT32);
+                    add_op(OP_RESHAPE, {a}, sig).new_shape = {1, T};
+                    h.frames = emit_frames(sig, T, L, hop, Nfft, window, oname, &h.F);
+                    h.Lfft = Nfft; h.part = 6; h.bins_major = true;
+                    make_spec(nd, ni, h, {});
+                    return 1;
+                }
+            }
+            return 0;
+        }
+        if (!any && (nd.op == "STFT" || nd.op == "DFT")) {
+            const int a = act_of(nd.in[0]);
+            if (a < 0 || chl.count(a) || tr3.count(a)) return 0;
+            const auto ash = m.tensors[a].shape;
+            SpecH h; h.part = 7;
+            if (nd.op == "STFT") {
+                std::vector<int64_t> step, flen; std::vector<float> win;
+                if (nd.ai("onesided", 1) != 1 || nd.in.size() < 2 || !const_i(nd.in[1], &step) || step.size() != 1 || step[0] < 1) return 0;
+                const bool has_w = nd.in.size() > 2 && !nd.in[2].empty();
+                if (has_w && !const_f(nd.in[2], &win, nullptr)) return 0;
+                int L = has_w ? (int)win.size() : 0;
+                if (nd.in.size() > 3 && !nd.in[3].empty()) { if (!const_i(nd.in[3], &flen) || flen.size() != 1) return 0; if (has_w && flen[0] != L) return 0; L = (int)flen[0]; }
+                if (!has_w) win.assign(L, 1.0f);
+                const bool sig3 = ash.size() == 3 && ash[2] == 1;
+                if (!(sig3 || ash.size() == 2) || L < 8 || (L & 1)) return 0;
+                const int T = ash[1];
+                if (L > T) return 0;
+                const int sig = new_t(oname + "/signal", {1, T}, TT_FLOAT32);
+                add_op(OP_RESHAPE, {a}, sig).new_shape = {1, T};
+                h.frames = emit_frames(sig, T, L, (int)step[0], L, win, oname, &h.F);
+                h.Lfft = L;
+            } else {
+                if (nd.ai("onesided", 0) != 1 || nd.ai("inverse", 0) != 0 || ash.size() != 4 || ash[3] != 1) return 0;
+                int64_t ax = nd.ai("axis", 1); if (ax < 0) ax += 4;
+                if (ax != 2 || !frames_canonical(a)) return 0;
+                int n = ash[2], N = n;
+                if (nd.in.size() > 1 && !nd.in[1].empty()) { std::vector<int64_t> dl; if (!const_i(nd.in[1], &dl) || dl.size() != 1) return 0; N = (int)dl[0]; }
+                if (N < n || N < 8 || (N & 1)) return 0;
+                int fr = new_t(oname + "/frames", {1, ash[1], n}, TT_FLOAT32);
+                add_op(OP_RESHAPE, {a}, fr).new_shape = {1, ash[1], n};
+                if (N != n) {
+                    const int pd = new_t(oname + "/padded", {1, ash[1], N}, TT_FLOAT32);
+                    add_op(OP_PAD, {fr, m.add_const_i32(oname + "/frame_pad", {3, 2}, {0, 0, 0, 0, 0, N - n})}, pd);
+                    fr = pd;
+                }
+                h.frames = fr; h.Lfft = N; h.F = ash[1];
+            }
+            for (int k = 0; k <= h.Lfft / 2; k++) h.bins.push_back(k);
+            make_spec(nd, ni, h, {});
+            return 1;
+        }
+        if (!any) return 0;
+        // ---- consumers
+        const SpecH* h0 = H(0);
+        const SpecH* h1 = H(1);
+        auto derive = [&](SpecH h, int part, std::initializer_list<std::string> from) { h.part = part; make_spec(nd, ni, h, from); return 1; };
+        auto same_src = [&](const SpecH& x, const SpecH& y) { return x.frames == y.frames && x.bins == y.bins && x.bins_major == y.bins_major && x.last1 == y.last1; };
+        if (nd.op == "Slice" && h0 && (h0->part == 6 || h0->part == 7) && nd.in.size() >= 4) {
+            std::vector<int64_t> st, en, ax, sp;
+            if (const_i(nd.in[1], &st) && const_i(nd.in[2], &en) && const_i(nd.in[3], &ax) && st.size() == 1 && en.size() == 1 && ax.size() == 1 &&
+                (nd.in.size() < 5 || nd.in[4].empty() || (const_i(nd.in[4], &sp) && sp.size() == 1 && sp[0] == 1))) {
+                const int K = (int)h0->bins.size();
+                if (h0->part == 6 && ax[0] == 1 && ((st[0] == 0 && en[0] == K) || (st[0] == K && en[0] >= 2 * K)))
+                    return derive(*h0, st[0] == 0 ? 0 : 1, {nd.in[0]});
+                if (h0->part == 7 && (ax[0] == 3 || ax[0] == -1) && ((st[0] == 0 && en[0] == 1) || (st[0] == 1 && en[0] >= 2))) {
+                    SpecH h = *h0; h.last1 = true;
+                    return derive(h, st[0] == 0 ? 0 : 1, {nd.in[0]});
+                }
+            }
+        } else if (nd.op == "Squeeze" && h0 && h0->last1 && (h0->part == 0 || h0->part == 1)) {
+            std::vector<int64_t> axes;
+            if (const OAttr* pa = nd.attr("axes")) axes = pa->ints; else if (nd.in.size() > 1) const_i(nd.in[1], &axes);
+            if (axes.size() == 1 && (axes[0] == 3 || axes[0] == -1)) { SpecH h = *h0; h.last1 = false; return derive(h, h0->part, {nd.in[0]}); }
+        } else if (nd.op == "Gather" && h0 && h0->part == 7 && nd.in.size() == 2) {
+            std::vector<int64_t> idx; auto it = inits.find(nd.in[1]);
+            const int64_t ax = nd.ai("axis", 0);
+            if (it != inits.end() && it->second.dims.empty() && tensor_ints(it->second, &idx) && idx.size() == 1 && (ax == 3 || ax == -1) && (idx[0] == 0 || idx[0] == 1))
+                return derive(*h0, (int)idx[0], {nd.in[0]});
+        } else if (nd.op == "Mul" && h0 && h1 && nd.in[0] == nd.in[1] && !h0->last1) {
+            if (h0->part == 0 || h0->part == 1) return derive(*h0, h0->part + 2, {nd.in[0]});
+            if (h0->part == 7) return derive(*h0, 8, {nd.in[0]});
+        } else if (nd.op == "Pow" && h0 && !h1 && !h0->last1 && nd.in.size() == 2) {
+            float e;
+            if (scalar_const(nd.in[1], &e) && e == 2.0f) {
+                if (h0->part == 0 || h0->part == 1) return derive(*h0, h0->part + 2, {nd.in[0]});
+                if (h0->part == 7) return derive(*h0, 8, {nd.in[0]});
+            }
+        } else if (nd.op == "Add" && h0 && h1 && same_src(*h0, *h1) && ((h0->part == 2 && h1->part == 3) || (h0->part == 3 && h1->part == 2))) {
+            return derive(*h0, 4, {nd.in[0], nd.in[1]});
+        } else if (nd.op == "ReduceSum" && h0 && h0->part == 8) {
+            std::vector<int64_t> axes;
+            if (const OAttr* pa = nd.attr("axes")) axes = pa->ints; else if (nd.in.size() > 1 && !nd.in[1].empty()) const_i(nd.in[1], &axes);
+            if (axes.size() == 1 && (axes[0] == 3 || axes[0] == -1) && nd.ai("keepdims", 1) == 0) return derive(*h0, 4, {nd.in[0]});
+        } else if (nd.op == "Sqrt" && h0 && h0->part == 4) {
+            return derive(*h0, 5, {nd.in[0]});
+        } else if (nd.op == "MatMul" && nd.in.size() == 2) {
+            // the mel projection: [N, F, K] x [K, M]  or  [M, K] x [N, K, F]
+            const SpecH* h = h0 && !h0->bins_major ? h0 : (h1 && h1->bins_major ? h1 : nullptr);
+            const std::string& cname = h == h0 ? nd.in[1] : nd.in[0];
+            std::vector<float> Mv; std::vector<int64_t> md;
+            if (h && !h->last1 && (h->part == 0 || h->part == 5) && const_f(cname, &Mv, &md) && md.size() == 2) {
+                const int K = (int)h->bins.size();
+                const bool left = h != h0;                            // constant on the left: [M, K]
+                const int n_mels = (int)(left ? md[0] : md[1]);
+                if ((left ? md[1] : md[0]) == K && tail_ok(oname, left ? 1 : 2)) {
+                    std::vector<float> km((size_t)K * n_mels);
+                    for (int k = 0; k < K; k++) for (int mm = 0; mm < n_mels; mm++) km[(size_t)k * n_mels + mm] = left ? Mv[(size_t)mm * K + k] : Mv[(size_t)k * n_mels + mm];
+                    const SpecH hc = *h;
+                    const int r3 = emit_fused(hc, km, n_mels, oname);
+                    tid[oname] = r3;
+                    if (hc.bins_major) tr3.insert(r3);
+                    return 1;
+                }
+            }
+        }
+        // unrecognised use: the literal graph
+        for (auto& nm : nd.in) if (spec.count(nm) && !materialise(nm)) return -1;
+        return 0;
+    };
+    lower_node = [&](const ONode& nd, bool sym) -> bool {
         const std::string where = nd.op + " (" + (nd.name.empty() ? (nd.out.empty() ? "?" : nd.out[0]) : nd.name) + ")";
         if (!nd.domain.empty() && nd.domain != "ai.onnx") return fail("ONNX: operator from unsupported domain " + nd.domain + ": " + where);
-        if (nd.op == "Constant") continue;
+        if (nd.op == "Constant") return true;
+        if (sym) {
+            const int r = try_symbolic(nd, node_index);
+            if (r < 0) return false;
+            if (r == 1) return true;
+        }
         if (nd.out.empty() || nd.in.empty()) { *code = BNHIP_E_MODEL; return fail("ONNX: node without inputs/outputs: " + where); }
+        {
+            // ops that understand the lazy [N, K, F] <-> [1, F, K] tag; everything else gets the plain tensor
+            static const std::set<std::string> tr3_aware = {"Add", "Sub", "Mul", "Div", "Pow", "Max", "Min", "Relu", "Sigmoid", "Tanh", "Exp", "Log", "Sqrt",
+                "Abs", "Neg", "Floor", "Ceil", "HardSwish", "LeakyRelu", "Elu", "Gelu", "Sin", "Cos", "Identity", "Dropout", "Cast", "Slice", "Transpose", "MatMul", "Conv"};
+            if (!tr3_aware.count(nd.op))
+                for (auto& nm : nd.in) { auto it = tid.find(nm); if (it != tid.end() && tr3.count(it->second)) it->second = untr3(it->second); }
+        }
         const std::string& oname = nd.out[0];
         auto in_act = [&](size_t k) -> int { if (k >= nd.in.size()) return -1; auto it = tid.find(nd.in[k]); return it == tid.end() || m.tensors[it->second].data ? -1 : it->second; };
-        if (nd.op == "Gemm" || nd.op == "MatMul") {
+        if (nd.op == "MatMul" && nd.in.size() == 2 && in_act(0) < 0 && in_act(1) >= 0 && m.tensors[in_act(1)].shape.size() == 3 && !chl.count(in_act(1))) {
+            // [M, K] x [N, K, F] (the mel projection of a bins-major spectrogram): a dense layer over the K axis of the [1, F, K] form
+            std::vector<float> A; std::vector<int64_t> ad;
+            if (!const_f(nd.in[0], &A, &ad) || ad.size() != 2) return fail("ONNX: " + where + ": first operand must be a constant matrix or an activation");
+            const int x = as_tr3(in_act(1));
+            const auto xs = m.tensors[x].shape;               // [1, F, K]
+            if (xs[2] != (int)ad[1]) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": inner dimensions disagree"); }
+            const int o = new_act(oname, {1, xs[1], (int)ad[0]});
+            add_op(OP_FULLY_CONNECTED, {x, m.add_const_f32(nd.in[0] + "/w", {(int)ad[0], (int)ad[1]}, A)}, o).keep_num_dims = true;
+            tr3.insert(o);
+        } else if (nd.op == "Gemm" || nd.op == "MatMul") {
             int a = in_act(0);
+            if (a >= 0) a = untr3(a);
             if (a < 0 || nd.in.size() < 2) return fail("ONNX: " + where + ": first operand must be an activation");
             a = to_nchw(a);
             std::vector<float> B; std::vector<int64_t> bd;
@@ -475,6 +920,13 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
                 if (a == -2 || b == -2) return fail("ONNX: " + where + ": an image and a non-image activation cannot be combined");
             } else { a = operand(nd.in[0]); b = operand(nd.in[1]); }
             if (a < 0 || b < 0) return fail("ONNX: " + where + ": operand is neither an activation nor a float constant");
+            bool out_tr3 = false;
+            if (tr3.count(a) || tr3.count(b)) {
+                // the tag survives arithmetic with a scalar or with another tagged value of the same shape
+                auto scalar = [&](int t) { return m.tensors[t].data != nullptr && m.tensors[t].numel() == 1; };
+                if ((tr3.count(a) && tr3.count(b) && m.tensors[a].shape == m.tensors[b].shape) || (tr3.count(a) && scalar(b)) || (tr3.count(b) && scalar(a))) out_tr3 = true;
+                else { a = untr3(a); b = untr3(b); }
+            }
             std::vector<int> z;
             if (!bshape(m.tensors[a].shape, m.tensors[b].shape, &z)) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": shapes do not broadcast"); }
             const int opc = nd.op == "Add" ? OP_ADD : nd.op == "Sub" ? OP_SUB : nd.op == "Mul" ? OP_MUL : nd.op == "Div" ? OP_DIV :
@@ -482,6 +934,7 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
             const int zo = new_act(oname, z);
             add_op(opc, {a, b}, zo);
             if (img) chl.insert(zo);
+            if (out_tr3) tr3.insert(zo);
         } else if (nd.op == "Relu" || nd.op == "Sigmoid" || nd.op == "Tanh" || nd.op == "Exp" || nd.op == "Log" || nd.op == "Sqrt" ||
                    nd.op == "Abs" || nd.op == "Neg" || nd.op == "Floor" || nd.op == "Ceil" || nd.op == "HardSwish" || nd.op == "LeakyRelu" ||
                    nd.op == "Elu" || nd.op == "Gelu" || nd.op == "Sin" || nd.op == "Cos") {
@@ -494,6 +947,7 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
             if (nd.op == "Elu" && nd.af("alpha", 1.0f) != 1.0f) return fail("ONNX: " + where + ": alpha != 1 is not supported");
             const int uo = new_act(oname, m.tensors[a].shape);
             if (chl.count(a)) chl.insert(uo);
+            if (tr3.count(a)) tr3.insert(uo);
             TflOp& o = add_op(opc, {a}, uo);
             if (nd.op == "LeakyRelu") o.alpha = nd.af("alpha", 0.01f);
             if (nd.op == "Gelu") { const OAttr* ap = nd.attr("approximate"); o.approximate = ap && ap->s == "tanh"; }
@@ -603,6 +1057,13 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
             std::vector<int> ins;
             bool cimg = false;
             for (size_t k = 0; k < nd.in.size(); k++) { int t = in_act(k); if (t >= 0 && chl.count(t)) cimg = true; }
+            if (!cimg) {
+                // one-channel planes [N, 1, H, W] stacked along the channel axis (the spectrogram branches of an audio front-end):
+                // each is its own channels-last form already, so the stack is built channels-last
+                bool planes = nd.ai("axis", 1) == 1 && nd.in.size() >= 2;
+                for (size_t k = 0; k < nd.in.size() && planes; k++) { int t = in_act(k); planes = t >= 0 && m.tensors[t].shape.size() == 4 && m.tensors[t].shape[1] == 1; }
+                cimg = planes;
+            }
             for (size_t k = 0; k < nd.in.size(); k++) {
                 int t = cimg ? in_act(k) : operand(nd.in[k]);
                 if (t < 0) return fail("ONNX: " + where + (cimg ? ": every operand of an image concatenation must be an activation" : ": operand has no value"));
@@ -620,24 +1081,44 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
             if (cimg) chl.insert(co);
         } else if (nd.op == "Conv") {
             int a = in_act(0);
-            if (a < 0 || nd.in.size() < 2 || m.tensors[a].shape.size() != 4) return fail("ONNX: " + where + ": input must be a rank-4 activation (2-D convolution)");
-            a = to_chl(a);
+            if (a < 0 || nd.in.size() < 2 || (m.tensors[a].shape.size() != 4 && m.tensors[a].shape.size() != 3))
+                return fail("ONNX: " + where + ": input must be a rank-3 or rank-4 activation (1-D / 2-D convolution)");
+            // Conv1d ([N, C, T], weights [M, C/group, k]): the 2-D operator with a unit height - the clip becomes the channels-last
+            // image [1, 1, T, C] (the same memory as the [1, T, C] form), the attributes gain a leading 1 / 0
+            const bool c1d = m.tensors[a].shape.size() == 3;
+            ONode nd1;
+            if (c1d) {
+                if (tr3.count(a) == 0 && chl.count(a)) return fail("ONNX: " + where + ": unexpected image operand");
+                const int x3 = as_tr3(a);                     // [1, T, C]
+                const auto xs = m.tensors[x3].shape;
+                const int x4 = new_t(m.tensors[x3].name + "/h1_" + std::to_string(tmp_id++), {1, 1, xs[1], xs[2]}, TT_FLOAT32);
+                add_op(OP_RESHAPE, {x3}, x4).new_shape = {1, 1, xs[1], xs[2]};
+                chl.insert(x4);
+                a = x4;
+                nd1 = nd;
+                for (auto& at : nd1.attrs) {
+                    if ((at.name == "strides" || at.name == "dilations" || at.name == "kernel_shape") && at.ints.size() == 1) at.ints.insert(at.ints.begin(), 1);
+                    else if (at.name == "pads" && at.ints.size() == 2) at.ints = {0, at.ints[0], 0, at.ints[1]};
+                }
+            } else a = to_chl(a);
+            const ONode& cn = c1d ? nd1 : nd;
             const auto ish = m.tensors[a].shape;              // [1, H, W, C]
             std::vector<float> Wv; std::vector<int64_t> wd;
-            if (!const_f(nd.in[1], &Wv, &wd) || wd.size() != 4) return fail("ONNX: " + where + ": weights must be a constant [M, C/group, kh, kw] tensor");
+            if (!const_f(nd.in[1], &Wv, &wd) || wd.size() != (c1d ? 3u : 4u)) return fail("ONNX: " + where + ": weights must be a constant [M, C/group, kh, kw] tensor");
+            if (c1d) wd.insert(wd.begin() + 2, 1);
             const int M = (int)wd[0], Cg = (int)wd[1], kh = (int)wd[2], kw = (int)wd[3], C = ish[3];
             const int64_t group = nd.ai("group", 1);
             auto two = [&](const char* key, int dflt, int* x, int* y) -> bool {
                 *x = *y = dflt;
-                if (const OAttr* p = nd.attr(key)) { if (p->ints.size() != 2) return false; *x = (int)p->ints[0]; *y = (int)p->ints[1]; }
+                if (const OAttr* p = cn.attr(key)) { if (p->ints.size() != 2) return false; *x = (int)p->ints[0]; *y = (int)p->ints[1]; }
                 return *x >= 1 && *y >= 1;
             };
             int sh_, sw_, dh, dw;
             if (!two("strides", 1, &sh_, &sw_) || !two("dilations", 1, &dh, &dw)) return fail("ONNX: " + where + ": strides / dilations must have two positive entries");
-            if (const OAttr* p = nd.attr("kernel_shape")) if (p->ints.size() != 2 || p->ints[0] != kh || p->ints[1] != kw) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": kernel_shape disagrees with the weights"); }
+            if (const OAttr* p = cn.attr("kernel_shape")) if (p->ints.size() != 2 || p->ints[0] != kh || p->ints[1] != kw) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": kernel_shape disagrees with the weights"); }
             if (M < 1 || kh < 1 || kw < 1 || group < 1 || (int64_t)Cg * group != C || M % group) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": weight shape disagrees with the input channels / group"); }
             int Ho, Wo, pt, pl; std::string why;
-            if (!window_geom(nd, ish[1], ish[2], kh, kw, sh_, sw_, dh, dw, &Ho, &Wo, &pt, &pl, &why)) return fail("ONNX: " + where + ": " + why);
+            if (!window_geom(cn, ish[1], ish[2], kh, kw, sh_, sw_, dh, dw, &Ho, &Wo, &pt, &pl, &why)) return fail("ONNX: " + where + ": " + why);
             std::vector<int> ins = {a};
             int opc;
             int mult = 1;
@@ -659,7 +1140,7 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
                 if (!const_f(nd.in[2], &bv, nullptr) || (int)bv.size() != M) return fail("ONNX: " + where + ": bias must be a constant [M] tensor");
                 ins.push_back(m.add_const_f32(nd.in[2] + "/b", {M}, bv));
             }
-            const int co = new_act(oname, {1, Ho, Wo, M});
+            const int co = c1d ? new_t(oname + "/h1", {1, Ho, Wo, M}, TT_FLOAT32) : new_act(oname, {1, Ho, Wo, M});
             TflOp& o = add_op(opc, ins, co);
             o.stride_h = sh_; o.stride_w = sw_; o.dil_h = dh; o.dil_w = dw; o.depth_multiplier = mult;
             // padding: VALID / TF-SAME where the pads say exactly that (the planner's fused patterns key on them), explicit otherwise
@@ -672,6 +1153,11 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
                 o.pad_b = std::max((Ho - 1) * sh_ + dh * (kh - 1) + 1 - ish[1] - pt, 0); o.pad_r = std::max((Wo - 1) * sw_ + dw * (kw - 1) + 1 - ish[2] - pl, 0);
             }
             chl.insert(co);
+            if (c1d) {                                        // [1, 1, Wo, M] is the [1, Wo, M] form of the ONNX value [N, M, Wo]
+                const int r = new_act(oname, {1, Wo, M});
+                add_op(OP_RESHAPE, {co}, r).new_shape = {1, Wo, M};
+                tr3.insert(r);
+            }
         } else if (nd.op == "GlobalAveragePool" || nd.op == "ReduceMean") {
             int a = in_act(0);
             if (a < 0) return fail("ONNX: " + where + ": operand must be an activation");
@@ -736,6 +1222,12 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
                     seen[pk] = 1;
                 }
             }
+            if (tr3.count(a) && perm == std::vector<int64_t>{0, 2, 1}) {
+                // [N, K, F] -> [N, F, K]: exactly the tensor the tag stands on
+                const int t = new_act(oname, m.tensors[a].shape);
+                add_op(OP_RESHAPE, {a}, t).new_shape = m.tensors[a].shape;
+                return true;
+            }
             const bool to_cf = rank == 4 && perm == std::vector<int64_t>{0, 3, 1, 2};     // NHWC data -> NCHW value
             const bool to_cl = rank == 4 && perm == std::vector<int64_t>{0, 2, 3, 1};     // NCHW value -> NHWC data
             if (to_cf && !chl.count(a)) {
@@ -748,7 +1240,7 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
                 const int t = new_act(oname, m.tensors[a].shape);
                 add_op(OP_RESHAPE, {a}, t).new_shape = m.tensors[a].shape;
             } else {
-                const int src = to_nchw(a);
+                const int src = to_nchw(untr3(a));
                 std::vector<int> osh; std::vector<int32_t> p32;
                 for (auto pk : perm) { if (pk < 0 || pk >= rank) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": bad permutation"); } osh.push_back(m.tensors[src].shape[pk]); p32.push_back((int32_t)pk); }
                 if (perm[0] != 0) return fail("ONNX: " + where + ": the batch axis cannot move");
@@ -788,14 +1280,167 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
             const int po = new_act(oname, osh);
             add_op(OP_PAD, {a, m.add_const_i32(oname + "/pads", {rank, 2}, pv)}, po);
             if (img) chl.insert(po);
+        } else if (nd.op == "ReduceMin" || nd.op == "ReduceMax" || nd.op == "ReduceSum") {
+            int a = in_act(0);
+            if (a < 0) return fail("ONNX: " + where + ": operand must be an activation");
+            a = to_nchw(a);
+            const int rank = (int)m.tensors[a].shape.size();
+            std::vector<int64_t> axes;
+            if (const OAttr* pa = nd.attr("axes")) axes = pa->ints;
+            else if (nd.in.size() > 1 && !nd.in[1].empty()) { if (!const_i(nd.in[1], &axes)) return fail("ONNX: " + where + ": axes must be constant"); }
+            else return fail("ONNX: " + where + ": reduction over all axes is not supported");
+            const bool keep = nd.ai("keepdims", 1) != 0;
+            std::vector<int32_t> ax32; std::vector<char> red(rank, 0);
+            for (auto ax : axes) { if (ax < 0) ax += rank; if (ax < 1 || ax >= rank || red[ax]) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": bad reduction axis"); } red[ax] = 1; ax32.push_back((int32_t)ax); }
+            std::sort(ax32.begin(), ax32.end());
+            std::vector<int> osh;
+            for (int k = 0; k < rank; k++) { if (red[k]) { if (keep) osh.push_back(1); } else osh.push_back(m.tensors[a].shape[k]); }
+            const int ro = new_act(oname, osh);
+            add_op(nd.op == "ReduceMin" ? OP_REDUCE_MIN : nd.op == "ReduceMax" ? OP_REDUCE_MAX : OP_SUM, {a, m.add_const_i32(oname + "/axes", {(int)ax32.size()}, ax32)}, ro).keep_dims = keep;
+        } else if (nd.op == "Gather") {
+            int a = in_act(0);
+            if (a < 0 || nd.in.size() < 2) return fail("ONNX: " + where + ": data must be an activation");
+            a = to_nchw(a);
+            auto it = inits.find(nd.in[1]);
+            std::vector<int64_t> idx;
+            if (it == inits.end() || !tensor_ints(it->second, &idx)) return fail("ONNX: " + where + ": indices must be a constant integer tensor");
+            const auto ish = m.tensors[a].shape;
+            const int rank = (int)ish.size();
+            int64_t ax = nd.ai("axis", 0); if (ax < 0) ax += rank;
+            if (ax < 1 || ax >= rank) return fail("ONNX: " + where + ": axis out of range (the batch axis cannot be gathered)");
+            std::vector<int32_t> i32v;
+            for (auto v : idx) { if (v < 0) v += ish[ax]; if (v < 0 || v >= ish[ax]) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": index out of range"); } i32v.push_back((int32_t)v); }
+            std::vector<int> idims; for (auto dv : it->second.dims) idims.push_back((int)dv);
+            std::vector<int> osh(ish.begin(), ish.begin() + ax);
+            osh.insert(osh.end(), idims.begin(), idims.end());
+            osh.insert(osh.end(), ish.begin() + ax + 1, ish.end());
+            if (idims.empty()) {                              // scalar index: the axis disappears
+                std::vector<int> gsh(ish.begin(), ish.begin() + ax); gsh.push_back(1); gsh.insert(gsh.end(), ish.begin() + ax + 1, ish.end());
+                const int g1 = new_act(oname + "/g", gsh);
+                { TflOp& g = add_op(OP_GATHER, {a, m.add_const_i32(oname + "/idx", {1}, i32v)}, g1); g.axis = (int)ax; g.batch_dims = 0; }
+                add_op(OP_RESHAPE, {g1}, new_act(oname, osh)).new_shape = osh;
+            } else {
+                TflOp& g = add_op(OP_GATHER, {a, m.add_const_i32(oname + "/idx", idims, i32v)}, new_act(oname, osh)); g.axis = (int)ax; g.batch_dims = 0;
+            }
+        } else if (nd.op == "Slice") {
+            int a = in_act(0);
+            if (a < 0 || nd.in.size() < 3) return fail("ONNX: " + where + ": data must be an activation (opset >= 10 form)");
+            const bool t3 = tr3.count(a) != 0;
+            if (!t3) a = to_nchw(a);
+            const auto ish = m.tensors[a].shape;
+            const int rank = (int)ish.size();
+            std::vector<int64_t> st, en, axs, sp;
+            if (!const_i(nd.in[1], &st) || !const_i(nd.in[2], &en)) return fail("ONNX: " + where + ": starts / ends must be constant");
+            if (nd.in.size() > 3 && !nd.in[3].empty()) { if (!const_i(nd.in[3], &axs)) return fail("ONNX: " + where + ": axes must be constant"); }
+            else for (size_t k = 0; k < st.size(); k++) axs.push_back((int64_t)k);
+            if (nd.in.size() > 4 && !nd.in[4].empty()) { if (!const_i(nd.in[4], &sp)) return fail("ONNX: " + where + ": steps must be constant"); }
+            else sp.assign(st.size(), 1);
+            if (en.size() != st.size() || axs.size() != st.size() || sp.size() != st.size()) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": starts / ends / axes / steps disagree"); }
+            std::vector<int32_t> b(rank, 0), e(rank), s1(rank, 1);
+            std::vector<int> osh = ish;
+            for (int k = 0; k < rank; k++) e[k] = ish[k];
+            int rev_axis = -1; bool plain_rev = st.size() == 1;
+            for (size_t q = 0; q < st.size(); q++) {
+                int64_t ax = axs[q]; if (ax < 0) ax += rank;
+                if (ax < 1 || ax >= rank) return fail("ONNX: " + where + ": axis out of range (the batch axis cannot be sliced)");
+                if (t3) ax = ax == 1 ? 2 : 1;                 // ONNX [N, K, F] axis -> axis of the [1, F, K] tensor
+                const int64_t n = ish[ax], step = sp[q];
+                if (step == 0) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": step 0"); }
+                int64_t s0 = st[q], e0 = en[q];
+                if (step > 0) {
+                    s0 = std::min<int64_t>(std::max<int64_t>(s0 < 0 ? s0 + n : s0, 0), n); e0 = std::min<int64_t>(std::max<int64_t>(e0 < 0 ? e0 + n : e0, 0), n);
+                    osh[ax] = (int)std::max<int64_t>(0, (e0 - s0 + step - 1) / step);
+                    plain_rev = false;
+                } else {
+                    s0 = std::min<int64_t>(std::max<int64_t>(s0 < 0 ? s0 + n : s0, -1), n - 1); e0 = std::min<int64_t>(std::max<int64_t>(e0 < 0 ? e0 + n : e0, -1), n - 1);
+                    osh[ax] = (int)std::max<int64_t>(0, (s0 - e0 + (-step) - 1) / (-step));
+                    if (!(step == -1 && s0 == n - 1 && e0 == -1)) plain_rev = false; else rev_axis = (int)ax;
+                }
+                if (osh[ax] < 1) { *code = BNHIP_E_MODEL; return fail("ONNX: " + where + ": empty slice"); }
+                b[ax] = (int32_t)s0; e[ax] = (int32_t)e0; s1[ax] = (int32_t)step;
+            }
+            const int so = new_act(oname, osh);
+            if (plain_rev && rev_axis >= 0) {
+                add_op(OP_REVERSE_V2, {a, m.add_const_i32(oname + "/axis", {1}, {rev_axis})}, so);      // tf ReverseV2 arrives as Slice(step -1)
+            } else {
+                // negative-step ends of -1 mean "through element 0": expressed with the end mask
+                TflOp& o = add_op(OP_STRIDED_SLICE, {a, m.add_const_i32(oname + "/begin", {rank}, b), m.add_const_i32(oname + "/end", {rank}, e),
+                                                     m.add_const_i32(oname + "/strides", {rank}, s1)}, so);
+                for (int k = 0; k < rank; k++) if (s1[k] < 0 && e[k] < 0) o.end_mask |= 1 << k;
+            }
+            if (t3) tr3.insert(so);
+        } else if (nd.op == "STFT" || nd.op == "DFT") {
+            // literal form (no recognised use): framing + one dense layer against the [2K, L] basis, rows interleaved (re_k, im_k)
+            int a = in_act(0);
+            if (a < 0) return fail("ONNX: " + where + ": signal must be an activation");
+            const auto ash = m.tensors[a].shape;
+            int frames = -1, L = 0, F = 0;
+            if (nd.op == "STFT") {
+                std::vector<int64_t> step, flen; std::vector<float> win;
+                if (nd.ai("onesided", 1) != 1) return fail("ONNX: " + where + ": only the one-sided transform is supported");
+                if (nd.in.size() < 2 || !const_i(nd.in[1], &step) || step.size() != 1 || step[0] < 1) return fail("ONNX: " + where + ": frame_step must be a constant");
+                const bool has_w = nd.in.size() > 2 && !nd.in[2].empty();
+                if (has_w && !const_f(nd.in[2], &win, nullptr)) return fail("ONNX: " + where + ": window must be a constant");
+                L = has_w ? (int)win.size() : 0;
+                if (nd.in.size() > 3 && !nd.in[3].empty()) { if (!const_i(nd.in[3], &flen) || flen.size() != 1 || (has_w && flen[0] != L)) return fail("ONNX: " + where + ": frame_length must be a constant equal to the window length"); L = (int)flen[0]; }
+                if (!has_w) win.assign(L, 1.0f);
+                if (!((ash.size() == 3 && ash[2] == 1) || ash.size() == 2) || L < 2 || L > ash[1]) return fail("ONNX: " + where + ": signal must be [N, T, 1] with T >= frame_length");
+                const int sig = new_t(oname + "/signal", {1, ash[1]}, TT_FLOAT32);
+                add_op(OP_RESHAPE, {a}, sig).new_shape = {1, ash[1]};
+                frames = emit_frames(sig, ash[1], L, (int)step[0], L, win, oname, &F);
+            } else {
+                int64_t ax = nd.ai("axis", 1); if (ax < 0) ax += (int64_t)ash.size();
+                if (nd.ai("onesided", 0) != 1 || nd.ai("inverse", 0) != 0 || ash.size() != 4 || ash[3] != 1 || ax != 2) return fail("ONNX: " + where + ": only the forward one-sided transform of [N, F, n, 1] along axis 2 is supported");
+                L = ash[2]; F = ash[1];
+                if (nd.in.size() > 1 && !nd.in[1].empty()) { std::vector<int64_t> dl; if (!const_i(nd.in[1], &dl) || dl.size() != 1 || dl[0] < L) return fail("ONNX: " + where + ": dft_length must be a constant >= the axis length"); L = (int)dl[0]; }
+                frames = new_t(oname + "/frames", {1, F, ash[2]}, TT_FLOAT32);
+                add_op(OP_RESHAPE, {a}, frames).new_shape = {1, F, ash[2]};
+            }
+            const int K = L / 2 + 1, n_in = m.tensors[frames].shape[2];
+            if ((size_t)2 * K * n_in > ((size_t)1 << 27)) return fail("ONNX: " + where + ": transform too large for the dense form");
+            std::vector<float> W((size_t)2 * K * n_in);
+            for (int k = 0; k < K; k++)
+                for (int n = 0; n < n_in; n++) {
+                    const double ph = 2.0 * M_PI * (double)(((long)k * n) % L) / L;
+                    W[((size_t)2 * k) * n_in + n] = (float)std::cos(ph);
+                    W[((size_t)2 * k + 1) * n_in + n] = (float)-std::sin(ph);
+                }
+            const int y = new_t(oname + "/ri", {1, F, 2 * K}, TT_FLOAT32);
+            add_op(OP_FULLY_CONNECTED, {frames, m.add_const_f32(oname + "/basis", {2 * K, n_in}, W)}, y).keep_num_dims = true;
+            add_op(OP_RESHAPE, {y}, new_act(oname, {1, F, K, 2})).new_shape = {1, F, K, 2};
         } else {
             return fail("ONNX: unsupported operator " + where);
         }
+        return true;
+    };
+    for (size_t ni = 0; ni < nodes.size(); ni++) {
+        node_index = (int)ni;
+        if (lowered.count((int)ni)) continue;
+        if (!lower_node(nodes[ni], true)) return false;
     }
+    for (auto& vi : g_out) if (spec.count(vi.name) && !materialise(vi.name)) return false;
     for (auto& vi : g_out) {
         auto it = tid.find(vi.name);
         if (it == tid.end()) { *code = BNHIP_E_MODEL; return fail("ONNX: graph output is not produced by any node: " + vi.name); }
-        m.outputs.push_back(to_nchw(it->second));             // an image output leaves in the graph's own (NCHW) order
+        m.outputs.push_back(to_nchw(untr3(it->second)));      // an image output leaves in the graph's own (NCHW) order
+    }
+    // operators nothing reads (the framing emitted for a spectrum that ended up in its literal form, Constant-folded leftovers)
+    for (bool again = true; again;) {
+        again = false;
+        std::vector<int> uses(m.tensors.size(), 0);
+        for (auto& o : m.ops) if (o.code != OP_NOP) for (int t : o.inputs) if (t >= 0) uses[t]++;
+        for (int t : m.outputs) uses[t]++;
+        for (auto& o : m.ops) {
+            if (o.code == OP_NOP) continue;
+            bool used = false;
+            for (int t : o.outputs) if (uses[t]) used = true;
+            if (!used) { o.code = OP_NOP; again = true; }
+        }
+    }
+    {
+        std::vector<TflOp> live;
+        for (auto& o : m.ops) if (o.code != OP_NOP) live.push_back(std::move(o));
+        m.ops.swap(live);
     }
     *code = BNHIP_OK;
     return true;

@@ -141,7 +141,10 @@ def _same_out(n, s):
     return (n + s - 1) // s
 
 
-def build_model(cfg: SynthConfig = None) -> bytes:
+def build_model(cfg: SynthConfig = None, container="tflite", dft="matmul", trunc=True) -> bytes:
+    """container="tflite": the flatbuffer the reference's default backend loads; "onnx": the SAME graph and weights as an ONNX
+    file (NCHW body) with the audio front-end in one of the forms exporters emit (onnx_audio.py: dft = "matmul" - the
+    reference's "dfttrunc" files with trunc=True - "conv1d", "stft", "dft")."""
     cfg = cfg or SynthConfig()
     rng = np.random.default_rng(cfg.seed)
     g = GraphBuilder(description=f"{cfg.name} seed={cfg.seed} (synthetic weights)")
@@ -327,6 +330,9 @@ def build_model(cfg: SynthConfig = None) -> bytes:
         assert len(chans) == 1
         spec3 = g.op("RESHAPE", [chans[0], g.const(i32([1, F0, cfg.n_mels]))], [1, F0, cfg.n_mels], dict(new_shape=[1, F0, cfg.n_mels]))
         outs = [emb4, t, spec3, logits]
+    if container == "onnx":
+        from . import onnx_audio
+        return onnx_audio.transcribe(g, [x], outs, dft=dft, trunc=trunc)
     return g.finish([x], outs)
 
 

@@ -182,7 +182,16 @@ def _window_pads(at, H, W, kh, kw, sh, sw, dh, dw):
 
 
 def _conv(x, w, b, at, fdt):
-    """Conv (2-D, NCHW, OIHW weights, group 1 or depthwise-style groups): direct sum over the kernel window."""
+    """Conv (2-D, NCHW, OIHW weights, group 1 or depthwise-style groups): direct sum over the kernel window.
+    A rank-3 input (Conv1d, NCW) is the same operator with a unit height."""
+    if x.ndim == 3:
+        at2 = dict(at)
+        for k, d in (("strides", 1), ("dilations", 1), ("kernel_shape", 1)):
+            if at.get(k):
+                at2[k] = [d if k != "kernel_shape" else 1] + list(at[k])
+        if at.get("pads"):
+            at2["pads"] = [0, at["pads"][0], 0, at["pads"][1]]
+        return _conv(x[:, :, None, :], w[:, :, None, :], b, at2, fdt)[:, :, 0, :]
     N, C, H, W = x.shape
     M, Cg, kh, kw = w.shape
     g = int(at.get("group", 1))
@@ -312,6 +321,61 @@ def run(blob, x, precision="f32"):
             y = np.clip(np.asarray(at.get("alpha", 0.2), fdt) * a[0] + np.asarray(at.get("beta", 0.5), fdt), 0, 1)
         elif op == "HardSwish":
             y = a[0] * np.clip(a[0] / np.asarray(6.0, fdt) + np.asarray(0.5, fdt), 0, 1)
+        elif op == "Gather":                  # out = data.take(indices, axis): indices of any rank replace that axis
+            y = np.take(a[0], a[1].astype(np.int64), axis=int(at.get("axis", 0)))
+        elif op == "Slice":                   # opset >= 10: starts, ends, axes, steps as inputs
+            starts, ends = [int(v) for v in a[1]], [int(v) for v in a[2]]
+            axes = [int(v) for v in a[3]] if len(a) > 3 and a[3] is not None else list(range(len(starts)))
+            steps = [int(v) for v in a[4]] if len(a) > 4 and a[4] is not None else [1] * len(starts)
+            sl = [slice(None)] * a[0].ndim
+            for st, en, ax, sp in zip(starts, ends, axes, steps):
+                n = a[0].shape[ax]
+                if sp > 0:
+                    st = min(max(st + n if st < 0 else st, 0), n); en = min(max(en + n if en < 0 else en, 0), n)
+                    sl[ax] = slice(st, en, sp)
+                else:                         # negative step: clamp to [-1, n-1] (ONNX Slice specification)
+                    st = min(max(st + n if st < 0 else st, -1), n - 1); en = min(max(en + n if en < 0 else en, -1), n - 1)
+                    sl[ax] = slice(st, None if en < 0 else en, sp)
+            y = a[0][tuple(sl)]
+        elif op in ("ReduceSum", "ReduceMin", "ReduceMax"):
+            axes = at.get("axes")
+            if axes is None and len(a) > 1 and a[1] is not None:
+                axes = [int(v) for v in a[1]]
+            f = {"ReduceSum": np.sum, "ReduceMin": np.min, "ReduceMax": np.max}[op]
+            y = f(a[0], axis=tuple(axes) if axes is not None else None, keepdims=bool(at.get("keepdims", 1)))
+        elif op == "Sqrt":
+            y = np.sqrt(a[0])
+        elif op == "Log":
+            y = np.log(a[0])
+        elif op == "Exp":
+            y = np.exp(a[0])
+        elif op == "Abs":
+            y = np.abs(a[0])
+        elif op == "Neg":
+            y = -a[0]
+        elif op == "STFT":
+            # ONNX STFT (opset 17): signal [B, T, 1] (real), frame_step, window [frame_length], frame_length; onesided ->
+            # [B, frames, frame_length / 2 + 1, 2] with frames = (T - frame_length) / frame_step + 1; evaluated in double, narrowed
+            sig = a[0][..., 0] if a[0].ndim == 3 else a[0]
+            step = int(np.asarray(a[1]).reshape(-1)[0])
+            win = a[2] if len(a) > 2 and a[2] is not None else None
+            flen = int(np.asarray(a[3]).reshape(-1)[0]) if len(a) > 3 and a[3] is not None else len(win)
+            nfr = (sig.shape[1] - flen) // step + 1
+            idx = np.arange(nfr)[:, None] * step + np.arange(flen)[None, :]
+            fr = sig[:, idx].astype(np.float64)
+            if win is not None:
+                fr = fr * win.astype(np.float64)
+            sp = np.fft.rfft(fr, axis=-1) if at.get("onesided", 1) else np.fft.fft(fr, axis=-1)
+            y = np.stack([sp.real, sp.imag], axis=-1)
+        elif op == "DFT":
+            # ONNX DFT (opset 17): input [..., n, 1] real or [..., n, 2] complex, attribute axis, optional dft_length
+            ax = int(at.get("axis", 1))
+            z = a[0][..., 0].astype(np.float64) if a[0].shape[-1] == 1 else a[0][..., 0].astype(np.float64) + 1j * a[0][..., 1].astype(np.float64)
+            nfft = int(np.asarray(a[1]).reshape(-1)[0]) if len(a) > 1 and a[1] is not None else z.shape[ax]
+            if at.get("inverse", 0):
+                raise ValueError("oracle: inverse DFT unsupported")
+            sp = np.fft.rfft(z.real, n=nfft, axis=ax) if at.get("onesided", 0) else np.fft.fft(z, n=nfft, axis=ax)
+            y = np.stack([sp.real, sp.imag], axis=-1)
         elif op == "Pad":
             pads = at.get("pads")
             if pads is None:

@@ -70,3 +70,76 @@ def test_readers_never_read_out_of_bounds(fuzz_bin, tmp_path, tiny_blob):
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-6000:])
     n, acc = [int(v) for v in r.stdout.split()[1::2]]
     assert n == len(corpus) and acc >= len(seeds) + 5          # the unmutated files are all accepted
+
+
+def _crafted_onnx():
+    """The files ADVICE r2 reproduced heap overflows with: initializer dims that are negative / wrap the element count while
+    the payload is empty, an Unsqueeze with a repeated axis, a Transpose whose perm is not a permutation."""
+    out = []
+    from birdnet_go_amd.onnx_build import OnnxBuilder, _ld, _str, _vi, _varint, _key
+
+    def raw_tensor(name, dims, payload=b""):
+        return b"".join(_key(1, 0) + _varint(d) for d in dims) + _vi(2, 1) + _str(8, name) + _ld(9, payload)
+
+    big = -(2 ** 32) + 4096
+    b = OnnxBuilder()
+    x = b.input("x", ["N", 4096])
+    b.inits.append(raw_tensor("w", [big, big]))                                   # numel wraps, no data
+    b.output(b.node("MatMul", [x, "w"]), ["N", 4096])
+    out.append(b.finish())
+    b = OnnxBuilder()
+    x = b.input("x", ["N", 3, 4, 4])
+    w = b.init(np.ones((3, 3, 1, 1), np.float32))
+    b.inits.append(raw_tensor("c", [3, (2 ** 64 + 2) // 3, 1, 1], b"\0" * 8))      # dims multiply to 2 (mod 2^64): 8 bytes "match"
+    b.output(b.node("Add", [b.node("Conv", [x, w], kernel_shape=[1, 1]), "c"]), ["N", 3, 4, 4])
+    out.append(b.finish())
+    b = OnnxBuilder()
+    x = b.input("x", ["N", 8])
+    b.output(b.node("Unsqueeze", [x, b.init(np.asarray([1, 1, 1, 1], np.int64))]), ["N", 1, 1, 1, 1, 8])
+    out.append(b.finish())
+    b = OnnxBuilder()
+    x = b.input("x", ["N", 4, 6])
+    b.output(b.node("Transpose", [x], perm=[0, 1, 1]), ["N", 4, 4])
+    out.append(b.finish())
+    return out
+
+
+def test_onnx_audio_front_ends_and_crafted_files_under_asan(fuzz_bin, tmp_path):
+    """The ONNX audio front-end recogniser (DFT MatMul / Conv1d / STFT / DFT forms, symbolic spectra, lazy transposition) and
+    the crafted files of ADVICE r2 under ASan + UBSan: accept or reject, never read or write out of bounds."""
+    rng = np.random.default_rng(77)
+    corpus = []
+    n_seed = 0
+    for cfg in (sm.tiny_config(), sm.tiny_config(complex_mode="abs"), sm.tiny_perch_config()):
+        for form in ("matmul", "conv1d", "stft", "dft"):
+            try:
+                ox = sm.build_model(cfg, container="onnx", dft=form)
+            except ValueError:
+                continue
+            n_seed += 1
+            corpus.append(ox)
+            # the nodes and small initializers sit at the front of the graph, the big weights behind them: mutate both ends
+            corpus += _mutations(ox, rng, 60, window=6000)
+            tail = ox[-3000:]
+            for mt in _mutations(tail, rng, 30):
+                corpus.append(ox[:-len(tail)] + mt[:len(tail)].ljust(len(tail), b"\0"))
+    crafted = _crafted_onnx()
+    corpus += crafted
+    path = tmp_path / "corpus_audio.bin"
+    with open(path, "wb") as f:
+        for b in corpus:
+            f.write(struct.pack("<I", len(b)) + b)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([fuzz_bin, str(path)], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-6000:])
+    n, acc = [int(v) for v in r.stdout.split()[1::2]]
+    assert n == len(corpus) and acc >= n_seed
+    # and none of the crafted files is accepted
+    path2 = tmp_path / "crafted.bin"
+    with open(path2, "wb") as f:
+        for b in crafted:
+            f.write(struct.pack("<I", len(b)) + b)
+    r = subprocess.run([fuzz_bin, str(path2)], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr[-4000:]
+    n, acc = [int(v) for v in r.stdout.split()[1::2]]
+    assert (n, acc) == (len(crafted), 0)
