@@ -522,7 +522,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
         }
         int v_spec = new_val(spec_tensor, (size_t)fms[0].n_mels * fms[0].F * C_spec);
         int v_xn = -1;                      // normalised clip (FFT front-end only)
-        struct FftFin { int v_bins, spec; size_t o_mel, o_span; bool banded; };
+        struct FftFin { int v_bins, spec; size_t o_mel, o_span; bool banded; bool fused; };
         std::vector<FftFin> fft_fin;                 // FFT-path channels awaiting mel + pow + NHWC store
         tv[spec_tensor] = v_spec;
         for (size_t i = 0; i < fms.size(); i++) {
@@ -612,13 +612,25 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                 memcpy(spanf.data(), span.data(), span.size() * sizeof(int));            // int32 image in the float arena
                 size_t o_span = wpush(spanf.data(), spanf.size());
                 const bool banded = !getenv("BNHIP_NO_MEL_BANDED") && span_sum * 4 <= (long)fm.n_mels * fs.nb;
-                int v_bins = new_val(-1, (size_t)fm.F * fs.nbp);
-                Step st; st.kind = S_STFT; st.name = "stft" + std::to_string(i); st.kclass = "stft"; st.in0 = v_xn; st.out = v_bins;
+                // a banded mel matrix is applied by the wave that transformed the frame (k_stft_bins<.., MEL>): no bins tensor,
+                // no separate mel kernel; the image value is written by the STFT step itself
+                int mel_quads = 0;
+                std::vector<float> meltab;
+                // OPT-IN (BNHIP_FUSE_MEL=1): measured slower than the separate banded kernel in every form tried - the STFT kernels
+                // are fp64-VALU / LDS-latency bound at two to three waves per SIMD, and the epilogue's extra LDS round trips land on
+                // their critical path: v2.4 batch 256, stft0 440 -> 512-531 us, stft1 209 -> 293-320 us against the 116 us
+                // k_mel_banded launch they replace (70.2 k -> 67.6-68.4 k clips/s).  It does remove 0.9 MB per clip of HBM traffic
+                // and a launch, and stays parity-tested.
+                if (banded && getenv("BNHIP_FUSE_MEL")) meltab = stft_mel_table(fm.Lfft, melw.data(), span.data(), fm.n_mels, fs.nb, fs.nbp, &mel_quads);
+                const bool fused = !meltab.empty();
+                int v_bins = fused ? -1 : new_val(-1, (size_t)fm.F * fs.nbp);
+                Step st; st.kind = S_STFT; st.name = "stft" + std::to_string(i); st.kclass = "stft"; st.in0 = v_xn; st.out = fused ? v_spec : v_bins;
                 st.spec = si;
                 st.flops = (double)fm.F * 2.5 * fm.Lfft * std::log2((double)fm.Lfft / 2);      // ~5 N/2 log2(N/2) per frame
-                st.bytes = (double)n_samples * 4 + (double)fm.F * fs.nbp * 4;
-                add_step(st, o_win, o_bins, o_tw);
-                fft_fin.push_back({v_bins, si, o_mel, o_span, banded});
+                st.bytes = (double)n_samples * 4 + (double)fm.F * (fused ? fm.n_mels : fs.nbp) * 4;
+                if (fused) { st.mode = 1; st.S = mel_quads; st.name += "+mel"; st.flops += 4.0 * fm.F * fs.nb; }
+                add_step(st, o_win, o_bins, o_tw, fused ? wpush(meltab.data(), meltab.size()) : SIZE_MAX);
+                fft_fin.push_back({v_bins, si, o_mel, o_span, banded, fused});
                 continue;
             }
             if (frontend_lds_bytes(fs.Lfft, fs.Kp, fs.hop, fs.NTP) > 160 * 1024) {
@@ -645,8 +657,9 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
         // mel + pow + NHWC store of the FFT-path channels: two adjacent channels go out as one float2 per pixel.  Banded mel
         // matrices take one fused kernel; otherwise the mel projection is a k_pw_gemm per channel followed by k_mel_finish.
         for (size_t k = 0; k < fft_fin.size();) {
+            if (fft_fin[k].fused) { k++; continue; }        // mel + compression + store happened in the STFT kernel
             const FrontSpec& a = specs[fft_fin[k].spec];
-            bool pair = k + 1 < fft_fin.size() && specs[fft_fin[k + 1].spec].c == a.c + 1 && (a.c & 1) == 0 &&
+            bool pair = k + 1 < fft_fin.size() && !fft_fin[k + 1].fused && specs[fft_fin[k + 1].spec].c == a.c + 1 && (a.c & 1) == 0 &&
                         specs[fft_fin[k + 1].spec].F == a.F && specs[fft_fin[k + 1].spec].n_mels == a.n_mels &&
                         specs[fft_fin[k + 1].spec].log_compress == a.log_compress && specs[fft_fin[k + 1].spec].log_floor == a.log_floor &&
                         specs[fft_fin[k + 1].spec].log_scale == a.log_scale;
@@ -2044,6 +2057,11 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
             case S_STFT: {
                 const FrontSpec& fs = specs[s.spec];
                 StftParams p{in0, fs.window_full, fs.bins, out, n_samples, fs.Lfft, fs.L, fs.hop, fs.F, fs.nb, fs.nbp, fs.mode, n, fs.stft_tw, fs.pad_left};
+                if (s.mode == 1) {                           // fused mel epilogue: `out` is the spectrogram image
+                    p.out = nullptr; p.img = out; p.mel = s.w3; p.mel_quads = s.S; p.n_mels = fs.n_mels; p.Ctot = C_spec; p.c0 = fs.c;
+                    p.logc = fs.log_compress ? 1 : 0; p.time_major = fs.time_major ? 1 : 0; p.p1 = fs.p1; p.p2 = fs.p2;
+                    p.lfloor = fs.log_floor; p.lscale = fs.log_scale;
+                }
                 launch_stft_bins(p, stream);
                 break;
             }

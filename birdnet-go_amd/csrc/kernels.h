@@ -41,8 +41,19 @@ struct StftParams {
     const double* tw = nullptr;   // plan-time twiddle image (stft_build_tables)
     int pad_left = 0;             // frame f starts at sample f * hop - pad_left; samples outside [0, n_samples) are zero
     int nb_cap = 0, fpw = 0;    // set by the launcher
+    // fused mel epilogue (mel != nullptr): the wave that transformed a frame also applies the banded mel matrix and the
+    // compression and writes the frame's n_mels values straight into the spectrogram image - the DFT bins never reach HBM.
+    // mel = stft_mel_table(): [64 lanes][8] int32 {band A, first quad, quads, weight offset; band B ...} then the band
+    // weights, each band's aligned quads back to back (mel_quads float4s).
+    const float* mel = nullptr;
+    int mel_quads = 0, n_mels = 0, Ctot = 1, c0 = 0, logc = 0, time_major = 0;
+    float p1 = 1.f, p2 = 1.f, lfloor = 0.f, lscale = 1.f;
+    float* img = nullptr;       // [B, n_mels, F, Ctot] (or [B, F, n_mels, Ctot] when time_major)
 };
 std::vector<double> stft_build_tables(int Lfft, const int* bins, int nb);
+// Fused-mel table for launch_stft_bins: melw [n_mels][nbp] (zero outside each row's band), span [2 n_mels] = [lo, hi) per row.
+// Empty when the front-end cannot take the fused form (more than 512 bins, more than 128 bands, table too large for LDS).
+std::vector<float> stft_mel_table(int Lfft, const float* melw, const int* span, int n_mels, int nb, int nbp, int* quads);
 void launch_normalize(const float* x, const float2* mm, float* out, int n_clips, int n_samples, float norm_sub,
                       float norm_mul, hipStream_t s);
 bool stft_supported(int Lfft, int nb);

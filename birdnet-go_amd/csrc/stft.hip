@@ -91,10 +91,18 @@ __device__ __forceinline__ void fft_regs(double (&re)[P], double (&im)[P]) {
     }
 }
 
+__device__ __forceinline__ float mel_pow(float v, float p1, float p2);
+__device__ __forceinline__ float mel_log(float v, float lfloor, float lscale);
+
 // ------------------------------------------------------------------------------------------ STFT -> needed bins
 // W = waves per block.  The 2048-point kernel (P = 16: 214 VGPRs, 16.6 KB of LDS per wave) holds two waves per SIMD
 // either way; the 1024-point one (146 VGPRs, 8.4 KB) fits three when the blocks are 4 waves (three blocks per CU).
-template <int P, int W>
+// MEL: fused epilogue - the frame's bins go to the wave's LDS slice instead of HBM, each lane sums (at most) two bands of the
+// banded mel matrix over them (a narrow and a wide one: lane l takes bands l and n_mels - 1 - l, so every lane walks about
+// the same number of quads), applies the compression and stores the values into the spectrogram image.  Same products in
+// the same order as k_mel_banded (aligned quads of four bins, ascending): bit-identical, minus a kernel launch and the
+// bins' round trip through HBM (0.9 MB per clip).
+template <int P, int W, bool MEL = false>
 __global__ __launch_bounds__(64 * W) void k_stft_bins(StftParams p) {
     constexpr int N2 = 64 * P;            // complex points
     constexpr int N = 2 * N2;             // real frame length (= fft length)
@@ -109,6 +117,8 @@ __global__ __launch_bounds__(64 * W) void k_stft_bins(StftParams p) {
     double* t2r = twi + P * 64;           // [Q][P]  W_64^{q j'}
     double* t2i = t2r + Q * P;
     double* work = t2i + Q * P;           // [W][2][WSZ]
+    float4* melw4 = reinterpret_cast<float4*>(work + (size_t)W * 2 * WSZ);     // MEL: band weights, p.mel_quads float4s ...
+    const int* binq = reinterpret_cast<const int*>(melw4 + p.mel_quads);        // ... and the bins quad each of them multiplies
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
 
@@ -116,6 +126,15 @@ __global__ __launch_bounds__(64 * W) void k_stft_bins(StftParams p) {
     // fp64 sincos per thread and block - a sixth of the kernel at 16 frames per wave
     constexpr int NTAB = 2 * P * 64 + 2 * Q * P;
     for (int i = tid; i < NTAB; i += blockDim.x) sm[i] = p.tw[i];
+    int mA = 0, loA = 0, nA = 0, wA = 0, mB = 0, loB = 0, nB = 0, wB = 0;
+    if (MEL) {
+        const float4* src = reinterpret_cast<const float4*>(p.mel + 64 * 8);
+        // (weights and the quad index list: mel_quads float4s + mel_quads ints rounded up to whole float4s)
+        for (int i = tid; i < p.mel_quads + (p.mel_quads + 3) / 4; i += blockDim.x) melw4[i] = src[i];
+        const int4* lt = reinterpret_cast<const int4*>(p.mel) + 2 * lane;
+        const int4 ta = lt[0], tb = lt[1];
+        mA = ta.x; loA = ta.y; nA = ta.z; wA = ta.w; mB = tb.x; loB = tb.y; nB = tb.z; wB = tb.w;
+    }
     __syncthreads();
 
     double* wre = work + (size_t)wave * 2 * WSZ;
@@ -228,10 +247,12 @@ __global__ __launch_bounds__(64 * W) void k_stft_bins(StftParams p) {
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
         // ---- 4. real-input split on the needed bins
-        float* orow = p.out + ((size_t)b * p.F + f) * p.nbp;
+        float* orow = MEL ? nullptr : p.out + ((size_t)b * p.F + f) * p.nbp;
+        float ov[NBL];
 #pragma unroll
         for (int t = 0; t < NBL; t++) {
             const int idx = lane + 64 * t;
+            ov[t] = 0.f;
             if (idx >= p.nbp) break;
             float o = 0.f;
             if (idx < p.nb) {
@@ -248,11 +269,48 @@ __global__ __launch_bounds__(64 * W) void k_stft_bins(StftParams p) {
                     o = hypotf((float)xr, (float)xi);        // COMPLEX_ABS on complex64
                 }
             }
-            orow[idx] = o;
+            if (MEL) ov[t] = o; else orow[idx] = o;
+        }
+        if (MEL) {
+            // every lane has read what it needs of Z: the slice now holds the frame's bins as one float row
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            float* brow = reinterpret_cast<float*>(wre);
+#pragma unroll
+            for (int t = 0; t < NBL; t++) { const int idx = lane + 64 * t; if (idx < p.nbp) brow[idx] = ov[t]; }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            const float4* b4 = reinterpret_cast<const float4*>(brow);
+            // phase a: the (band, quad) products spread evenly over the wave - ~2 K / 4 + n_mels quads per frame, 2-4 per lane
+            // (a band per lane would make every frame wait for the widest band: measured +53 % on the 1024-point kernel)
+            float* part = brow + 512;
+            for (int e = lane; e < p.mel_quads; e += 64) {
+                const float4 x4 = b4[binq[e]], w4 = melw4[e];
+                part[e] = fmaf(x4.w, w4.w, fmaf(x4.z, w4.z, fmaf(x4.y, w4.y, x4.x * w4.x)));
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            // phase b: each band's quad sums added up in ascending order by the band's lane, four reads in flight
+            (void)loA; (void)loB;
+#pragma unroll 1
+            for (int which = 0; which < 2; which++) {
+                const int mm = which ? mB : mA, n4 = which ? nB : nA, wo = which ? wB : wA;
+                if (n4 < 0) continue;                          // (no band in this slot; an EMPTY band still writes its pixel)
+                float acc = 0.f;
+                for (int g = 0; g < n4; g += 4) {
+                    const float t0 = part[wo + g], t1 = g + 1 < n4 ? part[wo + g + 1] : 0.f, t2 = g + 2 < n4 ? part[wo + g + 2] : 0.f,
+                                t3 = g + 3 < n4 ? part[wo + g + 3] : 0.f;
+                    acc = (((acc + t0) + t1) + t2) + t3;
+                }
+                const float v = p.logc ? mel_log(acc, p.lfloor, p.lscale) : mel_pow(acc, p.p1, p.p2);
+                const size_t o = p.time_major ? (((size_t)b * p.F + f) * p.n_mels + mm) * p.Ctot + p.c0
+                                              : (((size_t)b * p.n_mels + mm) * p.F + f) * p.Ctot + p.c0;
+                p.img[o] = v;
+            }
         }
         // more than 512 needed bins (a 2048-point transform under a wide mel bank): the rest take their bin index and twiddle
         // from the plan-time image each frame instead of from registers
-        for (int idx = lane + 64 * NBL; idx < p.nbp; idx += 64) {
+        for (int idx = lane + 64 * NBL; !MEL && idx < p.nbp; idx += 64) {
             float o = 0.f;
             if (idx < p.nb) {
                 const int k = p.bins[idx];
@@ -313,6 +371,42 @@ bool stft_supported(int Lfft, int nb) {
     int P = Lfft / 128, cap = (nb + 63) / 64 * 64;
     return nb <= Lfft / 2 + 1 && stft_lds_bytes(P, cap) <= 160 * 1024;      // (the first 512 bins' twiddles live in registers)
 }
+std::vector<float> stft_mel_table(int Lfft, const float* melw, const int* span, int n_mels, int nb, int nbp, int* quads) {
+    *quads = 0;
+    if (n_mels < 1 || n_mels > 128 || nbp > 512 || nb > nbp || (nbp & 3)) return {};
+    std::vector<int> lo4(n_mels), n4(n_mels), wo(n_mels);
+    int tot = 0;
+    for (int m = 0; m < n_mels; m++) {
+        const int lo = span[2 * m], hi = span[2 * m + 1];
+        lo4[m] = lo >> 2; n4[m] = hi > lo ? ((hi + 3) >> 2) - (lo >> 2) : 0; wo[m] = tot;
+        tot += n4[m];
+    }
+    const int P = Lfft / 128;
+    if (stft_lds_bytes(P, 0) + (size_t)tot * 16 + (size_t)(tot + 3) / 4 * 16 > 160 * 1024) return {};
+    if (nbp > 512 || tot > 256) return {};                       // (bins row and quad sums share the wave's LDS slice; four quads per lane)
+    std::vector<float> t((size_t)64 * 8 + (size_t)tot * 4 + (size_t)(tot + 3) / 4 * 4, 0.f);
+    int* lt = reinterpret_cast<int*>(t.data());
+    const int half = (n_mels + 1) / 2;
+    for (int l = 0; l < 64; l++) {
+        int* e = lt + 8 * l;
+        e[2] = e[6] = -1;                                      // quads < 0: no band in this slot
+        if (l >= half) continue;
+        const int a = l, bnd = n_mels - 1 - l;
+        e[0] = a; e[1] = lo4[a]; e[2] = n4[a]; e[3] = wo[a];
+        if (bnd != a) { e[4] = bnd; e[5] = lo4[bnd]; e[6] = n4[bnd]; e[7] = wo[bnd]; }
+    }
+    for (int m = 0; m < n_mels; m++)
+        for (int g = 0; g < n4[m]; g++)
+            for (int q = 0; q < 4; q++) {
+                const int k = 4 * (lo4[m] + g) + q;
+                t[(size_t)64 * 8 + 4 * ((size_t)wo[m] + g) + q] = k < nbp ? melw[(size_t)m * nbp + k] : 0.f;
+            }
+    int* bq = reinterpret_cast<int*>(t.data() + (size_t)64 * 8 + (size_t)tot * 4);
+    for (int m = 0; m < n_mels; m++)
+        for (int g = 0; g < n4[m]; g++) bq[wo[m] + g] = lo4[m] + g;
+    *quads = tot;
+    return t;
+}
 void launch_stft_bins(const StftParams& p0, hipStream_t s) {
     StftParams p = p0;
     p.nb_cap = (p.nb + 63) / 64 * 64;
@@ -326,6 +420,21 @@ void launch_stft_bins(const StftParams& p0, hipStream_t s) {
     size_t lds = stft_lds_bytes(P, p.nb_cap);
     dim3 grid((p.F + W * p.fpw - 1) / (W * p.fpw), p.n_clips);
     static bool attr16 = false;
+    if (p.mel) {
+        lds += (size_t)p.mel_quads * 16 + (size_t)(p.mel_quads + 3) / 4 * 16;
+        static bool am16 = false, am8 = false, am4 = false;
+        if (P == 16) {
+            if (!am16) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<16, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); am16 = true; }
+            hipLaunchKernelGGL((k_stft_bins<16, 8, true>), grid, dim3(64 * W), lds, s, p);
+        } else if (P == 8) {
+            if (!am8) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); am8 = true; }
+            hipLaunchKernelGGL((k_stft_bins<8, 4, true>), grid, dim3(64 * W), lds, s, p);
+        } else {
+            if (!am4) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<4, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); am4 = true; }
+            hipLaunchKernelGGL((k_stft_bins<4, 8, true>), grid, dim3(64 * W), lds, s, p);
+        }
+        return;
+    }
     if (P == 4) {
         hipLaunchKernelGGL((k_stft_bins<4, 8>), grid, dim3(64 * W), lds, s, p);      // < 64 KB of LDS
     } else if (P == 16) {

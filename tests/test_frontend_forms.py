@@ -80,3 +80,36 @@ def test_squeeze_excite_spellings_vs_oracle(gpu, form):
         finally:
             c.close()
         assert (got.argmax(1) == ref.argmax(1)).all() and np.abs(got - ref).max() < 1e-3
+
+
+@pytest.mark.gpu
+def test_fused_mel_epilogue_vs_the_separate_banded_kernel(gpu, full_blob):
+    """k_stft_bins<.., MEL> (mel projection + compression in the wave that transformed the frame; no bins tensor, no
+    k_mel_banded launch) against the separate kernel: the same products, summed per aligned quad and then per band instead of
+    in one running chain, so the logits agree to fp32 rounding - on the v2.4 layer (two channels, real part, power
+    compression), on silence (where the power-law compression amplifies everything), and on the log-mel / magnitude /
+    time-major variant.  Both forms are also held to the oracle."""
+    import os
+    from birdnet_go_amd import host, synth_model as sm
+    for blob, n, rate in ((full_blob, 144000, 48000), (sm.build_model(sm.tiny_perch_config()), 8000, 32000)):
+        x = sm.synth_clips(4, n, rate)
+        x[1] = 0.0
+        ref = Interpreter(blob).invoke(x)
+        ref = ref[3] if len(ref) == 4 else ref[0]
+        plain = host.HipClassifier(blob, max_batch=4, autotune=False)
+        os.environ["BNHIP_FUSE_MEL"] = "1"                     # opt-in: measured slower than the separate kernel (DESIGN.md section 10)
+        try:
+            fused = host.HipClassifier(blob, max_batch=4, autotune=False)
+        finally:
+            del os.environ["BNHIP_FUSE_MEL"]
+        try:
+            kf = [s["name"] for s in fused.describe()["steps"]]
+            kp = [s["name"] for s in plain.describe()["steps"]]
+            assert any(k.endswith("+mel") for k in kf) and not any(k.startswith("melband") for k in kf)
+            assert any(k.startswith("melband") for k in kp)
+            a, b = fused.predict_batch(x.reshape(-1), 4), plain.predict_batch(x.reshape(-1), 4)
+            assert np.isfinite(a).all() and np.abs(a - b).max() < 1e-4
+            for got in (a, b):
+                assert (got.argmax(1) == ref.argmax(1)).all() and np.abs(got - ref).max() < 1e-3
+        finally:
+            fused.close(); plain.close()

@@ -87,7 +87,7 @@ def test_cpp_reader_and_planner_fuse_everything(built_lib, full_blob):
     assert (clf.n_samples, clf.num_species(), clf.emb_dim) == (144000, 6522, 0)
     d = clf.describe()
     kinds = [s["kernel"] for s in d["steps"]]
-    # front-end (FFT path): clip_minmax, normalize, 2 x (stft + mel GEMM), one fused finish
+    # front-end (FFT path): clip_minmax, normalize, 2 x stft, one banded mel + compression + store launch
     assert kinds.count("stft") == 2 and kinds.count("frontend") == 2 and kinds.count("clip_minmax") == 1
     assert "elementwise" not in kinds, "an op fell back to the unfused elementwise path"
     # 16 MBConv blocks: 11 with the fused expand+depthwise kernel (Cin <= 128) + the stem fused with b1's depthwise in the same
@@ -98,9 +98,16 @@ def test_cpp_reader_and_planner_fuse_everything(built_lib, full_blob):
     assert sum(s["fused_sum"] for s in d["steps"]) == 16 and kinds.count("mean") == 2
     pw = [s for s in d["steps"] if s["kernel"] == "pw_gemm"]
     assert sum(s["fused_scale"] for s in pw) == 16 and sum(s["fused_res"] for s in pw) == 9
-    # FFT front-end: clip_minmax, normalize, 2 x stft, one banded mel + pow + store launch for both channels
+    # FFT front-end: clip_minmax, normalize, 2 x stft, one banded mel + pow + store launch for both channels; on request
+    # (BNHIP_FUSE_MEL) the mel projection moves into the STFT kernels' epilogue instead
     names = [s["name"] for s in d["steps"]]
     assert len(d["steps"]) == 61 and "melband0+1" in names and "mel0" not in names
+    os.environ["BNHIP_FUSE_MEL"] = "1"
+    try:
+        n1 = [s["name"] for s in host.HipClassifier(full_blob, plan_only=True).describe()["steps"]]
+    finally:
+        del os.environ["BNHIP_FUSE_MEL"]
+    assert len(n1) == 60 and "stft0+mel" in n1 and "stft1+mel" in n1
     # with the folded-GEMM front-end: clip_minmax + one k_frontend launch per channel
     d0 = host.HipClassifier(full_blob, plan_only=True, frontend_fft=0).describe()
     assert len(d0["steps"]) == 59 and [s["kernel"] for s in d0["steps"]].count("frontend") == 2
@@ -182,7 +189,7 @@ def test_magnitude_frontend_plans_onto_the_fft_path(built_lib):
     # mixed: the default tiny geometry has one 512-point and one 256-point branch
     d4 = host.HipClassifier(sm.build_model(sm.tiny_config()), plan_only=True).describe()
     k4 = [s["kernel"] for s in d4["steps"]]
-    assert k4.count("stft") == 1 and k4.count("frontend") >= 2
+    assert k4.count("stft") == 1 and k4.count("frontend") >= 2       # (normalize + the folded-GEMM 256-point branch)
     # the oracle executes the op generically
     assert np.isfinite(Interpreter(blob).invoke(sm.synth_clips(1, 12000))[0]).all()
 
