@@ -7,6 +7,8 @@
 #include <cstring>
 #include <sstream>
 
+#include <mutex>
+
 #include "../../include/bnhip.h"
 #include "hostpipe.h"
 
@@ -376,7 +378,7 @@ Engine::~Engine() {
     if (ev_ctx_fork) hipEventDestroy(ev_ctx_fork);
     for (int i = 0; i < kMaxLanes - 1; i++) if (ev_join[i]) hipEventDestroy(ev_join[i]);
     if (ev_fork) hipEventDestroy(ev_fork);
-    for (int i = 0; i < kMaxKStreams; i++) if (kstream[i]) hipStreamDestroy(kstream[i]);
+    release_streams();
 }
 
 bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* err, int* code) {
@@ -1686,10 +1688,57 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
     return true;
 }
 
+// Streams are pooled per DEVICE, not per engine: HIP maps all streams of a process on a device onto at most four hardware
+// queues, so a second engine on the same GPU (another model, or the second shard of a {"devices":[0,0]} handle) that created
+// streams of its own would push everybody onto shared queues - measured 0.61-0.69x the single-engine rate for two engines
+// on one GPU.  Engines on one device therefore share its (up to four) kernel streams and its one copy stream; their work
+// interleaves in stream order, which is all the ordering independent clips need.
+namespace {
+struct DevStreams { hipStream_t k[Engine::kMaxKStreams] = {nullptr, nullptr, nullptr, nullptr}; hipStream_t xfer = nullptr; int refs = 0; };
+std::mutex g_ds_mu;
+std::map<int, DevStreams> g_ds;
+}  // namespace
+
 hipStream_t Engine::kernel_stream(int i) {
-    if (i < 0 || i >= kMaxKStreams) return nullptr;
-    if (!kstream[i] && hipStreamCreateWithFlags(&kstream[i], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); kstream[i] = nullptr; }
+    if (i < 0 || i >= kMaxKStreams || device < 0) return nullptr;
+    if (kstream[i]) return kstream[i];
+    std::lock_guard<std::mutex> lk(g_ds_mu);
+    DevStreams& ds = g_ds[device];
+    if (!ds_ref) { ds.refs++; ds_ref = true; }
+    if (!ds.k[i] && hipStreamCreateWithFlags(&ds.k[i], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ds.k[i] = nullptr; }
+    kstream[i] = ds.k[i];
     return kstream[i];
+}
+hipStream_t Engine::copy_stream() {
+    if (device < 0) return nullptr;
+    if (xfer_stream) return xfer_stream;
+    std::lock_guard<std::mutex> lk(g_ds_mu);
+    DevStreams& ds = g_ds[device];
+    if (!ds_ref) { ds.refs++; ds_ref = true; }
+    if (!ds.xfer) {
+        // highest priority: copies are what should go first (and a queue pooled by priority is less likely to be a kernel queue)
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&ds.xfer, hipStreamNonBlocking, greatest) != hipSuccess) { (void)hipGetLastError(); ds.xfer = nullptr; }
+    }
+    xfer_stream = ds.xfer;
+    return xfer_stream;
+}
+void Engine::release_streams() {
+    for (int i = 0; i < kMaxKStreams; i++) if (kstream[i]) hipStreamSynchronize(kstream[i]);
+    if (xfer_stream) hipStreamSynchronize(xfer_stream);
+    std::lock_guard<std::mutex> lk(g_ds_mu);
+    if (ds_ref) {
+        auto it = g_ds.find(device);
+        if (it != g_ds.end() && --it->second.refs == 0) {
+            for (auto st : it->second.k) if (st) hipStreamDestroy(st);
+            if (it->second.xfer) hipStreamDestroy(it->second.xfer);
+            g_ds.erase(it);
+        }
+        ds_ref = false;
+    }
+    for (int i = 0; i < kMaxKStreams; i++) kstream[i] = nullptr;
+    xfer_stream = nullptr;
 }
 
 // Contexts 0..d-1 (stream, completion event, activation arena; context 0 shares the engine's own arena).  Idempotent.

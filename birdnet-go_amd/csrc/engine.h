@@ -143,7 +143,11 @@ class Engine {
     // main stream: a pipelined call forks from whatever the main stream has queued, which must not include the previous call).
     static constexpr int kMaxKStreams = 4;
     hipStream_t kstream[kMaxKStreams] = {nullptr, nullptr, nullptr, nullptr};
-    hipStream_t kernel_stream(int i);   // created on first use; nullptr on failure
+    hipStream_t kernel_stream(int i);   // created on first use; nullptr on failure.  Shared by every engine on the device.
+    hipStream_t copy_stream();          // the device's one copy stream (host pipeline: both directions)
+    hipStream_t xfer_stream = nullptr;
+    bool ds_ref = false;                // this engine holds a reference on its device's stream pool
+    void release_streams();
     bool profiling = false;
     std::string profile_filter;      // non-empty: only launches of this kernel class are bracketed by events
 

@@ -156,7 +156,7 @@ void hostpipe_free(HostPipe* hp) {
         if (s.ev_done) hipEventDestroy(s.ev_done);
         if (s.ev_comp) hipEventDestroy(s.ev_comp);
     }
-    if (hp->xfer) { hipStreamSynchronize(hp->xfer); hipStreamDestroy(hp->xfer); }
+    if (hp->xfer) hipStreamSynchronize(hp->xfer);       // (owned by the device's stream pool)
     delete hp;
 }
 
@@ -176,19 +176,16 @@ namespace {
 int ensure_pipe(Engine& e, const HostJob& j, size_t chunk_bytes, std::string& err) {
     if (!e.hostpipe) e.hostpipe = new HostPipe();
     HostPipe& hp = *e.hostpipe;
-    if (!hp.xfer) {
-        // Streams are a scarce resource here: HIP maps ALL streams of a process onto at most four hardware queues
-        // (GPU_MAX_HW_QUEUES; measured on ROCm 7.2: a fifth active stream lands on a queue another one uses, whatever its
-        // priority), and two streams on one queue serialise - a copy marker behind a context's kernels stalls the next
-        // chunk, two contexts on one queue stop overlapping altogether (both seen in BNHIP_HOST_TRACE timelines).  So the
-        // pipeline runs on exactly three: the engine's two kernel streams (the main stream and the lane stream, idle during
-        // a pipelined call) as the two contexts, and ONE copy stream that carries both directions in an order that never
-        // blocks a prefetch: ... H2D(c+1), D2H(c-2), H2D(c+2), D2H(c-1) ... (a copy-out waits for its chunk's kernels, which
-        // are done long before the input issued behind it is needed).
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        HP_TRY(hipStreamCreateWithPriority(&hp.xfer, hipStreamNonBlocking, greatest), "copy stream");
-    }
+    // Streams are a scarce resource: HIP maps ALL streams of a process on a device onto at most four hardware queues
+    // (GPU_MAX_HW_QUEUES; measured on ROCm 7.2: a fifth active stream lands on a queue another one uses, whatever its
+    // priority), and two streams on one queue serialise - a copy marker behind a context's kernels stalls the next chunk,
+    // two contexts on one queue stop overlapping altogether (both seen in BNHIP_HOST_TRACE timelines).  So the pipeline
+    // runs on exactly three, all owned by the DEVICE's pool (engine.cpp: engines on one GPU share them): the two kernel
+    // streams (main + lane stream, idle during a pipelined call) as the two contexts, and ONE copy stream that carries both
+    // directions in an order that never blocks a prefetch: ... H2D(c+1), D2H(c-2), H2D(c+2), D2H(c-1) ... (a copy-out waits
+    // for its chunk's kernels, which are done long before the input issued behind it is needed).
+    hp.xfer = e.copy_stream();
+    if (!hp.xfer) { err = "copy stream creation failed"; return BNHIP_E_RUNTIME; }
     const size_t mb = (size_t)e.max_batch;
     for (auto& s : hp.s) {
         if (!s.ev_h2d) HP_TRY(hipEventCreateWithFlags(&s.ev_h2d, hipEventDisableTiming), "event");

@@ -135,3 +135,43 @@ def test_bf16x3_expand_dw_variant_is_exercised(gpu, full_blob):
         assert sum(s["bx"] for s in ed) >= 10, [(s["name"], s["bx"]) for s in ed]      # b2..b12 (the fused stem stays f32)
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+def test_bf16x3_range_edges_huge_and_near_denormal_operands(gpu):
+    """The two ends DESIGN.md section 5 only described.  A dense layer (K = 64) on the split-bf16 kernel:
+    * operands up to 3.3e38 (just under the largest bf16, 3.39e38): finite, relative error vs float64 <= 4e-6, like fp32;
+    * operands whose mid / lo pieces are bf16 subnormals (|x| ~ 1e-37) or that are fp32 denormals themselves (1e-39): finite,
+      no NaN; whatever the matrix pipe does with subnormal pieces, at worst only the hi piece survives, so the ABSOLUTE error
+      is <= 2^-7 of the row's largest product - below 1e-37, i.e. nothing;
+    * an operand ABOVE the largest bf16 (still finite in fp32): its hi piece rounds to infinity and the row is not finite.
+      Pinned as the documented limit of the split (audio activations are O(1..1e3); the f32-MFMA path, bf16x3 = 0, has none)."""
+    K, N = 64, 32
+    rng = np.random.default_rng(3)
+    blob = sm.build_dense_model([K, N], seed=3)
+    x = np.zeros((6, K), np.float32)
+    x[0] = rng.uniform(0.5, 1.0, K) * 3.3e38 * rng.choice([-1, 1], K) / K          # huge, the sums stay finite
+    x[1, :4] = [3.3e38 / 8, -3.2e38 / 8, 1.0, -1.0]
+    x[2] = rng.uniform(1.0, 9.0, K) * 1e-37 * rng.choice([-1, 1], K)               # mid / lo pieces are subnormal bf16
+    x[3] = rng.uniform(1.0, 9.0, K) * 1e-39 * rng.choice([-1, 1], K)               # fp32 denormals
+    x[4] = rng.standard_normal(K)
+    x[5, 0] = 3.4e38                                                                 # > largest bf16
+    with np.errstate(over="ignore", invalid="ignore"):
+        ref64 = Interpreter(blob, precision="f64").invoke(x)[0].astype(np.float64)
+    out = {}
+    for bx in (2, 0):
+        c = host.HipClassifier(blob, max_batch=8, bf16x3=bx, autotune=False)
+        try:
+            out[bx] = c.predict_batch(x.reshape(-1), 6)
+        finally:
+            c.close()
+    g = out[2].astype(np.float64)
+    assert np.isfinite(out[2][:5]).all() and np.isfinite(out[0][:5]).all()
+    for r in (0, 1, 4):
+        assert np.abs(g[r] - ref64[r]).max() <= 4e-6 * np.abs(ref64[r]).max(), r
+    for r in (2, 3):
+        big = float(np.abs(x[r]).max()) * 1.0 * K           # (|w| < 1 for these weights)
+        bias_free = np.abs(g[r] - ref64[r]).max()
+        assert bias_free <= 2.0 ** -7 * big + 1e-6 * np.abs(ref64[r]).max(), r      # (the bias, O(0.1), dominates the row: relative part)
+    assert not np.isfinite(out[2][5]).all()                # documented limit: hi = bf16(3.4e38) = inf
+    assert np.isfinite(out[0][5]).all()                    # the f32-MFMA kernel has no such limit

@@ -67,3 +67,58 @@ def test_tone_survives_and_alias_is_rejected():
     kill = host.Resampler(fr, to).resample_f32(np.sin(2 * np.pi * 20000.0 * t).astype(np.float32))   # above the new Nyquist
     assert 0.95 < np.abs(keep[2000:-2000]).max() < 1.05
     assert np.abs(kill[2000:-2000]).max() < 0.02
+
+
+# ------------------------------------------------------------------------------------------------ the filter spec, as numbers
+# the reference's resampler values are unpinned, so the project states its own spec.  Prototype low-pass =
+# Kaiser window (beta 5.0), 20 x max(L, M) + 1 taps, cutoff at the lower of the two Nyquist frequencies (what
+# scipy.signal.resample_poly designs by default), applied zero-phase (no group delay in the output: sample i is time i / rate_out):
+#   passband   0 .. 0.80 x Nyquist_low : ripple <= 0.03 dB (peak to peak)
+#   cutoff     Nyquist_low             : -6.0 dB
+#   stopband   >= 1.25 x Nyquist_low   : attenuation >= 55 dB (the first side lobe; 50 dB asserted on the GPU with finite tones)
+SPEC_PAIRS = [(48000, 32000), (256000, 48000), (44100, 48000), (32000, 48000)]
+
+
+@pytest.mark.parametrize("fr,to", SPEC_PAIRS)
+def test_filter_design_meets_the_stated_spec(fr, to):
+    from math import gcd
+    from scipy import signal
+    g = gcd(fr, to)
+    L, M = to // g, fr // g
+    half = 10 * max(L, M)
+    h = signal.firwin(2 * half + 1, 1.0 / max(L, M), window=("kaiser", 5.0)) * L
+    n = 1 << 22
+    H = np.abs(np.fft.rfft(h, n)) / L
+    f = np.arange(len(H)) * (fr * L) / n
+    nyq = min(fr, to) / 2
+    pb = H[f <= 0.80 * nyq]
+    assert 20 * np.log10(pb.max() / pb.min()) <= 0.03
+    assert abs(20 * np.log10(H[np.argmin(np.abs(f - nyq))]) + 6.02) < 0.05
+    assert -20 * np.log10(H[f >= 1.25 * nyq].max()) >= 55.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fr,to", SPEC_PAIRS)
+def test_gpu_resampler_meets_the_stated_spec(fr, to):
+    """The same three figures measured THROUGH the GPU resampler with tones (Hann-weighted RMS over the middle of the clip),
+    plus the zero group delay: an impulse stays where it was."""
+    n = fr // 2
+    t = np.arange(n) / fr
+    nyq = min(fr, to) / 2
+    rs = host.Resampler(fr, to)
+
+    def gain_db(freq):
+        y = rs.resample_f32(np.sin(2 * np.pi * freq * t).astype(np.float32)).astype(np.float64)
+        mid = y[len(y) // 4: 3 * len(y) // 4]
+        w = np.hanning(len(mid))
+        return 10 * np.log10(2 * np.sum(w * mid * mid) / np.sum(w) + 1e-30)
+    for frac in (0.1, 0.5, 0.8):
+        assert abs(gain_db(frac * nyq)) <= 0.05, (fr, to, frac)
+    # (the -6 dB point sits ON the output's Nyquist frequency, where a tone and its image fold onto each other: it is checked
+    # on the design above, not with a tone)
+    if 1.25 * nyq < fr / 2:                              # (only a down-sampler can be fed a tone above the new Nyquist)
+        assert gain_db(1.3 * nyq) <= -50.0
+    imp = np.zeros(n, np.float32)
+    imp[n // 2] = 1.0
+    y = rs.resample_f32(imp)
+    assert abs(int(np.argmax(np.abs(y))) - round((n // 2) * to / fr)) <= 1
