@@ -33,11 +33,22 @@ typedef int  (*fn_predict)(bnhip_model*, const float*, int, float*, float*);
 typedef int  (*fn_predict_topk)(bnhip_model*, const float*, int, int, double, int, float*, int32_t*);
 typedef void (*fn_model_destroy)(bnhip_model*);
 typedef const char* (*fn_last_error)(void);
+typedef int  (*fn_predict_pcm16)(bnhip_model*, const int16_t*, int, float*, float*);
+typedef int  (*fn_us_frame_cv)(int, const double*, int, int, int, int, int, int, double*, int32_t*);
+typedef struct bnhip_resampler bnhip_resampler;
+typedef int  (*fn_rs_create)(int, int, int, bnhip_resampler**);
+typedef int  (*fn_rs_estimate)(const bnhip_resampler*, int);
+typedef int  (*fn_rs_process_pcm16)(bnhip_resampler*, const int16_t*, int, int16_t*, int, int*);
+typedef int  (*fn_rs_flush_pcm16)(bnhip_resampler*, int16_t*, int, int*);
+typedef void (*fn_rs_destroy)(bnhip_resampler*);
 
 typedef struct {
     void* handle;
     fn_init init; fn_shutdown shutdown; fn_model_create model_create; fn_model_info model_info;
     fn_predict predict; fn_predict_topk predict_topk; fn_model_destroy model_destroy; fn_last_error last_error;
+    fn_predict_pcm16 predict_pcm16; fn_us_frame_cv us_frame_cv;
+    fn_rs_create rs_create; fn_rs_estimate rs_estimate; fn_rs_process_pcm16 rs_process_pcm16; fn_rs_flush_pcm16 rs_flush_pcm16;
+    fn_rs_destroy rs_destroy;
 } bnbind_t;
 static bnbind_t BN;
 static char bnbind_errbuf[256];
@@ -61,6 +72,10 @@ static const char* bnbind_load(const char* path) {
     BN_RESOLVE(model_create, "bnhip_model_create"); BN_RESOLVE(model_info, "bnhip_model_info");
     BN_RESOLVE(predict, "bnhip_predict"); BN_RESOLVE(predict_topk, "bnhip_predict_topk");
     BN_RESOLVE(model_destroy, "bnhip_model_destroy"); BN_RESOLVE(last_error, "bnhip_last_error");
+    BN_RESOLVE(predict_pcm16, "bnhip_predict_pcm16"); BN_RESOLVE(us_frame_cv, "bnhip_us_frame_cv");
+    BN_RESOLVE(rs_create, "bnhip_resampler_create"); BN_RESOLVE(rs_estimate, "bnhip_resampler_estimate");
+    BN_RESOLVE(rs_process_pcm16, "bnhip_resampler_process_pcm16"); BN_RESOLVE(rs_flush_pcm16, "bnhip_resampler_flush_pcm16");
+    BN_RESOLVE(rs_destroy, "bnhip_resampler_destroy");
     return NULL;
 }
 static void bnbind_unload(void) {
@@ -78,12 +93,24 @@ static int bnbind_predict_topk(bnhip_model* m, const float* s, int n, int act, d
 }
 static void bnbind_model_destroy(bnhip_model* m) { BN.model_destroy(m); }
 static const char* bnbind_last_error(void) { return BN.last_error ? BN.last_error() : ""; }
+static int bnbind_predict_pcm16(bnhip_model* m, const int16_t* s, int n, float* l, float* e) { return BN.predict_pcm16(m, s, n, l, e); }
+static int bnbind_us_frame_cv(int dev, const double* s, int n_clips, int n, int rate, int fft, int hop, int split, double* cv, int32_t* ok) {
+    return BN.us_frame_cv(dev, s, n_clips, n, rate, fft, hop, split, cv, ok);
+}
+static int bnbind_rs_create(int dev, int from, int to, bnhip_resampler** r) { return BN.rs_create(dev, from, to, r); }
+static int bnbind_rs_estimate(const bnhip_resampler* r, int n) { return BN.rs_estimate(r, n); }
+static int bnbind_rs_process_pcm16(bnhip_resampler* r, const int16_t* in, int n, int16_t* out, int cap, int* n_out) {
+    return BN.rs_process_pcm16(r, in, n, out, cap, n_out);
+}
+static int bnbind_rs_flush_pcm16(bnhip_resampler* r, int16_t* out, int cap, int* n_out) { return BN.rs_flush_pcm16(r, out, cap, n_out); }
+static void bnbind_rs_destroy(bnhip_resampler* r) { BN.rs_destroy(r); }
 */
 import "C"
 
 import (
 	"errors"
 	"fmt"
+	"math"
 	"runtime"
 	"sync"
 	"unsafe"
@@ -155,6 +182,9 @@ type Options struct {
 	// LogitsOutput / EmbeddingOutput name graph outputs explicitly (1-based here so that the zero value means "the
 	// reference's per-family rule", internal/inference/onnx/detection.go:52-112).
 	LogitsOutput, EmbeddingOutput int
+	// StrictF32 keeps every contraction on the f32-input MFMA ("bf16x3":0) instead of letting compute-bound layers run as
+	// six exact bf16 products per fp32 product (fp32-equivalent to 2^-23, include/bnhip.h): for hosts that want one kernel family.
+	StrictF32 bool
 }
 
 // NewClassifierWithOptions is NewClassifier with explicit creation options (e.g. Perch v2 on bf16 operands).
@@ -182,6 +212,9 @@ func NewClassifierWithOptions(modelData []byte, o Options) (*Classifier, error) 
 		js += fmt.Sprintf(`,"precision":"%s"`, o.Precision)
 	} else if o.Precision != "" {
 		return nil, fmt.Errorf("hip: unknown precision %q", o.Precision)
+	}
+	if o.StrictF32 {
+		js += `,"bf16x3":0`
 	}
 	if o.LogitsOutput > 0 {
 		js += fmt.Sprintf(`,"logits_output":%d`, o.LogitsOutput-1)
@@ -311,4 +344,269 @@ func (c *Classifier) Close() {
 		C.free(unsafe.Pointer(c.in))
 		c.in = nil
 	}
+}
+
+// PredictPCM16 is Predict for a clip that is still 16-bit little-endian PCM: the conversion float32(s)/32768
+// (internal/analysis/process.go:479-497, internal/audiocore/convert/pcm.go:226-237) runs on the device and half the bytes
+// cross PCIe.  pcm holds batchSize clips of nSamples samples (2 bytes each); returns flat [batchSize*nClasses] logits.
+func (c *Classifier) PredictPCM16(pcm []byte, batchSize int) ([]float32, error) {
+	if c.h == nil {
+		return nil, errors.New("hip: classifier is closed")
+	}
+	if batchSize <= 0 || len(pcm) != batchSize*c.nSamples*2 {
+		return nil, fmt.Errorf("input size mismatch: expected %d bytes, got %d", batchSize*c.nSamples*2, len(pcm))
+	}
+	out := make([]float32, batchSize*c.nClasses)
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	if rc := C.bnbind_predict_pcm16(c.h, (*C.int16_t)(unsafe.Pointer(&pcm[0])), C.int(batchSize),
+		(*C.float)(unsafe.Pointer(&out[0])), nil); rc != 0 {
+		return nil, fmt.Errorf("hip: predict_pcm16 failed (%d): %s", int(rc), lastError())
+	}
+	return out, nil
+}
+
+// CustomClassifier implements inference.CustomClassifier (internal/inference/backend.go:31-53) for a dense head file - the
+// BattyBirdNET regional heads the reference loads next to the shared embeddings backbone (internal/classifier/bat_onnx.go:282).
+// PredictEmbedding returns sigmoid-applied scores with the reference's arithmetic: 1/(1+float32(exp(float64(-x)))), the
+// division in float32 (internal/inference/onnx/postprocess.go:8-10, custom_classifier.go:148-174).
+type CustomClassifier struct {
+	c      *Classifier
+	labels []string
+}
+
+// NewCustomClassifier loads the head (ONNX or TFLite bytes) and checks the label count against the model's class count
+// (the reference builder does the same, custom_classifier.go:74-136).
+func NewCustomClassifier(modelData []byte, labels []string, devices ...int) (*CustomClassifier, error) {
+	c, err := NewClassifierWithOptions(modelData, Options{Devices: devices, MaxBatch: 64})
+	if err != nil {
+		return nil, err
+	}
+	if len(labels) != c.nClasses {
+		c.Close()
+		return nil, fmt.Errorf("hip: label count %d does not match the model's %d classes", len(labels), c.nClasses)
+	}
+	return &CustomClassifier{c: c, labels: append([]string(nil), labels...)}, nil
+}
+
+// PredictEmbedding implements inference.CustomClassifier.
+func (cc *CustomClassifier) PredictEmbedding(embeddings []float32) ([]float32, error) {
+	if cc.c == nil {
+		return nil, errors.New("hip: classifier is closed")
+	}
+	if len(embeddings) != cc.c.nSamples {
+		return nil, fmt.Errorf("embedding size mismatch: expected %d, got %d", cc.c.nSamples, len(embeddings))
+	}
+	logits, err := cc.c.Predict(embeddings)
+	if err != nil {
+		return nil, err
+	}
+	for i, x := range logits {
+		logits[i] = 1.0 / (1.0 + float32(math.Exp(float64(-x))))
+	}
+	return logits, nil
+}
+
+// NumClasses, InputDim, Labels, Close implement the rest of inference.CustomClassifier.
+func (cc *CustomClassifier) NumClasses() int { return cc.c.nClasses }
+func (cc *CustomClassifier) InputDim() int   { return cc.c.nSamples }
+func (cc *CustomClassifier) Labels() []string { return cc.labels }
+func (cc *CustomClassifier) Close() {
+	if cc.c != nil {
+		cc.c.Close()
+		cc.c = nil
+	}
+}
+
+// RangeFilter implements inference.RangeFilter and inference.BatchRangeFilter (internal/inference/backend.go:55-76) for
+// the [lat, lon, week] -> per-species occurrence meta-model: the one inference the product already batches (heat-map grids,
+// internal/classifier/heatmap_service.go:17-36; internal/inference/onnx/rangefilter.go:106-153).  Scores are whatever the
+// graph produces (the reference's models end in an in-graph sigmoid).
+type RangeFilter struct{ c *Classifier }
+
+// NewRangeFilter loads the meta-model bytes (TFLite - fp16 constants behind DEQUANTIZE are widened at load - or ONNX).
+func NewRangeFilter(modelData []byte, devices ...int) (*RangeFilter, error) {
+	c, err := NewClassifierWithOptions(modelData, Options{Devices: devices, MaxBatch: 4096})
+	if err != nil {
+		return nil, err
+	}
+	if c.nSamples != 3 {
+		c.Close()
+		return nil, fmt.Errorf("hip: range filter expects 3 inputs (lat, lon, week), the model takes %d", c.nSamples)
+	}
+	return &RangeFilter{c: c}, nil
+}
+
+// Predict implements inference.RangeFilter.
+func (r *RangeFilter) Predict(latitude, longitude, week float32) ([]float32, error) {
+	return r.PredictBatch([]float32{latitude, longitude, week}, 1)
+}
+
+// PredictBatch implements inference.BatchRangeFilter: len(inputs) must equal batchSize * 3; row-major [batchSize*numSpecies] out.
+func (r *RangeFilter) PredictBatch(inputs []float32, batchSize int) ([]float32, error) {
+	if r.c == nil {
+		return nil, errors.New("hip: range filter is closed")
+	}
+	if batchSize <= 0 || len(inputs) != batchSize*3 {
+		return nil, fmt.Errorf("input size mismatch: expected %d values, got %d", batchSize*3, len(inputs))
+	}
+	return r.c.PredictBatch(inputs, batchSize)
+}
+
+func (r *RangeFilter) NumSpecies() int { return r.c.nClasses }
+func (r *RangeFilter) Close() {
+	if r.c != nil {
+		r.c.Close()
+		r.c = nil
+	}
+}
+
+// USFilterConfig carries the three geometry fields of conf.UltrasonicFilterConfig that ComputeUSFrameCV reads
+// (internal/conf/config.go:1389-1395).
+type USFilterConfig struct {
+	FFTSize, HopSize, FrequencySplitHz int
+}
+
+// ComputeUSFrameCV is internal/audiocore/ultrasonic/filter.go:20-66 on the GPU: frame-to-frame coefficient of variation of
+// the ultrasonic band power of one chunk (samples = int16/32768 as float64, convert/pcm.go:108-113); (0, false) when the
+// filter's guards reject the geometry - decided before any device work, exactly as the Go code does.  Call site:
+// internal/analysis/processor/processor.go:893-935.
+func ComputeUSFrameCV(samples []float64, sampleRate int, cfg USFilterConfig, device int) (float64, bool, error) {
+	if len(samples) == 0 {
+		return 0, false, nil
+	}
+	var cv C.double
+	var ok C.int32_t
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	if rc := C.bnbind_us_frame_cv(C.int(device), (*C.double)(unsafe.Pointer(&samples[0])), 1, C.int(len(samples)), C.int(sampleRate),
+		C.int(cfg.FFTSize), C.int(cfg.HopSize), C.int(cfg.FrequencySplitHz), &cv, &ok); rc != 0 {
+		return 0, false, fmt.Errorf("hip: us_frame_cv failed (%d): %s", int(rc), lastError())
+	}
+	return float64(cv), ok != 0, nil
+}
+
+// Resampler mirrors internal/audiocore/resample.Resampler (resample.go:44-224) method for method: a stateful PCM16 resampler
+// whose filter history lives on the device between calls, so ~100 ms frames (analysis/buffer_consumer.go:118,192) resample to
+// exactly the samples one call over the whole stream would give.  Not safe for concurrent use (resample.go:43).
+type Resampler struct {
+	h        *C.bnhip_resampler
+	fromRate int
+	toRate   int
+	outBuf   []byte
+}
+
+const bytesPerSample = 2
+
+// NewResampler returns nil, nil when fromRate == toRate - no resampling is required (resample.go:57-60).
+func NewResampler(fromRate, toRate int, device int) (*Resampler, error) {
+	if fromRate == toRate {
+		return nil, nil //nolint:nilnil // as the reference: nil means "no resampling needed"
+	}
+	var h *C.bnhip_resampler
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	if rc := C.bnbind_rs_create(C.int(device), C.int(fromRate), C.int(toRate), &h); rc != 0 || h == nil {
+		return nil, fmt.Errorf("failed to create resampler from %d Hz to %d Hz: %s", fromRate, toRate, lastError())
+	}
+	return &Resampler{h: h, fromRate: fromRate, toRate: toRate}, nil
+}
+
+// EstimateOutputBytes: the maximum number of bytes ResampleTo may write for the given input length (resample.go:83-88).
+func (r *Resampler) EstimateOutputBytes(inputBytes int) int {
+	if inputBytes <= 0 {
+		return 0
+	}
+	return int(C.bnbind_rs_estimate(r.h, C.int(inputBytes/bytesPerSample))) * bytesPerSample
+}
+
+// ResampleTo resamples raw 16-bit PCM into dst and returns the bytes written; a dst shorter than EstimateOutputBytes is an
+// error that leaves the resampler state untouched; empty input writes nothing (resample.go:99-172).
+func (r *Resampler) ResampleTo(input, dst []byte) (int, error) {
+	if len(input) == 0 {
+		return 0, nil
+	}
+	if len(input)%bytesPerSample != 0 {
+		return 0, fmt.Errorf("input length %d is not a multiple of %d", len(input), bytesPerSample)
+	}
+	if need := r.EstimateOutputBytes(len(input)); len(dst) < need {
+		return 0, fmt.Errorf("destination buffer too small: need %d bytes, have %d", need, len(dst))
+	}
+	var n C.int
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	if rc := C.bnbind_rs_process_pcm16(r.h, (*C.int16_t)(unsafe.Pointer(&input[0])), C.int(len(input)/bytesPerSample),
+		(*C.int16_t)(unsafe.Pointer(&dst[0])), C.int(len(dst)/bytesPerSample), &n); rc != 0 {
+		return 0, fmt.Errorf("hip: resample failed (%d): %s", int(rc), lastError())
+	}
+	return int(n) * bytesPerSample, nil
+}
+
+// ResampleInto resamples into the resampler's own output buffer; the returned slice is valid until the next call
+// (resample.go:179-196).
+func (r *Resampler) ResampleInto(input []byte) ([]byte, error) {
+	need := r.EstimateOutputBytes(len(input))
+	if cap(r.outBuf) < need {
+		r.outBuf = make([]byte, need)
+	}
+	r.outBuf = r.outBuf[:cap(r.outBuf)]
+	n, err := r.ResampleTo(input, r.outBuf)
+	if err != nil {
+		return nil, err
+	}
+	return r.outBuf[:n], nil
+}
+
+// Flush emits the tail that needs zero-padded future input and resets the state for a new stream (the go-audio-resampler
+// engine's Flush, which the reference's one-shot ResampleBytes relies on, resample.go:228-262).
+func (r *Resampler) Flush() ([]byte, error) {
+	out := make([]byte, r.EstimateOutputBytes(2*bytesPerSample)+64*bytesPerSample)
+	var n C.int
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	for {
+		rc := C.bnbind_rs_flush_pcm16(r.h, (*C.int16_t)(unsafe.Pointer(&out[0])), C.int(len(out)/bytesPerSample), &n)
+		if rc == 0 {
+			return out[:int(n)*bytesPerSample], nil
+		}
+		if rc != -1 || len(out) > 1<<26 {
+			return nil, fmt.Errorf("hip: resample flush failed (%d): %s", int(rc), lastError())
+		}
+		out = make([]byte, 2*len(out)) // destination too small: nothing was consumed, retry larger
+	}
+}
+
+func (r *Resampler) FromRate() int { return r.fromRate }
+func (r *Resampler) ToRate() int   { return r.toRate }
+
+// Close releases the device state; idempotent (resample.go:206-217).
+func (r *Resampler) Close() error {
+	if r != nil && r.h != nil {
+		C.bnbind_rs_destroy(r.h)
+		r.h = nil
+	}
+	return nil
+}
+
+func (r *Resampler) String() string { return fmt.Sprintf("Resampler(%d Hz -> %d Hz, hip)", r.fromRate, r.toRate) }
+
+// ResampleBytes is the one-shot helper (resample.go:228-262): equal rates return the input unchanged; otherwise a fresh
+// resampler processes the input once and an independent copy of what it emitted is returned (like the reference, without a
+// flush: the last ~10 output samples, which need future input, are not produced).
+func ResampleBytes(pcm []byte, fromRate, toRate int, device int) ([]byte, error) {
+	if fromRate == toRate {
+		return pcm, nil
+	}
+	r, err := NewResampler(fromRate, toRate, device)
+	if err != nil {
+		return nil, err
+	}
+	defer func() { _ = r.Close() }()
+	out, err := r.ResampleInto(pcm)
+	if err != nil {
+		return nil, err
+	}
+	result := make([]byte, len(out))
+	copy(result, out)
+	return result, nil
 }

@@ -5,10 +5,13 @@
  *
  *   cabi_driver <libbnhip.so> <model file> cpu               error paths + plan-only sequence (no GPU needed)
  *   cabi_driver <libbnhip.so> <model file> gpu <in.f32> <out.f32> <n_clips>
- *        Init -> NewClassifier -> Predict (clip 0) -> PredictBatch (all) -> PredictTopK -> Close, logits written to out.f32
+ *        Init -> NewClassifier -> Predict (clip 0) -> PredictBatch (all) -> PredictTopK -> PredictPCM16 -> ComputeUSFrameCV (the
+ *        reference's known answers) -> Resampler (chunked == one shot) -> Close, logits written to out.f32.  With a dense model
+ *        (a CustomClassifier head, a RangeFilter meta-model) the same sequence is what PredictEmbedding / PredictBatch do.
  */
 #include "preamble_extracted.h"
 
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -67,6 +70,34 @@ int main(int argc, char** argv) {
         CHECK(rc != 0, "predict_topk on a plan-only handle must fail");
         bnbind_model_destroy(h);
         free(x); free(y);
+        /* PredictPCM16 on a plan-only handle is rejected the same way */
+        {
+            rc = bnbind_model_create(blob, nb, "{\"plan_only\":1}", &h);
+            CHECK(rc == 0 && h, "plan-only create (2): %s", bnbind_last_error());
+            int16_t* xp = calloc((size_t)ns, 2); float* yp = calloc((size_t)nc, 4);
+            rc = bnbind_predict_pcm16(h, xp, 1, yp, NULL);
+            CHECK(rc == -1 && strstr(bnbind_last_error(), "plan-only"), "predict_pcm16 on a plan-only handle: rc %d", rc);
+            bnbind_model_destroy(h);
+            free(xp); free(yp);
+        }
+        /* NewResampler(equal rates) = nil, nil (resample.go:57-60): success with a NULL handle, and every method accepts it */
+        {
+            bnhip_resampler* r = (bnhip_resampler*)1;
+            rc = bnbind_rs_create(0, 48000, 48000, &r);
+            CHECK(rc == 0 && r == NULL, "equal rates must give a NULL resampler (rc %d)", rc);
+            CHECK(bnbind_rs_estimate(NULL, 100) == 0, "estimate on a NULL resampler");
+            bnbind_rs_destroy(NULL);
+            rc = bnbind_rs_create(0, 0, 48000, &r);
+            CHECK(rc == -1 && r == NULL, "rate 0 must be invalid (rc %d)", rc);
+        }
+        /* ComputeUSFrameCV's guards (filter.go:21-37) answer (0, false) before any device work */
+        {
+            double sm[64] = {0}, cv = 1.0; int32_t ok = 1;
+            rc = bnbind_us_frame_cv(0, sm, 1, 64, 256000, 8192, 4096, 20000, &cv, &ok);
+            CHECK(rc == 0 && cv == 0.0 && ok == 0, "us_frame_cv: clip shorter than the FFT must be (0, false) (rc %d)", rc);
+            rc = bnbind_us_frame_cv(0, sm, 1, 64, 48000, 32, 16, 30000, &cv, &ok);
+            CHECK(rc == 0 && ok == 0, "us_frame_cv: split above Nyquist must be (0, false)");
+        }
         /* without a GPU Init reports "unavailable" (-2) and the message names the reason; with one it succeeds */
         int n = -1;
         rc = bnbind_init(&n);
@@ -112,6 +143,63 @@ int main(int argc, char** argv) {
             CHECK(ix[c * k + j] >= 0 && ix[c * k + j] < nc, "index out of range");
             if (j) CHECK(cf[c * k + j] <= cf[c * k + j - 1], "confidences not descending");
         }
+    }
+    /* PredictPCM16: int16 clips converted on the device (float32(s)/32768) == Predict on the same values converted here */
+    if (ns >= 1000) {
+        int16_t* pcm = malloc((size_t)n_clips * ns * 2);
+        float* deq = malloc((size_t)n_clips * ns * 4);
+        float* o1 = malloc((size_t)n_clips * nc * 4); float* o2 = malloc((size_t)n_clips * nc * 4);
+        for (size_t i = 0; i < (size_t)n_clips * ns; i++) {
+            float v = in[i] < -1.f ? -1.f : (in[i] > 1.f ? 1.f : in[i]);
+            pcm[i] = (int16_t)(v * 32767.f);
+            deq[i] = (float)pcm[i] / 32768.0f;
+        }
+        CHECK(bnbind_predict_pcm16(h, pcm, n_clips, o1, NULL) == 0, "predict_pcm16: %s", bnbind_last_error());
+        CHECK(bnbind_predict(h, deq, n_clips, o2, NULL) == 0, "predict (dequantised): %s", bnbind_last_error());
+        for (size_t i = 0; i < (size_t)n_clips * nc; i++) CHECK(o1[i] == o2[i], "PredictPCM16 differs from Predict at %zu: %g vs %g", i, o1[i], o2[i]);
+        free(pcm); free(deq); free(o1); free(o2);
+    }
+    /* ComputeUSFrameCV: the reference's own known answers (ultrasonic/filter_test.go:23-60): a steady 40 kHz tone of amplitude
+     * 0.01 at 256 kHz has CV < 0.15; a 45 kHz burst of amplitude 0.5 in the middle third has CV > 0.15 */
+    {
+        const int N = 144000, rate = 256000;
+        double* s1 = malloc((size_t)2 * N * 8);
+        for (int i = 0; i < N; i++) {
+            s1[i] = 0.01 * sin(2.0 * M_PI * 40000.0 * i / rate);
+            s1[N + i] = (i >= N / 3 && i < 2 * N / 3) ? 0.5 * sin(2.0 * M_PI * 45000.0 * i / rate) : 0.0;
+        }
+        double cv[2]; int32_t ok[2];
+        CHECK(bnbind_us_frame_cv(0, s1, 2, N, rate, 8192, 4096, 20000, cv, ok) == 0, "us_frame_cv: %s", bnbind_last_error());
+        CHECK(ok[0] && ok[1] && cv[0] < 0.15 && cv[1] > 0.15, "us_frame_cv known answers: cv %g %g ok %d %d", cv[0], cv[1], ok[0], ok[1]);
+        free(s1);
+    }
+    /* Resampler: 48 kHz -> 32 kHz in 100 ms frames == one call over the whole stream, sample for sample; a destination that
+     * is too small fails WITHOUT advancing the state (resample.go:137-144) */
+    {
+        const int N = 48000, fr = 4800;
+        int16_t* x = malloc((size_t)N * 2);
+        for (int i = 0; i < N; i++) x[i] = (int16_t)(12000.0 * sin(2.0 * M_PI * 1000.0 * i / 48000.0) + 5000.0 * sin(2.0 * M_PI * 7000.0 * i / 48000.0));
+        bnhip_resampler *ra = NULL, *rb = NULL;
+        CHECK(bnbind_rs_create(0, 48000, 32000, &ra) == 0 && ra, "resampler create: %s", bnbind_last_error());
+        CHECK(bnbind_rs_create(0, 48000, 32000, &rb) == 0 && rb, "resampler create: %s", bnbind_last_error());
+        const int cap = bnbind_rs_estimate(ra, N) + 64;
+        int16_t* ya = malloc((size_t)cap * 2); int16_t* yb = malloc((size_t)cap * 2);
+        int na = 0, nb2 = 0, n = 0;
+        CHECK(bnbind_rs_process_pcm16(ra, x, N, ya, cap, &na) == 0, "one-shot: %s", bnbind_last_error());
+        CHECK(bnbind_rs_flush_pcm16(ra, ya + na, cap - na, &n) == 0, "flush: %s", bnbind_last_error());
+        na += n;
+        CHECK(na == 32000, "one-shot output length %d != 32000", na);
+        int16_t tiny[4];
+        CHECK(bnbind_rs_process_pcm16(rb, x, fr, tiny, 4, &n) == -1 && n == 0, "a too-small destination must fail");
+        for (int off = 0; off < N; off += fr) {
+            CHECK(bnbind_rs_process_pcm16(rb, x + off, fr, yb + nb2, cap - nb2, &n) == 0, "chunk: %s", bnbind_last_error());
+            nb2 += n;
+        }
+        CHECK(bnbind_rs_flush_pcm16(rb, yb + nb2, cap - nb2, &n) == 0, "flush: %s", bnbind_last_error());
+        nb2 += n;
+        CHECK(nb2 == na && memcmp(ya, yb, (size_t)na * 2) == 0, "chunked resampling differs from one call (%d vs %d samples)", nb2, na);
+        bnbind_rs_destroy(ra); bnbind_rs_destroy(rb);
+        free(x); free(ya); free(yb);
     }
     FILE* fo = fopen(argv[5], "wb");
     CHECK(fo && fwrite(out, 4, (size_t)n_clips * nc, fo) == (size_t)n_clips * nc, "write %s", argv[5]);
