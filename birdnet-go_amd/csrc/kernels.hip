@@ -1832,16 +1832,19 @@ struct ExpDwParams {
 // lanes cover 16 distinct 16-byte slots of a 256-byte row.  With the E row stride of 36 floats the slot of a lane is
 // (a * tx + c4) mod 16, a = SW * S (2 or 4 for every instantiated shape); the natural lane = tx * 8 + c4 order put three
 // lanes of a group on one slot (PMC: up to 25 % of CU cycles in LDS bank conflicts).  These permutations give each group
-// two tx values whose slot ranges are disjoint; ED_INV* are the inverse maps (for the cross-lane sum).
+// two tx values whose slot ranges are disjoint.
 // Every group of four lanes moves as a unit, so a permutation is 16 nibbles (lane group -> lane group) in one 64-bit
 // constant, decoded with a shift and a mask - a table in memory cost every block a dependent global load right before its
 // first operand loads.
 #define ED_PERM2 0xfdce5764b98a1320ull
-#define ED_INV2 0xfced7465a9b82130ull
 #define ED_PERM4 0xfdce9ba875461320ull
-#define ED_INV4 0xfceda9b874652130ull
 __device__ __forceinline__ int ed_perm(unsigned long long magic, int lane) {
     return (int)((magic >> ((lane >> 2) * 4)) & 15ull) * 4 + (lane & 3);
+}
+constexpr bool ed_perm_c4_rule(unsigned long long magic) {
+    for (int g = 0; g < 16; g++)
+        if (((magic >> (4 * g)) & 1ull) != (unsigned long long)((g >> 1) & 1)) return false;
+    return true;
 }
 // BX: phase 1 on the split-bf16 MFMA (see k_pw_bx3): the expand weights come pre-split ([Cp][3 planes][Kp] bf16, Kp = K rounded
 // up to 32), the lane's 8 input channels of a 32-wide slab are split in registers.  The split is amortised over only two
@@ -1857,19 +1860,25 @@ constexpr int expdw_min_waves(int K, int S, int TOW, int TRH) {
 // COPY: no expand at all - phase 1 only stages the tile's input footprint (32 channels of x itself) in LDS and phase 2 runs
 // as above: a plain depthwise convolution whose taps read LDS instead of L1/L2 (k_dwconv_t re-reads every input value
 // (TIH x TIW) / (TH x TW) = 6x for a 5 x 5 filter), with the fused kernel's tile shapes, orientations and per-tile sums.
-template <int K, int S, int TOH, int TOW, int TRH, bool STEM = false, bool H8 = STEM, bool BX = false, bool COPY = false>
+// SK ("small K", compile time: carrying both forms in one kernel costs the K-loop layers 14-16 VGPRs and with them the fourth
+// wave per SIMD): Kw <= 32, every operand of the block's K range is in registers before the first MFMA and the tiles are
+// walked tile-outer with the activation of one tile issued under the MFMAs of the next; otherwise the K loop.
+template <int K, int S, int TOH, int TOW, int TRH, bool STEM = false, bool H8 = STEM, bool BX = false, bool COPY = false, bool SK = STEM>
 __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void k_expand_dw(ExpDwParams p, unsigned nblk) {
+    static_assert(!(SK && (BX || COPY)) && (!STEM || SK), "SK is a form of the f32 expand; the stem's K is 24");
     constexpr int TIH = (TOH - 1) * S + K, TIW = (TOW - 1) * S + K;
     static_assert(TRH <= TIH, "TRH is a cap on the footprint rows");
     constexpr int NPIX = TRH * TIW, NPIXP = (NPIX + 15) / 16 * 16;
     constexpr int JT = NPIXP / 16, JTW = (JT + 3) / 4;
     constexpr int SH = TOH / 4, SW = TOW / 8;                 // outputs per thread in phase 2 (thread-tiles are 4 x 8)
     constexpr int RW = (SW - 1) * S + K;
-    __shared__ __attribute__((aligned(16))) float lds[NPIX * ED_ES + 128 + K * K * 32];
+    __shared__ __attribute__((aligned(16))) float lds[NPIX * ED_ES + 256 + K * K * 32];
     float* E = lds;                                                      // [<=TRH rows][TIW][36] expanded footprint
-    float4* red = reinterpret_cast<float4*>(lds + NPIX * ED_ES);         // [4 waves][8] sum scratch
-    float4* wds = reinterpret_cast<float4*>(lds + NPIX * ED_ES + 128);   // [K*K][8] depthwise taps of this chunk
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float4* red = reinterpret_cast<float4*>(lds + NPIX * ED_ES);         // [4 waves][2 half waves][8] sum scratch
+    float4* wds = reinterpret_cast<float4*>(lds + NPIX * ED_ES + 256);   // [K*K][8] depthwise taps of this chunk
+    // (the wave index through readfirstlane: the compiler then keeps every "which tiles / rows does this wave own" test
+    // on the scalar unit instead of comparing per lane and branching on exec)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
 
     const unsigned L = xcd_remap(blockIdx.x, nblk);
@@ -1891,7 +1900,7 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
 
     // ---- small parameters first (registers; the taps go to LDS after phase 1)
     static_assert(SW * S == 2 || SW * S == 4, "lane permutation tables cover SW*S in {2, 4}");
-    constexpr unsigned long long PERM = SW * S == 2 ? ED_PERM2 : ED_PERM4, IPERM = SW * S == 2 ? ED_INV2 : ED_INV4;
+    constexpr unsigned long long PERM = SW * S == 2 ? ED_PERM2 : ED_PERM4;
     const int pl = ed_perm(PERM, lane);                  // logical lane: tx * 8 + c4
     const int c4 = pl & 7, tt = (wave << 3) | (pl >> 3);
     float4 wdreg = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1941,9 +1950,11 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
     const float* wrow0 = p.we + (size_t)(n_base + li) * Kw + 4 * kq;
     const float* wrow1 = wrow0 + (size_t)16 * Kw;
 
+    // the accumulators start at the bias (the lane's four rows are channels 4 kq .. + 3 of its pixel): the first MFMA of a
+    // tile reads it as its C operand, which removes both the zero fill and the bias add of the epilogue
     f32x4 acc[JTW][2];
 #pragma unroll
-    for (int a = 0; a < JTW; a++) { acc[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int a = 0; a < JTW; a++) { acc[a][0] = (f32x4){bq0.x, bq0.y, bq0.z, bq0.w}; acc[a][1] = (f32x4){bq1.x, bq1.y, bq1.z, bq1.w}; }
 
     auto fload = [&](int k0, f32x4& wf0, f32x4& wf1, f32x4 (&xf)[JTW]) {
         float4 t0 = *reinterpret_cast<const float4*>(wrow0 + k0), t1 = *reinterpret_cast<const float4*>(wrow1 + k0);
@@ -2016,6 +2027,66 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
             }
         }
     };
+    // ---- tile-outer order for the layers whose whole K range sits in registers before the first MFMA (Kw <= 32: the stem and
+    // the early blocks, where the wave spends more issue slots on the swish than on the MFMAs and too few waves fit a SIMD
+    // to hide one behind the other): the activation + LDS store of tile a - 1 is issued under the MFMAs of tile a
+    // (sched_group_barrier: per MFMA - 8 passes = 32 cycles of the matrix pipe - two plain and two transcendental VALU ops).
+    const bool border = iw0 < 0 || iw0 + TIW > p.W;       // block-uniform: only such tiles have columns to mask in E
+    bool e_done = false;
+    auto mma1 = [&](int a, const f32x4& wf0, const f32x4& wf1, const f32x4 (&xf)[JTW]) {
+#pragma unroll
+        for (int sidx = 0; sidx < 4; sidx++) {
+            acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf0[sidx], xf[a][sidx], acc[a][0], 0, 0, 0);
+            acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf1[sidx], xf[a][sidx], acc[a][1], 0, 0, 0);
+        }
+    };
+    auto mma1h = [&](int a, const f32x2& wh0, const f32x2& wh1, const f32x2 (&xh)[JTW]) {
+#pragma unroll
+        for (int sidx = 0; sidx < 2; sidx++) {
+            acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh0[sidx], xh[a][sidx], acc[a][0], 0, 0, 0);
+            acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh1[sidx], xh[a][sidx], acc[a][1], 0, 0, 0);
+        }
+    };
+    auto fin_swish = [&](int a, auto masked) {
+        acc[a][0] = swish4(acc[a][0]);
+        acc[a][1] = swish4(acc[a][1]);
+        const int j = 16 * (wave + 4 * a) + li;
+        if (j < nvalid) {
+            const int e = j * ED_ES + 4 * kq;
+            if constexpr (decltype(masked)::value) {
+                const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(&E[e]) = xin[a] ? acc[a][0] : z;
+                *reinterpret_cast<f32x4*>(&E[e + 16]) = xin[a] ? acc[a][1] : z;
+            } else {
+                *reinterpret_cast<f32x4*>(&E[e]) = acc[a][0];
+                *reinterpret_cast<f32x4*>(&E[e + 16]) = acc[a][1];
+            }
+        }
+    };
+    auto piped = [&](auto masked, auto nm, auto&& tile_mma) {
+#pragma unroll
+        for (int a = 0; a < JTW; a++) {
+            if (wave + 4 * a < jtv) {                     // (tile a valid => tile a - 1 valid)
+                tile_mma(a);
+                if (a > 0) {
+                    fin_swish(a - 1, masked);
+#pragma unroll
+                    for (int q = 0; q < decltype(nm)::value; q++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+                    }
+                }
+            } else if (a > 0 && wave + 4 * (a - 1) < jtv) fin_swish(a - 1, masked);
+        }
+        if (wave + 4 * (JTW - 1) < jtv) fin_swish(JTW - 1, masked);
+    };
+    auto piped_run = [&](auto nm, auto&& tile_mma) {
+        if (border) piped(std::true_type{}, nm, tile_mma);
+        else piped(std::false_type{}, nm, tile_mma);
+        e_done = true;
+    };
+    const bool pipe_e = p.act_e == ACT_SWISH;
     // H8 (compile time: the half slab costs ~10 VGPRs when it is a run-time option, which drops every shape at 120
     // VGPRs from four waves per SIMD to three) = Kw is 8 mod 16
     const int Kfull = Kw & ~15;
@@ -2066,34 +2137,41 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
                 }
             }
         }
-    } else if (!H8) {
+    } else if constexpr (!H8 && SK) {
         if (Kw <= 16) {
             f32x4 wA0, wA1, xA[JTW];
             fload(0, wA0, wA1, xA);
-            fmma(wA0, wA1, xA);
-        } else if (Kw <= 32) {
+            if (pipe_e) piped_run(std::integral_constant<int, 8>{}, [&](int a) { mma1(a, wA0, wA1, xA); });
+            else fmma(wA0, wA1, xA);
+        } else {
             // early blocks (Cin 17..32): both K slabs requested back-to-back -> one memory latency instead of two
             f32x4 wA0, wA1, xA[JTW], wB0, wB1, xB[JTW];
             fload(0, wA0, wA1, xA);
             fload(16, wB0, wB1, xB);
-            fmma(wA0, wA1, xA);
-            fmma(wB0, wB1, xB);
-        } else {
-            // (a rolling two-slab register prefetch was measured here: the extra VGPRs cost more occupancy than it buys)
-            for (int k0 = 0; k0 < Kw; k0 += 16) {
-                f32x4 wf0, wf1, xf[JTW];
-                fload(k0, wf0, wf1, xf);
-                fmma(wf0, wf1, xf);
+            if (pipe_e) piped_run(std::integral_constant<int, 16>{}, [&](int a) { mma1(a, wA0, wA1, xA); mma1(a, wB0, wB1, xB); });
+            else {
+                fmma(wA0, wA1, xA);
+                fmma(wB0, wB1, xB);
             }
         }
-    } else if (Kfull == 16) {
+    } else if constexpr (!H8) {
+        // (a rolling two-slab register prefetch was measured here: the extra VGPRs cost more occupancy than it buys)
+        for (int k0 = 0; k0 < Kw; k0 += 16) {
+            f32x4 wf0, wf1, xf[JTW];
+            fload(k0, wf0, wf1, xf);
+            fmma(wf0, wf1, xf);
+        }
+    } else if constexpr (SK) {
         // Cin 17..24 (and the stem's 3 x 4 x 2 window): slab + half slab requested back-to-back
         f32x4 wA0, wA1, xA[JTW];
         f32x2 hA0, hA1, hx[JTW];
         fload(0, wA0, wA1, xA);
         fload8(16, hA0, hA1, hx);
-        fmma(wA0, wA1, xA);
-        fmma8(hA0, hA1, hx);
+        if (pipe_e) piped_run(std::integral_constant<int, 12>{}, [&](int a) { mma1(a, wA0, wA1, xA); mma1h(a, hA0, hA1, hx); });
+        else {
+            fmma(wA0, wA1, xA);
+            fmma8(hA0, hA1, hx);
+        }
     } else {
         for (int k0 = 0; k0 < Kfull; k0 += 16) {
             f32x4 wf0, wf1, xf[JTW];
@@ -2105,27 +2183,33 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
         fmma8(hA0, hA1, hx);
     }
 
-    // ---- E <- act_e(acc + be) at compacted footprint coordinates (masked columns are zero)
+    // ---- E <- act_e(acc) at compacted footprint coordinates (masked columns are zero).  Only a tile on the left / right
+    // image border has columns to mask: interior tiles store without the eight selects per 16 pixels
 #pragma unroll
     for (int a = 0; a < JTW; a++) {
-        if (wave + 4 * a < jtv) {                         // wave-uniform: tiles beyond the valid rows cost nothing
+        if (!e_done && wave + 4 * a < jtv) {                         // wave-uniform: tiles beyond the valid rows cost nothing
             if (p.act_e == ACT_SWISH) {
-                acc[a][0] = swish4(acc[a][0] + (f32x4){bq0.x, bq0.y, bq0.z, bq0.w});
-                acc[a][1] = swish4(acc[a][1] + (f32x4){bq1.x, bq1.y, bq1.z, bq1.w});
+                acc[a][0] = swish4(acc[a][0]);
+                acc[a][1] = swish4(acc[a][1]);
             } else {
                 with_act(p.act_e, [&](auto f) {
                     f32x4& v0 = acc[a][0];
                     f32x4& v1 = acc[a][1];
-                    v0[0] = f(v0[0] + bq0.x); v0[1] = f(v0[1] + bq0.y); v0[2] = f(v0[2] + bq0.z); v0[3] = f(v0[3] + bq0.w);
-                    v1[0] = f(v1[0] + bq1.x); v1[1] = f(v1[1] + bq1.y); v1[2] = f(v1[2] + bq1.z); v1[3] = f(v1[3] + bq1.w);
+                    v0[0] = f(v0[0]); v0[1] = f(v0[1]); v0[2] = f(v0[2]); v0[3] = f(v0[3]);
+                    v1[0] = f(v1[0]); v1[1] = f(v1[1]); v1[2] = f(v1[2]); v1[3] = f(v1[3]);
                 });
             }
             int j = 16 * (wave + 4 * a) + li;
             if (j < nvalid) {
                 int e = j * ED_ES + 4 * kq;
-                const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4*>(&E[e]) = xin[a] ? acc[a][0] : z;
-                *reinterpret_cast<f32x4*>(&E[e + 16]) = xin[a] ? acc[a][1] : z;
+                if (border) {
+                    const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(&E[e]) = xin[a] ? acc[a][0] : z;
+                    *reinterpret_cast<f32x4*>(&E[e + 16]) = xin[a] ? acc[a][1] : z;
+                } else {
+                    *reinterpret_cast<f32x4*>(&E[e]) = acc[a][0];
+                    *reinterpret_cast<f32x4*>(&E[e + 16]) = acc[a][1];
+                }
             }
         }
     }
@@ -2134,7 +2218,7 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
     }   // !COPY
 
     // ---- depthwise from LDS
-    const int ty = tt >> 3, tx = tt & 7;                 // ty == wave: row tests below are wave-uniform
+    const int ty = wave, tx = tt & 7;                    // (tt >> 3 == wave: the row tests below are wave-uniform, scalar)
     const int n = n_base + 4 * c4;
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n < p.Cmid) {
@@ -2167,6 +2251,7 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
                 }
             }
         }
+        float* const ybase = p.y + ((size_t)b * p.Ho * p.Wo + (size_t)(oh0 + ty * SH) * p.ysh + (size_t)(ow0 + tx * SW) * p.ysw) * p.Cmid + n;
 #pragma unroll
         for (int a = 0; a < SH; a++) {
             int oh = oh0 + ty * SH + a;
@@ -2192,25 +2277,32 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
                 int ow = ow0 + tx * SW + c;
                 if (ow >= p.Wo) continue;
                 float4 v = acc2[a][c];
-                *reinterpret_cast<float4*>(p.y + ((size_t)b * p.Ho * p.Wo + (size_t)oh * p.ysh + (size_t)ow * p.ysw) * p.Cmid + n) = v;
+                // (ybase holds everything that depends on the lane; the rest of the address is a block-uniform offset)
+                *reinterpret_cast<float4*>(ybase + (size_t)((a * p.ysh + c * p.ysw) * p.Cmid)) = v;
                 sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
             }
         }
     }
     if (p.partial) {
-        // lanes with equal (lane & 7) hold the same channel quad: butterfly over the other lane bits, then 4 waves
-#pragma unroll
-        for (int o = 8; o < 64; o <<= 1) {
-            const int src = ed_perm(IPERM, pl ^ o);      // physical lane of the logical partner
-            sum.x += __shfl(sum.x, src, 64); sum.y += __shfl(sum.y, src, 64);
-            sum.z += __shfl(sum.z, src, 64); sum.w += __shfl(sum.w, src, 64);
-        }
-        if (pl < 8) red[wave * 8 + pl] = sum;
+        // Both lane permutations keep c4 = 4 * (physical lane bit 3) + (lane & 3), so the lanes that share a channel quad differ
+        // in physical lane bits 2, 4 and 5: two ds_swizzle xor steps (immediate pattern - no partner-address arithmetic, no
+        // inverse permutation) leave the sum of each half wave in its lanes, and the eight (wave, half) partials meet in LDS.
+        static_assert(ed_perm_c4_rule(ED_PERM2) && ed_perm_c4_rule(ED_PERM4), "lane permutation: c4 bit 2 must be physical lane bit 3");
+        auto xsum = [&](auto pat) {
+            constexpr int P = decltype(pat)::value;      // ds_swizzle bit mode: and 0x1f, or 0, xor (P >> 10)
+            sum.x += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, sum.x), P));
+            sum.y += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, sum.y), P));
+            sum.z += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, sum.z), P));
+            sum.w += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, sum.w), P));
+        };
+        xsum(std::integral_constant<int, 0x101f>{});     // xor 4
+        xsum(std::integral_constant<int, 0x401f>{});     // xor 16
+        if ((lane & 0x14) == 0) red[(wave * 2 + (lane >> 5)) * 8 + c4] = sum;
         __syncthreads();
         if (tid < 8 && n_base + 4 * tid < p.Cmid) {
             float4 t = red[tid];
 #pragma unroll
-            for (int w = 1; w < 4; w++) { float4 v = red[w * 8 + tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            for (int w = 1; w < 8; w++) { float4 v = red[w * 8 + tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
             *reinterpret_cast<float4*>(p.partial + ((size_t)b * tiles + tile) * p.Cmid + n_base + 4 * tid) = t;
         }
     }
@@ -2357,7 +2449,9 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
 #define ED_CASE(K_, S_, TH_, TW_, TR_)                                                                        \
     if (sh->k == K_ && sh->s == S_ && sh->toh == TH_ && sh->tow == TW_ && sh->trh == TR_) {                   \
         if (bx) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        else if (p.Kw == 24) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, true, false, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         else if (p.Kw & 8) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        else if (p.Kw <= 32) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, false, false, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         else hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_>), dim3(nblk), dim3(256), 0, st, p, nblk);  \
         return;                                                                                               \
     }
