@@ -1857,21 +1857,121 @@ constexpr int expdw_min_waves(int K, int S, int TOW, int TRH) {
     const int tiw = (TOW - 1) * S + K, jt = (TRH * tiw + 15) / 16, jtw = (jt + 3) / 4;
     return jtw <= 4 ? 4 : (jtw == 5 ? 3 : 2);
 }
+constexpr int expdw_sk_waves(int K, int S, int TOW, int TRH, bool one_chunk) {
+    const int tiw = (TOW - 1) * S + K, jt = (TRH * tiw + 15) / 16, jtw = (jt + 3) / 4;
+    return one_chunk && jtw <= 3 ? 5 : expdw_min_waves(K, S, TOW, TRH);
+}
 // COPY: no expand at all - phase 1 only stages the tile's input footprint (32 channels of x itself) in LDS and phase 2 runs
 // as above: a plain depthwise convolution whose taps read LDS instead of L1/L2 (k_dwconv_t re-reads every input value
 // (TIH x TIW) / (TH x TW) = 6x for a 5 x 5 filter), with the fused kernel's tile shapes, orientations and per-tile sums.
-// SK ("small K", compile time: carrying both forms in one kernel costs the K-loop layers 14-16 VGPRs and with them the fourth
-// wave per SIMD): Kw <= 32, every operand of the block's K range is in registers before the first MFMA and the tiles are
-// walked tile-outer with the activation of one tile issued under the MFMAs of the next; otherwise the K loop.
-template <int K, int S, int TOH, int TOW, int TRH, bool STEM = false, bool H8 = STEM, bool BX = false, bool COPY = false, bool SK = STEM>
+// ---- phase 2 of the fused kernel (shared by its forms): depthwise taps from the expanded footprint in LDS, bias + activation,
+// store; returns the lane's sum of what it stored (for the squeeze-excite mean).  ty is the wave index (scalar): every row
+// test is wave-uniform.
+template <int K, int S, int TOH, int TOW, int TRH>
+__device__ __forceinline__ float4 ed_phase2(const ExpDwParams& p, const float* E, const float4* wds, int b, int oh0, int ow0, int vr0,
+                                            int vr1, int ty, int tx, int c4, int n_base, const float4& bv) {
+    constexpr int TIW = (TOW - 1) * S + K;
+    constexpr int SH = TOH / 4, SW = TOW / 8;                 // outputs per thread (thread-tiles are 4 x 8)
+    constexpr int RW = (SW - 1) * S + K;
+    const int n = n_base + 4 * c4;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < p.Cmid) {
+        float4 acc2[SH][SW];
+#pragma unroll
+        for (int a = 0; a < SH; a++)
+#pragma unroll
+            for (int c = 0; c < SW; c++) acc2[a][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* e0 = E + (tx * SW * S) * ED_ES + 4 * c4;
+#pragma unroll 1
+        for (int i = 0; i < K; i++) {                 // kernel row (kept rolled: bounds the live weight registers)
+            float4 w[K];
+#pragma unroll
+            for (int j = 0; j < K; j++) w[j] = wds[(i * K + j) * 8 + c4];
+#pragma unroll
+            for (int a = 0; a < SH; a++) {
+                const int fr = (ty * SH + a) * S + i;                       // footprint row of this tap
+                if (fr < vr0 || fr >= vr1 || oh0 + ty * SH + a >= p.Ho) continue;   // padding row / no such output row
+                float4 xr[RW];
+#pragma unroll
+                for (int c = 0; c < RW; c++) xr[c] = *reinterpret_cast<const float4*>(e0 + ((fr - vr0) * TIW + c) * ED_ES);
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+#pragma unroll
+                    for (int c = 0; c < SW; c++) {
+                        const float4 xv = xr[c * S + j];
+                        acc2[a][c].x = fmaf(xv.x, w[j].x, acc2[a][c].x); acc2[a][c].y = fmaf(xv.y, w[j].y, acc2[a][c].y);
+                        acc2[a][c].z = fmaf(xv.z, w[j].z, acc2[a][c].z); acc2[a][c].w = fmaf(xv.w, w[j].w, acc2[a][c].w);
+                    }
+                }
+            }
+        }
+        // (ybase holds everything that depends on the lane; the rest of a store address is a block-uniform offset)
+        float* const ybase = p.y + ((size_t)b * p.Ho * p.Wo + (size_t)(oh0 + ty * SH) * p.ysh + (size_t)(ow0 + tx * SW) * p.ysw) * p.Cmid + n;
+#pragma unroll
+        for (int a = 0; a < SH; a++) {
+            int oh = oh0 + ty * SH + a;
+            if (oh >= p.Ho) continue;
+            if (p.act_d == ACT_SWISH) {
+#pragma unroll
+                for (int c = 0; c < SW; c++) {
+                    float4& v = acc2[a][c];
+                    const f32x4 r = swish4((f32x4){v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w});
+                    v = make_float4(r[0], r[1], r[2], r[3]);
+                }
+            } else {
+                with_act(p.act_d, [&](auto f) {
+#pragma unroll
+                    for (int c = 0; c < SW; c++) {
+                        float4& v = acc2[a][c];
+                        v.x = f(v.x + bv.x); v.y = f(v.y + bv.y); v.z = f(v.z + bv.z); v.w = f(v.w + bv.w);
+                    }
+                });
+            }
+#pragma unroll
+            for (int c = 0; c < SW; c++) {
+                int ow = ow0 + tx * SW + c;
+                if (ow >= p.Wo) continue;
+                float4 v = acc2[a][c];
+                *reinterpret_cast<float4*>(ybase + (size_t)((a * p.ysh + c * p.ysw) * p.Cmid)) = v;
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+        }
+    }
+    return sum;
+}
+// Per-tile channel sums, first half: both lane permutations keep c4 = 4 * (physical lane bit 3) + (lane & 3), so the lanes that
+// share a channel quad differ in physical lane bits 2, 4 and 5: two ds_swizzle xor steps (immediate pattern - no
+// partner-address arithmetic, no inverse permutation) leave the sum of each half wave in its lanes, and the eight
+// (wave, half) partials meet in LDS (red: [4 waves][2 halves][8 quads]).  Second half, after a barrier: ed_sums_out.
+__device__ __forceinline__ void ed_sums_lanes(float4 sum, float4* red, int wave, int lane, int c4) {
+    static_assert(ed_perm_c4_rule(ED_PERM2) && ed_perm_c4_rule(ED_PERM4), "lane permutation: c4 bit 2 must be physical lane bit 3");
+    auto xsum = [&](auto pat) {
+        constexpr int P = decltype(pat)::value;      // ds_swizzle bit mode: and 0x1f, or 0, xor (P >> 10)
+        sum.x += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, sum.x), P));
+        sum.y += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, sum.y), P));
+        sum.z += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, sum.z), P));
+        sum.w += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, sum.w), P));
+    };
+    xsum(std::integral_constant<int, 0x101f>{});     // xor 4
+    xsum(std::integral_constant<int, 0x401f>{});     // xor 16
+    if ((lane & 0x14) == 0) red[(wave * 2 + (lane >> 5)) * 8 + c4] = sum;
+}
+__device__ __forceinline__ void ed_sums_out(const ExpDwParams& p, const float4* red, int tid, size_t tile_index, int n_base) {
+    if (tid < 8 && n_base + 4 * tid < p.Cmid) {
+        float4 t = red[tid];
+#pragma unroll
+        for (int w = 1; w < 8; w++) { float4 v = red[w * 8 + tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        *reinterpret_cast<float4*>(p.partial + tile_index * p.Cmid + n_base + 4 * tid) = t;
+    }
+}
+
+template <int K, int S, int TOH, int TOW, int TRH, bool H8 = false, bool BX = false, bool COPY = false>
 __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void k_expand_dw(ExpDwParams p, unsigned nblk) {
-    static_assert(!(SK && (BX || COPY)) && (!STEM || SK), "SK is a form of the f32 expand; the stem's K is 24");
     constexpr int TIH = (TOH - 1) * S + K, TIW = (TOW - 1) * S + K;
     static_assert(TRH <= TIH, "TRH is a cap on the footprint rows");
     constexpr int NPIX = TRH * TIW, NPIXP = (NPIX + 15) / 16 * 16;
     constexpr int JT = NPIXP / 16, JTW = (JT + 3) / 4;
-    constexpr int SH = TOH / 4, SW = TOW / 8;                 // outputs per thread in phase 2 (thread-tiles are 4 x 8)
-    constexpr int RW = (SW - 1) * S + K;
+    constexpr int SW = TOW / 8;                               // output columns per thread in phase 2 (thread-tiles are 4 x 8)
     __shared__ __attribute__((aligned(16))) float lds[NPIX * ED_ES + 256 + K * K * 32];
     float* E = lds;                                                      // [<=TRH rows][TIW][36] expanded footprint
     float4* red = reinterpret_cast<float4*>(lds + NPIX * ED_ES);         // [4 waves][2 half waves][8] sum scratch
@@ -1902,7 +2002,7 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
     static_assert(SW * S == 2 || SW * S == 4, "lane permutation tables cover SW*S in {2, 4}");
     constexpr unsigned long long PERM = SW * S == 2 ? ED_PERM2 : ED_PERM4;
     const int pl = ed_perm(PERM, lane);                  // logical lane: tx * 8 + c4
-    const int c4 = pl & 7, tt = (wave << 3) | (pl >> 3);
+    const int c4 = pl & 7, tx = pl >> 3;
     float4 wdreg = make_float4(0.f, 0.f, 0.f, 0.f);
     // (COPY: the tap table and bias are the graph's own unpadded tensors - row stride Cp = C, loads guarded)
     if (tid < K * K * 8 && (!COPY || n_base + 4 * (tid & 7) < p.Cmid)) {
@@ -1933,8 +2033,7 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
     } else {
 
     // this lane's pixel per owned tile (a): clamped global offset + validity
-    int xoff[JTW];               // STEM: top input row of the pixel's 3x4 window, and (scol) its left input column
-    int scol[JTW];
+    int xoff[JTW];
     bool xin[JTW];
 #pragma unroll
     for (int a = 0; a < JTW; a++) {
@@ -1943,10 +2042,8 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
         int iw = iw0 + c;
         xin[a] = j < nvalid && iw >= 0 && iw < p.W;
         int ihc = min(ih0 + vr0 + r, p.H - 1), iwc = min(max(iw, 0), p.W - 1);
-        if (STEM) { xoff[a] = ihc * 2 - p.pts; scol[a] = iwc * 2 - p.pls + (kq & 1) * 2; }
-        else { xoff[a] = (b * p.H * p.W + ihc * p.xsh + iwc * p.xsw) * Cin + (BX ? 8 : 4) * kq; scol[a] = 0; }
+        xoff[a] = (b * p.H * p.W + ihc * p.xsh + iwc * p.xsw) * Cin + (BX ? 8 : 4) * kq;
     }
-    const float* xb = STEM ? p.x + (size_t)b * p.Hin * p.Win * 2 : p.x;
     const float* wrow0 = p.we + (size_t)(n_base + li) * Kw + 4 * kq;
     const float* wrow1 = wrow0 + (size_t)16 * Kw;
 
@@ -1959,21 +2056,6 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
     auto fload = [&](int k0, f32x4& wf0, f32x4& wf1, f32x4 (&xf)[JTW]) {
         float4 t0 = *reinterpret_cast<const float4*>(wrow0 + k0), t1 = *reinterpret_cast<const float4*>(wrow1 + k0);
         wf0 = (f32x4){t0.x, t0.y, t0.z, t0.w}; wf1 = (f32x4){t1.x, t1.y, t1.z, t1.w};
-        if (STEM) {
-            // k-group of this lane: window row i (slab 0: kq >> 1, slab 1: 2), columns j0, j0 + 1 (in scol), both channels
-            const int i = k0 == 0 ? (kq >> 1) : 2;
-#pragma unroll
-            for (int a = 0; a < JTW; a++) {
-                const int row = xoff[a] + i, col = scol[a];
-                const bool rv = row >= 0 && row < p.Hin;
-                const bool v0 = rv && col >= 0 && col < p.Win, v1 = rv && col + 1 >= 0 && col + 1 < p.Win;
-                const size_t ro = (size_t)min(max(row, 0), p.Hin - 1) * p.Win;
-                const float2 u = *reinterpret_cast<const float2*>(xb + (ro + min(max(col, 0), p.Win - 1)) * 2);
-                const float2 w = *reinterpret_cast<const float2*>(xb + (ro + min(max(col + 1, 0), p.Win - 1)) * 2);
-                xf[a] = (f32x4){v0 ? u.x : 0.f, v0 ? u.y : 0.f, v1 ? w.x : 0.f, v1 ? w.y : 0.f};
-            }
-            return;
-        }
         const int kx = (k0 + 4 * kq < Cin) ? k0 : -4 * kq;     // K tail: any in-bounds address (its weights are zero)
 #pragma unroll
         for (int a = 0; a < JTW; a++) {
@@ -1997,17 +2079,6 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
     auto fload8 = [&](int k0, f32x2& wh0, f32x2& wh1, f32x2 (&xh)[JTW]) {
         const float2 t0 = *reinterpret_cast<const float2*>(wrow0 - 2 * kq + k0), t1 = *reinterpret_cast<const float2*>(wrow1 - 2 * kq + k0);
         wh0 = (f32x2){t0.x, t0.y}; wh1 = (f32x2){t1.x, t1.y};
-        if (STEM) {
-            // window row 2, column kq, both channels
-#pragma unroll
-            for (int a = 0; a < JTW; a++) {
-                const int row = xoff[a] + 2, col = scol[a] - (kq & 1) * 2 + kq;
-                const bool v = row >= 0 && row < p.Hin && col >= 0 && col < p.Win;
-                const float2 u = *reinterpret_cast<const float2*>(xb + ((size_t)min(max(row, 0), p.Hin - 1) * p.Win + min(max(col, 0), p.Win - 1)) * 2);
-                xh[a] = (f32x2){v ? u.x : 0.f, v ? u.y : 0.f};
-            }
-            return;
-        }
         const int kx = (k0 + 2 * kq + 1 < Cin) ? k0 - 2 * kq : -4 * kq;     // K tail: any in-bounds address (its weights are zero)
 #pragma unroll
         for (int a = 0; a < JTW; a++) {
@@ -2027,66 +2098,6 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
             }
         }
     };
-    // ---- tile-outer order for the layers whose whole K range sits in registers before the first MFMA (Kw <= 32: the stem and
-    // the early blocks, where the wave spends more issue slots on the swish than on the MFMAs and too few waves fit a SIMD
-    // to hide one behind the other): the activation + LDS store of tile a - 1 is issued under the MFMAs of tile a
-    // (sched_group_barrier: per MFMA - 8 passes = 32 cycles of the matrix pipe - two plain and two transcendental VALU ops).
-    const bool border = iw0 < 0 || iw0 + TIW > p.W;       // block-uniform: only such tiles have columns to mask in E
-    bool e_done = false;
-    auto mma1 = [&](int a, const f32x4& wf0, const f32x4& wf1, const f32x4 (&xf)[JTW]) {
-#pragma unroll
-        for (int sidx = 0; sidx < 4; sidx++) {
-            acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf0[sidx], xf[a][sidx], acc[a][0], 0, 0, 0);
-            acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf1[sidx], xf[a][sidx], acc[a][1], 0, 0, 0);
-        }
-    };
-    auto mma1h = [&](int a, const f32x2& wh0, const f32x2& wh1, const f32x2 (&xh)[JTW]) {
-#pragma unroll
-        for (int sidx = 0; sidx < 2; sidx++) {
-            acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh0[sidx], xh[a][sidx], acc[a][0], 0, 0, 0);
-            acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh1[sidx], xh[a][sidx], acc[a][1], 0, 0, 0);
-        }
-    };
-    auto fin_swish = [&](int a, auto masked) {
-        acc[a][0] = swish4(acc[a][0]);
-        acc[a][1] = swish4(acc[a][1]);
-        const int j = 16 * (wave + 4 * a) + li;
-        if (j < nvalid) {
-            const int e = j * ED_ES + 4 * kq;
-            if constexpr (decltype(masked)::value) {
-                const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4*>(&E[e]) = xin[a] ? acc[a][0] : z;
-                *reinterpret_cast<f32x4*>(&E[e + 16]) = xin[a] ? acc[a][1] : z;
-            } else {
-                *reinterpret_cast<f32x4*>(&E[e]) = acc[a][0];
-                *reinterpret_cast<f32x4*>(&E[e + 16]) = acc[a][1];
-            }
-        }
-    };
-    auto piped = [&](auto masked, auto nm, auto&& tile_mma) {
-#pragma unroll
-        for (int a = 0; a < JTW; a++) {
-            if (wave + 4 * a < jtv) {                     // (tile a valid => tile a - 1 valid)
-                tile_mma(a);
-                if (a > 0) {
-                    fin_swish(a - 1, masked);
-#pragma unroll
-                    for (int q = 0; q < decltype(nm)::value; q++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
-                    }
-                }
-            } else if (a > 0 && wave + 4 * (a - 1) < jtv) fin_swish(a - 1, masked);
-        }
-        if (wave + 4 * (JTW - 1) < jtv) fin_swish(JTW - 1, masked);
-    };
-    auto piped_run = [&](auto nm, auto&& tile_mma) {
-        if (border) piped(std::true_type{}, nm, tile_mma);
-        else piped(std::false_type{}, nm, tile_mma);
-        e_done = true;
-    };
-    const bool pipe_e = p.act_e == ACT_SWISH;
     // H8 (compile time: the half slab costs ~10 VGPRs when it is a run-time option, which drops every shape at 120
     // VGPRs from four waves per SIMD to three) = Kw is 8 mod 16
     const int Kfull = Kw & ~15;
@@ -2137,40 +2148,12 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
                 }
             }
         }
-    } else if constexpr (!H8 && SK) {
-        if (Kw <= 16) {
-            f32x4 wA0, wA1, xA[JTW];
-            fload(0, wA0, wA1, xA);
-            if (pipe_e) piped_run(std::integral_constant<int, 8>{}, [&](int a) { mma1(a, wA0, wA1, xA); });
-            else fmma(wA0, wA1, xA);
-        } else {
-            // early blocks (Cin 17..32): both K slabs requested back-to-back -> one memory latency instead of two
-            f32x4 wA0, wA1, xA[JTW], wB0, wB1, xB[JTW];
-            fload(0, wA0, wA1, xA);
-            fload(16, wB0, wB1, xB);
-            if (pipe_e) piped_run(std::integral_constant<int, 16>{}, [&](int a) { mma1(a, wA0, wA1, xA); mma1(a, wB0, wB1, xB); });
-            else {
-                fmma(wA0, wA1, xA);
-                fmma(wB0, wB1, xB);
-            }
-        }
-    } else if constexpr (!H8) {
+    } else if (!H8) {
         // (a rolling two-slab register prefetch was measured here: the extra VGPRs cost more occupancy than it buys)
         for (int k0 = 0; k0 < Kw; k0 += 16) {
             f32x4 wf0, wf1, xf[JTW];
             fload(k0, wf0, wf1, xf);
             fmma(wf0, wf1, xf);
-        }
-    } else if constexpr (SK) {
-        // Cin 17..24 (and the stem's 3 x 4 x 2 window): slab + half slab requested back-to-back
-        f32x4 wA0, wA1, xA[JTW];
-        f32x2 hA0, hA1, hx[JTW];
-        fload(0, wA0, wA1, xA);
-        fload8(16, hA0, hA1, hx);
-        if (pipe_e) piped_run(std::integral_constant<int, 12>{}, [&](int a) { mma1(a, wA0, wA1, xA); mma1h(a, hA0, hA1, hx); });
-        else {
-            fmma(wA0, wA1, xA);
-            fmma8(hA0, hA1, hx);
         }
     } else {
         for (int k0 = 0; k0 < Kfull; k0 += 16) {
@@ -2184,10 +2167,11 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
     }
 
     // ---- E <- act_e(acc) at compacted footprint coordinates (masked columns are zero).  Only a tile on the left / right
-    // image border has columns to mask: interior tiles store without the eight selects per 16 pixels
+    // image border has columns to mask (block-uniform test): interior tiles store without the eight selects per 16 pixels
+    const bool border = iw0 < 0 || iw0 + TIW > p.W;
 #pragma unroll
     for (int a = 0; a < JTW; a++) {
-        if (!e_done && wave + 4 * a < jtv) {                         // wave-uniform: tiles beyond the valid rows cost nothing
+        if (wave + 4 * a < jtv) {                         // wave-uniform: tiles beyond the valid rows cost nothing
             if (p.act_e == ACT_SWISH) {
                 acc[a][0] = swish4(acc[a][0]);
                 acc[a][1] = swish4(acc[a][1]);
@@ -2217,94 +2201,241 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
     __syncthreads();
     }   // !COPY
 
-    // ---- depthwise from LDS
-    const int ty = wave, tx = tt & 7;                    // (tt >> 3 == wave: the row tests below are wave-uniform, scalar)
-    const int n = n_base + 4 * c4;
-    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n < p.Cmid) {
-        float4 acc2[SH][SW];
+    // ---- depthwise from LDS, per-tile channel sums
+    const float4 sum = ed_phase2<K, S, TOH, TOW, TRH>(p, E, wds, b, oh0, ow0, vr0, vr1, wave, tx, c4, n_base, bv);
+    if (p.partial) {
+        ed_sums_lanes(sum, red, wave, lane, c4);
+        __syncthreads();
+        ed_sums_out(p, red, tid, (size_t)b * tiles + tile, n_base);
+    }
+}
+
+// Small-K form (Kw = 16, 24 or 32: the stem - an implicit GEMM over its 3 x 4 x 2 window - and the early blocks).  These layers
+// are the VALU-bound ones: a wave spends more issue slots on the swish of the expanded tensor and on set-up (pixel offsets,
+// validity, parameter addresses) than on its MFMAs, and with three to five waves per SIMD little of one hides behind the
+// other.  So here
+//   - a block owns (clip, tile) and walks ALL the 32-channel chunks of the expanded width: the pixel set-up, the footprint's
+//     input operands (the whole K range: 4-8 registers per owned 16-pixel tile) and their memory latency are paid once per
+//     block instead of once per chunk; per chunk only the 32 x Kw weight panel, biases and taps are fetched - requested one
+//     chunk ahead, right after the barrier that publishes E, so they arrive under phase 2;
+//   - tiles are walked tile-outer with the activation + LDS store of tile a - 1 issued under the MFMAs of tile a
+//     (sched_group_barrier: per MFMA - 8 passes = 32 cycles of the matrix pipe - two plain and two transcendental VALU ops);
+//   - two barriers per chunk, as before: "E free" sits after the first tile's MFMAs of the next chunk (they need no LDS), and
+//     the per-tile channel sums of chunk c are written out by wave 0 between the two barriers of chunk c + 1.
+// (LOOP = false - the stem, whose expanded width is normally a single chunk: one block per (clip, tile, chunk) as in
+// k_expand_dw; without the chunk loop's live ranges it keeps the registers for five waves per SIMD)
+template <int K, int S, int TOH, int TOW, int TRH, bool STEM, int KW, bool LOOP = !STEM>
+__global__ __launch_bounds__(256, expdw_sk_waves(K, S, TOW, TRH, !LOOP)) void k_expand_dw_sk(ExpDwParams p, unsigned nblk) {
+    static_assert(KW == 16 || KW == 24 || KW == 32, "one or two K slabs, or a slab and a half");
+    static_assert(!STEM || KW == 24, "the stem's window is 3 rows x 4 columns x 2 channels");
+    constexpr int TIH = (TOH - 1) * S + K, TIW = (TOW - 1) * S + K;
+    static_assert(TRH <= TIH, "TRH is a cap on the footprint rows");
+    constexpr int NPIX = TRH * TIW, NPIXP = (NPIX + 15) / 16 * 16;
+    constexpr int JT = NPIXP / 16, JTW = (JT + 3) / 4;
+    constexpr int SW = TOW / 8;
+    constexpr int NMMA = KW / 2;                              // MFMAs per 16-pixel tile (two 16-channel halves)
+    __shared__ __attribute__((aligned(16))) float lds[NPIX * ED_ES + 256 + K * K * 32];
+    float* E = lds;
+    float4* red = reinterpret_cast<float4*>(lds + NPIX * ED_ES);
+    float4* wds = reinterpret_cast<float4*>(lds + NPIX * ED_ES + 256);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+
+    const unsigned L = xcd_remap(blockIdx.x, nblk);
+    const int tiles = p.tiles_h * p.tiles_w;
+    int b, tile, cc0 = 0;
+    if constexpr (LOOP) {
+        b = (int)fdiv(L, p.d_bpc); tile = (int)L - b * tiles;               // (d_bpc divides by tiles here)
+    } else {
+        b = (int)fdiv(L, p.d_bpc);
+        const int rest = (int)L - b * tiles * p.cchunks;
+        tile = (int)fdiv((unsigned)rest, p.d_cch); cc0 = rest - tile * p.cchunks;
+    }
+    const int trow = (int)fdiv((unsigned)tile, p.d_tw);
+    const int oh0 = trow * TOH, ow0 = (tile - trow * p.tiles_w) * TOW;
+    const int ih0 = oh0 * S - p.pt, iw0 = ow0 * S - p.pl;
+    const int vr0 = max(ih0, 0) - ih0, vr1 = min(ih0 + TIH, p.H) - ih0;
+    const int nvalid = (vr1 - vr0) * TIW;
+    const int jtv = (nvalid + 15) >> 4;
+    const int Cin = p.Cin;
+    const int ncc = LOOP ? p.cchunks : 1;
+    const size_t tile_index = (size_t)b * tiles + tile;
+
+    static_assert(SW * S == 2 || SW * S == 4, "lane permutation tables cover SW*S in {2, 4}");
+    constexpr unsigned long long PERM = SW * S == 2 ? ED_PERM2 : ED_PERM4;
+    const int pl = ed_perm(PERM, lane);                  // logical lane: tx * 8 + c4
+    const int c4 = pl & 7, tx = pl >> 3;
+
+    // ---- once per block: this lane's pixel per owned tile, and its input operands for the whole K range
+    bool xin[JTW];
+    f32x4 xA[JTW];                                       // k = 4 kq .. + 3 (slab 0)
+    f32x4 xB[KW == 32 ? JTW : 1];                        // k = 16 + 4 kq .. (slab 1)
+    f32x2 xH[KW == 24 ? JTW : 1];                        // k = 16 + 2 kq, + 1 (half slab)
+    auto load_x = [&]() {
+        const float* xb = STEM ? p.x + (size_t)b * p.Hin * p.Win * 2 : p.x;
 #pragma unroll
-        for (int a = 0; a < SH; a++)
-#pragma unroll
-            for (int c = 0; c < SW; c++) acc2[a][c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* e0 = E + (tx * SW * S) * ED_ES + 4 * c4;
-#pragma unroll 1
-        for (int i = 0; i < K; i++) {                 // kernel row (kept rolled: bounds the live weight registers)
-            float4 w[K];
-#pragma unroll
-            for (int j = 0; j < K; j++) w[j] = wds[(i * K + j) * 8 + c4];
-#pragma unroll
-            for (int a = 0; a < SH; a++) {
-                const int fr = (ty * SH + a) * S + i;                       // footprint row of this tap
-                if (fr < vr0 || fr >= vr1 || oh0 + ty * SH + a >= p.Ho) continue;   // padding row / no such output row
-                float4 xr[RW];
-#pragma unroll
-                for (int c = 0; c < RW; c++) xr[c] = *reinterpret_cast<const float4*>(e0 + ((fr - vr0) * TIW + c) * ED_ES);
-#pragma unroll
-                for (int j = 0; j < K; j++) {
-#pragma unroll
-                    for (int c = 0; c < SW; c++) {
-                        const float4 xv = xr[c * S + j];
-                        acc2[a][c].x = fmaf(xv.x, w[j].x, acc2[a][c].x); acc2[a][c].y = fmaf(xv.y, w[j].y, acc2[a][c].y);
-                        acc2[a][c].z = fmaf(xv.z, w[j].z, acc2[a][c].z); acc2[a][c].w = fmaf(xv.w, w[j].w, acc2[a][c].w);
-                    }
+        for (int a = 0; a < JTW; a++) {
+            const int j = 16 * (wave + 4 * a) + li;
+            const int r = j / TIW, c = j - r * TIW;
+            const int iw = iw0 + c;
+            xin[a] = j < nvalid && iw >= 0 && iw < p.W;
+            const int ihc = min(ih0 + vr0 + r, p.H - 1), iwc = min(max(iw, 0), p.W - 1);
+            if constexpr (STEM) {
+                // the pixel (ihc, iwc) of the stem's output: its window starts at input (2 ihc - pts, 2 iwc - pls).  K layout of
+                // k_stem_mfma: slab 0 lane group kq = window row kq >> 1, columns 2 (kq & 1), + 1, both channels; the half slab
+                // = window row 2, column kq, both channels.  Taps outside the input image are zero (the stem's own padding).
+                const int row0 = ihc * 2 - p.pts, col0 = iwc * 2 - p.pls;
+                auto tap2 = [&](int row, int col) {
+                    const bool v = row >= 0 && row < p.Hin && col >= 0 && col < p.Win;
+                    const float2 u = *reinterpret_cast<const float2*>(xb + ((size_t)min(max(row, 0), p.Hin - 1) * p.Win + min(max(col, 0), p.Win - 1)) * 2);
+                    return (f32x2){v ? u.x : 0.f, v ? u.y : 0.f};
+                };
+                const f32x2 u = tap2(row0 + (kq >> 1), col0 + (kq & 1) * 2), w = tap2(row0 + (kq >> 1), col0 + (kq & 1) * 2 + 1);
+                xA[a] = (f32x4){u[0], u[1], w[0], w[1]};
+                xH[a] = tap2(row0 + 2, col0 + kq);
+            } else {
+                const float* xp = xb + (size_t)((b * p.H * p.W + ihc * p.xsh + iwc * p.xsw) * Cin);
+                // K tail: lanes whose channels lie beyond Cin read any in-bounds address (their weights are zero)
+                const float4 t = *reinterpret_cast<const float4*>(xp + (4 * kq < Cin ? 4 * kq : 0));
+                xA[a] = (f32x4){t.x, t.y, t.z, t.w};
+                if constexpr (KW == 32) {
+                    const float4 t2 = *reinterpret_cast<const float4*>(xp + (16 + 4 * kq < Cin ? 16 + 4 * kq : 0));
+                    xB[a] = (f32x4){t2.x, t2.y, t2.z, t2.w};
+                }
+                if constexpr (KW == 24) {
+                    const float2 t2 = *reinterpret_cast<const float2*>(xp + (16 + 2 * kq + 1 < Cin ? 16 + 2 * kq : 0));
+                    xH[a] = (f32x2){t2.x, t2.y};
                 }
             }
         }
-        float* const ybase = p.y + ((size_t)b * p.Ho * p.Wo + (size_t)(oh0 + ty * SH) * p.ysh + (size_t)(ow0 + tx * SW) * p.ysw) * p.Cmid + n;
+    };
+    load_x();
+
+    // ---- per chunk: weight panel rows n_base + li and n_base + 16 + li (this lane's k range), biases, taps
+    struct Chunk {
+        f32x4 wA0, wA1, wB0, wB1;
+        f32x2 wH0, wH1;
+        float4 bq0, bq1, bv, wd;
+    };
+    const float* const wlane = p.we + (size_t)li * KW + 4 * kq;
+    const int tap = tid >> 3, tsrc = p.tr ? (tap % K) * K + tap / K : tap;
+    const float* const wdlane = p.wd + (size_t)tsrc * p.Cp + 4 * (tid & 7);
+    auto fetch = [&](int cc, Chunk& q) {
+        const int n_base = cc * 32;
+        const float* w0 = wlane + (size_t)n_base * KW;
+        const float* w1 = w0 + 16 * KW;
+        const float4 t0 = *reinterpret_cast<const float4*>(w0), t1 = *reinterpret_cast<const float4*>(w1);
+        q.wA0 = (f32x4){t0.x, t0.y, t0.z, t0.w}; q.wA1 = (f32x4){t1.x, t1.y, t1.z, t1.w};
+        if constexpr (KW == 32) {
+            const float4 u0 = *reinterpret_cast<const float4*>(w0 + 16), u1 = *reinterpret_cast<const float4*>(w1 + 16);
+            q.wB0 = (f32x4){u0.x, u0.y, u0.z, u0.w}; q.wB1 = (f32x4){u1.x, u1.y, u1.z, u1.w};
+        }
+        if constexpr (KW == 24) {
+            const float2 u0 = *reinterpret_cast<const float2*>(w0 - 2 * kq + 16), u1 = *reinterpret_cast<const float2*>(w1 - 2 * kq + 16);
+            q.wH0 = (f32x2){u0.x, u0.y}; q.wH1 = (f32x2){u1.x, u1.y};
+        }
+        q.bq0 = *reinterpret_cast<const float4*>(p.be + n_base + 4 * kq);
+        q.bq1 = *reinterpret_cast<const float4*>(p.be + n_base + 16 + 4 * kq);
+        q.bv = *reinterpret_cast<const float4*>(p.bd + n_base + 4 * c4);
+        if (tid < K * K * 8) q.wd = *reinterpret_cast<const float4*>(wdlane + n_base);
+    };
+    Chunk q;
+    q.wd = make_float4(0.f, 0.f, 0.f, 0.f);
+    fetch(cc0, q);
+
+    const bool border = iw0 < 0 || iw0 + TIW > p.W;       // block-uniform: only such tiles have columns to mask in E
+    const int e_lane = li * ED_ES + 4 * kq;
+
+    for (int ci = 0; ci < ncc; ci++) {
+        const int cc = cc0 + ci, n_base = cc * 32;
+        // the accumulators start at the bias (the lane's four rows are channels 4 kq .. + 3 of its pixel): the first MFMA of a
+        // tile reads it as its C operand - no zero fill, no bias add in the epilogue
+        f32x4 acc[JTW][2];
 #pragma unroll
-        for (int a = 0; a < SH; a++) {
-            int oh = oh0 + ty * SH + a;
-            if (oh >= p.Ho) continue;
-            if (p.act_d == ACT_SWISH) {
+        for (int a = 0; a < JTW; a++) {
+            acc[a][0] = (f32x4){q.bq0.x, q.bq0.y, q.bq0.z, q.bq0.w};
+            acc[a][1] = (f32x4){q.bq1.x, q.bq1.y, q.bq1.z, q.bq1.w};
+        }
+        auto tile_mma = [&](int a) {
 #pragma unroll
-                for (int c = 0; c < SW; c++) {
-                    float4& v = acc2[a][c];
-                    const f32x4 r = swish4((f32x4){v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w});
-                    v = make_float4(r[0], r[1], r[2], r[3]);
+            for (int sidx = 0; sidx < 4; sidx++) {
+                acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wA0[sidx], xA[a][sidx], acc[a][0], 0, 0, 0);
+                acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wA1[sidx], xA[a][sidx], acc[a][1], 0, 0, 0);
+            }
+            if constexpr (KW == 32) {
+#pragma unroll
+                for (int sidx = 0; sidx < 4; sidx++) {
+                    acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wB0[sidx], xB[a][sidx], acc[a][0], 0, 0, 0);
+                    acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wB1[sidx], xB[a][sidx], acc[a][1], 0, 0, 0);
                 }
-            } else {
-                with_act(p.act_d, [&](auto f) {
+            }
+            if constexpr (KW == 24) {
 #pragma unroll
-                    for (int c = 0; c < SW; c++) {
-                        float4& v = acc2[a][c];
-                        v.x = f(v.x + bv.x); v.y = f(v.y + bv.y); v.z = f(v.z + bv.z); v.w = f(v.w + bv.w);
+                for (int sidx = 0; sidx < 2; sidx++) {
+                    acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wH0[sidx], xH[a][sidx], acc[a][0], 0, 0, 0);
+                    acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wH1[sidx], xH[a][sidx], acc[a][1], 0, 0, 0);
+                }
+            }
+        };
+        // E <- act_e(acc) for tile a, at compacted footprint coordinates (masked columns are zero)
+        auto tile_out = [&](int a, auto masked, auto&& act4) {
+            acc[a][0] = act4(acc[a][0]);
+            acc[a][1] = act4(acc[a][1]);
+            if (16 * (wave + 4 * a) + li < nvalid) {
+                float* e = E + (16 * (wave + 4 * a)) * ED_ES + e_lane;
+                if constexpr (decltype(masked)::value) {
+                    const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(e) = xin[a] ? acc[a][0] : z;
+                    *reinterpret_cast<f32x4*>(e + 16) = xin[a] ? acc[a][1] : z;
+                } else {
+                    *reinterpret_cast<f32x4*>(e) = acc[a][0];
+                    *reinterpret_cast<f32x4*>(e + 16) = acc[a][1];
+                }
+            }
+        };
+        auto phase1 = [&](auto masked, auto&& act4) {
+            if (wave < jtv) tile_mma(0);
+            if (LOOP && ci > 0) {
+                __syncthreads();                           // every wave is through phase 2 of the previous chunk: E, taps and sums
+                if (p.partial) ed_sums_out(p, red, tid, tile_index, n_base - 32);
+            }
+#pragma unroll
+            for (int a = 1; a < JTW; a++) {
+                if (wave + 4 * a < jtv) {                 // (tile a valid => tile a - 1 valid)
+                    tile_mma(a);
+                    tile_out(a - 1, masked, act4);
+#pragma unroll
+                    for (int m = 0; m < NMMA; m++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
                     }
+                } else if (wave + 4 * (a - 1) < jtv) tile_out(a - 1, masked, act4);
+            }
+            if (wave + 4 * (JTW - 1) < jtv) tile_out(JTW - 1, masked, act4);
+        };
+        auto phase1_act = [&](auto masked) {
+            if (p.act_e == ACT_SWISH) phase1(masked, [](f32x4 v) { return swish4(v); });
+            else {
+                const int act = p.act_e;
+                phase1(masked, [act](f32x4 v) {
+                    return (f32x4){apply_act(v[0], act), apply_act(v[1], act), apply_act(v[2], act), apply_act(v[3], act)};
                 });
             }
-#pragma unroll
-            for (int c = 0; c < SW; c++) {
-                int ow = ow0 + tx * SW + c;
-                if (ow >= p.Wo) continue;
-                float4 v = acc2[a][c];
-                // (ybase holds everything that depends on the lane; the rest of the address is a block-uniform offset)
-                *reinterpret_cast<float4*>(ybase + (size_t)((a * p.ysh + c * p.ysw) * p.Cmid)) = v;
-                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-            }
-        }
+        };
+        if (border) phase1_act(std::true_type{});
+        else phase1_act(std::false_type{});
+        if (tid < K * K * 8) wds[tid] = q.wd;
+        const float4 bv = q.bv;
+        __syncthreads();
+        if (LOOP && ci + 1 < ncc) fetch(cc + 1, q);               // next chunk's parameters: in flight during phase 2
+
+        const float4 sum = ed_phase2<K, S, TOH, TOW, TRH>(p, E, wds, b, oh0, ow0, vr0, vr1, wave, tx, c4, n_base, bv);
+        if (p.partial) ed_sums_lanes(sum, red, wave, lane, c4);
     }
     if (p.partial) {
-        // Both lane permutations keep c4 = 4 * (physical lane bit 3) + (lane & 3), so the lanes that share a channel quad differ
-        // in physical lane bits 2, 4 and 5: two ds_swizzle xor steps (immediate pattern - no partner-address arithmetic, no
-        // inverse permutation) leave the sum of each half wave in its lanes, and the eight (wave, half) partials meet in LDS.
-        static_assert(ed_perm_c4_rule(ED_PERM2) && ed_perm_c4_rule(ED_PERM4), "lane permutation: c4 bit 2 must be physical lane bit 3");
-        auto xsum = [&](auto pat) {
-            constexpr int P = decltype(pat)::value;      // ds_swizzle bit mode: and 0x1f, or 0, xor (P >> 10)
-            sum.x += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, sum.x), P));
-            sum.y += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, sum.y), P));
-            sum.z += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, sum.z), P));
-            sum.w += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, sum.w), P));
-        };
-        xsum(std::integral_constant<int, 0x101f>{});     // xor 4
-        xsum(std::integral_constant<int, 0x401f>{});     // xor 16
-        if ((lane & 0x14) == 0) red[(wave * 2 + (lane >> 5)) * 8 + c4] = sum;
         __syncthreads();
-        if (tid < 8 && n_base + 4 * tid < p.Cmid) {
-            float4 t = red[tid];
-#pragma unroll
-            for (int w = 1; w < 8; w++) { float4 v = red[w * 8 + tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
-            *reinterpret_cast<float4*>(p.partial + ((size_t)b * tiles + tile) * p.Cmid + n_base + 4 * tid) = t;
-        }
+        ed_sums_out(p, red, tid, tile_index, (cc0 + ncc - 1) * 32);
     }
 }
 
@@ -2435,11 +2566,17 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
     p.d_tw = make_fdiv((unsigned)p.tiles_w);
     const bool bx = wep != nullptr && !stem && expdw_bx_ok(Cin);
     if (bx) { p.wep = wep; p.Kp = expdw_kp(Cin); p.prec = prec; }
+    if (stem) p.Kw = 24;                               // 3 rows x 4 columns x 2 channels
+    if (!bx && !stem && (p.Kw == 16 || p.Kw == 24 || p.Kw == 32)) {
+        // small-K form: a block owns (clip, tile) and walks the channel chunks itself
+        nblk = (unsigned)B * p.tiles_h * p.tiles_w;
+        p.d_bpc = make_fdiv((unsigned)(p.tiles_h * p.tiles_w));
+    }
     if (stem) {
-        p.Hin = stem->Hin; p.Win = stem->Win; p.pts = stem->pt; p.pls = stem->pl; p.Kw = 24;    // 3 rows x 4 columns x 2 channels
+        p.Hin = stem->Hin; p.Win = stem->Win; p.pts = stem->pt; p.pls = stem->pl;
 #define ED_STEM(TH_, TW_, TR_)                                                                                \
     if (sh->k == 3 && sh->s == 1 && sh->toh == TH_ && sh->tow == TW_ && sh->trh == TR_) {                     \
-        hipLaunchKernelGGL((k_expand_dw<3, 1, TH_, TW_, TR_, true>), dim3(nblk), dim3(256), 0, st, p, nblk);  \
+        hipLaunchKernelGGL((k_expand_dw_sk<3, 1, TH_, TW_, TR_, true, 24>), dim3(nblk), dim3(256), 0, st, p, nblk);  \
         return;                                                                                               \
     }
         ED_STEM(8, 16, 10) ED_STEM(4, 16, 6) ED_STEM(8, 32, 6) ED_STEM(8, 32, 10)
@@ -2448,10 +2585,11 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
     }
 #define ED_CASE(K_, S_, TH_, TW_, TR_)                                                                        \
     if (sh->k == K_ && sh->s == S_ && sh->toh == TH_ && sh->tow == TW_ && sh->trh == TR_) {                   \
-        if (bx) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
-        else if (p.Kw == 24) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, true, false, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
-        else if (p.Kw & 8) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
-        else if (p.Kw <= 32) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, false, false, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        if (bx) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        else if (p.Kw == 16) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 16>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        else if (p.Kw == 24) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 24>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        else if (p.Kw == 32) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 32>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        else if (p.Kw & 8) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         else hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_>), dim3(nblk), dim3(256), 0, st, p, nblk);  \
         return;                                                                                               \
     }
@@ -2482,7 +2620,7 @@ void launch_dwconv_lds(const DwParams& q, float* partial, int shape, hipStream_t
     p.d_tw = make_fdiv((unsigned)p.tiles_w);
 #define DL_CASE(K_, S_, TH_, TW_, TR_)                                                                        \
     if (sh->k == K_ && sh->s == S_ && sh->toh == TH_ && sh->tow == TW_ && sh->trh == TR_) {                   \
-        hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, false, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         return;                                                                                               \
     }
     DL_CASE(3, 1, 8, 16, 10) DL_CASE(3, 1, 4, 16, 6) DL_CASE(3, 1, 8, 32, 6) DL_CASE(3, 1, 8, 32, 10)
