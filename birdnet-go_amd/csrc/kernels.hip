@@ -1857,9 +1857,17 @@ constexpr int expdw_min_waves(int K, int S, int TOW, int TRH) {
     const int tiw = (TOW - 1) * S + K, jt = (TRH * tiw + 15) / 16, jtw = (jt + 3) / 4;
     return jtw <= 4 ? 4 : (jtw == 5 ? 3 : 2);
 }
-constexpr int expdw_sk_waves(int K, int S, int TOW, int TRH, bool one_chunk) {
+// Waves per SIMD the small-K form is compiled for (the VGPR budget; measured against the register allocator's spills): what
+// stays live across the chunk loop - the footprint's input operands, the prefetched chunk parameters - plus the larger of
+// the two phases' working sets.  A spill here is worse than a lost wave: the reload (scratch is VMEM) waits on vmcnt behind
+// the prefetch.
+constexpr int expdw_sk_waves(int K, int S, int TOH, int TOW, int TRH, int KW, bool one_chunk) {
     const int tiw = (TOW - 1) * S + K, jt = (TRH * tiw + 15) / 16, jtw = (jt + 3) / 4;
-    return one_chunk && jtw <= 3 ? 5 : expdw_min_waves(K, S, TOW, TRH);
+    if (one_chunk) return jtw <= 3 ? 5 : expdw_min_waves(K, S, TOW, TRH);
+    const int sh = TOH / 4, sw = TOW / 8, rw = (sw - 1) * S + K;
+    const int p1 = jtw * 8 + 8, p2 = sh * sw * 4 + rw * 4 + K * 4;
+    const int est = jtw * KW / 4 + (KW / 2 + 16) + 24 + (p1 > p2 ? p1 : p2);
+    return est <= 120 ? 4 : (est <= 160 ? 3 : 2);
 }
 // COPY: no expand at all - phase 1 only stages the tile's input footprint (32 channels of x itself) in LDS and phase 2 runs
 // as above: a plain depthwise convolution whose taps read LDS instead of L1/L2 (k_dwconv_t re-reads every input value
@@ -1867,20 +1875,21 @@ constexpr int expdw_sk_waves(int K, int S, int TOW, int TRH, bool one_chunk) {
 // ---- phase 2 of the fused kernel (shared by its forms): depthwise taps from the expanded footprint in LDS, bias + activation,
 // store; returns the lane's sum of what it stored (for the squeeze-excite mean).  ty is the wave index (scalar): every row
 // test is wave-uniform.
-template <int K, int S, int TOH, int TOW, int TRH>
+// pre_store() runs after the taps and before the first global store (k_expand_dw_sk makes its prefetched loads land there).
+template <int K, int S, int TOH, int TOW, int TRH, typename PreStore>
 __device__ __forceinline__ float4 ed_phase2(const ExpDwParams& p, const float* E, const float4* wds, int b, int oh0, int ow0, int vr0,
-                                            int vr1, int ty, int tx, int c4, int n_base, const float4& bv) {
+                                            int vr1, int ty, int tx, int c4, int n_base, const float4& bv, PreStore&& pre_store) {
     constexpr int TIW = (TOW - 1) * S + K;
     constexpr int SH = TOH / 4, SW = TOW / 8;                 // outputs per thread (thread-tiles are 4 x 8)
     constexpr int RW = (SW - 1) * S + K;
     const int n = n_base + 4 * c4;
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc2[SH][SW];
+#pragma unroll
+    for (int a = 0; a < SH; a++)
+#pragma unroll
+        for (int c = 0; c < SW; c++) acc2[a][c] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n < p.Cmid) {
-        float4 acc2[SH][SW];
-#pragma unroll
-        for (int a = 0; a < SH; a++)
-#pragma unroll
-            for (int c = 0; c < SW; c++) acc2[a][c] = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* e0 = E + (tx * SW * S) * ED_ES + 4 * c4;
 #pragma unroll 1
         for (int i = 0; i < K; i++) {                 // kernel row (kept rolled: bounds the live weight registers)
@@ -1905,8 +1914,13 @@ __device__ __forceinline__ float4 ed_phase2(const ExpDwParams& p, const float* E
                 }
             }
         }
-        // (ybase holds everything that depends on the lane; the rest of a store address is a block-uniform offset)
-        float* const ybase = p.y + ((size_t)b * p.Ho * p.Wo + (size_t)(oh0 + ty * SH) * p.ysh + (size_t)(ow0 + tx * SW) * p.ysw) * p.Cmid + n;
+    }
+    pre_store();                                          // (on every path: outside the per-lane channel test)
+    if (n < p.Cmid) {
+        // store address = block-uniform 64-bit base (scalar registers) + 32-bit element offset inside the clip's image: one
+        // VGPR per lane instead of a 64-bit pointer that the chunk loop of k_expand_dw_sk would have to keep (or spill)
+        float* const yclip = p.y + (size_t)b * p.Ho * p.Wo * p.Cmid;
+        const unsigned ylane = (unsigned)(((oh0 + ty * SH) * p.ysh + (ow0 + tx * SW) * p.ysw) * p.Cmid + n);
 #pragma unroll
         for (int a = 0; a < SH; a++) {
             int oh = oh0 + ty * SH + a;
@@ -1932,7 +1946,7 @@ __device__ __forceinline__ float4 ed_phase2(const ExpDwParams& p, const float* E
                 int ow = ow0 + tx * SW + c;
                 if (ow >= p.Wo) continue;
                 float4 v = acc2[a][c];
-                *reinterpret_cast<float4*>(ybase + (size_t)((a * p.ysh + c * p.ysw) * p.Cmid)) = v;
+                *reinterpret_cast<float4*>(yclip + (ylane + (unsigned)((a * p.ysh + c * p.ysw) * p.Cmid))) = v;
                 sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
             }
         }
@@ -1961,7 +1975,9 @@ __device__ __forceinline__ void ed_sums_out(const ExpDwParams& p, const float4* 
         float4 t = red[tid];
 #pragma unroll
         for (int w = 1; w < 8; w++) { float4 v = red[w * 8 + tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
-        *reinterpret_cast<float4*>(p.partial + tile_index * p.Cmid + n_base + 4 * tid) = t;
+        unsigned l4 = 4u * (unsigned)tid;
+        asm volatile("" : "+v"(l4));                     // (opaque: scalar base + 32-bit lane offset, nothing 64-bit per lane to hoist)
+        *reinterpret_cast<float4*>(p.partial + tile_index * p.Cmid + n_base + l4) = t;
     }
 }
 
@@ -2202,7 +2218,7 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
     }   // !COPY
 
     // ---- depthwise from LDS, per-tile channel sums
-    const float4 sum = ed_phase2<K, S, TOH, TOW, TRH>(p, E, wds, b, oh0, ow0, vr0, vr1, wave, tx, c4, n_base, bv);
+    const float4 sum = ed_phase2<K, S, TOH, TOW, TRH>(p, E, wds, b, oh0, ow0, vr0, vr1, wave, tx, c4, n_base, bv, [] {});
     if (p.partial) {
         ed_sums_lanes(sum, red, wave, lane, c4);
         __syncthreads();
@@ -2225,7 +2241,7 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
 // (LOOP = false - the stem, whose expanded width is normally a single chunk: one block per (clip, tile, chunk) as in
 // k_expand_dw; without the chunk loop's live ranges it keeps the registers for five waves per SIMD)
 template <int K, int S, int TOH, int TOW, int TRH, bool STEM, int KW, bool LOOP = !STEM>
-__global__ __launch_bounds__(256, expdw_sk_waves(K, S, TOW, TRH, !LOOP)) void k_expand_dw_sk(ExpDwParams p, unsigned nblk) {
+__global__ __launch_bounds__(256, expdw_sk_waves(K, S, TOH, TOW, TRH, KW, !LOOP)) void k_expand_dw_sk(ExpDwParams p, unsigned nblk) {
     static_assert(KW == 16 || KW == 24 || KW == 32, "one or two K slabs, or a slab and a half");
     static_assert(!STEM || KW == 24, "the stem's window is 3 rows x 4 columns x 2 channels");
     constexpr int TIH = (TOH - 1) * S + K, TIW = (TOW - 1) * S + K;
@@ -2317,12 +2333,18 @@ __global__ __launch_bounds__(256, expdw_sk_waves(K, S, TOW, TRH, !LOOP)) void k_
         f32x2 wH0, wH1;
         float4 bq0, bq1, bv, wd;
     };
-    const float* const wlane = p.we + (size_t)li * KW + 4 * kq;
+    // (addresses as block-uniform base + 32-bit lane offset: nothing 64-bit per lane stays live across the chunk loop)
+    const unsigned wlane = (unsigned)(li * KW + 4 * kq);
     const int tap = tid >> 3, tsrc = p.tr ? (tap % K) * K + tap / K : tap;
-    const float* const wdlane = p.wd + (size_t)tsrc * p.Cp + 4 * (tid & 7);
+    const unsigned wdlane = (unsigned)(tsrc * p.Cp + 4 * (tid & 7));
     auto fetch = [&](int cc, Chunk& q) {
         const int n_base = cc * 32;
-        const float* w0 = wlane + (size_t)n_base * KW;
+        // (the empty asm keeps the lane offsets opaque per call: left alone, the compiler hoists "pointer + lane offset" out of
+        // the chunk loop as 64-bit per-lane values, runs out of registers at the four-wave budget and reloads them from
+        // scratch - a vmcnt(0) wait right behind the prefetch it has just issued)
+        unsigned wl = wlane, wdl = wdlane;
+        asm volatile("" : "+v"(wl), "+v"(wdl));
+        const float* w0 = p.we + (size_t)n_base * KW + wl;
         const float* w1 = w0 + 16 * KW;
         const float4 t0 = *reinterpret_cast<const float4*>(w0), t1 = *reinterpret_cast<const float4*>(w1);
         q.wA0 = (f32x4){t0.x, t0.y, t0.z, t0.w}; q.wA1 = (f32x4){t1.x, t1.y, t1.z, t1.w};
@@ -2337,11 +2359,17 @@ __global__ __launch_bounds__(256, expdw_sk_waves(K, S, TOW, TRH, !LOOP)) void k_
         q.bq0 = *reinterpret_cast<const float4*>(p.be + n_base + 4 * kq);
         q.bq1 = *reinterpret_cast<const float4*>(p.be + n_base + 16 + 4 * kq);
         q.bv = *reinterpret_cast<const float4*>(p.bd + n_base + 4 * c4);
-        if (tid < K * K * 8) q.wd = *reinterpret_cast<const float4*>(wdlane + n_base);
+        if (tid < K * K * 8) q.wd = *reinterpret_cast<const float4*>(p.wd + n_base + wdl);
     };
     Chunk q;
     q.wd = make_float4(0.f, 0.f, 0.f, 0.f);
     fetch(cc0, q);
+    auto land = [&] {
+        asm volatile("" :: "v"(q.wA0), "v"(q.wA1), "v"(q.bq0.x), "v"(q.bq1.x), "v"(q.bv.x), "v"(q.wd.x));
+        if constexpr (KW == 32) asm volatile("" :: "v"(q.wB0), "v"(q.wB1));
+        if constexpr (KW == 24) asm volatile("" :: "v"(q.wH0), "v"(q.wH1));
+    };
+    if constexpr (LOOP) land();     // (also on the way in: the wait at the loop head would otherwise be shared with the back edge)
 
     const bool border = iw0 < 0 || iw0 + TIW > p.W;       // block-uniform: only such tiles have columns to mask in E
     const int e_lane = li * ED_ES + 4 * kq;
@@ -2356,45 +2384,49 @@ __global__ __launch_bounds__(256, expdw_sk_waves(K, S, TOW, TRH, !LOOP)) void k_
             acc[a][0] = (f32x4){q.bq0.x, q.bq0.y, q.bq0.z, q.bq0.w};
             acc[a][1] = (f32x4){q.bq1.x, q.bq1.y, q.bq1.z, q.bq1.w};
         }
-        auto tile_mma = [&](int a) {
+        // (hi = the chunk's upper 16 channels exist: false only for the tail chunk of a width that is 16 mod 32 - b3 / b4's
+        // 144 - which then skips half of its MFMAs, activations and LDS stores; phase 2 never reads those E columns)
+        auto tile_mma = [&](int a, auto hi) {
+            constexpr bool HI = decltype(hi)::value;
 #pragma unroll
             for (int sidx = 0; sidx < 4; sidx++) {
                 acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wA0[sidx], xA[a][sidx], acc[a][0], 0, 0, 0);
-                acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wA1[sidx], xA[a][sidx], acc[a][1], 0, 0, 0);
+                if (HI) acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wA1[sidx], xA[a][sidx], acc[a][1], 0, 0, 0);
             }
             if constexpr (KW == 32) {
 #pragma unroll
                 for (int sidx = 0; sidx < 4; sidx++) {
                     acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wB0[sidx], xB[a][sidx], acc[a][0], 0, 0, 0);
-                    acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wB1[sidx], xB[a][sidx], acc[a][1], 0, 0, 0);
+                    if (HI) acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wB1[sidx], xB[a][sidx], acc[a][1], 0, 0, 0);
                 }
             }
             if constexpr (KW == 24) {
 #pragma unroll
                 for (int sidx = 0; sidx < 2; sidx++) {
                     acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wH0[sidx], xH[a][sidx], acc[a][0], 0, 0, 0);
-                    acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wH1[sidx], xH[a][sidx], acc[a][1], 0, 0, 0);
+                    if (HI) acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wH1[sidx], xH[a][sidx], acc[a][1], 0, 0, 0);
                 }
             }
         };
         // E <- act_e(acc) for tile a, at compacted footprint coordinates (masked columns are zero)
-        auto tile_out = [&](int a, auto masked, auto&& act4) {
+        auto tile_out = [&](int a, auto masked, auto hi, auto&& act4) {
+            constexpr bool HI = decltype(hi)::value;
             acc[a][0] = act4(acc[a][0]);
-            acc[a][1] = act4(acc[a][1]);
+            if (HI) acc[a][1] = act4(acc[a][1]);
             if (16 * (wave + 4 * a) + li < nvalid) {
                 float* e = E + (16 * (wave + 4 * a)) * ED_ES + e_lane;
                 if constexpr (decltype(masked)::value) {
                     const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
                     *reinterpret_cast<f32x4*>(e) = xin[a] ? acc[a][0] : z;
-                    *reinterpret_cast<f32x4*>(e + 16) = xin[a] ? acc[a][1] : z;
+                    if (HI) *reinterpret_cast<f32x4*>(e + 16) = xin[a] ? acc[a][1] : z;
                 } else {
                     *reinterpret_cast<f32x4*>(e) = acc[a][0];
-                    *reinterpret_cast<f32x4*>(e + 16) = acc[a][1];
+                    if (HI) *reinterpret_cast<f32x4*>(e + 16) = acc[a][1];
                 }
             }
         };
-        auto phase1 = [&](auto masked, auto&& act4) {
-            if (wave < jtv) tile_mma(0);
+        auto phase1 = [&](auto masked, auto hi, auto&& act4) {
+            if (wave < jtv) tile_mma(0, hi);
             if (LOOP && ci > 0) {
                 __syncthreads();                           // every wave is through phase 2 of the previous chunk: E, taps and sums
                 if (p.partial) ed_sums_out(p, red, tid, tile_index, n_base - 32);
@@ -2402,35 +2434,46 @@ __global__ __launch_bounds__(256, expdw_sk_waves(K, S, TOW, TRH, !LOOP)) void k_
 #pragma unroll
             for (int a = 1; a < JTW; a++) {
                 if (wave + 4 * a < jtv) {                 // (tile a valid => tile a - 1 valid)
-                    tile_mma(a);
-                    tile_out(a - 1, masked, act4);
+                    tile_mma(a, hi);
+                    tile_out(a - 1, masked, hi, act4);
 #pragma unroll
-                    for (int m = 0; m < NMMA; m++) {
+                    for (int m = 0; m < (decltype(hi)::value ? NMMA : NMMA / 2); m++) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
                         __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
                     }
-                } else if (wave + 4 * (a - 1) < jtv) tile_out(a - 1, masked, act4);
+                } else if (wave + 4 * (a - 1) < jtv) tile_out(a - 1, masked, hi, act4);
             }
-            if (wave + 4 * (JTW - 1) < jtv) tile_out(JTW - 1, masked, act4);
+            if (wave + 4 * (JTW - 1) < jtv) tile_out(JTW - 1, masked, hi, act4);
         };
-        auto phase1_act = [&](auto masked) {
-            if (p.act_e == ACT_SWISH) phase1(masked, [](f32x4 v) { return swish4(v); });
+        auto phase1_act = [&](auto masked, auto hi) {
+            // (the chunk-loop instantiations are launched for swish layers only - the others take k_expand_dw - so that the
+            // generic activation's per-element switch is not compiled into 48 more kernels)
+            if (LOOP || p.act_e == ACT_SWISH) phase1(masked, hi, [](f32x4 v) { return swish4(v); });
             else {
                 const int act = p.act_e;
-                phase1(masked, [act](f32x4 v) {
+                phase1(masked, hi, [act](f32x4 v) {
                     return (f32x4){apply_act(v[0], act), apply_act(v[1], act), apply_act(v[2], act), apply_act(v[3], act)};
                 });
             }
         };
-        if (border) phase1_act(std::true_type{});
-        else phase1_act(std::false_type{});
+        if (LOOP && n_base + 16 >= p.Cmid) {
+            if (border) phase1_act(std::true_type{}, std::false_type{});
+            else phase1_act(std::false_type{}, std::false_type{});
+        } else {
+            if (border) phase1_act(std::true_type{}, std::true_type{});
+            else phase1_act(std::false_type{}, std::true_type{});
+        }
         if (tid < K * K * 8) wds[tid] = q.wd;
         const float4 bv = q.bv;
         __syncthreads();
         if (LOOP && ci + 1 < ncc) fetch(cc + 1, q);               // next chunk's parameters: in flight during phase 2
 
-        const float4 sum = ed_phase2<K, S, TOH, TOW, TRH>(p, E, wds, b, oh0, ow0, vr0, vr1, wave, tx, c4, n_base, bv);
+        // The prefetched registers are "used" before phase 2's stores are issued: vmcnt retires in order, so a wait for those
+        // loads placed after the stores (the top of the next chunk is where the compiler would put it) is a wait for the
+        // stores' write acknowledgements as well - measured as vmcnt(0) at the loop head.  Here it only covers loads that
+        // have had the whole tap loop to arrive.
+        const float4 sum = ed_phase2<K, S, TOH, TOW, TRH>(p, E, wds, b, oh0, ow0, vr0, vr1, wave, tx, c4, n_base, bv, land);
         if (p.partial) ed_sums_lanes(sum, red, wave, lane, c4);
     }
     if (p.partial) {
@@ -2567,7 +2610,8 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
     const bool bx = wep != nullptr && !stem && expdw_bx_ok(Cin);
     if (bx) { p.wep = wep; p.Kp = expdw_kp(Cin); p.prec = prec; }
     if (stem) p.Kw = 24;                               // 3 rows x 4 columns x 2 channels
-    if (!bx && !stem && (p.Kw == 16 || p.Kw == 24 || p.Kw == 32)) {
+    const bool sk = !bx && (stem || (act_e == ACT_SWISH && (p.Kw == 16 || p.Kw == 24 || p.Kw == 32)));
+    if (sk && !stem) {
         // small-K form: a block owns (clip, tile) and walks the channel chunks itself
         nblk = (unsigned)B * p.tiles_h * p.tiles_w;
         p.d_bpc = make_fdiv((unsigned)(p.tiles_h * p.tiles_w));
@@ -2586,9 +2630,9 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
 #define ED_CASE(K_, S_, TH_, TW_, TR_)                                                                        \
     if (sh->k == K_ && sh->s == S_ && sh->toh == TH_ && sh->tow == TW_ && sh->trh == TR_) {                   \
         if (bx) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
-        else if (p.Kw == 16) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 16>), dim3(nblk), dim3(256), 0, st, p, nblk); \
-        else if (p.Kw == 24) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 24>), dim3(nblk), dim3(256), 0, st, p, nblk); \
-        else if (p.Kw == 32) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 32>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        else if (sk && p.Kw == 16) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 16>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        else if (sk && p.Kw == 24) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 24>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        else if (sk && p.Kw == 32) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 32>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         else if (p.Kw & 8) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         else hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_>), dim3(nblk), dim3(256), 0, st, p, nblk);  \
         return;                                                                                               \
