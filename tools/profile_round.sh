@@ -11,7 +11,7 @@ TAG=${1:-r02}
 WL=${2:-}          # extra bench.py arguments, e.g. "--workload perch --precision bf16" (tag the outputs accordingly)
 OUT=$PWD/gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-BENCH="python bench.py $WL --steps 20 --warmup 3 --no-cpu-baseline --no-fp32-run --no-oracle-check"
+BENCH="python bench.py $WL --steps 20 --warmup 3 --no-cpu-baseline --no-fp32-run --no-oracle-check --no-host-pointer --no-secondary --no-distribution"
 rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- $BENCH > $OUT/${TAG}_bench_under_rocprof.json 2> /tmp/kt.err
 DB=$(find /tmp/kt -name "*.db" | head -1)
 NL=$(python - <<PY
@@ -23,7 +23,7 @@ PY
 python tools/prof_summary.py $DB --csv $OUT/${TAG}_kernel_stats.csv > /dev/null
 python tools/prof_summary.py $DB --csv $OUT/${TAG}_kernel_stats_timed.csv --window $NL:$((20 * NL)) > /dev/null
 echo "launches per step: $NL" > $OUT/${TAG}_profile_notes.txt
-PB="python bench.py $WL --steps 5 --warmup 2 --no-cpu-baseline --no-fp32-run --no-oracle-check --no-profile"
+PB="python bench.py $WL --steps 5 --warmup 2 --no-cpu-baseline --no-fp32-run --no-oracle-check --no-profile --no-host-pointer --no-secondary --no-distribution"
 DBS=""
 i=0
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
@@ -32,5 +32,5 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU
   DBS="$DBS $(find /tmp/pmc$i -name '*.db' | head -1)"
 done
 python tools/pmc_summary.py --traffic-json $OUT/${TAG}_traffic.json --window $NL:$((5 * NL)) $DBS > $OUT/${TAG}_pmc.csv
-python bench.py $WL --depth 1 --detail --steps 5 --warmup 3 --no-cpu-baseline --no-fp32-run --no-oracle-check > /dev/null 2> $OUT/${TAG}_step_detail_depth1.txt
+python bench.py $WL --depth 1 --detail --steps 5 --warmup 3 --no-cpu-baseline --no-fp32-run --no-oracle-check --no-host-pointer --no-secondary --no-distribution > /dev/null 2> $OUT/${TAG}_step_detail_depth1.txt
 echo done
