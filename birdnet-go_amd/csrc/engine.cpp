@@ -1806,6 +1806,11 @@ void Engine::autotune_expdw() {
             }
         }
         if (best_idx < 0) continue;
+        if (const char* f = getenv("BNHIP_EXPDW_FORCE")) {          // debug / A-B: "b3/expand+dw=0,b2/expand+dw=10"
+            const std::string key = s.name + "=";
+            const char* q = strstr(f, key.c_str());
+            if (q) { const int idx = atoi(q + key.size()); if (expdw_shape_fits(idx, sg0)) best_idx = idx; }
+        }
         s.shape = best_idx;
         s.bx = best_bx;
         if (s.out2 >= 0) {                       // the consumers of the per-tile sums index them by tile count
