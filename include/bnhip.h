@@ -56,8 +56,8 @@ void bnhip_shutdown(void);
  * container is sniffed: "TFL3" at byte 4 = TFLite flatbuffer, otherwise ONNX ModelProto.  The blob is consumed during the
  * call and may be freed afterwards (classifier.go:37).
  * opts_json (nullable): {"device":0,"devices":[0,1,..],"replicate":"auto","max_batch":256,"plan_only":0,"debug_no_reuse":0,
- *                        "autotune":1,"graphs":0,"lanes":2,"frontend_fft":-1,"depth":1,"bf16x3":1,"precision":"f32",
- *                        "logits_output":0,"embedding_output":1}
+ *                        "autotune":1,"graphs":0,"lanes":2,"frontend_fft":-1,"depth":1,"host_depth":2,"bf16x3":1,
+ *                        "precision":"f32","logits_output":0,"embedding_output":1}
  * "devices": one handle over several GPUs: one engine per listed device, the clips of every host-
  *          pointer call are sharded index-contiguously over them and run concurrently (one worker thread per device, own
  *          streams and pinned-order staging per device).  The frozen weights are uploaded to the first device only and
@@ -69,11 +69,15 @@ void bnhip_shutdown(void);
  * "lanes": batches of >= 32 clips are split over this many concurrent streams inside one call (default 2).
  * "depth": > 1 lets successive bnhip_predict_device calls overlap on alternating contexts (own stream and activation
  *          arena each); their outputs are complete after bnhip_synchronize, not merely in the caller's stream order.
+ * "host_depth": 2 (default) runs a host-pointer call of >= 128 clips as a pipeline of chunks over two contexts fed from pinned
+ *          staging (csrc/hostpipe.cpp; env BNHIP_HOST_DEPTH): still blocking, outputs complete on return, results
+ *          bit-identical to "host_depth":1 (one chunk at a time, round 2's behaviour).  Costs a second activation arena.
  * "frontend_fft": 0 selects the folded-GEMM mel front-end for real-part graphs instead of the FFT path.
  * "bf16x3": pointwise / dense layers on the split-bf16 MFMA path (three exact bf16 pieces per fp32 operand, six
  *          v_mfma_f32_16x16x32_bf16 products per k, fp32 accumulation: every product is reproduced to within 2^-23, see
- *          DESIGN.md): 1 (default) = per layer where the create-time autotuner measures it faster, 0 = f32 MFMA only,
- *          2 = every eligible layer (K >= 16, K a multiple of 4).
+ *          DESIGN.md): 1 (default) = the layers whose arithmetic intensity at max_batch is >= 12 flop/B (a shape rule, so the
+ *          arithmetic never depends on create-time timing; the autotuner only picks tiles), 0 = f32 MFMA only (the Go shim's
+ *          Options.StrictF32), 2 = every eligible layer (K >= 16, K a multiple of 4) including the fused expand + depthwise.
  * "logits_output" / "embedding_output": indices of the graph outputs returned as logits / embedding.  Default: the reference's
  *          per-family rule (internal/inference/onnx/detection.go:24-112): output 0 (+ 1 as embedding); 160000-sample graphs
  *          with 4 outputs (Perch v2) logits 3 / embedding 0; with 2 outputs (BirdNET v3.0) the 1280-wide one is the embedding.
