@@ -1683,6 +1683,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
     HIPCHK(hipMalloc((void**)&d_stage_logits, (size_t)max_batch * n_classes * 4));
     HIPCHK(hipMalloc((void**)&d_post_conf, (size_t)max_batch * n_classes * 4));
     if (emb_dim) HIPCHK(hipMalloc((void**)&d_stage_emb, (size_t)max_batch * emb_dim * 4));
+    if (!defer_weights) mark_bf16_storage();
     if (autotune && !defer_weights) { autotune_pw(); autotune_expdw(); autotune_dw(); }
     *code = BNHIP_OK;
     return true;
@@ -1763,8 +1764,57 @@ bool Engine::ensure_contexts(int d, std::string* err, bool with_streams) {
 void Engine::finish_deferred() {
     if (device < 0) return;
     hipSetDevice(device);
+    mark_bf16_storage();
     if (autotune) { autotune_pw(); autotune_expdw(); autotune_dw(); }
     defer_weights = false;
+}
+
+// bf16 activation storage ("precision":"bf16" only; BNHIP_BF16_ACT=0 keeps fp32 storage for A/B runs).  A value is kept as
+// bf16 in HBM when its one producer can round on the way out and every consumer can widen on the way in: the outputs of the
+// split-bf16 GEMMs (no residual), of the tiled / LDS-staged depthwise kernels and of the fused expand + depthwise kernel,
+// consumed only as the A operand of split-bf16 GEMMs (which round that operand to bf16 anyway - storing it rounded changes
+// nothing for them, except that a fused squeeze-excite scale is applied to the rounded value) or as the input of a tiled /
+// LDS-staged depthwise convolution (fp32 taps on bf16-rounded inputs: the only place the rounding is new).  That is exactly
+// the set of 6x-expanded tensors, the ones the HBM-bound layers of an MBConv stack move.  Graph inputs / outputs, residual
+// and scale operands, squeeze-excite sums and everything touched by any other kernel stay fp32.  Arena offsets are
+// unchanged (a bf16 value uses the first half of its block).
+void Engine::mark_bf16_storage() {
+    for (auto& v : vals) v.half = false;
+    if (precision != 1 || device < 0) return;
+    if (const char* e = getenv("BNHIP_BF16_ACT")) if (atoi(e) == 0) return;
+    auto bx_pw = [&](const Step& s) { return s.kind == S_PW && s.bx && s.wbx && s.wm >= 5 && s.wm_full >= 5; };
+    auto dw_ok = [&](const Step& s) {
+        if (s.kind != S_DW || (s.C & 3)) return false;
+        DwParams p{nullptr, nullptr, nullptr, nullptr, 1, s.H, s.W, s.C, s.Ho, s.Wo, s.kh, s.kw, s.sh, s.sw, s.pt, s.pl, s.act};
+        return dwconv_sum_slabs(p) > 0;
+    };
+    for (size_t vi = 0; vi < vals.size(); vi++) {
+        Value& v = vals[vi];
+        const int id = (int)vi;
+        if (v.external || id == v_input || id == v_logits || id == v_emb) continue;
+        int producers = 0, consumers = 0;
+        bool ok = true;
+        for (const Step& s : steps) {
+            if (s.out == id) {
+                producers++;
+                const bool p_ok = (bx_pw(s) && (s.Co & 3) == 0 && s.in2 < 0) || dw_ok(s) || (s.kind == S_EXPAND_DW && (s.Co & 3) == 0);
+                if (!p_ok) ok = false;
+            }
+            if (s.out2 == id) ok = false;
+            if (s.in1 == id || s.in2 == id) ok = false;
+            if (s.in0 == id) {
+                consumers++;
+                const bool c_ok = (bx_pw(s) && (s.C & 7) == 0) || dw_ok(s);     // (the GEMM fetches 8 channels per load)
+                if (!c_ok) ok = false;
+            }
+        }
+        if (ok && producers == 1 && consumers >= 1) v.half = true;
+    }
+    // accounting: the algorithmic bytes of the steps that touch a bf16 value shrink with it
+    for (Step& s : steps) {
+        if (s.in0 >= 0 && vals[s.in0].half) s.bytes -= 2.0 * (double)vals[s.in0].elems;
+        if (s.out >= 0 && vals[s.out].half) s.bytes -= 2.0 * (double)vals[s.out].elems;
+    }
 }
 
 // Per-layer choice of the pw_gemm N-tile width: the best width depends on (M, N, K) through occupancy, grid size and
@@ -2151,12 +2201,14 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
                 PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, nl > 1 ? s.nt : s.nt_full,
                            nl > 1 ? s.wm : s.wm_full};
                 p.prec = precision;
+                p.a_bf16 = vals[s.in0].half ? 1 : 0; p.out_bf16 = vals[s.out].half ? 1 : 0;
                 if (p.wm >= 5 && s.wbx) launch_pw_bx3(p, s.wbx, stream);
                 else launch_pw_gemm(p, stream);
                 break;
             }
             case S_DW: {
                 DwParams p{in0, s.w0, s.w1, out, n, s.H, s.W, s.C, s.Ho, s.Wo, s.kh, s.kw, s.sh, s.sw, s.pt, s.pl, s.act};
+                p.in_bf16 = vals[s.in0].half ? 1 : 0; p.out_bf16 = vals[s.out].half ? 1 : 0;
                 if (s.dwl) launch_dwconv_lds(p, out2, s.shape, stream);
                 else launch_dwconv(p, out2, stream);
                 break;
@@ -2166,7 +2218,7 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
                     StemGeom sg{s.H2, s.W2, s.pt2, s.pl2};
                     launch_expand_dw(in0, s.w0, s.w1, s.w2, s.w3, out, out2, n, s.H, s.W, s.C, s.Co,
                                      s.Ho, s.Wo, s.kh, s.sh, s.pt, s.pl, s.act, s.act2, s.shape, s.mode == 1 ? &sg : nullptr, stream,
-                                     s.bx ? s.wbx : nullptr, precision);
+                                     s.bx ? s.wbx : nullptr, precision, vals[s.out].half ? 1 : 0);
                 }
                 break;
             case S_MEAN_PARTIAL:
@@ -2291,7 +2343,8 @@ std::string Engine::describe() const {
         os << "\",\"H\":" << s.H << ",\"W\":" << s.W << ",\"C\":" << s.C << ",\"Co\":" << s.Co << ",\"k\":" << s.kh
            << ",\"stride\":" << s.sh << ",\"act\":" << s.act << ",\"fused_scale\":" << (s.kind == S_PW && s.in1 >= 0 ? 1 : 0)
            << ",\"shape\":" << s.shape << ",\"dw_lds\":" << s.dwl << ",\"bx\":" << s.bx << ",\"nt\":" << s.nt << ",\"wm\":" << s.wm << ",\"nt_full\":" << s.nt_full << ",\"wm_full\":" << s.wm_full << ",\"fused_res\":" << (s.kind == S_PW && s.in2 >= 0 ? 1 : 0) << ",\"fused_sum\":" << (s.out2 >= 0 ? 1 : 0) << ",\"flops\":" << s.flops << ",\"bytes\":" << s.bytes << ",\"wbytes\":" << s.wbytes
-           << ",\"out_v\":" << s.out << ",\"out2_v\":" << s.out2 << "}";
+           << ",\"out_v\":" << s.out << ",\"out2_v\":" << s.out2
+           << ",\"in_bf16\":" << ((s.in0 >= 0 && vals[s.in0].half) ? 1 : 0) << ",\"out_bf16\":" << ((s.out >= 0 && vals[s.out].half) ? 1 : 0) << "}";
     }
     os << "]}";
     return os.str();

@@ -59,6 +59,7 @@ struct Value {               // an activation tensor (per clip geometry)
     size_t offset_lane = 0;  // byte offset inside one lane's region (layout for lane_cap clips)
     int first = -1, last = -1;   // step liveness
     bool external = false;   // bound at run time (graph input / outputs)
+    bool half = false;       // stored as bf16 (first half of its block): "precision":"bf16" engines, Engine::mark_bf16_storage
 };
 
 struct FrontSpec {
@@ -106,6 +107,7 @@ class Engine {
     bool use_graphs = false;            // opt-in: replay the plan as a hipGraph once a (pointers, n) combination repeats (measured: no gain on ROCm 7.2)
     void drop_graphs();
     void autotune_expdw();
+    void mark_bf16_storage();           // "precision":"bf16": which activation values are kept as bf16 in HBM
     void autotune_dw();                 // S_DW: register-tiled k_dwconv_t vs the LDS-staged form, per layer
     // Pipelining across calls ("depth" option, bnhip_predict_device only): call i runs on context i % depth (own stream,
     // own activation arena), so the tail of one batch overlaps the head of the next.  Completion is then signalled by

@@ -106,6 +106,8 @@ struct PwParams {         // pointwise conv / fully-connected as GEMM: out[M,N] 
     int wm = 0;           // row tile: 1 = 64 rows per block, otherwise 128; 3 / 4 = the same tiles on k_pw_pipe
     int prec = 0;         // k_pw_bx3 only: 0 = six bf16 products per fp32 product (fp32-equivalent), 1 = one (plain bf16 operands,
                           // fp32 accumulate: the "precision":"bf16" engines)
+    int a_bf16 = 0;       // k_pw_bx3 / k_pw_bx3p only: A holds bf16 values (bf16 activation storage, K % 4 == 0)
+    int out_bf16 = 0;     // any pw kernel: out is written as bf16 (N % 4 == 0, no residual)
 };
 void launch_pw_gemm(const PwParams& p, hipStream_t s);
 bool pw_pipe_ok(int nt, int wm, int K);   // PwParams::wm = 2 + wm selects the software-pipelined kernel (k_pw_pipe)
@@ -122,6 +124,7 @@ void launch_pw_bx3(const PwParams& p, const uint16_t* Wimg, hipStream_t s);
 struct DwParams {
     const float* in; const float* w /*[kh][kw][C]*/; const float* bias; float* out;
     int B, H, W, C, Ho, Wo, kh, kw, sh, sw, pt, pl, act;
+    int in_bf16 = 0, out_bf16 = 0;   // bf16 activation storage (tiled and LDS-staged kernels only: dwconv_sum_slabs(p) > 0 or dwl)
 };
 // partial (nullable): [B, dwconv_sum_slabs(p), C] per-slab channel sums of the OUTPUT (fused squeeze-excite mean);
 // dwconv_sum_slabs returns 0 when the shape has no tiled kernel (then no fused sums are available).
@@ -150,7 +153,8 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
                       int pl, int act_e, int act_d, int shape /* index into the shape table; -1 = cost model */,
                       const StemGeom* stem /* non-null: x is the raw image and the expand is the 3x3/2 stem (see kernels.hip) */,
                       hipStream_t st, const uint16_t* wep = nullptr /* non-null: phase 1 on the split-bf16 MFMA (expdw_bx_image) */,
-                      int prec = 0 /* with wep: 1 = plain bf16 operands (one product) */);
+                      int prec = 0 /* with wep: 1 = plain bf16 operands (one product) */,
+                      int out_bf16 = 0 /* y is written as bf16 (bf16 activation storage; Cmid % 4 == 0) */);
 // plain depthwise convolution through the same kernel (COPY mode: LDS-staged taps); shape as for launch_expand_dw, partial
 // (nullable) [B, expdw_shape_slabs(shape, geo), C]
 bool dwconv_lds_supported(const DwParams& p);

@@ -60,6 +60,22 @@ __device__ __forceinline__ f32x4 swish4(f32x4 v) {
     return (f32x4){lo[0], lo[1], hi[0], hi[1]};
 }
 
+// bf16 activation storage ("precision":"bf16" engines, engine.cpp mark_bf16_storage): a value whose producer and consumers all
+// understand it is kept as bf16 in HBM - the 6x-expanded tensors between expand, depthwise and projection, which are what the
+// HBM-bound layers move.  Round to nearest even on the way out (v_cvt_pk_bf16_f32), a 16-bit shift on the way in; arithmetic
+// and accumulation stay fp32.  Four channels = one 8-byte access instead of a 16-byte one.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 bf16x4_load(const float* base, size_t quad) {       // quad: index in units of 4 elements
+    const uint2 r = reinterpret_cast<const uint2*>(base)[quad];
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+}
+__device__ __forceinline__ void bf16x4_store(float* base, size_t quad, const float4& v) {
+    uint2 r;
+    r.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v.x, v.y}, bf16x2_t));
+    r.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v.z, v.w}, bf16x2_t));
+    reinterpret_cast<uint2*>(base)[quad] = r;
+}
+
 // XCD-aware logical block id: the dispatcher places block b on XCD b % 8; remapping so that each XCD walks a
 // contiguous range of logical blocks keeps halo rows / shared operand panels in ONE XCD's L2 (bijective form).
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
@@ -763,7 +779,9 @@ __device__ __forceinline__ void pw_epilogue(const PwParams& p, f32x4 (&acc)[NT][
             if (row < 16 && m < p.M && n < p.N) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * CS + 4 * c4]);
                 float* op = p.out + (size_t)m * p.N + n;
-                if (vec_ok) {
+                if (p.out_bf16) {                         // (planner: only with N % 4 == 0 and no residual)
+                    bf16x4_store(p.out, ((size_t)m * p.N + n) >> 2, make_float4(v[0], v[1], v[2], v[3]));
+                } else if (vec_ok) {
                     if (p.res) { float4 rv = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.N + n); v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
                     *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
@@ -1168,13 +1186,43 @@ __global__ __launch_bounds__(256) void k_pw_bx3(PwParams p, const uint16_t* __re
     float4 xreg[XQ], sreg[SC ? XQ : 1];
     u32x4 wreg[WQ];
     const u32x4* W16 = reinterpret_cast<const u32x4*>(Wimg);
+    // bf16 activation storage (p.a_bf16, K % 8 == 0): a thread fetches 8 channels = the same 16 bytes per load instruction as
+    // the fp32 path, in half as many instructions (4 threads per 32-wide row instead of 8; the first XQ / 2 entries of the
+    // same offset / register arrays, so the fp32 path pays nothing for it).  The first form of this path kept the fp32 thread
+    // mapping with 8-byte loads and made every projection 20-30 % SLOWER: these layers are bound by loads in flight per wave,
+    // not by bytes.
+    constexpr int XH = XQ / 2;
+    constexpr int LQH = 64 * PW_LS;
+    if (p.a_bf16) {
+#pragma unroll
+        for (int q = 0; q < XH; q++) {
+            const int row = (tid >> 2) + 64 * q;
+            const int m = min(m0 + row, p.M - 1);
+            xoff[q] = (unsigned)m * (unsigned)K + 8u * (unsigned)(tid & 3);
+            if (SC) soff[SC ? q : 0] = fdiv((unsigned)m, dhw) * (unsigned)K + 8u * (unsigned)(tid & 3);
+        }
+    }
     auto gload = [&](int sl) {
         const float* Ak = p.A + sl * PW_BK;
         const bool kin = sl * PW_BK + kc4 < K;             // K tail (K % 32 != 0): columns beyond K are zeros (their weights too)
+        if (p.a_bf16) {
+            const bool kinh = sl * PW_BK + 8 * (tid & 3) < K;
+            const uint16_t* A16 = reinterpret_cast<const uint16_t*>(p.A) + sl * PW_BK;
 #pragma unroll
-        for (int q = 0; q < XQ; q++) {
-            xreg[q] = kin ? *reinterpret_cast<const float4*>(Ak + xoff[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (SC) sreg[SC ? q : 0] = kin ? *reinterpret_cast<const float4*>(p.ascale + sl * PW_BK + soff[SC ? q : 0]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < XH; q++) {
+                xreg[q] = kinh ? *reinterpret_cast<const float4*>(A16 + xoff[q]) : make_float4(0.f, 0.f, 0.f, 0.f);   // (8 raw bf16)
+                if (SC) {
+                    const float* sp = p.ascale + sl * PW_BK + soff[SC ? q : 0];
+                    sreg[SC ? 2 * q : 0] = kinh ? *reinterpret_cast<const float4*>(sp) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    sreg[SC ? 2 * q + 1 : 0] = kinh ? *reinterpret_cast<const float4*>(sp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < XQ; q++) {
+                xreg[q] = kin ? *reinterpret_cast<const float4*>(Ak + xoff[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (SC) sreg[SC ? q : 0] = kin ? *reinterpret_cast<const float4*>(p.ascale + sl * PW_BK + soff[SC ? q : 0]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         const u32x4* Ws = W16 + (size_t)sl * 12 * Npad;
 #pragma unroll
@@ -1183,11 +1231,26 @@ __global__ __launch_bounds__(256) void k_pw_bx3(PwParams p, const uint16_t* __re
     };
     u32x4* Wl = reinterpret_cast<u32x4*>(lds + BM * PW_LS);
     auto lstore = [&]() {
+        if (p.a_bf16) {
+#pragma unroll
+            for (int q = 0; q < XH; q++) {
+                const unsigned r[4] = {__float_as_uint(xreg[q].x), __float_as_uint(xreg[q].y), __float_as_uint(xreg[q].z), __float_as_uint(xreg[q].w)};
+                float4 v0 = make_float4(__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u));
+                float4 v1 = make_float4(__uint_as_float(r[2] << 16), __uint_as_float(r[2] & 0xffff0000u), __uint_as_float(r[3] << 16), __uint_as_float(r[3] & 0xffff0000u));
+                if (SC) {
+                    const float4 s0 = sreg[SC ? 2 * q : 0], s1 = sreg[SC ? 2 * q + 1 : 0];
+                    v0.x *= s0.x; v0.y *= s0.y; v0.z *= s0.z; v0.w *= s0.w; v1.x *= s1.x; v1.y *= s1.y; v1.z *= s1.z; v1.w *= s1.w;
+                }
+                *reinterpret_cast<float4*>(&lds[((tid >> 2) * PW_LS + 8 * (tid & 3)) + q * LQH]) = v0;
+                *reinterpret_cast<float4*>(&lds[((tid >> 2) * PW_LS + 8 * (tid & 3)) + q * LQH + 4]) = v1;
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < XQ; q++) {
             float4 v = xreg[q];
             if (SC) { const float4 sc = sreg[SC ? q : 0]; v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
             *reinterpret_cast<float4*>(&lds[lbase + q * LQ]) = v;
+        }
         }
 #pragma unroll
         for (int q = 0; q < WQ; q++)
@@ -1308,13 +1371,43 @@ __global__ __launch_bounds__(256) void k_pw_bx3p(PwParams p, const uint16_t* __r
     float4 xreg[XQ], sreg[SC ? XQ : 1];
     u32x4 wreg[WQ];
     const u32x4* W16 = reinterpret_cast<const u32x4*>(Wimg);
+    // bf16 activation storage (p.a_bf16, K % 8 == 0): a thread fetches 8 channels = the same 16 bytes per load instruction as
+    // the fp32 path, in half as many instructions (4 threads per 32-wide row instead of 8; the first XQ / 2 entries of the
+    // same offset / register arrays, so the fp32 path pays nothing for it).  The first form of this path kept the fp32 thread
+    // mapping with 8-byte loads and made every projection 20-30 % SLOWER: these layers are bound by loads in flight per wave,
+    // not by bytes.
+    constexpr int XH = XQ / 2;
+    constexpr int LQH = 64 * PW_LS;
+    if (p.a_bf16) {
+#pragma unroll
+        for (int q = 0; q < XH; q++) {
+            const int row = (tid >> 2) + 64 * q;
+            const int m = min(m0 + row, p.M - 1);
+            xoff[q] = (unsigned)m * (unsigned)K + 8u * (unsigned)(tid & 3);
+            if (SC) soff[SC ? q : 0] = fdiv((unsigned)m, dhw) * (unsigned)K + 8u * (unsigned)(tid & 3);
+        }
+    }
     auto gload = [&](int sl) {
         const float* Ak = p.A + sl * PW_BK;
         const bool kin = sl * PW_BK + kc4 < K;             // K tail (K % 32 != 0): columns beyond K are zeros (their weights too)
+        if (p.a_bf16) {
+            const bool kinh = sl * PW_BK + 8 * (tid & 3) < K;
+            const uint16_t* A16 = reinterpret_cast<const uint16_t*>(p.A) + sl * PW_BK;
 #pragma unroll
-        for (int q = 0; q < XQ; q++) {
-            xreg[q] = kin ? *reinterpret_cast<const float4*>(Ak + xoff[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (SC) sreg[SC ? q : 0] = kin ? *reinterpret_cast<const float4*>(p.ascale + sl * PW_BK + soff[SC ? q : 0]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < XH; q++) {
+                xreg[q] = kinh ? *reinterpret_cast<const float4*>(A16 + xoff[q]) : make_float4(0.f, 0.f, 0.f, 0.f);   // (8 raw bf16)
+                if (SC) {
+                    const float* sp = p.ascale + sl * PW_BK + soff[SC ? q : 0];
+                    sreg[SC ? 2 * q : 0] = kinh ? *reinterpret_cast<const float4*>(sp) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    sreg[SC ? 2 * q + 1 : 0] = kinh ? *reinterpret_cast<const float4*>(sp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < XQ; q++) {
+                xreg[q] = kin ? *reinterpret_cast<const float4*>(Ak + xoff[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (SC) sreg[SC ? q : 0] = kin ? *reinterpret_cast<const float4*>(p.ascale + sl * PW_BK + soff[SC ? q : 0]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         const u32x4* Ws = W16 + (size_t)sl * 12 * Npad;
 #pragma unroll
@@ -1322,11 +1415,26 @@ __global__ __launch_bounds__(256) void k_pw_bx3p(PwParams p, const uint16_t* __r
             if (tid + 256 * q < wslots) wreg[q] = Ws[woff[q]];
     };
     auto lstore = [&](float* buf) {
+        if (p.a_bf16) {
+#pragma unroll
+            for (int q = 0; q < XH; q++) {
+                const unsigned r[4] = {__float_as_uint(xreg[q].x), __float_as_uint(xreg[q].y), __float_as_uint(xreg[q].z), __float_as_uint(xreg[q].w)};
+                float4 v0 = make_float4(__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u));
+                float4 v1 = make_float4(__uint_as_float(r[2] << 16), __uint_as_float(r[2] & 0xffff0000u), __uint_as_float(r[3] << 16), __uint_as_float(r[3] & 0xffff0000u));
+                if (SC) {
+                    const float4 s0 = sreg[SC ? 2 * q : 0], s1 = sreg[SC ? 2 * q + 1 : 0];
+                    v0.x *= s0.x; v0.y *= s0.y; v0.z *= s0.z; v0.w *= s0.w; v1.x *= s1.x; v1.y *= s1.y; v1.z *= s1.z; v1.w *= s1.w;
+                }
+                *reinterpret_cast<float4*>(&buf[((tid >> 2) * PW_LS + 8 * (tid & 3)) + q * LQH]) = v0;
+                *reinterpret_cast<float4*>(&buf[((tid >> 2) * PW_LS + 8 * (tid & 3)) + q * LQH + 4]) = v1;
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < XQ; q++) {
             float4 v = xreg[q];
             if (SC) { const float4 sc = sreg[SC ? q : 0]; v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
             *reinterpret_cast<float4*>(&buf[lbase + q * LQ]) = v;
+        }
         }
         u32x4* Wl = reinterpret_cast<u32x4*>(buf + BM * PW_LS);
 #pragma unroll
@@ -1633,7 +1741,9 @@ __global__ __launch_bounds__(256) void k_dwconv_t(DwParams p, int CX, int PY, in
 #pragma unroll
             for (int c = 0; c < RW; c++) {
                 int wi = wi0 + c;
-                x[c] = (wi >= 0 && wi < p.W) ? in4[((size_t)hi * p.W + wi) * C4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!(wi >= 0 && wi < p.W)) x[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                else if (p.in_bf16) x[c] = bf16x4_load(p.in, ((size_t)b * p.H * p.W + (size_t)hi * p.W + wi) * C4 + c4);
+                else x[c] = in4[((size_t)hi * p.W + wi) * C4];
             }
 #pragma unroll
             for (int a = 0; a < TH; a++) {
@@ -1685,7 +1795,8 @@ __global__ __launch_bounds__(256) void k_dwconv_t(DwParams p, int CX, int PY, in
                 int wo = tw0 + c;
                 if (wo >= p.Wo) continue;
                 float4 v = acc[a][c];
-                out4[((size_t)ho * p.Wo + wo) * C4] = v;
+                if (p.out_bf16) bf16x4_store(p.out, ((size_t)b * p.Ho * p.Wo + (size_t)ho * p.Wo + wo) * C4 + c4, v);
+                else out4[((size_t)ho * p.Wo + wo) * C4] = v;
                 sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
             }
         }
@@ -1811,6 +1922,7 @@ struct ExpDwParams {
     // (1, W') / (1, Wo') when rows and columns are swapped (tr = 1: H, W, Ho, Wo, pt, pl above are then the swapped values and
     // the depthwise taps are read transposed)
     int xsh = 0, xsw = 1, ysh = 0, ysw = 1, tr = 0;
+    int in_bf16 = 0, out_bf16 = 0;      // bf16 activation storage: x (COPY form only) / y hold bf16 values (see bf16x4_load)
     FDiv d_bpc{}, d_cch{}, d_tw{};      // blocks per clip, channel chunks, tiles per row (set by the launcher)
 };
 #define ED_ES 36     // E row stride (floats)
@@ -1946,7 +2058,9 @@ __device__ __forceinline__ float4 ed_phase2(const ExpDwParams& p, const float* E
                 int ow = ow0 + tx * SW + c;
                 if (ow >= p.Wo) continue;
                 float4 v = acc2[a][c];
-                *reinterpret_cast<float4*>(yclip + (ylane + (unsigned)((a * p.ysh + c * p.ysw) * p.Cmid))) = v;
+                const unsigned yo = ylane + (unsigned)((a * p.ysh + c * p.ysw) * p.Cmid);
+                if (p.out_bf16) bf16x4_store(p.y, ((size_t)b * p.Ho * p.Wo * p.Cmid + yo) >> 2, v);   // (bf16 image: same element offsets)
+                else *reinterpret_cast<float4*>(yclip + yo) = v;
                 sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
             }
         }
@@ -2041,7 +2155,10 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
             const int r = j / TIW, c = j - r * TIW;
             const int iw = iw0 + c, ih = ih0 + vr0 + r;
             float4 v = zero4;
-            if (cin && iw >= 0 && iw < p.W) v = x4[(img + (size_t)ih * p.xsh + (size_t)iw * p.xsw) * C4 + q4];
+            if (cin && iw >= 0 && iw < p.W) {
+                const size_t quad = (img + (size_t)ih * p.xsh + (size_t)iw * p.xsw) * C4 + q4;
+                v = p.in_bf16 ? bf16x4_load(p.x, quad) : x4[quad];
+            }
             *reinterpret_cast<float4*>(&E[j * ED_ES + 4 * (tid & 7)]) = v;
         }
         if (tid < K * K * 8) wds[tid] = wdreg;
@@ -2592,7 +2709,7 @@ bool expdw_supported(int k, int s, int Cin, int Cmid) {
 }
 void launch_expand_dw(const float* x, const float* we, const float* be, const float* wd, const float* bd, float* y,
                       float* partial, int B, int H, int W, int Cin, int Cmid, int Ho, int Wo, int k, int s, int pt,
-                      int pl, int act_e, int act_d, int shape, const StemGeom* stem, hipStream_t st, const uint16_t* wep, int prec) {
+                      int pl, int act_e, int act_d, int shape, const StemGeom* stem, hipStream_t st, const uint16_t* wep, int prec, int out_bf16) {
     const ExpDwGeo g0{k, s, H, W, Ho, Wo, pt, pl, stem != nullptr};
     if (!expdw_shape_fits(shape, g0)) shape = expdw_default_shape(g0);
     if (shape < 0) return;                             // the planner only fuses layers some shape accepts
@@ -2603,6 +2720,7 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
                   (g.Ho + sh->toh - 1) / sh->toh, (g.Wo + sh->tow - 1) / sh->tow, (Cmid + 31) / 32, expdw_kw(Cin), expdw_cp(Cmid)};
     // the kernel's rows are image columns when tr: one kernel row step = one pixel, one kernel column step = an image row
     p.xsh = tr ? 1 : W; p.xsw = tr ? W : 1; p.ysh = tr ? 1 : Wo; p.ysw = tr ? Wo : 1; p.tr = tr ? 1 : 0;
+    p.out_bf16 = out_bf16;
     unsigned nblk = (unsigned)B * p.tiles_h * p.tiles_w * p.cchunks;
     p.d_bpc = make_fdiv((unsigned)(p.tiles_h * p.tiles_w * p.cchunks));
     p.d_cch = make_fdiv((unsigned)p.cchunks);
@@ -2658,6 +2776,7 @@ void launch_dwconv_lds(const DwParams& q, float* partial, int shape, hipStream_t
     ExpDwParams p{q.in, nullptr, nullptr, q.w, q.bias, q.out, partial, q.B, g.H, g.W, q.C, q.C, g.Ho, g.Wo, g.pt, g.pl, ACT_NONE, q.act,
                   (g.Ho + sh->toh - 1) / sh->toh, (g.Wo + sh->tow - 1) / sh->tow, (q.C + 31) / 32, 0, q.C};
     p.xsh = tr ? 1 : q.W; p.xsw = tr ? q.W : 1; p.ysh = tr ? 1 : q.Wo; p.ysw = tr ? q.Wo : 1; p.tr = tr ? 1 : 0;
+    p.in_bf16 = q.in_bf16; p.out_bf16 = q.out_bf16;
     unsigned nblk = (unsigned)q.B * p.tiles_h * p.tiles_w * p.cchunks;
     p.d_bpc = make_fdiv((unsigned)(p.tiles_h * p.tiles_w * p.cchunks));
     p.d_cch = make_fdiv((unsigned)p.cchunks);

@@ -83,8 +83,9 @@ void bnhip_shutdown(void);
  *          with 4 outputs (Perch v2) logits 3 / embedding 0; with 2 outputs (BirdNET v3.0) the 1280-wide one is the embedding.
  *          Other outputs are not computed.  "embedding_output": -1 = none.
  * "precision": "f32" (default) keeps every product fp32 (f32 MFMA or the six-product split above).  "bf16" rounds the MFMA
- *          operands of the pointwise / dense / fused-expand layers to bf16 (one product per k, fp32 accumulation, fp32
- *          storage; depthwise, squeeze-excite, front-end and head bias stay fp32): the reduced-precision deployment the
+ *          operands of the pointwise / dense / fused-expand layers to bf16 (one product per k, fp32 accumulation) and keeps
+ *          the expanded tensors between expand, depthwise and projection as bf16 in HBM (everything else fp32 storage;
+ *          depthwise, squeeze-excite, front-end and head bias arithmetic stay fp32): the reduced-precision deployment the
  *          reference runs Perch v2 in (openvino f16 drift ~0.08 accepted, openvino_parity_functional_test.go:156-158;
  *          BASELINE configs[4]).  Never a default: BirdNET v2.4 is known not to survive f16 (model_openvino.go:99-103).  */
 int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, bnhip_model** out);

@@ -168,6 +168,53 @@ def test_bf16_precision_drift_is_bounded(gpu):
 
 
 @pytest.mark.gpu
+def test_bf16_activation_storage_plan_and_drift(gpu, monkeypatch):
+    """"precision":"bf16" also keeps the 6x-expanded tensors as bf16 in HBM (engine.cpp mark_bf16_storage: outputs of the
+    split-bf16 expand GEMMs, of the depthwise kernels and of the fused expand + depthwise kernel, consumed by depthwise /
+    projection).  The plan must mark exactly those, an f32 engine none; against the same engine with fp32 storage
+    (BNHIP_BF16_ACT=0) the only new rounding is the depthwise input, so logits move little; and the oracle bounds of the
+    drift test above still hold.  Run on the Perch-size stand-in (fused and unfused blocks, both depthwise forms) and on the
+    v2.4-topology model."""
+    for cfg, n in ((sm.perch_config(), 3), (sm.SynthConfig(), 4)):
+        blob = sm.build_model(cfg)
+        x = sm.synth_clips(n, cfg.n_samples, cfg.sample_rate, first=23)
+        ref = oracle_logits_emb(blob, x)[0]
+        f32 = host.HipClassifier(blob, max_batch=8)
+        try:
+            assert not any(s["out_bf16"] or s["in_bf16"] for s in f32.describe()["steps"])
+        finally:
+            f32.close()
+        out = {}
+        for act in ("1", "0"):
+            monkeypatch.setenv("BNHIP_BF16_ACT", act)
+            c = host.HipClassifier(blob, max_batch=8, precision="bf16")
+            try:
+                st = c.describe()["steps"]
+                marked = [s for s in st if s["out_bf16"]]
+                if act == "1":
+                    kinds = {s["kernel"] for s in marked}
+                    assert marked and kinds <= {"pw_gemm", "dwconv", "expand_dw"}, kinds
+                    # every marked value is read by a step that knows: its consumers carry in_bf16
+                    outs = {s["out_v"] for s in marked}
+                    assert outs == {v for v in outs if any(t["in_bf16"] for t in st)}
+                    assert all(s["out_bf16"] for s in st if s["kernel"] == "expand_dw")      # the fused kernels' outputs all qualify
+                    assert not st[-1]["out_bf16"]                                            # never a graph output
+                else:
+                    assert not marked
+                out[act] = c.predict_batch(x.reshape(-1), n)
+            finally:
+                c.close()
+        monkeypatch.delenv("BNHIP_BF16_ACT")
+        a, b = out["1"], out["0"]
+        assert np.isfinite(a).all() and (a.argmax(1) == ref.argmax(1)).all() and (a.argmax(1) == b.argmax(1)).all()
+        d_store = np.abs(softmax64(a) - softmax64(b)).max()
+        d_ref = np.abs(softmax64(a) - softmax64(ref)).max()
+        print(f"{cfg.name}: softmax drift bf16-storage vs fp32-storage {d_store:.2e}, vs oracle {d_ref:.2e}, "
+              f"max |logit| diff {np.abs(a - b).max():.3e}")
+        assert d_ref <= 0.02 and d_store <= 0.01
+
+
+@pytest.mark.gpu
 def test_lds_staged_depthwise_vs_oracle(gpu, monkeypatch):
     """Plain depthwise layers forced onto the LDS-staged kernel (the fused kernel's second phase on a copied footprint:
     3x3 / 5x5, stride 1 / 2, channel counts that are not multiples of 32, fused squeeze-excite sums) vs the oracle, on the
