@@ -2725,10 +2725,13 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
     p.d_bpc = make_fdiv((unsigned)(p.tiles_h * p.tiles_w * p.cchunks));
     p.d_cch = make_fdiv((unsigned)p.cchunks);
     p.d_tw = make_fdiv((unsigned)p.tiles_w);
-    const bool bx = wep != nullptr && !stem && expdw_bx_ok(Cin);
-    if (bx) { p.wep = wep; p.Kp = expdw_kp(Cin); p.prec = prec; }
     if (stem) p.Kw = 24;                               // 3 rows x 4 columns x 2 channels
-    const bool sk = !bx && (stem || (act_e == ACT_SWISH && (p.Kw == 16 || p.Kw == 24 || p.Kw == 32)));
+    // the small-K form (f32 MFMA) also serves the bf16x3 = 2 / "precision":"bf16" engines: with one or two K slabs the MFMAs
+    // are a small part of the wave either way, and the chunk loop is worth more than the cheaper products (fp32 products where
+    // bf16 ones were asked for are never less accurate)
+    const bool sk = stem || (act_e == ACT_SWISH && (p.Kw == 16 || p.Kw == 24 || p.Kw == 32));
+    const bool bx = wep != nullptr && !sk && expdw_bx_ok(Cin);
+    if (bx) { p.wep = wep; p.Kp = expdw_kp(Cin); p.prec = prec; }
     if (sk && !stem) {
         // small-K form: a block owns (clip, tile) and walks the channel chunks itself
         nblk = (unsigned)B * p.tiles_h * p.tiles_w;
