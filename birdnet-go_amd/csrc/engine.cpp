@@ -1797,7 +1797,12 @@ void Engine::mark_bf16_storage() {
         for (const Step& s : steps) {
             if (s.out == id) {
                 producers++;
-                const bool p_ok = (bx_pw(s) && (s.Co & 3) == 0 && s.in2 < 0) || dw_ok(s) || (s.kind == S_EXPAND_DW && (s.Co & 3) == 0);
+                bool stem_ok = false;
+                if (s.kind == S_CONV_DIRECT && !s.w2) {        // the direct stem (not the MFMA one): 4-pixel kernels only
+                    ConvParams cp{nullptr, nullptr, nullptr, nullptr, 1, s.H, s.W, s.C, s.Ho, s.Wo, s.Co, s.kh, s.kw, s.sh, s.sw, s.pt, s.pl, s.act};
+                    stem_ok = conv_direct_bf16_ok(cp);
+                }
+                const bool p_ok = (bx_pw(s) && (s.Co & 3) == 0 && s.in2 < 0) || dw_ok(s) || (s.kind == S_EXPAND_DW && (s.Co & 3) == 0) || stem_ok;
                 if (!p_ok) ok = false;
             }
             if (s.out2 == id) ok = false;
@@ -2189,6 +2194,7 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
             }
             case S_CONV_DIRECT: {
                 ConvParams p{in0, s.w0, s.w1, out, n, s.H, s.W, s.C, s.Ho, s.Wo, s.Co, s.kh, s.kw, s.sh, s.sw, s.pt, s.pl, s.act};
+                p.out_bf16 = vals[s.out].half ? 1 : 0;
                 if (s.w2) launch_stem_mfma(p, s.w2, s.w3, stream);
                 else launch_conv_direct(p, stream);
                 break;

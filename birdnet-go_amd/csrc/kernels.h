@@ -88,8 +88,10 @@ int frontend_kc(int Lfft, int hop, int NTP);   // K-chunk of the front-end GEMM 
 struct ConvParams {       // direct conv, small Cin (stem)
     const float* in; const float* w /*[kh][kw][Cin][Cout]*/; const float* bias; float* out;
     int B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, pt, pl, act;
+    int out_bf16 = 0;     // bf16 activation storage (conv_direct_bf16_ok shapes only)
 };
 void launch_conv_direct(const ConvParams& p, hipStream_t s);
+bool conv_direct_bf16_ok(const ConvParams& p);
 // general convolution as an implicit GEMM on the f32 MFMA (weights OHWI as in the file): Cin % 4 == 0, kh * kw * Cin >= 32
 bool conv_igemm_supported(int Cin, int Cout, int kh, int kw);
 void launch_conv_igemm(const float* in, const float* w_ohwi, const float* bias, float* out, int B, int H, int W, int Cin, int Ho, int Wo,

@@ -558,10 +558,18 @@ __global__ __launch_bounds__(256) void k_conv_direct_px(ConvParams p, int wgroup
             a2[q].x = f(a2[q].x + bv.x); a2[q].y = f(a2[q].y + bv.y); a2[q].z = f(a2[q].z + bv.z); a2[q].w = f(a2[q].w + bv.w);
         }
     });
-    float4* op = reinterpret_cast<float4*>(p.out) + (((size_t)b * p.Ho + ho) * p.Wo + wo0) * C4 + c4;
+    const size_t o0 = (((size_t)b * p.Ho + ho) * p.Wo + wo0) * C4 + c4;
+    float4* op = reinterpret_cast<float4*>(p.out) + o0;
 #pragma unroll
     for (int q = 0; q < PX; q++)
-        if (wo0 + q < p.Wo) op[(size_t)q * C4] = a2[q];
+        if (wo0 + q < p.Wo) {
+            if (p.out_bf16) bf16x4_store(p.out, o0 + (size_t)q * C4, a2[q]);
+            else op[(size_t)q * C4] = a2[q];
+        }
+}
+// (bf16 activation storage: only the 4-pixel kernels below write bf16)
+bool conv_direct_bf16_ok(const ConvParams& p) {
+    return p.kh == 3 && p.kw == 3 && (p.Cin == 1 || p.Cin == 2) && p.sh == 2 && p.sw == 2 && (p.Cout & 3) == 0;
 }
 void launch_conv_direct(const ConvParams& p, hipStream_t s) {
     if (p.kh == 3 && p.kw == 3 && p.Cin == 2 && p.sh == 2 && p.sw == 2 && (p.Cout & 3) == 0) {

@@ -193,7 +193,7 @@ def test_bf16_activation_storage_plan_and_drift(gpu, monkeypatch):
                 marked = [s for s in st if s["out_bf16"]]
                 if act == "1":
                     kinds = {s["kernel"] for s in marked}
-                    assert marked and kinds <= {"pw_gemm", "dwconv", "expand_dw"}, kinds
+                    assert marked and kinds <= {"pw_gemm", "dwconv", "expand_dw", "conv_direct"}, kinds
                     # every marked value is read by a step that knows: its consumers carry in_bf16
                     outs = {s["out_v"] for s in marked}
                     assert outs == {v for v in outs if any(t["in_bf16"] for t in st)}
