@@ -141,3 +141,25 @@ def test_two_contexts_with_different_data_equal_the_serial_results(gpu, full_blo
         clf.close(); o.free()
         for d in xd:
             d.free()
+
+
+@pytest.mark.gpu
+def test_bf16_storage_engine_through_the_pipeline_equals_its_serial_path(gpu, full_blob):
+    """A "precision":"bf16" engine keeps the expanded tensors as bf16 in HBM (engine.cpp mark_bf16_storage); every context of
+    the host pipeline has its own activation arena with the same value layout, so 512 distinct clips through two contexts
+    must equal the same engine's serial path (host_depth 1) bit for bit, and a repeat of the call must equal itself."""
+    x256 = sm.synth_clips(256, 144000, 48000)
+    pcm = np.concatenate([(np.clip(x256, -1, 1) * 32767).astype(np.int16), np.roll((np.clip(x256, -1, 1) * 32767).astype(np.int16), 17, axis=0)], axis=0)
+    outs = {}
+    for hd in (2, 1):
+        clf = host.HipClassifier(full_blob, max_batch=256, precision="bf16", host_depth=hd, autotune=False)
+        try:
+            assert any(s["out_bf16"] for s in clf.describe()["steps"])
+            outs[hd] = clf.predict_pcm16(pcm.reshape(-1), 512).copy()
+            if hd == 2:
+                assert np.array_equal(clf.predict_pcm16(pcm.reshape(-1), 512), outs[hd])
+        finally:
+            clf.close()
+    assert np.isfinite(outs[2]).all()
+    assert np.array_equal(outs[2][256:], np.roll(outs[2][:256], 17, axis=0))
+    assert np.array_equal(outs[2], outs[1])
