@@ -501,13 +501,15 @@ __global__ __launch_bounds__(256) void k_mel_finish(MelFinParams p) {
 // total, not K x n_mels).  As a dense GEMM it was 0.13 ms of MFMA time per batch for 98 % zero products; as a banded sum
 // it is a bandwidth-class kernel, and with both channels in one launch the mel values never go to HBM either:
 //   out[b][m][f][c] = pow(pow(sum_{k in [lo_m, hi_m)} bins_c[b][f][k] * w_c[m][k], p1_c), p2_c).
-// Block = 16 consecutive frames of one clip (their bin rows are one contiguous chunk, staged in LDS), 192 threads = 96 bands
-// x 2 frame groups of 8.  A thread walks its band in aligned groups of four columns: one float4 of the (dense, zero
+// Block = MSP_F = 8 consecutive frames of one clip (their bin rows are one contiguous chunk, staged in LDS), 192 threads = 96
+// bands x 2 frame groups of 4 (16 frames per block measured 116 us, 8: 104 us, 4: 132 us: the kernel is three serial phases -
+// stage, sum, store - and waits 70 % of its life, so smaller blocks = more of them per CU in different phases win until the
+// weight rows are re-read too often).  A thread walks its band in aligned groups of four columns: one float4 of the (dense, zero
 // outside the band) weight row from L1/L2 and one ds_read_b128 per frame - LDS instruction issue is what bounds the
 // kernel (PMC/A-B: scalar reads with the weights in LDS were 10 % slower than with the weights in global memory), so
 // the wide read is the lever.  Products are added in ascending k with fmaf (the GEMM summed them in its slab order).
 // Bands are dealt to waves in order (wave w: bands 32 w ..), so the wide top bands do not set the trip count of every wave.
-#define MSP_F 16
+#define MSP_F 8
 template <int C, int VAR = 0>
 __global__ __launch_bounds__(256) void k_mel_banded(MelBandParams p) {
     extern __shared__ __attribute__((aligned(16))) float msm[];
