@@ -282,8 +282,14 @@ def build_model(cfg: SynthConfig = None, container="tflite", dft="matmul", trunc
             if er != 1:
                 t, H, W = conv(t, cin, mid, 1, 1, "swish", 1.6, H, W, name + "/expand")
             t, H, W = dwconv(t, mid, k, stride, 1.6, H, W, name + "/dw")
-            # squeeze-excite
+            # squeeze-excite (se_form "none": a plain inverted-residual block, MobileNetV2-style - no per-tile sums in the fused kernels)
             cse = max(1, int(cin * cfg.se_ratio))
+            if cfg.se_form == "none":
+                t, H, W = conv(t, mid, cout, 1, 1, None, 1.4, H, W, name + "/project")
+                if stride == 1 and cin == cout:
+                    t = g.op("ADD", [t, inp], [1, H, W, cout], dict(fused_activation_function=S.ACT_NONE))
+                cin = cout
+                continue
             if cfg.se_form in ("conv", "avgpool"):
                 if cfg.se_form == "avgpool":
                     m = g.op("AVERAGE_POOL_2D", [t], [1, 1, 1, mid], dict(padding=S.PAD_VALID, stride_w=W, stride_h=H, filter_width=W,

@@ -188,6 +188,28 @@ def test_geometry_sweep_vs_oracle(built_lib, i):
         assert_parity(got, ref)
 
 
+@pytest.mark.parametrize("i", [0, 3, 5])
+def test_blocks_without_squeeze_excite_vs_oracle(built_lib, i):
+    """Inverted-residual blocks with no squeeze-excite (se_form "none"): the fused expand + depthwise kernels then run without
+    their per-tile channel sums (partial == nullptr: no sums pass, and in the chunk-loop form no sums hand-over between the
+    barriers) and the projection without a fused scale - on the geometry sweep's layer mix (3x3 / 5x5, stride 1 / 2, channel
+    counts on both sides of the small-K limit, tail chunks, border tiles)."""
+    import dataclasses
+    cfg = dataclasses.replace(_geo_cfg(i), se_form="none")
+    blob = sm.build_model(cfg)
+    x = sm.synth_clips(5, cfg.n_samples, cfg.sample_rate, first=7 * i)
+    ref = Interpreter(blob).invoke(x)[0]
+    for opts in (dict(), dict(lanes=1, autotune=False)):
+        c = host.HipClassifier(blob, max_batch=8, **opts)
+        try:
+            kinds = [s["kernel"] for s in c.describe()["steps"]]
+            assert "se" not in kinds and "expand_dw" in kinds and not any(k.startswith("generic") for k in kinds), kinds
+            got = c.predict_batch(x.reshape(-1), 5)
+        finally:
+            c.close()
+        assert_parity(got, ref)
+
+
 # ---- FFT front-end (stft.hip): serves the magnitude (COMPLEX_ABS) graph and, on request, the real-part graph
 FFT_TINY_SPECS = (sm.SpecConfig(512, 94, 0.0, 3000.0), sm.SpecConfig(512, 94, 500.0, 15000.0))
 
