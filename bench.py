@@ -353,7 +353,16 @@ def main():
         return
     out = run_model(args)
     if out is not None:
-        print(json.dumps(out))
+        # The contract is ONE JSON line from rank 0, and a driver may read it as the last line of stdout: RCCL prints a version
+        # banner through C stdio when a communicator is created (N > 1), which would otherwise surface after this line when
+        # libc flushes at exit.  Flush C stdio first so that the JSON line is the last thing on stdout.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 def run_model(args):
@@ -379,6 +388,8 @@ def run_model(args):
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
+        if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
+            os.environ["NCCL_DEBUG"] = "WARN"          # no version banner on stdout (see the note where the JSON line is printed)
         dist.init_process_group("nccl", device_id=dev)
 
     perch = args.workload == "perch"
