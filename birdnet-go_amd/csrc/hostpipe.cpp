@@ -29,8 +29,10 @@ namespace bnhip {
 // calling thread helps).  Process-wide, shared by every engine and every worker thread of a multi-device handle.
 namespace {
 
+// `remaining` is only touched under `mu`: the waiter may own the Ticket on its stack (parallel_copy), so the last worker must
+// be done with the mutex and the condition variable before the waiter can observe zero and pop the frame.
 struct Ticket {
-    std::atomic<int> remaining{0};
+    int remaining = 0;
     std::mutex mu;
     std::condition_variable cv;
 };
@@ -58,7 +60,7 @@ class CopyPool {
     void submit(void* dst, const void* src, size_t bytes, Ticket* t) {
         const size_t piece = 2u << 20;
         const int np = (int)std::max<size_t>(1, (bytes + piece - 1) / piece);
-        t->remaining.store(np, std::memory_order_relaxed);
+        { std::lock_guard<std::mutex> lk(t->mu); t->remaining = np; }
         {
             std::lock_guard<std::mutex> lk(mu_);
             for (int i = 0; i < np; i++) {
@@ -71,7 +73,7 @@ class CopyPool {
     // the caller works on queued pieces (its own or anybody's) until its ticket is done
     void wait(Ticket* t) {
         for (;;) {
-            if (t->remaining.load(std::memory_order_acquire) == 0) return;
+            { std::lock_guard<std::mutex> lk(t->mu); if (t->remaining == 0) return; }
             Task k;
             bool got = false;
             {
@@ -80,7 +82,7 @@ class CopyPool {
             }
             if (got) { run(k); continue; }
             std::unique_lock<std::mutex> lk(t->mu);
-            t->cv.wait(lk, [t] { return t->remaining.load(std::memory_order_acquire) == 0; });
+            t->cv.wait(lk, [t] { return t->remaining == 0; });
             return;
         }
     }
@@ -88,10 +90,8 @@ class CopyPool {
   private:
     static void run(const Task& k) {
         if (k.n) memcpy(k.dst, k.src, k.n);
-        if (k.t->remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) {
-            std::lock_guard<std::mutex> lk(k.t->mu);
-            k.t->cv.notify_all();
-        }
+        std::lock_guard<std::mutex> lk(k.t->mu);
+        if (--k.t->remaining == 0) k.t->cv.notify_all();
     }
     void loop() {
         std::unique_lock<std::mutex> lk(mu_);
@@ -300,6 +300,7 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
         if (const char* sc = getenv("BNHIP_HOST_SCHED")) sscanf(sc, "%d,%d,%d,%d", &h1, &h2, &t1, &t2);   // experiments
         h1 = std::max(1, std::min(h1, e.max_batch)); h2 = std::max(1, std::min(h2, e.max_batch));
         t1 = std::max(1, std::min(t1, e.max_batch)); t2 = std::max(1, std::min(t2, e.max_batch));
+        if (h1 + h2 + t1 + t2 > j.n_clips) { h1 = unit; h2 = 2 * unit; t1 = 5 * unit / 2; t2 = std::max(1, unit / 2); }   // (a BNHIP_HOST_SCHED that does not fit the call)
         const int mid = j.n_clips - (h1 + h2 + t1 + t2), nm = (mid + e.max_batch - 1) / e.max_batch;
         csize.push_back(h1); csize.push_back(h2);
         for (int k = 0, left = mid; k < nm; k++) { const int c = (left + (nm - k) - 1) / (nm - k); csize.push_back(c); left -= c; }
@@ -317,6 +318,12 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
     if (!e.ensure_contexts(D, &err, false)) return BNHIP_E_NOMEM;
     HostPipe& hp = *e.hostpipe;
     constexpr int K = HostPipe::K;
+    // The chunks run in the context arenas on the device's kernel streams; context 0's arena is the engine's own.  Anything an
+    // earlier asynchronous bnhip_predict_device call (or a caller-owned stream, bnhip_set_stream) still has queued on them must
+    // be finished first - the old one-batch path got that ordering from Engine::run().  Idle streams return immediately.
+    e.sync_contexts();
+    if (e.stream) hipStreamSynchronize(e.stream);
+    for (int c = 0; c < Engine::kMaxDepth; c++) if (e.ctx_stream[c]) hipStreamSynchronize(e.ctx_stream[c]);
 
     auto chunk_n = [&](int c) { return csize[c]; };
     auto abort_all = [&]() {

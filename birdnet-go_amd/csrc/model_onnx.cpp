@@ -581,7 +581,8 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
             if (u->op == "Slice" && u->in.size() >= 5) {
                 std::vector<int64_t> st, en, ax, sp;
                 if (!const_i(u->in[1], &st) || !const_i(u->in[2], &en) || !const_i(u->in[3], &ax) || !const_i(u->in[4], &sp)) return false;
-                if (st.size() != 1 || sp[0] != -1 || st[0] != -1 || (ax[0] != mel_ax && ax[0] != mel_ax - 3)) return false;
+                if (st.size() != 1 || en.size() != 1 || ax.size() != 1 || sp.size() != 1) return false;      // (an empty initializer has no data() to index)
+                if (sp[0] != -1 || st[0] != -1 || (ax[0] != mel_ax && ax[0] != mel_ax - 3)) return false;
                 nm = u->out[0];
                 u = only_user(nm);
                 if (!u) return false;
@@ -615,6 +616,7 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
     };
     // framing of a [1, T] signal into windowed, zero-padded frames [1, F, Lfft], written the way tf.signal.frame converts
     auto emit_frames = [&](int sig, int T, int L, int hop, int Lfft, const std::vector<float>& window, const std::string& base, int* F_out) -> int {
+        if (hop < 1 || L < 1 || L > T || Lfft < L) { *F_out = 0; return -1; }     // callers range-check; a zero hop must never reach the division
         const int F = (T - L) / hop + 1;
         int sub = igcd_(igcd_(L, hop), T);
         const int nsub = T / sub, Q = L / sub, step = hop / sub;
@@ -714,7 +716,8 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
             if (a >= 0 && !chl.count(a) && m.tensors[a].shape.size() == 3 && !tr3.count(a) && m.tensors[a].shape[1] == 1 && const_f(nd.in[1], &Wv, &wd) &&
                 wd.size() == 3 && wd[1] == 1 && nd.ai("group", 1) == 1) {
                 const OAttr* st = nd.attr("strides"); const OAttr* pd = nd.attr("pads"); const OAttr* dl = nd.attr("dilations"); const OAttr* ap = nd.attr("auto_pad");
-                const int hop = st && st->ints.size() == 1 ? (int)st->ints[0] : 1;
+                const int64_t hop64 = st && st->ints.size() == 1 ? st->ints[0] : 1;
+                const int hop = hop64 >= 1 && hop64 <= m.tensors[a].shape[2] ? (int)hop64 : 0;       // (0 = not a framing stride: lowered literally)
                 bool plain = (!pd || (pd->ints.size() == 2 && pd->ints[0] == 0 && pd->ints[1] == 0)) && (!dl || (dl->ints.size() == 1 && dl->ints[0] == 1)) &&
                              (!ap || ap->s.empty() || ap->s == "NOTSET" || ap->s == "VALID");
                 SpecH h; std::vector<float> window; int Nfft = 0;
@@ -740,13 +743,15 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
                 if (nd.ai("onesided", 1) != 1 || nd.in.size() < 2 || !const_i(nd.in[1], &step) || step.size() != 1 || step[0] < 1) return 0;
                 const bool has_w = nd.in.size() > 2 && !nd.in[2].empty();
                 if (has_w && !const_f(nd.in[2], &win, nullptr)) return 0;
-                int L = has_w ? (int)win.size() : 0;
-                if (nd.in.size() > 3 && !nd.in[3].empty()) { if (!const_i(nd.in[3], &flen) || flen.size() != 1) return 0; if (has_w && flen[0] != L) return 0; L = (int)flen[0]; }
-                if (!has_w) win.assign(L, 1.0f);
                 const bool sig3 = ash.size() == 3 && ash[2] == 1;
-                if (!(sig3 || ash.size() == 2) || L < 8 || (L & 1)) return 0;
+                if (!(sig3 || ash.size() == 2)) return 0;
                 const int T = ash[1];
-                if (L > T) return 0;
+                int64_t L64 = has_w ? (int64_t)win.size() : 0;
+                if (nd.in.size() > 3 && !nd.in[3].empty()) { if (!const_i(nd.in[3], &flen) || flen.size() != 1) return 0; if (has_w && flen[0] != L64) return 0; L64 = flen[0]; }
+                // range checks on the int64 values, before any narrowing (2^32 would become hop 0, a negative length a huge allocation)
+                if (L64 < 8 || L64 > T || (L64 & 1) || step[0] > T) return 0;
+                const int L = (int)L64;
+                if (!has_w) win.assign(L, 1.0f);
                 const int sig = new_t(oname + "/signal", {1, T}, TT_FLOAT32);
                 add_op(OP_RESHAPE, {a}, sig).new_shape = {1, T};
                 h.frames = emit_frames(sig, T, L, (int)step[0], L, win, oname, &h.F);
@@ -756,7 +761,7 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
                 int64_t ax = nd.ai("axis", 1); if (ax < 0) ax += 4;
                 if (ax != 2 || !frames_canonical(a)) return 0;
                 int n = ash[2], N = n;
-                if (nd.in.size() > 1 && !nd.in[1].empty()) { std::vector<int64_t> dl; if (!const_i(nd.in[1], &dl) || dl.size() != 1) return 0; N = (int)dl[0]; }
+                if (nd.in.size() > 1 && !nd.in[1].empty()) { std::vector<int64_t> dl; if (!const_i(nd.in[1], &dl) || dl.size() != 1 || dl[0] < 0 || dl[0] > (1 << 20)) return 0; N = (int)dl[0]; }
                 if (N < n || N < 8 || (N & 1)) return 0;
                 int fr = new_t(oname + "/frames", {1, ash[1], n}, TT_FLOAT32);
                 add_op(OP_RESHAPE, {a}, fr).new_shape = {1, ash[1], n};
@@ -1110,7 +1115,7 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
             const int64_t group = nd.ai("group", 1);
             auto two = [&](const char* key, int dflt, int* x, int* y) -> bool {
                 *x = *y = dflt;
-                if (const OAttr* p = cn.attr(key)) { if (p->ints.size() != 2) return false; *x = (int)p->ints[0]; *y = (int)p->ints[1]; }
+                if (const OAttr* p = cn.attr(key)) { if (p->ints.size() != 2) return false; if (p->ints[0] < 1 || p->ints[0] > (1 << 20) || p->ints[1] < 1 || p->ints[1] > (1 << 20)) return false; *x = (int)p->ints[0]; *y = (int)p->ints[1]; }
                 return *x >= 1 && *y >= 1;
             };
             int sh_, sw_, dh, dw;
@@ -1191,9 +1196,10 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
             const OAttr* ks = nd.attr("kernel_shape");
             if (!ks || ks->ints.size() != 2) return fail("ONNX: " + where + ": kernel_shape must have two entries");
             int sh_ = 1, sw_ = 1;
-            if (const OAttr* p = nd.attr("strides")) { if (p->ints.size() != 2) return fail("ONNX: " + where + ": strides"); sh_ = (int)p->ints[0]; sw_ = (int)p->ints[1]; }
+            if (const OAttr* p = nd.attr("strides")) { if (p->ints.size() != 2 || p->ints[0] < 1 || p->ints[0] > (1 << 20) || p->ints[1] < 1 || p->ints[1] > (1 << 20)) return fail("ONNX: " + where + ": strides"); sh_ = (int)p->ints[0]; sw_ = (int)p->ints[1]; }
             if (const OAttr* p = nd.attr("dilations")) for (auto dv : p->ints) if (dv != 1) return fail("ONNX: " + where + ": dilated pooling is not supported");
             if (nd.op == "AveragePool" && nd.ai("count_include_pad", 0) != 0) return fail("ONNX: " + where + ": count_include_pad is not supported");
+            if (ks->ints[0] < 1 || ks->ints[0] > (1 << 20) || ks->ints[1] < 1 || ks->ints[1] > (1 << 20)) return fail("ONNX: " + where + ": kernel_shape out of range");
             const int kh = (int)ks->ints[0], kw = (int)ks->ints[1];
             int Ho, Wo, pt, pl; std::string why;
             if (kh < 1 || kw < 1 || sh_ < 1 || sw_ < 1 || !window_geom(nd, ish[1], ish[2], kh, kw, sh_, sw_, 1, 1, &Ho, &Wo, &pt, &pl, &why)) return fail("ONNX: " + where + ": " + why);
@@ -1381,10 +1387,12 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
                 if (nd.in.size() < 2 || !const_i(nd.in[1], &step) || step.size() != 1 || step[0] < 1) return fail("ONNX: " + where + ": frame_step must be a constant");
                 const bool has_w = nd.in.size() > 2 && !nd.in[2].empty();
                 if (has_w && !const_f(nd.in[2], &win, nullptr)) return fail("ONNX: " + where + ": window must be a constant");
-                L = has_w ? (int)win.size() : 0;
-                if (nd.in.size() > 3 && !nd.in[3].empty()) { if (!const_i(nd.in[3], &flen) || flen.size() != 1 || (has_w && flen[0] != L)) return fail("ONNX: " + where + ": frame_length must be a constant equal to the window length"); L = (int)flen[0]; }
+                int64_t L64 = has_w ? (int64_t)win.size() : 0;
+                if (nd.in.size() > 3 && !nd.in[3].empty()) { if (!const_i(nd.in[3], &flen) || flen.size() != 1 || (has_w && flen[0] != L64)) return fail("ONNX: " + where + ": frame_length must be a constant equal to the window length"); L64 = flen[0]; }
+                if (!((ash.size() == 3 && ash[2] == 1) || ash.size() == 2) || L64 < 2 || L64 > ash[1]) return fail("ONNX: " + where + ": signal must be [N, T, 1] with T >= frame_length");
+                if (step[0] > ash[1]) return fail("ONNX: " + where + ": frame_step exceeds the signal length");      // (int64 check before narrowing: 2^32 would become hop 0)
+                L = (int)L64;
                 if (!has_w) win.assign(L, 1.0f);
-                if (!((ash.size() == 3 && ash[2] == 1) || ash.size() == 2) || L < 2 || L > ash[1]) return fail("ONNX: " + where + ": signal must be [N, T, 1] with T >= frame_length");
                 const int sig = new_t(oname + "/signal", {1, ash[1]}, TT_FLOAT32);
                 add_op(OP_RESHAPE, {a}, sig).new_shape = {1, ash[1]};
                 frames = emit_frames(sig, ash[1], L, (int)step[0], L, win, oname, &F);
@@ -1392,7 +1400,7 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
                 int64_t ax = nd.ai("axis", 1); if (ax < 0) ax += (int64_t)ash.size();
                 if (nd.ai("onesided", 0) != 1 || nd.ai("inverse", 0) != 0 || ash.size() != 4 || ash[3] != 1 || ax != 2) return fail("ONNX: " + where + ": only the forward one-sided transform of [N, F, n, 1] along axis 2 is supported");
                 L = ash[2]; F = ash[1];
-                if (nd.in.size() > 1 && !nd.in[1].empty()) { std::vector<int64_t> dl; if (!const_i(nd.in[1], &dl) || dl.size() != 1 || dl[0] < L) return fail("ONNX: " + where + ": dft_length must be a constant >= the axis length"); L = (int)dl[0]; }
+                if (nd.in.size() > 1 && !nd.in[1].empty()) { std::vector<int64_t> dl; if (!const_i(nd.in[1], &dl) || dl.size() != 1 || dl[0] < L || dl[0] > (1 << 20)) return fail("ONNX: " + where + ": dft_length must be a constant >= the axis length"); L = (int)dl[0]; }
                 frames = new_t(oname + "/frames", {1, F, ash[2]}, TT_FLOAT32);
                 add_op(OP_RESHAPE, {a}, frames).new_shape = {1, F, ash[2]};
             }

@@ -101,7 +101,41 @@ def _crafted_onnx():
     x = b.input("x", ["N", 4, 6])
     b.output(b.node("Transpose", [x], perm=[0, 1, 1]), ["N", 4, 4])
     out.append(b.finish())
+    # STFT whose frame_step is 2^32 (narrowed to hop 0 -> SIGFPE in the framing), a negative frame_length without
+    # a window (-> a huge window allocation), and a conv-DFT-sized stride of 2^32
+    for step, flen, win in ((2 ** 32, 256, True), (64, -8, False), (2 ** 32 + 64, 256, True), (64, 2 ** 40, False)):
+        b = OnnxBuilder()
+        x = b.input("x", ["N", 4096])
+        sig = b.node("Unsqueeze", [x, b.init(np.asarray([2], np.int64))])
+        ins = [sig, b.init(np.asarray(step, np.int64).reshape(())), b.init(np.hanning(256).astype(np.float32)) if win else "",
+               b.init(np.asarray(flen, np.int64).reshape(()))]
+        b.output(b.node("STFT", ins, onesided=1), ["N", 61, 129, 2])
+        out.append(b.finish())
     return out
+
+
+def _crafted_empty_slice_axes():
+    """the reverse `Slice` behind the mel MatMul with an EMPTY `axes` initializer (dims=[0]): tail_ok() indexed
+    ax[0] of an empty vector.  Written by the audio transcriber with the Slice's axes operand swapped for an empty one."""
+    from birdnet_go_amd import onnx_audio
+    Builder = onnx_audio.OnnxBuilder          # (the class object the transcriber uses, whatever name the module was imported under)
+    orig = Builder.node
+    made = []
+
+    def node(self, op, inputs, *a, **k):
+        if op == "Slice" and len(inputs) == 5:
+            inputs = list(inputs)
+            inputs[3] = self.init(np.zeros((0,), np.int64))
+            made.append(1)
+        return orig(self, op, inputs, *a, **k)
+
+    Builder.node = node
+    try:
+        blob = sm.build_model(sm.tiny_config(), container="onnx", dft="matmul")
+    finally:
+        Builder.node = orig
+    assert made, "the transcriber no longer writes the reverse Slice this file is about"
+    return blob
 
 
 def test_onnx_audio_front_ends_and_crafted_files_under_asan(fuzz_bin, tmp_path):
@@ -123,7 +157,7 @@ def test_onnx_audio_front_ends_and_crafted_files_under_asan(fuzz_bin, tmp_path):
             tail = ox[-3000:]
             for mt in _mutations(tail, rng, 30):
                 corpus.append(ox[:-len(tail)] + mt[:len(tail)].ljust(len(tail), b"\0"))
-    crafted = _crafted_onnx()
+    crafted = _crafted_onnx() + [_crafted_empty_slice_axes()]
     corpus += crafted
     path = tmp_path / "corpus_audio.bin"
     with open(path, "wb") as f:
