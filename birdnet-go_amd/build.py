@@ -11,10 +11,12 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libbnhip.so")
 SOURCES = ["kernels.hip", "generic.hip", "resample.hip", "stft.hip", "engine.cpp", "graph_passes.cpp", "tflite_model.cpp", "model_onnx.cpp", "hostpipe.cpp", "api.cpp"]
 HEADERS = ["kernels.h", "engine.h", "tflite_model.h", "model_onnx.h", "hostpipe.h", "fft_r8.h", os.path.join("..", "..", "include", "bnhip.h")]
-# -fno-slp-vectorize: the SLP vectorizer turns independent scalar fmaf chains into dependent v_pk_fma_f32 chains.  On gfx950 /
-# ROCm 7.2 such a chain (k_mel_banded's band sums) returned wrong LOW halves in a few lanes whenever another stream's kernels
-# shared the CU (2-4 % of clips wrong with two contexts in flight, never when run alone: tools/debug/race_stat.py, DESIGN.md
-# section 10); packed fp32 buys no issue slots on this part anyway ("v_pk_fma_f32 pairs").
+# -fno-slp-vectorize: gfx950 hazard, reproduced standalone (tools/ubench/pkf32_vs_bf16mfma.hip, profiles/r04_pk_hazard.txt): a
+# packed-fp32 VALU instruction whose op_sel bit for src1 is set (v_pk_fma_f32 / v_pk_mul_f32 ... op_sel:[0,1,..]: the LOW result
+# computed from src1's HIGH half) returns a wrong low half in lanes 48-63 while another wave on the same CU executes
+# v_mfma_f32_16x16x32_bf16 - i.e. whenever the other pipeline context runs a split-bf16 GEMM.  The SLP vectoriser forms exactly
+# these when it packs two scalar fmaf chains that share a broadcast operand (176 of them in stft.hip: 2-4 % of clips wrong with
+# two contexts in flight).  tests/test_isa_audit.py disassembles the built library and fails on any such instruction.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 NO_VGPR_FORM = set()     # sources to compile without the VGPR-form MFMA rewrite (none at present)
 

@@ -2060,9 +2060,11 @@ bool Engine::run_pipelined(const float* d_in, int n, float* d_logits, float* d_e
     }
     cur_arena = ctx_arena[c];
     cur_stream = ctx_stream[c];
+    cur_ctx = c;
     bool ok = run_eager(d_in, n, d_logits, d_emb, err);
     cur_arena = nullptr;
     cur_stream = nullptr;
+    cur_ctx = -1;
     return ok;
 }
 // One chunk of a host-pointer call in context c's arena on stream st (hostpipe.cpp orders st behind the chunk's copy and
@@ -2164,6 +2166,15 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
         float* out = vptr(s.out, d_in, d_logits, d_emb, clip0);
         float* out2 = vptr(s.out2, d_in, d_logits, d_emb, clip0);
         ProfEntry pe{};
+        // diagnostics (tools/debug): a host-side synchronize before / after every launch of one kernel class
+        static const char* dbg_sync_before = getenv("BNHIP_DEBUG_SYNC_BEFORE");
+        static const char* dbg_sync_after = getenv("BNHIP_DEBUG_SYNC_AFTER");
+        // ... and a co-runner filter: context 1 launches only the listed kernel classes (its outputs are then garbage)
+        static const char* dbg_ctx1_only = getenv("BNHIP_DEBUG_CTX1_ONLY");
+        if (dbg_ctx1_only && cur_ctx == 1 && !strstr(dbg_ctx1_only, s.kclass)) continue;
+        static const char* dbg_ctx1_skip = getenv("BNHIP_DEBUG_CTX1_SKIP");
+        if (dbg_ctx1_skip && cur_ctx == 1 && strstr(dbg_ctx1_skip, s.kclass)) continue;
+        if (dbg_sync_before && (!strcmp(dbg_sync_before, s.kclass) || s.name.rfind(dbg_sync_before, 0) == 0)) hipStreamSynchronize(stream);
         const bool prof_this = profiling && (profile_filter.empty() || profile_filter == s.kclass);
         if (prof_this) { pe.a = get_event(); pe.b = get_event(); pe.step = si; pe.n = n; hipEventRecord(pe.a, stream); }
         switch (s.kind) {
@@ -2309,6 +2320,7 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
             }
         }
         if (prof_this) { hipEventRecord(pe.b, stream); prof.push_back(pe); }
+        if (dbg_sync_after && (!strcmp(dbg_sync_after, s.kclass) || s.name.rfind(dbg_sync_after, 0) == 0)) hipStreamSynchronize(stream);
       }
     }
     for (int li = 0; li < nl; li++) {

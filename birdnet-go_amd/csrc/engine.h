@@ -186,6 +186,7 @@ class Engine {
     char* act_arena = nullptr;
     char* cur_arena = nullptr;          // arena the launches of the current call address (act_arena or a context's)
     hipStream_t cur_stream = nullptr;   // main stream of the current call (stream or a context's)
+    int cur_ctx = -1;                   // context index of the current pipelined call (diagnostics)
     size_t act_bytes = 0;
     char* w_arena = nullptr;
     size_t w_bytes = 0;

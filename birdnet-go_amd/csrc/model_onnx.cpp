@@ -570,12 +570,16 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
             if (!u || u->out.empty()) return false;
             if (u->op == "Pow" && npow < 2 && !logc && u->in.size() == 2 && u->in[0] == nm && scalar_const(u->in[1], &v)) { npow++; nm = u->out[0]; continue; }
             if (u->op == "Mul" && npow == 0 && !logc && u->in.size() == 2 && u->in[0] == nm && u->in[1] == nm) { npow = 1; nm = u->out[0]; continue; }
-            if (u->op == "Max" && npow == 0 && !logc && u->in.size() == 2 && u->in[0] == nm && scalar_const(u->in[1], &v) && v > 0.f) {
+            const bool is_max = u->op == "Max" && u->in.size() == 2 && u->in[0] == nm && scalar_const(u->in[1], &v) && v > 0.f;
+            // torch.clamp(min = floor): Clip with a constant min and no max
+            const bool is_clip = u->op == "Clip" && !u->attr("max") && !u->attr("min") && u->in.size() >= 2 && u->in[0] == nm && scalar_const(u->in[1], &v) && v > 0.f &&
+                                 (u->in.size() < 3 || u->in[2].empty());
+            if ((is_max || is_clip) && npow == 0 && !logc) {
                 const ONode* lg = only_user(u->out[0]);
                 if (!lg || lg->op != "Log") return false;
                 logc = true; nm = lg->out[0];
                 const ONode* mu = only_user(nm);
-                if (mu && mu->op == "Mul" && mu->in.size() == 2 && mu->in[0] == nm && scalar_const(mu->in[1], &v)) nm = mu->out[0];
+                if (mu && mu->op == "Mul" && mu->in.size() == 2 && ((mu->in[0] == nm && scalar_const(mu->in[1], &v)) || (mu->in[1] == nm && scalar_const(mu->in[0], &v)))) nm = mu->out[0];
                 continue;
             }
             if (u->op == "Slice" && u->in.size() >= 5) {
@@ -803,6 +807,14 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
             const int64_t ax = nd.ai("axis", 0);
             if (it != inits.end() && it->second.dims.empty() && tensor_ints(it->second, &idx) && idx.size() == 1 && (ax == 3 || ax == -1) && (idx[0] == 0 || idx[0] == 1))
                 return derive(*h0, (int)idx[0], {nd.in[0]});
+        } else if (nd.op == "Transpose" && h0 && nd.in.size() == 1 && h0->part != 6) {
+            // torch.stft's layout change [N, F, K, 2] -> [N, K, F, 2] and `.transpose(1, 2)` of a rank-3 spectrum: only the tag flips
+            const OAttr* pa = nd.attr("perm");
+            const bool r4 = h0->part == 7 || h0->part == 8 || h0->last1;
+            if (pa && ((r4 && pa->ints == std::vector<int64_t>{0, 2, 1, 3}) || (!r4 && pa->ints == std::vector<int64_t>{0, 2, 1}))) {
+                SpecH h = *h0; h.bins_major = !h.bins_major;
+                return derive(h, h0->part, {nd.in[0]});
+            }
         } else if (nd.op == "Mul" && h0 && h1 && nd.in[0] == nd.in[1] && !h0->last1) {
             if (h0->part == 0 || h0->part == 1) return derive(*h0, h0->part + 2, {nd.in[0]});
             if (h0->part == 7) return derive(*h0, 8, {nd.in[0]});

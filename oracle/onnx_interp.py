@@ -247,6 +247,10 @@ def run(blob, x, precision="f32"):
     vals = {k: (v.astype(fdt) if v.dtype.kind == "f" else v) for k, v in m.inits.items()}
     vals[m.runtime_inputs[0]] = np.asarray(x, np.float32).astype(fdt)
     for op, ins, outs, at in m.nodes:
+        if op == "Constant":                  # (torch's exporter writes scalars and index vectors as Constant nodes)
+            v = at["value"] if "value" in at else np.asarray(at["value_float"], np.float32)
+            vals[outs[0]] = v.astype(fdt) if v.dtype.kind == "f" else v
+            continue
         a = [vals[i] if i else None for i in ins]
         if op == "Gemm":
             A = a[0].T if at.get("transA") else a[0]
