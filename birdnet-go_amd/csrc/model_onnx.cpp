@@ -243,6 +243,210 @@ bool tensor_ints(const OTensor& t, std::vector<int64_t>* out) {
     return false;
 }
 
+// ---------------------------------------------------------------------------------------------- constant folding
+// Exporters leave small all-constant subgraphs behind - torch writes the pads of F.pad as ConstantOfShape -> Concat -> Reshape ->
+// Slice -> Transpose -> Reshape -> Cast on int64 constants - which an ONNX runtime folds at load time.  So does this reader:
+// a node whose inputs are all constants (initialisers, Constant nodes, earlier folds) and whose op is in the small vocabulary
+// below is evaluated here and its output becomes an initialiser.  Tensors are int64 or float32, at most 65 536 elements.
+struct CT {
+    std::vector<int64_t> dims;
+    bool is_int = true;
+    std::vector<int64_t> iv;
+    std::vector<float> fv;
+    size_t size() const { return is_int ? iv.size() : fv.size(); }
+};
+bool ct_from(const OTensor& t, CT* c) {
+    c->dims = t.dims;
+    if (numel(t.dims) > 65536) return false;
+    if (t.dtype == 7 || t.dtype == 6) { c->is_int = true; return tensor_ints(t, &c->iv); }
+    if (t.dtype == 1) { c->is_int = false; return tensor_floats(t, &c->fv); }
+    return false;
+}
+OTensor ct_to(const CT& c, const std::string& name) {
+    OTensor t; t.name = name; t.dims = c.dims;
+    if (c.is_int) { t.dtype = 7; t.i64 = c.iv; } else { t.dtype = 1; t.f = c.fv; }
+    return t;
+}
+// gather elements of `c` by flat source index
+CT ct_take(const CT& c, const std::vector<int64_t>& dims, const std::vector<size_t>& src) {
+    CT o; o.dims = dims; o.is_int = c.is_int;
+    if (c.is_int) { o.iv.resize(src.size()); for (size_t k = 0; k < src.size(); k++) o.iv[k] = c.iv[src[k]]; }
+    else { o.fv.resize(src.size()); for (size_t k = 0; k < src.size(); k++) o.fv[k] = c.fv[src[k]]; }
+    return o;
+}
+std::vector<size_t> ct_strides(const std::vector<int64_t>& d) {
+    std::vector<size_t> st(d.size(), 1);
+    for (int k = (int)d.size() - 2; k >= 0; k--) st[k] = st[k + 1] * (size_t)d[k + 1];
+    return st;
+}
+// returns false when the node cannot (or need not) be folded
+bool fold_node(const ONode& nd, const std::vector<CT>& in, const std::vector<bool>& present, CT* out) {
+    auto has = [&](size_t k) { return k < in.size() && present[k]; };
+    const std::string& op = nd.op;
+    if (op == "Identity" && has(0)) { *out = in[0]; return true; }
+    if (op == "Cast" && has(0)) {
+        const int64_t to = nd.ai("to", 0);
+        *out = in[0];
+        if (to == 7 || to == 6) { if (!in[0].is_int) { out->is_int = true; out->iv.resize(in[0].fv.size()); for (size_t k = 0; k < in[0].fv.size(); k++) out->iv[k] = (int64_t)in[0].fv[k]; out->fv.clear(); } return true; }
+        if (to == 1) { if (in[0].is_int) { out->is_int = false; out->fv.resize(in[0].iv.size()); for (size_t k = 0; k < in[0].iv.size(); k++) out->fv[k] = (float)in[0].iv[k]; out->iv.clear(); } return true; }
+        return false;
+    }
+    if (op == "ConstantOfShape" && has(0) && in[0].is_int && in[0].dims.size() == 1) {
+        size_t n = 1;
+        for (int64_t d : in[0].iv) { if (d < 0 || d > 65536) return false; n *= (size_t)d; if (n > 65536) return false; }
+        out->dims = in[0].iv;
+        const OAttr* a = nd.attr("value");
+        CT v; v.is_int = false; v.fv = {0.f};
+        if (a && a->has_t && !ct_from(a->t, &v)) return false;
+        if (v.size() != 1) return false;
+        out->is_int = v.is_int;
+        if (v.is_int) out->iv.assign(n, v.iv[0]); else out->fv.assign(n, v.fv[0]);
+        return true;
+    }
+    if (op == "Shape" && has(0)) { out->is_int = true; out->dims = {(int64_t)in[0].dims.size()}; out->iv = in[0].dims; return true; }
+    if (op == "Concat") {
+        if (in.empty()) return false;
+        for (size_t k = 0; k < in.size(); k++) if (!present[k] || in[k].is_int != in[0].is_int || in[k].dims.size() != in[0].dims.size()) return false;
+        const int r = (int)in[0].dims.size();
+        int64_t ax = nd.ai("axis", 0); if (ax < 0) ax += r;
+        if (r < 1 || ax < 0 || ax >= r) return false;
+        size_t outer = 1, inner = 1;
+        for (int k = 0; k < ax; k++) outer *= (size_t)in[0].dims[k];
+        for (int k = (int)ax + 1; k < r; k++) inner *= (size_t)in[0].dims[k];
+        out->dims = in[0].dims; out->dims[ax] = 0; out->is_int = in[0].is_int;
+        for (auto& c : in) {
+            for (int k = 0; k < r; k++) if (k != ax && c.dims[k] != in[0].dims[k]) return false;
+            out->dims[ax] += c.dims[ax];
+        }
+        if (numel(out->dims) > 65536) return false;
+        for (size_t o = 0; o < outer; o++)
+            for (auto& c : in) {
+                const size_t n = (size_t)c.dims[ax] * inner;
+                if (c.is_int) out->iv.insert(out->iv.end(), c.iv.begin() + o * n, c.iv.begin() + (o + 1) * n);
+                else out->fv.insert(out->fv.end(), c.fv.begin() + o * n, c.fv.begin() + (o + 1) * n);
+            }
+        return true;
+    }
+    if (op == "Reshape" && has(0) && has(1) && in[1].is_int) {
+        const size_t total = in[0].size();
+        std::vector<int64_t> d = in[1].iv;
+        size_t known = 1; int neg = -1;
+        for (size_t k = 0; k < d.size(); k++) {
+            if (d[k] == 0 && nd.ai("allowzero", 0) == 0) { if (k >= in[0].dims.size()) return false; d[k] = in[0].dims[k]; }
+            if (d[k] == -1) { if (neg >= 0) return false; neg = (int)k; } else { if (d[k] < 0) return false; known *= (size_t)d[k]; }
+        }
+        if (neg >= 0) { if (!known || total % known) return false; d[neg] = (int64_t)(total / known); known *= (size_t)d[neg]; }
+        if (known != total) return false;
+        *out = in[0]; out->dims = d;
+        return true;
+    }
+    if ((op == "Unsqueeze" || op == "Squeeze") && has(0)) {
+        std::vector<int64_t> axes;
+        if (const OAttr* a = nd.attr("axes")) axes = a->ints; else if (has(1) && in[1].is_int) axes = in[1].iv; else if (op == "Unsqueeze") return false;
+        std::vector<int64_t> d = in[0].dims;
+        if (op == "Unsqueeze") {
+            const int r = (int)(d.size() + axes.size());
+            std::vector<char> mark(r, 0);
+            for (auto a : axes) { if (a < 0) a += r; if (a < 0 || a >= r || mark[a]) return false; mark[a] = 1; }
+            std::vector<int64_t> o; size_t q = 0;
+            for (int k = 0; k < r; k++) o.push_back(mark[k] ? 1 : d[q++]);
+            d = o;
+        } else {
+            std::vector<int64_t> o;
+            const int r = (int)d.size();
+            for (int k = 0; k < r; k++) {
+                bool drop = axes.empty() ? d[k] == 1 : false;
+                for (auto a : axes) { if (a < 0) a += r; if (a == k) { if (d[k] != 1) return false; drop = true; } }
+                if (!drop) o.push_back(d[k]);
+            }
+            d = o;
+        }
+        *out = in[0]; out->dims = d;
+        return true;
+    }
+    if (op == "Transpose" && has(0)) {
+        const int r = (int)in[0].dims.size();
+        std::vector<int64_t> perm;
+        if (const OAttr* a = nd.attr("perm")) perm = a->ints; else for (int k = r - 1; k >= 0; k--) perm.push_back(k);
+        if ((int)perm.size() != r) return false;
+        std::vector<char> seen(r, 0);
+        for (auto q : perm) { if (q < 0 || q >= r || seen[q]) return false; seen[q] = 1; }
+        std::vector<int64_t> od(r);
+        for (int k = 0; k < r; k++) od[k] = in[0].dims[perm[k]];
+        const auto ist = ct_strides(in[0].dims), ost = ct_strides(od);
+        std::vector<size_t> src(in[0].size());
+        for (size_t o = 0; o < src.size(); o++) { size_t rem = o, s = 0; for (int k = 0; k < r; k++) { const size_t c = rem / ost[k]; rem %= ost[k]; s += c * ist[perm[k]]; } src[o] = s; }
+        *out = ct_take(in[0], od, src);
+        return true;
+    }
+    if (op == "Slice" && has(0) && has(1) && has(2) && in[1].is_int && in[2].is_int) {
+        const int r = (int)in[0].dims.size();
+        const size_t ns = in[1].iv.size();
+        std::vector<int64_t> axes, steps(ns, 1);
+        if (has(3)) { if (!in[3].is_int) return false; axes = in[3].iv; } else for (size_t k = 0; k < ns; k++) axes.push_back((int64_t)k);
+        if (has(4)) { if (!in[4].is_int) return false; steps = in[4].iv; }
+        if (in[2].iv.size() != ns || axes.size() != ns || steps.size() != ns) return false;
+        std::vector<int64_t> st(r, 0), sp(r, 1), cnt(in[0].dims);
+        for (size_t k = 0; k < ns; k++) {
+            int64_t ax = axes[k]; if (ax < 0) ax += r;
+            if (ax < 0 || ax >= r || steps[k] == 0) return false;
+            const int64_t n = in[0].dims[ax];
+            int64_t a = in[1].iv[k], b = in[2].iv[k];
+            if (steps[k] > 0) {
+                if (a < 0) a += n; if (b < 0) b += n;
+                a = std::min(std::max<int64_t>(a, 0), n); b = std::min(std::max<int64_t>(b, 0), n);
+                cnt[ax] = b > a ? (b - a + steps[k] - 1) / steps[k] : 0;
+            } else {
+                if (a < 0) a += n; if (b < 0) b = b < -n ? -1 : b + n;        // (ends far below -n mean "through element 0")
+                a = std::min(std::max<int64_t>(a, -1), n - 1); b = std::min(std::max<int64_t>(b, -1), n - 1);
+                cnt[ax] = a > b ? (a - b + (-steps[k]) - 1) / (-steps[k]) : 0;
+            }
+            st[ax] = a; sp[ax] = steps[k];
+        }
+        const auto ist = ct_strides(in[0].dims), ost = ct_strides(cnt);
+        std::vector<size_t> src(numel(cnt));
+        for (size_t o = 0; o < src.size(); o++) { size_t rem = o; int64_t s = 0; for (int k = 0; k < r; k++) { const int64_t c = (int64_t)(rem / ost[k]); rem %= ost[k]; s += (st[k] + c * sp[k]) * (int64_t)ist[k]; } src[o] = (size_t)s; }
+        *out = ct_take(in[0], cnt, src);
+        return true;
+    }
+    if (op == "Gather" && has(0) && has(1) && in[1].is_int) {
+        const int r = (int)in[0].dims.size();
+        int64_t ax = nd.ai("axis", 0); if (ax < 0) ax += r;
+        if (r < 1 || ax < 0 || ax >= r) return false;
+        std::vector<int64_t> od(in[0].dims.begin(), in[0].dims.begin() + ax);
+        od.insert(od.end(), in[1].dims.begin(), in[1].dims.end());
+        od.insert(od.end(), in[0].dims.begin() + ax + 1, in[0].dims.end());
+        if (numel(od) > 65536) return false;
+        size_t outer = 1, inner = 1;
+        for (int k = 0; k < ax; k++) outer *= (size_t)in[0].dims[k];
+        for (int k = (int)ax + 1; k < r; k++) inner *= (size_t)in[0].dims[k];
+        const int64_t n = in[0].dims[ax];
+        std::vector<size_t> src;
+        for (size_t o = 0; o < outer; o++)
+            for (int64_t idx : in[1].iv) {
+                if (idx < 0) idx += n;
+                if (idx < 0 || idx >= n) return false;
+                for (size_t q = 0; q < inner; q++) src.push_back((o * (size_t)n + (size_t)idx) * inner + q);
+            }
+        *out = ct_take(in[0], od, src);
+        return true;
+    }
+    if ((op == "Add" || op == "Sub" || op == "Mul" || op == "Div") && has(0) && has(1) && in[0].is_int && in[1].is_int) {
+        // integer shape arithmetic: equal shapes, or one side a single element
+        const CT& a = in[0]; const CT& b = in[1];
+        if (!(a.dims == b.dims || a.size() == 1 || b.size() == 1)) return false;
+        const size_t n = std::max(a.size(), b.size());
+        out->is_int = true; out->dims = a.size() >= b.size() ? a.dims : b.dims; out->iv.resize(n);
+        for (size_t k = 0; k < n; k++) {
+            const int64_t x = a.iv[a.size() == 1 ? 0 : k], y = b.iv[b.size() == 1 ? 0 : k];
+            if (op == "Div" && y == 0) return false;
+            out->iv[k] = op == "Add" ? x + y : op == "Sub" ? x - y : op == "Mul" ? x * y : x / y;
+        }
+        return true;
+    }
+    return false;
+}
+
 // ---------------------------------------------------------------------------------------------- in-graph audio front-ends
 // Every ONNX classifier the reference ships computes its spectrogram inside the graph (internal/classifier/model_catalog.go:
 // 412-426 BirdNET v2.4 "dfttrunc", :490-501 the BattyBirdNET backbone, :273-311 Perch v2 "with in-graph DFT",
@@ -386,6 +590,23 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
             else if ((a = nd.attr("value_float"))) { OTensor t; t.name = nd.out[0]; t.dtype = 1; t.f.push_back(a->f); inits[nd.out[0]] = std::move(t); }
             else { *code = BNHIP_E_UNSUPPORTED; return fail("ONNX: Constant node without a tensor value: " + nd.name); }
         }
+    // ... and so do small all-constant subgraphs (fold_node): evaluated in graph order, their outputs become initialisers
+    std::set<int> folded;
+    for (size_t ni = 0; ni < nodes.size(); ni++) {
+        const ONode& nd = nodes[ni];
+        if (nd.op == "Constant" || nd.out.size() != 1 || nd.in.empty() || (!nd.domain.empty() && nd.domain != "ai.onnx")) continue;
+        std::vector<CT> cin(nd.in.size()); std::vector<bool> present(nd.in.size(), false);
+        bool all_const = true;
+        for (size_t k = 0; k < nd.in.size() && all_const; k++) {
+            if (nd.in[k].empty()) continue;
+            auto it = inits.find(nd.in[k]);
+            if (it == inits.end() || !ct_from(it->second, &cin[k])) all_const = false; else present[k] = true;
+        }
+        CT res;
+        if (!all_const || !fold_node(nd, cin, present, &res)) continue;
+        inits[nd.out[0]] = ct_to(res, nd.out[0]);
+        folded.insert((int)ni);
+    }
     // the runtime input: the graph input that is not an initializer
     const OValue* gin = nullptr;
     for (auto& vi : g_in) if (!inits.count(vi.name)) { if (gin) { *code = BNHIP_E_UNSUPPORTED; return fail("ONNX: more than one runtime input"); } gin = &vi; }
@@ -562,10 +783,16 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
     // Does the chain behind the mel MatMul output `nm` (mel axis = ONNX axis `mel_ax` of a rank-3 value) have the shape the
     // engine's recogniser fuses?  (Pow, Pow | Mul self, Pow | Max, Log, Mul) -> [reverse Slice over the mel axis] -> [Transpose 0 2 1]
     // -> Unsqueeze / Reshape to a rank-4 image
+    // (the compressed spectrogram may ALSO be a graph output - Perch v2 exports its in-graph spectrogram as output 2,
+    // internal/inference/onnx/classifier.go:495-505 - which the engine drops unless asked for; the tail is judged by its one consumer)
+    auto sole_consumer = [&](const std::string& nm) -> const ONode* {
+        auto it = users.find(nm);
+        return it == users.end() || it->second.size() != 1 ? nullptr : &nodes[it->second[0]];
+    };
     auto tail_ok = [&](std::string nm, int mel_ax) -> bool {
         int npow = 0; bool logc = false;
         for (int guard = 0; guard < 12; guard++) {
-            const ONode* u = only_user(nm);
+            const ONode* u = sole_consumer(nm);
             float v;
             if (!u || u->out.empty()) return false;
             if (u->op == "Pow" && npow < 2 && !logc && u->in.size() == 2 && u->in[0] == nm && scalar_const(u->in[1], &v)) { npow++; nm = u->out[0]; continue; }
@@ -575,10 +802,10 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
             const bool is_clip = u->op == "Clip" && !u->attr("max") && !u->attr("min") && u->in.size() >= 2 && u->in[0] == nm && scalar_const(u->in[1], &v) && v > 0.f &&
                                  (u->in.size() < 3 || u->in[2].empty());
             if ((is_max || is_clip) && npow == 0 && !logc) {
-                const ONode* lg = only_user(u->out[0]);
+                const ONode* lg = sole_consumer(u->out[0]);
                 if (!lg || lg->op != "Log") return false;
                 logc = true; nm = lg->out[0];
-                const ONode* mu = only_user(nm);
+                const ONode* mu = sole_consumer(nm);
                 if (mu && mu->op == "Mul" && mu->in.size() == 2 && ((mu->in[0] == nm && scalar_const(mu->in[1], &v)) || (mu->in[1] == nm && scalar_const(mu->in[0], &v)))) nm = mu->out[0];
                 continue;
             }
@@ -588,14 +815,14 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
                 if (st.size() != 1 || en.size() != 1 || ax.size() != 1 || sp.size() != 1) return false;      // (an empty initializer has no data() to index)
                 if (sp[0] != -1 || st[0] != -1 || (ax[0] != mel_ax && ax[0] != mel_ax - 3)) return false;
                 nm = u->out[0];
-                u = only_user(nm);
+                u = sole_consumer(nm);
                 if (!u) return false;
             }
             if (u->op == "Transpose") {
                 const OAttr* pa = u->attr("perm");
                 if (!pa || pa->ints != std::vector<int64_t>{0, 2, 1}) return false;
                 nm = u->out[0];
-                u = only_user(nm);
+                u = sole_consumer(nm);
                 if (!u) return false;
             }
             return u->op == "Unsqueeze" || u->op == "Reshape";
@@ -859,7 +1086,7 @@ bool parse_onnx(const void* blob, size_t nbytes, TflModel* out, std::string* err
     lower_node = [&](const ONode& nd, bool sym) -> bool {
         const std::string where = nd.op + " (" + (nd.name.empty() ? (nd.out.empty() ? "?" : nd.out[0]) : nd.name) + ")";
         if (!nd.domain.empty() && nd.domain != "ai.onnx") return fail("ONNX: operator from unsupported domain " + nd.domain + ": " + where);
-        if (nd.op == "Constant") return true;
+        if (nd.op == "Constant" || folded.count((int)(&nd - nodes.data()))) return true;
         if (sym) {
             const int r = try_symbolic(nd, node_index);
             if (r < 0) return false;

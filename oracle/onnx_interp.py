@@ -281,8 +281,11 @@ def run(blob, x, precision="f32"):
             if x_.ndim == 4:                     # per-channel parameters of an NCHW image
                 sc, bi, mu, va = (v.reshape(1, -1, 1, 1) for v in (sc, bi, mu, va))
             y = (x_ - mu) / np.sqrt(va + np.asarray(at.get("epsilon", 1e-5), fdt)) * sc + bi
-        elif op in ("Identity", "Dropout"):
+        elif op in ("Identity", "Dropout", "Cast"):      # Cast: the oracle computes in one float type; index tensors are converted where they are used
             y = a[0]
+        elif op == "ConstantOfShape":
+            v = at.get("value")
+            y = np.full([int(d) for d in np.asarray(a[0]).reshape(-1)], 0.0 if v is None else np.asarray(v).reshape(-1)[0])
         elif op == "Flatten":
             y = a[0].reshape(a[0].shape[0], -1)
         elif op == "Clip":
