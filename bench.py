@@ -64,8 +64,8 @@ def pmc_traffic(kclass, workload="birdnet"):
                    if ("perch" in os.path.basename(f)) == (workload == "perch"))
     if not files:
         return None
-    names = {"expand_dw": "k_expand_dw", "pw_gemm": "k_pw_gemm", "frontend": "k_frontend", "dwconv": "k_dwconv",
-             "conv_direct": "k_conv_direct", "se": "k_se"}
+    names = {"expand_dw": "k_expand_dw", "pw_gemm": "k_pw_", "frontend": "k_frontend", "dwconv": "k_dwconv",
+             "conv_direct": "k_conv_direct", "se": "k_se", "stft": "k_stft"}
     pref = names.get(kclass)
     if not pref:
         return None
@@ -78,6 +78,24 @@ def pmc_traffic(kclass, workload="birdnet"):
     if not n:
         return None
     return {"bytes_per_launch": tot / n, "source": os.path.relpath(files[-1], ROOT)}
+
+
+def pmc_mfma_util(workload="birdnet"):
+    """BASELINE.md section 4's figure: MFMA-pipe utilisation of the pointwise-conv + dense kernels over THEIR OWN time, from the
+    newest committed PMC pass (profiles/rNN_mfma_util.json, tools/pmc_summary.py): SQ_VALU_MFMA_BUSY_CYCLES summed over the
+    class's dispatches / (their summed durations x 2.4 GHz x 1024 SIMDs).  Counters cannot be collected inside the timed run."""
+    import glob
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_util.json"))
+                   if ("perch" in os.path.basename(f)) == (workload == "perch"))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    cls = d.get("classes", {})
+    out = {"source": os.path.relpath(files[-1], ROOT), "numerator": d.get("numerator"), "denominator": d.get("denominator"),
+           "pointwise_and_dense": cls.get("pw_gemm", {}).get("mfma_util"), "expand_dw": cls.get("expand_dw", {}).get("mfma_util"),
+           "valu_per_mfma": {k: v.get("valu_per_mfma") for k, v in cls.items() if v.get("valu_per_mfma")},
+           "target": ">= 0.40 over the pointwise + dense kernels' own time (BASELINE.md section 4)"}
+    return out
 
 
 def cpu_worker_main(argv):
@@ -365,23 +383,16 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def run_model(args):
-    """One model workload (birdnet = the contract's line, perch = BASELINE configs[4]); returns the JSON object on rank 0."""
-    import torch
-    import torch.distributed as dist
-    import birdnet_go_amd  # noqa: F401
-    from birdnet_go_amd import host, shard, synth_model as sm
+def dist_env():
+    """(world, rank, local_rank) from the launcher's environment (torch.distributed.run sets them; plain `python bench.py` = 1, 0, 0)."""
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback exists by design)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # BENCH_FORCE_DIST=1 exercises the RCCL code path (init, broadcast, barrier, all-reduce) even on one GPU
+
+def dist_begin(dev, backend="nccl"):
+    """Process-group set-up of the N-rank run: one process per GPU, backend nccl (= RCCL over xGMI); the CPU test of this very
+    code path substitutes gloo (tests/test_dist_cpu.py).  BENCH_FORCE_DIST=1 exercises it on one GPU.  Returns use_dist."""
+    import torch.distributed as dist
+    world, rank, _ = dist_env()
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -390,18 +401,59 @@ def run_model(args):
         os.environ.setdefault("WORLD_SIZE", str(world))
         if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
             os.environ["NCCL_DEBUG"] = "WARN"          # no version banner on stdout (see the note where the JSON line is printed)
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return use_dist
+
+
+def dist_model_bytes(cfg, use_dist, dev):
+    """Frozen weights: built once on rank 0, broadcast to the other ranks (the only collective on this path)."""
+    import birdnet_go_amd  # noqa: F401
+    from birdnet_go_amd import shard, synth_model as sm
+    _, rank, _ = dist_env()
+    if not use_dist:
+        return sm.build_model(cfg)
+    blob = sm.build_model(cfg) if rank == 0 else None
+    return shard.broadcast_model_bytes(blob, src=0, device=dev)
+
+
+def dist_timing(dt, clips_per_rank_step, steps, use_dist, dev):
+    """Contract: the job's time is the MAX over ranks.  Also returns every rank's own clips/s (all-gathered) and the group size the
+    collective layer reports, so a scaling run shows at a glance whether all ranks were really there and which one was slow."""
+    import torch
+    import torch.distributed as dist
+    if not use_dist:
+        return dt, [clips_per_rank_step * steps / dt], 1
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, t)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item()), [clips_per_rank_step * steps / float(e.item()) for e in every], dist.get_world_size()
+
+
+def run_model(args):
+    """One model workload (birdnet = the contract's line, perch = BASELINE configs[4]); returns the JSON object on rank 0."""
+    import torch
+    import torch.distributed as dist
+    import birdnet_go_amd  # noqa: F401
+    from birdnet_go_amd import host, shard, synth_model as sm
+
+    world, rank, local_rank = dist_env()
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists by design)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = dist_begin(dev)
 
     perch = args.workload == "perch"
     cfg = sm.perch_config() if perch else sm.SynthConfig()
     if not args.batch:
         args.batch = 512 if perch else 256          # configs[4]: 4096 clips over 8 GPUs; configs[1]: 256 per GPU
-    # frozen weights: built once on rank 0, broadcast over RCCL/xGMI (the only collective on this path)
-    if use_dist:
-        blob = sm.build_model(cfg) if rank == 0 else None
-        blob = shard.broadcast_model_bytes(blob, src=0, device=dev)
-    else:
-        blob = sm.build_model(cfg)
+    blob = dist_model_bytes(cfg, use_dist, dev)
 
     B = args.batch
     depth = max(1, args.depth)
@@ -488,10 +540,7 @@ def run_model(args):
                           "clips_per_s_at_p50_interval": B / (pct(iv, 50) * 1e-3),
                           "method": "one HIP event pair per step on the step's own stream; interval = spacing of step completions "
                                     "`pipeline_depth` apart / pipeline_depth (steps on alternating contexts overlap and finish in bursts)"}
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, rank_rates, rccl_ranks = dist_timing(dt, B, args.steps, use_dist, dev)
 
     ok = all(bool(torch.isfinite(o).all().item()) for o in outs[:min(NSETS, args.steps + args.warmup)])
     # set 0 was last computed inside (or, for short runs, before) the timed region by the same engine: checks below use it
@@ -533,7 +582,7 @@ def run_model(args):
             "max_abs_prob_diff_vs_oracle": prob_diff, "top1_identical_vs_oracle": top1_same,
             "prob_diff_reference": f"oracle restatement of the TFLite float op semantics on rows {oracle_rows} of the timed batch "
                                    "(tolerance 1e-4; no TFLite runtime or real weights exist in this environment)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "per_rank_clips_per_s": rank_rates, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 MFMA operands, f32 accumulate and storage" if args.precision == "bf16" else "f32",
             "data": ("synthetic sine+noise clips at 32 kHz; random-init weights of a Perch-v2-DIMENSION stand-in (synth_model.perch_config: "
@@ -605,6 +654,9 @@ def run_model(args):
                     roof["exclusive"] = {"achieved": ex, "frac": ex / roof["peak"], "avg_launch_ms": w["ms"] / w["launches"],
                                          "launches": w["launches"]}
             out["roofline"] = roof
+            mu = pmc_mfma_util(args.workload)
+            if mu:
+                out["mfma_util"] = mu
             wsum = sum(r["ms"] for r in warm_prof) or 1.0
             roof["share_of_kernel_time"] = next((r["ms"] for r in warm_prof if r["kernel"] == dom["kernel"]), 0.0) / wsum
             out["kernels_warmup_pass"] = [{"kernel": r["kernel"], "ms_per_step": r["ms"], "launches_per_step": r["launches"],

@@ -134,6 +134,8 @@ class Engine {
     hipStream_t lane_stream[kMaxLanes - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kMaxLanes - 1] = {nullptr, nullptr, nullptr};
     void autotune_pw();
+    bool save_tuning(const char* path) const;      // BNHIP_TUNE_FILE: the create-time tuners' decisions, one line per step
+    bool load_tuning(const char* path);             // false (and nothing changed) unless the file describes exactly this plan
     std::map<int, int> tensor_value;    // tflite tensor index -> value id (diagnostics)
     const float* value_ptr(int v) const { return reinterpret_cast<const float*>(act_arena + vals[v].offset); }
     int n_samples = 0, n_classes = 0, emb_dim = 0, C_spec = 0;

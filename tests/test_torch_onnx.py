@@ -186,12 +186,6 @@ def test_full_size_torch_exports_plan_onto_the_fused_kernels(tm, fx, built_lib, 
 
 
 # ------------------------------------------------------------------------------------------------ GPU: the engine vs torch
-@pytest.fixture(scope="module")
-def gpu(built_lib):
-    if host.device_count() < 1:
-        pytest.fail("no gfx950 device visible: the HIP path cannot run (there is no CPU fallback)")
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", TINY + FULL)
 def test_hip_engine_matches_torch_cpu_on_torch_exported_files(tm, fx, gpu, name):

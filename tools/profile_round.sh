@@ -3,7 +3,8 @@
 #   tools/profile_round.sh r02 ["extra bench.py arguments"]
 # -> gpurun_out/<tag>_kernel_stats.csv         rocprofv3 --kernel-trace --stats of `bench.py` (whole process)
 #    gpurun_out/<tag>_kernel_stats_timed.csv   the same trace restricted to the 20 timed steps
-#    gpurun_out/<tag>_pmc.csv, <tag>_traffic.json   PMC passes (one rocprofv3 run per counter group; no tracing flags mixed in)
+#    gpurun_out/<tag>_bench_default.json       the plain bench line (writes the tuning file the other runs read)
+#    gpurun_out/<tag>_pmc.csv, <tag>_traffic.json, <tag>_mfma_util.json   PMC passes (one rocprofv3 run per counter group; no tracing flags mixed in)
 #    gpurun_out/<tag>_step_detail_depth1.txt   per-launch table of one serial step (bench.py --depth 1 --detail)
 #    gpurun_out/<tag>_bench_under_rocprof.json the bench line of the traced run
 # Copy what should be judged into profiles/ afterwards.
@@ -11,6 +12,11 @@ TAG=${1:-r02}
 WL=${2:-}          # extra bench.py arguments, e.g. "--workload perch --precision bf16" (tag the outputs accordingly)
 OUT=$PWD/gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+# one tuning for every process of this script: the first bench run times the candidates and writes the file, every later run
+# (kernel trace, each PMC pass, the serial detail run) reads it - so all of them launch the same kernel instantiations
+export BNHIP_TUNE_FILE=$OUT/${TAG}_tune.txt
+rm -f $BNHIP_TUNE_FILE
+python bench.py $WL --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/${TAG}_bench_default.json 2> /dev/null
 BENCH="python bench.py $WL --steps 20 --warmup 3 --no-cpu-baseline --no-fp32-run --no-oracle-check --no-host-pointer --no-secondary --no-distribution"
 rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- $BENCH > $OUT/${TAG}_bench_under_rocprof.json 2> /tmp/kt.err
 DB=$(find /tmp/kt -name "*.db" | head -1)
@@ -31,6 +37,7 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU
   rocprofv3 --pmc $c -d /tmp/pmc$i -o p -- $PB > /dev/null 2>&1
   DBS="$DBS $(find /tmp/pmc$i -name '*.db' | head -1)"
 done
-python tools/pmc_summary.py --traffic-json $OUT/${TAG}_traffic.json --window $NL:$((5 * NL)) $DBS > $OUT/${TAG}_pmc.csv
-python bench.py $WL --depth 1 --detail --steps 5 --warmup 3 --no-cpu-baseline --no-fp32-run --no-oracle-check --no-host-pointer --no-secondary --no-distribution > /dev/null 2> $OUT/${TAG}_step_detail_depth1.txt
+python tools/pmc_summary.py --traffic-json $OUT/${TAG}_traffic.json --mfma-json $OUT/${TAG}_mfma_util.json --window $NL:$((5 * NL)) $DBS > $OUT/${TAG}_pmc.csv 2> $OUT/${TAG}_pmc_errors.txt
+# (the serial detail run is a depth-1 engine: its own tuning, not the pipelined one)
+BNHIP_TUNE_FILE= python bench.py $WL --depth 1 --detail --steps 5 --warmup 3 --no-cpu-baseline --no-fp32-run --no-oracle-check --no-host-pointer --no-secondary --no-distribution > /dev/null 2> $OUT/${TAG}_step_detail_depth1.txt
 echo done
