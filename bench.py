@@ -260,8 +260,24 @@ def host_pointer_rates(clf, x, reps_small=100, reps_mid=12, reps_big=5):
     big = np.tile(x, (8, 1))
     dt = t(lambda: clf.predict_batch(big.reshape(-1), 2048, out=out2048), reps_big)
     res["f32_2048"] = {"ms": dt * 1e3, "clips_per_s": 2048 / dt}
-    res["note"] = ("blocking C-ABI entries bnhip_predict / bnhip_predict_pcm16 on pageable numpy memory, outputs complete on return; "
-                   "calls of >= 128 clips run as chunks on two contexts fed from pinned staging (csrc/hostpipe.cpp); median of the calls")
+    del big
+    # the same calls from page-locked caller memory (bnhip_host_alloc: what the Go shim keeps per classifier, as the OpenVINO shim
+    # keeps its C-allocated input, backend_openvino.go:673-680): the copy engines read / write the caller's buffers directly
+    from birdnet_go_amd import host as _host
+    with _host.PinnedArray((256, x.shape[1]), np.float32) as pi, _host.PinnedArray((256, x.shape[1]), np.int16) as pp, \
+            _host.PinnedArray((256, ncls), np.float32) as po:
+        pi.array[:] = x; pp.array[:] = pcm
+        same = bool(np.array_equal(clf.predict_batch(pi.array.reshape(-1), 256, out=po.array), clf.predict_batch(x.reshape(-1), 256, out=out256)))
+        dt = t(lambda: clf.predict_batch(pi.array[:1].reshape(-1), 1, out=po.array[:1]), reps_small)
+        res["f32_1_pinned"] = {"ms": dt * 1e3, "clips_per_s": 1 / dt}
+        dt = t(lambda: clf.predict_batch(pi.array.reshape(-1), 256, out=po.array), reps_mid)
+        res["f32_256_pinned"] = {"ms": dt * 1e3, "clips_per_s": 256 / dt}
+        dt = t(lambda: clf.predict_pcm16(pp.array.reshape(-1), 256, out=po.array), reps_mid)
+        res["pcm16_256_pinned"] = {"ms": dt * 1e3, "clips_per_s": 256 / dt}
+        res["pinned_bit_identical_to_pageable"] = same
+    res["note"] = ("blocking C-ABI entries bnhip_predict / bnhip_predict_pcm16, outputs complete on return; calls of >= 128 clips run as chunks "
+                   "on two contexts (csrc/hostpipe.cpp): pageable caller memory is staged through the library's pinned slots by copy threads, "
+                   "`_pinned` legs pass bnhip_host_alloc memory, which the copy engines read and write directly; median of the calls")
     return res
 
 

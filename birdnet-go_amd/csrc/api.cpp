@@ -416,6 +416,29 @@ int bnhip_init(int* n_devices) {
     BN_GUARD_END((void)0)
 }
 
+int bnhip_host_alloc(size_t n_bytes, void** out) {
+    BN_GUARD_BEGIN
+    if (!out || !n_bytes) return set_err(BNHIP_E_INVALID, "bnhip_host_alloc: null output pointer or zero size");
+    *out = nullptr;
+    int rc = bnhip_init(nullptr);
+    if (rc != BNHIP_OK) return rc;
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, n_bytes, hipHostMallocPortable);      // portable: pinned for every device of a multi-GPU handle
+    if (e != hipSuccess) { (void)hipGetLastError(); return set_err(e == hipErrorOutOfMemory ? BNHIP_E_NOMEM : BNHIP_E_RUNTIME, std::string("pinned host allocation failed: ") + hipGetErrorString(e)); }
+    *out = p;
+    return BNHIP_OK;
+    BN_GUARD_END((void)0)
+}
+
+int bnhip_host_free(void* p) {
+    BN_GUARD_BEGIN
+    if (!p) return BNHIP_OK;
+    hipError_t e = hipHostFree(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return set_err(BNHIP_E_INVALID, std::string("bnhip_host_free: not a bnhip_host_alloc pointer: ") + hipGetErrorString(e)); }
+    return BNHIP_OK;
+    BN_GUARD_END((void)0)
+}
+
 void bnhip_shutdown(void) {
     try {
         std::lock_guard<std::mutex> lk(g_init_mu);

@@ -1684,7 +1684,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
     HIPCHK(hipMalloc((void**)&d_post_conf, (size_t)max_batch * n_classes * 4));
     if (emb_dim) HIPCHK(hipMalloc((void**)&d_stage_emb, (size_t)max_batch * emb_dim * 4));
     if (!defer_weights) mark_bf16_storage();
-    if (autotune && !defer_weights) { autotune_pw(); autotune_expdw(); autotune_dw(); }
+    if (autotune && !defer_weights) tune_or_load();
     *code = BNHIP_OK;
     return true;
 }
@@ -1765,7 +1765,12 @@ void Engine::finish_deferred() {
     if (device < 0) return;
     hipSetDevice(device);
     mark_bf16_storage();
-    if (autotune) {
+    if (autotune) tune_or_load();
+    defer_weights = false;
+}
+
+void Engine::tune_or_load() {
+    {
         // BNHIP_TUNE_FILE: reuse a recorded tuning instead of timing again, so that separate processes (the bench, a rocprofv3
         // kernel trace, every PMC pass) run the SAME kernel instantiations; written after a timed tuning when the file does not
         // exist yet (a file that describes another plan - other batch size, depth, precision - is ignored and left alone).
@@ -1775,7 +1780,6 @@ void Engine::finish_deferred() {
             if (tf && *tf) { FILE* ex = fopen(tf, "r"); if (ex) fclose(ex); else save_tuning(tf); }     // (never overwritten: another engine of the process may own it)
         }
     }
-    defer_weights = false;
 }
 
 // One line per step: what the three create-time tuners decide (tile shapes, kernel flavour, LDS-staged depthwise, slab counts).

@@ -134,6 +134,7 @@ class Engine {
     hipStream_t lane_stream[kMaxLanes - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kMaxLanes - 1] = {nullptr, nullptr, nullptr};
     void autotune_pw();
+    void tune_or_load();                            // the three create-time tuners, or their recorded result (BNHIP_TUNE_FILE)
     bool save_tuning(const char* path) const;      // BNHIP_TUNE_FILE: the create-time tuners' decisions, one line per step
     bool load_tuning(const char* path);             // false (and nothing changed) unless the file describes exactly this plan
     std::map<int, int> tensor_value;    // tflite tensor index -> value id (diagnostics)

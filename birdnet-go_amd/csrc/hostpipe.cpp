@@ -219,6 +219,19 @@ int ensure_pipe(Engine& e, const HostJob& j, size_t chunk_bytes, std::string& er
     return BNHIP_OK;
 }
 
+// Is [p, p + bytes) page-locked host memory the runtime knows (bnhip_host_alloc / hipHostMalloc / hipHostRegister)?  Then the
+// copy engines can read / write it directly and the staging pass through the pinned slots is skipped: the reference's own
+// accelerator shim keeps a C-allocated input buffer for the same reason (backend_openvino.go:673-680).
+bool is_pinned(const void* p, size_t bytes) {
+    if (!p || !bytes) return false;
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (a.type != hipMemoryTypeHost) return false;
+    hipPointerAttribute_t b{};
+    if (hipPointerGetAttributes(&b, (const char*)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return b.type == hipMemoryTypeHost;
+}
+
 int ensure_small_topk(Engine& e, int k, std::string& err) {
     if (k <= e.topk_cap) return BNHIP_OK;
     if (e.d_topk_conf) hipFree(e.d_topk_conf);
@@ -325,6 +338,9 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
     if (e.stream) hipStreamSynchronize(e.stream);
     for (int c = 0; c < Engine::kMaxDepth; c++) if (e.ctx_stream[c]) hipStreamSynchronize(e.ctx_stream[c]);
 
+    const bool src_pinned = is_pinned(j.src, (size_t)j.n_clips * clip_bytes);
+    const bool logits_pinned = j.logits && is_pinned(j.logits, (size_t)j.n_clips * e.n_classes * 4);
+    const bool emb_pinned = j.emb && is_pinned(j.emb, (size_t)j.n_clips * e.emb_dim * 4);
     auto chunk_n = [&](int c) { return csize[c]; };
     auto abort_all = [&]() {
         for (auto& s : hp.s) { pool().wait(&s.fill); s.chunk = -1; }
@@ -339,8 +355,8 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
         hipError_t he = hipEventSynchronize(s.ev_done);
         if (he != hipSuccess) return he;
         const size_t off = (size_t)cfirst[s.chunk], n = (size_t)chunk_n(s.chunk);
-        if (j.logits) parallel_copy(j.logits + off * e.n_classes, s.h_logits, n * e.n_classes * 4);
-        if (j.emb) memcpy(j.emb + off * e.emb_dim, s.h_emb, n * e.emb_dim * 4);
+        if (j.logits && !logits_pinned) parallel_copy(j.logits + off * e.n_classes, s.h_logits, n * e.n_classes * 4);
+        if (j.emb && !emb_pinned) memcpy(j.emb + off * e.emb_dim, s.h_emb, n * e.emb_dim * 4);
         if (kk) {
             memcpy(j.out_conf + off * kk, s.h_tkc, n * kk * 4);
             memcpy(j.out_idx + off * kk, s.h_tki, n * kk * 4);
@@ -353,7 +369,7 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
         hipError_t he = finish(s);                       // the slot's previous chunk (c - K) must have left it
         if (he != hipSuccess) return he;
         s.chunk = c;
-        pool().submit(s.h_in, (const char*)j.src + (size_t)cfirst[c] * clip_bytes, (size_t)chunk_n(c) * clip_bytes, &s.fill);
+        if (!src_pinned) pool().submit(s.h_in, (const char*)j.src + (size_t)cfirst[c] * clip_bytes, (size_t)chunk_n(c) * clip_bytes, &s.fill);
         return hipSuccess;
     };
 #define HP_PIPE(call, what)                                                                \
@@ -384,8 +400,9 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
         hipError_t he = hipStreamWaitEvent(hp.xfer, s.ev_comp, 0);
         if (he == hipSuccess && kk) he = hipMemcpyAsync(s.h_tkc, s.d_tkc, (size_t)n * kk * 4, hipMemcpyDeviceToHost, hp.xfer);
         if (he == hipSuccess && kk) he = hipMemcpyAsync(s.h_tki, s.d_tki, (size_t)n * kk * 4, hipMemcpyDeviceToHost, hp.xfer);
-        if (he == hipSuccess && j.logits) he = hipMemcpyAsync(s.h_logits, s.d_logits, (size_t)n * e.n_classes * 4, hipMemcpyDeviceToHost, hp.xfer);
-        if (he == hipSuccess && j.emb) he = hipMemcpyAsync(s.h_emb, s.d_emb, (size_t)n * e.emb_dim * 4, hipMemcpyDeviceToHost, hp.xfer);
+        const size_t off = (size_t)cfirst[c];
+        if (he == hipSuccess && j.logits) he = hipMemcpyAsync(logits_pinned ? (void*)(j.logits + off * e.n_classes) : (void*)s.h_logits, s.d_logits, (size_t)n * e.n_classes * 4, hipMemcpyDeviceToHost, hp.xfer);
+        if (he == hipSuccess && j.emb) he = hipMemcpyAsync(emb_pinned ? (void*)(j.emb + off * e.emb_dim) : (void*)s.h_emb, s.d_emb, (size_t)n * e.emb_dim * 4, hipMemcpyDeviceToHost, hp.xfer);
         if (he == hipSuccess) he = hipEventRecord(s.ev_done, hp.xfer);
         return he;
     };
@@ -398,9 +415,10 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
         const size_t cnt = (size_t)n * e.n_samples;
         hipStream_t cs = e.kernel_stream(ctx);
         if (!cs) { abort_all(); err = "hipStreamCreate failed"; return BNHIP_E_RUNTIME; }
-        pool().wait(&s.fill);
+        if (!src_pinned) pool().wait(&s.fill);
         if (trace) tr.push_back(now_ms() - t_call);
-        HP_PIPE(hipMemcpyAsync(j.pcm_bits ? (void*)s.d_raw : (void*)s.d_in, s.h_in, cnt * bps, hipMemcpyHostToDevice, hp.xfer), "H2D copy");
+        const void* h_src = src_pinned ? (const void*)((const char*)j.src + (size_t)cfirst[c] * clip_bytes) : (const void*)s.h_in;
+        HP_PIPE(hipMemcpyAsync(j.pcm_bits ? (void*)s.d_raw : (void*)s.d_in, h_src, cnt * bps, hipMemcpyHostToDevice, hp.xfer), "H2D copy");
         HP_PIPE(hipEventRecord(s.ev_h2d, hp.xfer), "event record");
         if (trace) hipEventRecord(tev[1 + 3 * c], hp.xfer);
         if (c >= LAG) HP_PIPE(issue_d2h(c - LAG), "D2H copy");

@@ -41,6 +41,8 @@ typedef int  (*fn_rs_estimate)(const bnhip_resampler*, int);
 typedef int  (*fn_rs_process_pcm16)(bnhip_resampler*, const int16_t*, int, int16_t*, int, int*);
 typedef int  (*fn_rs_flush_pcm16)(bnhip_resampler*, int16_t*, int, int*);
 typedef void (*fn_rs_destroy)(bnhip_resampler*);
+typedef int  (*fn_host_alloc)(size_t, void**);
+typedef int  (*fn_host_free)(void*);
 
 typedef struct {
     void* handle;
@@ -49,6 +51,7 @@ typedef struct {
     fn_predict_pcm16 predict_pcm16; fn_us_frame_cv us_frame_cv;
     fn_rs_create rs_create; fn_rs_estimate rs_estimate; fn_rs_process_pcm16 rs_process_pcm16; fn_rs_flush_pcm16 rs_flush_pcm16;
     fn_rs_destroy rs_destroy;
+    fn_host_alloc host_alloc; fn_host_free host_free;
 } bnbind_t;
 static bnbind_t BN;
 static char bnbind_errbuf[256];
@@ -76,6 +79,7 @@ static const char* bnbind_load(const char* path) {
     BN_RESOLVE(rs_create, "bnhip_resampler_create"); BN_RESOLVE(rs_estimate, "bnhip_resampler_estimate");
     BN_RESOLVE(rs_process_pcm16, "bnhip_resampler_process_pcm16"); BN_RESOLVE(rs_flush_pcm16, "bnhip_resampler_flush_pcm16");
     BN_RESOLVE(rs_destroy, "bnhip_resampler_destroy");
+    BN_RESOLVE(host_alloc, "bnhip_host_alloc"); BN_RESOLVE(host_free, "bnhip_host_free");
     return NULL;
 }
 static void bnbind_unload(void) {
@@ -104,6 +108,8 @@ static int bnbind_rs_process_pcm16(bnhip_resampler* r, const int16_t* in, int n,
 }
 static int bnbind_rs_flush_pcm16(bnhip_resampler* r, int16_t* out, int cap, int* n_out) { return BN.rs_flush_pcm16(r, out, cap, n_out); }
 static void bnbind_rs_destroy(bnhip_resampler* r) { BN.rs_destroy(r); }
+static int bnbind_host_alloc(size_t n, void** p) { return BN.host_alloc(n, p); }
+static int bnbind_host_free(void* p) { return BN.host_free ? BN.host_free(p) : 0; }
 */
 import "C"
 
@@ -162,7 +168,11 @@ type Classifier struct {
 	nSamples int
 	nClasses int
 	embDim   int
-	in       *C.float // C-allocated staging: the Go slice returns to a pool right after Predict (process.go:280-291)
+	// C-side staging, as the OpenVINO shim keeps it (backend_openvino.go:673-680): the Go slice returns to a pool right after
+	// Predict (process.go:280-291) and the GC may move Go memory.  Both buffers are PAGE-LOCKED (bnhip_host_alloc), so the
+	// library DMAs one clip in and the logits out without its own staging copy.
+	in  *C.float // [nSamples]
+	out *C.float // [nClasses + embDim]
 }
 
 // NewClassifier builds a classifier from the same in-memory model bytes the TFLite backend takes
@@ -237,11 +247,19 @@ func NewClassifierWithOptions(modelData []byte, o Options) (*Classifier, error) 
 	var ns, nc, ed C.int
 	C.bnbind_model_info(h, &ns, &nc, &ed)
 	c := &Classifier{h: h, nSamples: int(ns), nClasses: int(nc), embDim: int(ed)}
-	c.in = (*C.float)(C.malloc(C.size_t(c.nSamples) * 4))
-	if c.in == nil {
+	var pin, pout unsafe.Pointer
+	if rc := C.bnbind_host_alloc(C.size_t(c.nSamples)*4, &pin); rc != 0 {
+		msg := lastError()
 		C.bnbind_model_destroy(h)
-		return nil, errors.New("hip: out of memory")
+		return nil, fmt.Errorf("hip: pinned input allocation failed (%d): %s", int(rc), msg)
 	}
+	if rc := C.bnbind_host_alloc(C.size_t(c.nClasses+c.embDim)*4, &pout); rc != 0 {
+		msg := lastError()
+		C.bnbind_host_free(pin)
+		C.bnbind_model_destroy(h)
+		return nil, fmt.Errorf("hip: pinned output allocation failed (%d): %s", int(rc), msg)
+	}
+	c.in, c.out = (*C.float)(pin), (*C.float)(pout)
 	return c, nil
 }
 
@@ -264,17 +282,22 @@ func (c *Classifier) predict(samples []float32, wantEmb bool) ([]float32, []floa
 		return nil, nil, fmt.Errorf("input size mismatch: expected %d samples, got %d", c.nSamples, len(samples))
 	}
 	C.memcpy(unsafe.Pointer(c.in), unsafe.Pointer(&samples[0]), C.size_t(c.nSamples)*4)
-	logits := make([]float32, c.nClasses)
-	var emb []float32
 	var ep *C.float
 	if wantEmb {
-		emb = make([]float32, c.embDim)
-		ep = (*C.float)(unsafe.Pointer(&emb[0]))
+		ep = (*C.float)(unsafe.Add(unsafe.Pointer(c.out), c.nClasses*4))
 	}
 	runtime.LockOSThread()
 	defer runtime.UnlockOSThread()
-	if rc := C.bnbind_predict(c.h, c.in, 1, (*C.float)(unsafe.Pointer(&logits[0])), ep); rc != 0 {
+	if rc := C.bnbind_predict(c.h, c.in, 1, c.out, ep); rc != 0 {
 		return nil, nil, fmt.Errorf("hip: predict failed (%d): %s", int(rc), lastError())
+	}
+	// a freshly allocated slice the caller owns (tflite/classifier.go:115-116)
+	logits := make([]float32, c.nClasses)
+	copy(logits, unsafe.Slice((*float32)(unsafe.Pointer(c.out)), c.nClasses))
+	var emb []float32
+	if wantEmb {
+		emb = make([]float32, c.embDim)
+		copy(emb, unsafe.Slice((*float32)(unsafe.Pointer(ep)), c.embDim))
 	}
 	return logits, emb, nil
 }
@@ -341,8 +364,42 @@ func (c *Classifier) Close() {
 		c.h = nil
 	}
 	if c.in != nil {
-		C.free(unsafe.Pointer(c.in))
+		C.bnbind_host_free(unsafe.Pointer(c.in))
 		c.in = nil
+	}
+	if c.out != nil {
+		C.bnbind_host_free(unsafe.Pointer(c.out))
+		c.out = nil
+	}
+}
+
+// PinnedF32 is a float32 slice over page-locked memory (bnhip_host_alloc) for batch callers: fill Data, pass it to PredictBatch /
+// PredictTopK - the library recognises pinned memory per call and lets the copy engines read it directly instead of staging it.
+// The memory is C-owned: Free it, do not let the slice outlive Free.
+type PinnedF32 struct {
+	Data []float32
+	p    unsafe.Pointer
+}
+
+// AllocPinnedF32 returns n page-locked floats (Init must have succeeded).
+func AllocPinnedF32(n int) (*PinnedF32, error) {
+	if n <= 0 {
+		return nil, errors.New("hip: pinned allocation of zero elements")
+	}
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	var p unsafe.Pointer
+	if rc := C.bnbind_host_alloc(C.size_t(n)*4, &p); rc != 0 {
+		return nil, fmt.Errorf("hip: pinned allocation failed (%d): %s", int(rc), lastError())
+	}
+	return &PinnedF32{Data: unsafe.Slice((*float32)(p), n), p: p}, nil
+}
+
+// Free releases the buffer; idempotent.
+func (b *PinnedF32) Free() {
+	if b.p != nil {
+		C.bnbind_host_free(b.p)
+		b.p, b.Data = nil, nil
 	}
 }
 

@@ -31,7 +31,8 @@ SYMBOLS = ["bnhip_init", "bnhip_shutdown", "bnhip_model_create", "bnhip_model_in
            "bnhip_resample_f32", "bnhip_resample_pcm16", "bnhip_model_devices", "bnhip_last_error_copy",
            "bnhip_resampler_create", "bnhip_resampler_estimate", "bnhip_resampler_process_pcm16",
            "bnhip_resampler_process_f32", "bnhip_resampler_flush_pcm16", "bnhip_resampler_flush_f32",
-           "bnhip_resampler_destroy", "bnhip_us_frame_cv_device", "bnhip_profile_steps", "bnhip_profile_steps_read"]
+           "bnhip_resampler_destroy", "bnhip_us_frame_cv_device", "bnhip_profile_steps", "bnhip_profile_steps_read",
+           "bnhip_host_alloc", "bnhip_host_free"]
 
 
 class HipError(RuntimeError):
@@ -95,6 +96,35 @@ def init():
     n = C.c_int(0)
     _check(lib, lib.bnhip_init(C.byref(n)))
     return n.value
+
+
+class PinnedArray:
+    """A numpy array over page-locked memory from bnhip_host_alloc (the reference's shim keeps a C-allocated input buffer per
+    classifier, backend_openvino.go:673-680): bnhip_predict* read / write such buffers by DMA, without the staging copy.
+    `.array` is the view; free() (or the with-statement) releases it."""
+
+    def __init__(self, shape, dtype=np.float32):
+        self._lib = load_library()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._lib.bnhip_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+        _check(self._lib, self._lib.bnhip_host_alloc(n, C.byref(p)))          # (zero bytes: BNHIP_E_INVALID)
+        self._p = p
+        buf = (C.c_char * n).from_address(p.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if self._p:
+            self.array = None
+            self._lib.bnhip_host_free.argtypes = [C.c_void_p]
+            self._lib.bnhip_host_free(self._p)
+            self._p = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.free()
 
 
 class HipClassifier:

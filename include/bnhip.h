@@ -111,6 +111,14 @@ int bnhip_predict_pcm16(bnhip_model* m, const int16_t* pcm, int n_clips, float* 
  * bits_per_sample / 8 bytes each.  Any other depth is BNHIP_E_INVALID (pcm.go:215-222 "supported_bit_depths 16,24,32"). */
 int bnhip_predict_pcm(bnhip_model* m, const void* pcm, int bits_per_sample, int n_clips, float* logits, float* emb);
 
+/* Page-locked host buffers for the host-pointer entries above.  The reference's accelerator shim keeps a C-allocated input
+ * buffer per classifier so that the native side reads memory the Go GC cannot move (backend_openvino.go:673-680); here the same
+ * buffer is page-locked as well: when `samples` / `pcm` (and `logits`, `emb`) of a bnhip_predict* call lie in memory from
+ * bnhip_host_alloc - detected per call, nothing to flag - the copy engines read and write the caller's buffers directly and the
+ * staging pass through the library's own pinned slots is skipped.  Results are bit-identical either way.  Needs bnhip_init. */
+int bnhip_host_alloc(size_t n_bytes, void** out);
+int bnhip_host_free(void* p);
+
 /* Device-resident variant: all pointers are device memory on the model's device; work is enqueued on
  * the model's stream and NOT synchronised (call bnhip_synchronize). Used by the throughput harness so
  * timing starts with inputs already in HBM.  With "depth" > 1 successive calls run on alternating contexts and may

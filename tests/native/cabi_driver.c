@@ -5,7 +5,7 @@
  *
  *   cabi_driver <libbnhip.so> <model file> cpu               error paths + plan-only sequence (no GPU needed)
  *   cabi_driver <libbnhip.so> <model file> gpu <in.f32> <out.f32> <n_clips>
- *        Init -> NewClassifier -> Predict (clip 0) -> PredictBatch (all) -> PredictTopK -> PredictPCM16 -> ComputeUSFrameCV (the
+ *        Init -> NewClassifier -> Predict (clip 0) -> PredictBatch (all) -> the same from page-locked buffers -> PredictTopK -> PredictPCM16 -> ComputeUSFrameCV (the
  *        reference's known answers) -> Resampler (chunked == one shot) -> Close, logits written to out.f32.  With a dense model
  *        (a CustomClassifier head, a RangeFilter meta-model) the same sequence is what PredictEmbedding / PredictBatch do.
  */
@@ -131,6 +131,26 @@ int main(int argc, char** argv) {
     /* PredictBatch */
     CHECK(bnbind_predict(h, in, n_clips, out, NULL) == 0, "predict batch: %s", bnbind_last_error());
     for (int i = 0; i < nc; i++) CHECK(out[i] == one[i], "Predict and PredictBatch disagree on clip 0 at class %d: %g vs %g", i, one[i], out[i]);
+    /* the shim's own buffers are page-locked (bnhip_host_alloc): the same calls from pinned memory - one clip and the whole batch,
+     * input and output - must give the very same bits as from malloc'd memory */
+    {
+        void *pin = NULL, *pout = NULL, *none = (void*)1;
+        CHECK(bnbind_host_alloc(0, &none) == -1, "zero-byte pinned allocation must be invalid");
+        CHECK(bnbind_host_alloc((size_t)n_clips * ns * 4, &pin) == 0 && pin, "host_alloc: %s", bnbind_last_error());
+        CHECK(bnbind_host_alloc((size_t)n_clips * nc * 4, &pout) == 0 && pout, "host_alloc: %s", bnbind_last_error());
+        memcpy(pin, in, (size_t)n_clips * ns * 4);
+        memset(pout, 0xff, (size_t)n_clips * nc * 4);
+        CHECK(bnbind_predict(h, (const float*)pin, 1, (float*)pout, NULL) == 0, "predict (pinned): %s", bnbind_last_error());
+        CHECK(memcmp(pout, one, (size_t)nc * 4) == 0, "pinned Predict differs from the pageable one");
+        CHECK(bnbind_predict(h, (const float*)pin, n_clips, (float*)pout, NULL) == 0, "predict batch (pinned): %s", bnbind_last_error());
+        CHECK(memcmp(pout, out, (size_t)n_clips * nc * 4) == 0, "pinned PredictBatch differs from the pageable one");
+        /* mixed: pinned input, pageable output */
+        float* o3 = malloc((size_t)n_clips * nc * 4);
+        CHECK(bnbind_predict(h, (const float*)pin, n_clips, o3, NULL) == 0, "predict batch (pinned in): %s", bnbind_last_error());
+        CHECK(memcmp(o3, out, (size_t)n_clips * nc * 4) == 0, "pinned-input PredictBatch differs");
+        free(o3);
+        CHECK(bnbind_host_free(pin) == 0 && bnbind_host_free(pout) == 0 && bnbind_host_free(NULL) == 0, "host_free: %s", bnbind_last_error());
+    }
     /* PredictTopK: confidences descending, indices in range, top-1 == argmax of the logits */
     const int k = nc < 10 ? nc : 10;
     float* cf = malloc((size_t)n_clips * k * 4); int32_t* ix = malloc((size_t)n_clips * k * 4);

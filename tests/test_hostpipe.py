@@ -164,3 +164,34 @@ def test_bf16_storage_engine_through_the_pipeline_equals_its_serial_path(gpu, fu
     assert np.isfinite(outs[2]).all()
     assert np.array_equal(outs[2][256:], np.roll(outs[2][:256], 17, axis=0))
     assert np.array_equal(outs[2], outs[1])
+
+
+@pytest.mark.gpu
+def test_pinned_caller_buffers_are_bit_identical_and_skip_the_staging(gpu, full_blob):
+    """memory from bnhip_host_alloc is recognised per call; input read and logits / embeddings written by DMA
+    straight from / to the caller's buffers.  Same bits as the pageable path: one clip, a serial-path batch, a pipelined call with
+    ragged chunking, int16 input, pinned input with pageable output and the reverse."""
+    clf = host.HipClassifier(full_blob, max_batch=256)
+    try:
+        n = 300                                               # pipelined (>= 128), not a multiple of the chunk unit
+        x = sm.synth_clips(n, 144000, 48000)
+        pcm = (np.clip(x, -1, 1) * 32767).astype(np.int16)
+        ref = clf.predict_batch(x.reshape(-1), n)
+        ref_pcm = clf.predict_pcm16(pcm.reshape(-1), n)
+        with host.PinnedArray((n, 144000), np.float32) as pi, host.PinnedArray((n, 144000), np.int16) as pp, \
+                host.PinnedArray((n, clf.num_species()), np.float32) as po:
+            pi.array[:] = x; pp.array[:] = pcm
+            po.array[:] = np.nan
+            got = clf.predict_batch(pi.array.reshape(-1), n, out=po.array)
+            assert got.ctypes.data == po.array.ctypes.data and np.array_equal(got, ref)
+            assert np.array_equal(clf.predict_batch(pi.array.reshape(-1), n), ref)             # pinned in, pageable out
+            po.array[:] = np.nan
+            assert np.array_equal(clf.predict_batch(x.reshape(-1), n, out=po.array), ref)      # pageable in, pinned out
+            po.array[:] = np.nan
+            assert np.array_equal(clf.predict_pcm16(pp.array.reshape(-1), n, out=po.array), ref_pcm)
+            for k in (1, 7, 64):                              # the serial path (below the pipelining threshold)
+                assert np.array_equal(clf.predict_batch(pi.array[:k].reshape(-1), k, out=po.array[:k]), clf.predict_batch(x[:k].reshape(-1), k))
+    finally:
+        clf.close()
+    with pytest.raises(host.HipError):
+        host.PinnedArray((0,), np.float32)
