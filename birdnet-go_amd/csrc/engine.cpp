@@ -1810,7 +1810,9 @@ bool Engine::load_tuning(const char* path) {
         if (ok && steps[i].kind == S_PW) ok = r.nt >= 0 && r.nt <= 8 && r.ntf >= 0 && r.ntf <= 8 && r.wm >= 0 && r.wm <= 8 && r.wmf >= 0 && r.wmf <= 8 &&
                                               ((r.wm >= 5) == (steps[i].wm >= 5) || !steps[i].wbx);       // (never switches the arithmetic family)
         if (ok && (steps[i].kind == S_EXPAND_DW || (steps[i].kind == S_DW && r.dwl))) {
-            const ExpDwGeo g{steps[i].kh, steps[i].sh, steps[i].H, steps[i].W, steps[i].Ho, steps[i].Wo, steps[i].pt, steps[i].pl, steps[i].kind == S_EXPAND_DW && steps[i].mode == 1};
+            const bool st_ = steps[i].kind == S_EXPAND_DW && steps[i].mode == 1;
+            const ExpDwGeo g{steps[i].kh, steps[i].sh, steps[i].H, steps[i].W, steps[i].Ho, steps[i].Wo, steps[i].pt, steps[i].pl, st_,
+                             steps[i].kind == S_EXPAND_DW ? expdw_skw(steps[i].C, steps[i].act, st_) : 0};
             ok = r.shape >= 0 && r.shape < expdw_num_shapes() && expdw_shape_fits(r.shape, g);
         }
     }
@@ -1896,7 +1898,7 @@ void Engine::autotune_expdw() {
         float best = 1e30f; int best_idx = -1, best_bx = 0;
         const bool can_bx = s.wbx != nullptr && s.mode != 1 && bf16x3;
         const int bx_fixed = (can_bx && s.bx) ? 1 : 0;      // arithmetic is the planner's decision (shape rule); only the tile is timed
-        const ExpDwGeo sg0{s.kh, s.sh, s.H, s.W, s.Ho, s.Wo, s.pt, s.pl, s.mode == 1};
+        const ExpDwGeo sg0{s.kh, s.sh, s.H, s.W, s.Ho, s.Wo, s.pt, s.pl, s.mode == 1, expdw_skw(s.C, s.act, s.mode == 1)};
         // Two clocks per candidate: three launches back to back (how the layer runs inside a step: the next kernel's head
         // fills this one's tail) and the best of three isolated launches (what it costs when nothing covers its tail).  The
         // back-to-back time decides; the isolated one breaks near-ties (within 8 %), because a shape with few, long blocks can

@@ -139,7 +139,8 @@ bool expdw_supported(int k, int s, int Cin, int Cmid);
 // n .. 2n-1 the same shapes with the roles of rows and columns swapped (tall, narrow images - a time-major spectrogram -
 // tile badly with 16- / 32-column tiles): the kernel then walks the image through pixel strides and reads the depthwise taps
 // transposed.  `stem` layers (raw-image variant) only exist in image orientation.
-struct ExpDwGeo { int k, s, H, W, Ho, Wo, pt, pl; bool stem = false; };
+struct ExpDwGeo { int k, s, H, W, Ho, Wo, pt, pl; bool stem = false; int skw = 0; };   // skw: expdw_skw() of the layer (0: not the small-K chunk-loop form)
+int expdw_skw(int Cin, int act_e, bool stem);
 int expdw_sum_slabs(const ExpDwGeo& g);   // slabs of the cost-model shape; 0 = no tile shape fits (do not fuse)
 int expdw_num_shapes();                   // 2n
 bool expdw_shape_fits(int idx, const ExpDwGeo& g);

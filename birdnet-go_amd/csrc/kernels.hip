@@ -1559,6 +1559,23 @@ std::vector<uint16_t> pw_bx3_image(const float* W, int N, int K) {
     return img;
 }
 
+// The tile of a contraction is tuned at batch size.  A call with fewer clips (one clip per Predict; the 64-clip chunks of a
+// blocking 256-clip host call) can leave most of the 256 CUs without a workgroup with that tile: shrink it - 64-row tiles first,
+// then narrower column tiles - until the grid has at least one workgroup per CU or the smallest tile is reached.  Pipelined
+// kernel forms keep their own constraints, so they fall back to the plain form when the tile changes.
+static inline bool pw_fill_grid(int M, int N, int* nt, int* wm, unsigned* nblk, int* nblk_n) {
+    static const int target = getenv("BNHIP_PW_FILL") ? atoi(getenv("BNHIP_PW_FILL")) : 256;
+    bool changed = false;
+    auto count = [&]() { *nblk_n = (N + *nt * 16 - 1) / (*nt * 16); *nblk = (unsigned)((M + 64 * *wm - 1) / (64 * *wm)) * (unsigned)*nblk_n; };
+    count();
+    while ((int)*nblk < target && (*wm > 1 || *nt > 1)) {
+        if (*wm > 1) *wm = 1;
+        else *nt = (*nt + 1) / 2;
+        changed = true;
+        count();
+    }
+    return changed;
+}
 void launch_pw_bx3(const PwParams& p, const uint16_t* Wimg, hipStream_t s) {
     int nt = (p.nt >= 1 && p.nt <= 8) ? p.nt : pick_nt(p.M, p.N);
     int wm = (p.wm == 5 || p.wm == 7) ? 1 : 2;             // PwParams::wm 5 / 6: 64- / 128-row tiles on the split-bf16 kernel, 7 / 8: pipelined
@@ -1566,11 +1583,8 @@ void launch_pw_bx3(const PwParams& p, const uint16_t* Wimg, hipStream_t s) {
     int bm = 64 * wm;
     int nblk_n = (p.N + nt * 16 - 1) / (nt * 16);
     unsigned nblk = (unsigned)((p.M + bm - 1) / bm) * nblk_n;
-    if (nblk < 64 && (nt > 1 || wm > 1)) {                 // a handful of clips: smallest tile, as in launch_pw_gemm
-        nt = 1; wm = 1; bm = 64; pipe = false;
-        nblk_n = (p.N + 15) / 16;
-        nblk = (unsigned)((p.M + bm - 1) / bm) * nblk_n;
-    }
+    if (pw_fill_grid(p.M, p.N, &nt, &wm, &nblk, &nblk_n)) { bm = 64 * wm; pipe = false; }
+    (void)bm;
     const int Npad = pw_bx3_npad(p.N);
     const FDiv dn = make_fdiv((unsigned)nblk_n), dhw = make_fdiv((unsigned)std::max(p.HW, 1));
     const bool sc = p.ascale != nullptr;
@@ -1654,11 +1668,8 @@ void launch_pw_gemm(const PwParams& p, hipStream_t s) {
     // the tile was tuned at batch size; a call with a handful of clips would leave most CUs idle with it (one clip:
     // 1-5 workgroups each walking the whole K loop): fall back to the smallest tile to get workgroups
     static const bool forced = getenv("BNHIP_PW_NT") != nullptr || getenv("BNHIP_PW_WM") != nullptr;   // tests pin the tile
-    if (nblk < 64 && (nt > 1 || wm > 1) && !forced) {
-        nt = 1; wm = 1; bm = 64; pipe = false;
-        nblk_n = (p.N + 15) / 16;
-        nblk = (unsigned)((p.M + bm - 1) / bm) * nblk_n;
-    }
+    if (!forced && pw_fill_grid(p.M, p.N, &nt, &wm, &nblk, &nblk_n)) { bm = 64 * wm; pipe = false; }
+    (void)bm;
     dim3 grid(nblk);
     const FDiv dn = make_fdiv((unsigned)nblk_n), dhw = make_fdiv((unsigned)std::max(p.HW, 1));
     const bool sc = p.ascale != nullptr;
@@ -1981,12 +1992,17 @@ constexpr int expdw_min_waves(int K, int S, int TOW, int TRH) {
 // stays live across the chunk loop - the footprint's input operands, the prefetched chunk parameters - plus the larger of
 // the two phases' working sets.  A spill here is worse than a lost wave: the reload (scratch is VMEM) waits on vmcnt behind
 // the prefetch.
-constexpr int expdw_sk_waves(int K, int S, int TOH, int TOW, int TRH, int KW, bool one_chunk) {
-    const int tiw = (TOW - 1) * S + K, jt = (TRH * tiw + 15) / 16, jtw = (jt + 3) / 4;
+#ifndef EXPDW_NW8_WAVES
+#define EXPDW_NW8_WAVES (est <= 76 ? 6 : 4)
+#endif
+constexpr int expdw_sk_waves(int K, int S, int TOH, int TOW, int TRH, int KW, bool one_chunk, int NW = 4) {
+    const int tiw = (TOW - 1) * S + K, jt = (TRH * tiw + 15) / 16, jtw = (jt + NW - 1) / NW;
     if (one_chunk) return jtw <= 3 ? 5 : expdw_min_waves(K, S, TOW, TRH);
-    const int sh = TOH / 4, sw = TOW / 8, rw = (sw - 1) * S + K;
+    const int sh = TOH / NW, sw = TOW / 8, rw = (sw - 1) * S + K;
     const int p1 = jtw * 8 + 8, p2 = sh * sw * 4 + rw * 4 + K * 4;
     const int est = jtw * KW / 4 + (KW / 2 + 16) + 24 + (p1 > p2 ? p1 : p2);
+    // eight-wave blocks (two waves per SIMD share one footprint): waves per SIMD come in pairs
+    if (NW == 8) return EXPDW_NW8_WAVES;
     return est <= 120 ? 4 : (est <= 160 ? 3 : 2);
 }
 // COPY: no expand at all - phase 1 only stages the tile's input footprint (32 channels of x itself) in LDS and phase 2 runs
@@ -1996,11 +2012,12 @@ constexpr int expdw_sk_waves(int K, int S, int TOH, int TOW, int TRH, int KW, bo
 // store; returns the lane's sum of what it stored (for the squeeze-excite mean).  ty is the wave index (scalar): every row
 // test is wave-uniform.
 // pre_store() runs after the taps and before the first global store (k_expand_dw_sk makes its prefetched loads land there).
-template <int K, int S, int TOH, int TOW, int TRH, typename PreStore>
+template <int K, int S, int TOH, int TOW, int TRH, int NW = 4, typename PreStore>
 __device__ __forceinline__ float4 ed_phase2(const ExpDwParams& p, const float* E, const float4* wds, int b, int oh0, int ow0, int vr0,
                                             int vr1, int ty, int tx, int c4, int n_base, const float4& bv, PreStore&& pre_store) {
     constexpr int TIW = (TOW - 1) * S + K;
-    constexpr int SH = TOH / 4, SW = TOW / 8;                 // outputs per thread (thread-tiles are 4 x 8)
+    static_assert(TOH % NW == 0, "a wave owns TOH / NW output rows");
+    constexpr int SH = TOH / NW, SW = TOW / 8;                // outputs per thread (thread-tiles are NW x 8)
     constexpr int RW = (SW - 1) * S + K;
     const int n = n_base + 4 * c4;
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2092,11 +2109,12 @@ __device__ __forceinline__ void ed_sums_lanes(float4 sum, float4* red, int wave,
     xsum(std::integral_constant<int, 0x401f>{});     // xor 16
     if ((lane & 0x14) == 0) red[(wave * 2 + (lane >> 5)) * 8 + c4] = sum;
 }
+template <int NW = 4>
 __device__ __forceinline__ void ed_sums_out(const ExpDwParams& p, const float4* red, int tid, size_t tile_index, int n_base) {
     if (tid < 8 && n_base + 4 * tid < p.Cmid) {
         float4 t = red[tid];
 #pragma unroll
-        for (int w = 1; w < 8; w++) { float4 v = red[w * 8 + tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        for (int w = 1; w < 2 * NW; w++) { float4 v = red[w * 8 + tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
         unsigned l4 = 4u * (unsigned)tid;
         asm volatile("" : "+v"(l4));                     // (opaque: scalar base + 32-bit lane offset, nothing 64-bit per lane to hoist)
         *reinterpret_cast<float4*>(p.partial + tile_index * p.Cmid + n_base + l4) = t;
@@ -2343,7 +2361,7 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
     }   // !COPY
 
     // ---- depthwise from LDS, per-tile channel sums
-    const float4 sum = ed_phase2<K, S, TOH, TOW, TRH>(p, E, wds, b, oh0, ow0, vr0, vr1, wave, tx, c4, n_base, bv, [] {});
+    const float4 sum = ed_phase2<K, S, TOH, TOW, TRH, 4>(p, E, wds, b, oh0, ow0, vr0, vr1, wave, tx, c4, n_base, bv, [] {});
     if (p.partial) {
         ed_sums_lanes(sum, red, wave, lane, c4);
         __syncthreads();
@@ -2365,20 +2383,25 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
 //     the per-tile channel sums of chunk c are written out by wave 0 between the two barriers of chunk c + 1.
 // (LOOP = false - the stem, whose expanded width is normally a single chunk: one block per (clip, tile, chunk) as in
 // k_expand_dw; without the chunk loop's live ranges it keeps the registers for five waves per SIMD)
-template <int K, int S, int TOH, int TOW, int TRH, bool STEM, int KW, bool LOOP = !STEM>
-__global__ __launch_bounds__(256, expdw_sk_waves(K, S, TOH, TOW, TRH, KW, !LOOP)) void k_expand_dw_sk(ExpDwParams p, unsigned nblk) {
+// NW = 8 (chunk-loop form only): an eight-wave block - TWO waves per SIMD share one expanded footprint in LDS.  The early layers
+// are bound by unhidden latency at the three blocks per CU their 40-50 KB footprints allow (a wave waits two thirds of its
+// life); with the same LDS the CU then holds twice the waves, each owning half the pixel tiles in phase 1 and half the output
+// rows in phase 2 (so the registers that stay live across the chunk loop halve too).
+template <int K, int S, int TOH, int TOW, int TRH, bool STEM, int KW, bool LOOP = !STEM, int NW = 4>
+__global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, KW, !LOOP, NW)) void k_expand_dw_sk(ExpDwParams p, unsigned nblk) {
+    static_assert(NW == 4 || (NW == 8 && LOOP && TOH % 8 == 0), "eight-wave blocks: chunk-loop form, tile height a multiple of 8");
     static_assert(KW == 16 || KW == 24 || KW == 32, "one or two K slabs, or a slab and a half");
     static_assert(!STEM || KW == 24, "the stem's window is 3 rows x 4 columns x 2 channels");
     constexpr int TIH = (TOH - 1) * S + K, TIW = (TOW - 1) * S + K;
     static_assert(TRH <= TIH, "TRH is a cap on the footprint rows");
     constexpr int NPIX = TRH * TIW, NPIXP = (NPIX + 15) / 16 * 16;
-    constexpr int JT = NPIXP / 16, JTW = (JT + 3) / 4;
+    constexpr int JT = NPIXP / 16, JTW = (JT + NW - 1) / NW;
     constexpr int SW = TOW / 8;
     constexpr int NMMA = KW / 2;                              // MFMAs per 16-pixel tile (two 16-channel halves)
-    __shared__ __attribute__((aligned(16))) float lds[NPIX * ED_ES + 256 + K * K * 32];
+    __shared__ __attribute__((aligned(16))) float lds[NPIX * ED_ES + 64 * NW + K * K * 32];
     float* E = lds;
     float4* red = reinterpret_cast<float4*>(lds + NPIX * ED_ES);
-    float4* wds = reinterpret_cast<float4*>(lds + NPIX * ED_ES + 256);
+    float4* wds = reinterpret_cast<float4*>(lds + NPIX * ED_ES + 64 * NW);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
 
@@ -2416,7 +2439,7 @@ __global__ __launch_bounds__(256, expdw_sk_waves(K, S, TOH, TOW, TRH, KW, !LOOP)
         const float* xb = STEM ? p.x + (size_t)b * p.Hin * p.Win * 2 : p.x;
 #pragma unroll
         for (int a = 0; a < JTW; a++) {
-            const int j = 16 * (wave + 4 * a) + li;
+            const int j = 16 * (wave + NW * a) + li;
             const int r = j / TIW, c = j - r * TIW;
             const int iw = iw0 + c;
             xin[a] = j < nvalid && iw >= 0 && iw < p.W;
@@ -2538,8 +2561,8 @@ __global__ __launch_bounds__(256, expdw_sk_waves(K, S, TOH, TOW, TRH, KW, !LOOP)
             constexpr bool HI = decltype(hi)::value;
             acc[a][0] = act4(acc[a][0]);
             if (HI) acc[a][1] = act4(acc[a][1]);
-            if (16 * (wave + 4 * a) + li < nvalid) {
-                float* e = E + (16 * (wave + 4 * a)) * ED_ES + e_lane;
+            if (16 * (wave + NW * a) + li < nvalid) {
+                float* e = E + (16 * (wave + NW * a)) * ED_ES + e_lane;
                 if constexpr (decltype(masked)::value) {
                     const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
                     *reinterpret_cast<f32x4*>(e) = xin[a] ? acc[a][0] : z;
@@ -2554,11 +2577,11 @@ __global__ __launch_bounds__(256, expdw_sk_waves(K, S, TOH, TOW, TRH, KW, !LOOP)
             if (wave < jtv) tile_mma(0, hi);
             if (LOOP && ci > 0) {
                 __syncthreads();                           // every wave is through phase 2 of the previous chunk: E, taps and sums
-                if (p.partial) ed_sums_out(p, red, tid, tile_index, n_base - 32);
+                if (p.partial) ed_sums_out<NW>(p, red, tid, tile_index, n_base - 32);
             }
 #pragma unroll
             for (int a = 1; a < JTW; a++) {
-                if (wave + 4 * a < jtv) {                 // (tile a valid => tile a - 1 valid)
+                if (wave + NW * a < jtv) {                // (tile a valid => tile a - 1 valid)
                     tile_mma(a, hi);
                     tile_out(a - 1, masked, hi, act4);
 #pragma unroll
@@ -2567,9 +2590,9 @@ __global__ __launch_bounds__(256, expdw_sk_waves(K, S, TOH, TOW, TRH, KW, !LOOP)
                         __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
                         __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
                     }
-                } else if (wave + 4 * (a - 1) < jtv) tile_out(a - 1, masked, hi, act4);
+                } else if (wave + NW * (a - 1) < jtv) tile_out(a - 1, masked, hi, act4);
             }
-            if (wave + 4 * (JTW - 1) < jtv) tile_out(JTW - 1, masked, hi, act4);
+            if (wave + NW * (JTW - 1) < jtv) tile_out(JTW - 1, masked, hi, act4);
         };
         auto phase1_act = [&](auto masked, auto hi) {
             // (the chunk-loop instantiations are launched for swish layers only - the others take k_expand_dw - so that the
@@ -2598,29 +2621,38 @@ __global__ __launch_bounds__(256, expdw_sk_waves(K, S, TOH, TOW, TRH, KW, !LOOP)
         // loads placed after the stores (the top of the next chunk is where the compiler would put it) is a wait for the
         // stores' write acknowledgements as well - measured as vmcnt(0) at the loop head.  Here it only covers loads that
         // have had the whole tap loop to arrive.
-        const float4 sum = ed_phase2<K, S, TOH, TOW, TRH>(p, E, wds, b, oh0, ow0, vr0, vr1, wave, tx, c4, n_base, bv, land);
+        const float4 sum = ed_phase2<K, S, TOH, TOW, TRH, NW>(p, E, wds, b, oh0, ow0, vr0, vr1, wave, tx, c4, n_base, bv, land);
         if (p.partial) ed_sums_lanes(sum, red, wave, lane, c4);
     }
     if (p.partial) {
         __syncthreads();
-        ed_sums_out(p, red, tid, tile_index, (cc0 + ncc - 1) * 32);
+        ed_sums_out<NW>(p, red, tid, tile_index, (cc0 + ncc - 1) * 32);
     }
 }
 
 // K of the expand GEMM as the kernel walks it: 16-wide slabs plus, when Cin <= 8 mod 16, one 8-wide half slab (two MFMA
 // steps instead of four: Cin = 24 / 40 would otherwise spend 25 % / 17 % of their MFMAs on zero columns)
 int expdw_kw(int Cin) { return (Cin & 1) ? (Cin + 15) / 16 * 16 : (Cin + 7) / 8 * 8; }
+// K width of the small-K chunk-loop form when the layer takes it (swish expand, one or two K slabs, not the stem), else 0
+int expdw_skw(int Cin, int act_e, bool stem) {
+    const int kw = expdw_kw(Cin);
+    return !stem && act_e == ACT_SWISH && (kw == 16 || kw == 24 || kw == 32) ? kw : 0;
+}
 int expdw_cp(int Cmid) { return (Cmid + 31) / 32 * 32; }
 // Instantiated tile shapes.  The chooser takes, per layer, the shape that computes the fewest expanded pixels
 // (rows x TIW summed over the tiles of one image; halo recompute and masked padding columns both count) among those
 // whose in-image footprint rows fit TRH.
-struct ExpDwShape { int k, s, toh, tow, trh; };
+struct ExpDwShape { int k, s, toh, tow, trh, nw = 4; };
 static const ExpDwShape kExpDwShapes[] = {
     {3, 1, 8, 16, 10}, {3, 1, 4, 16, 6}, {3, 1, 8, 32, 6}, {3, 1, 8, 32, 10},
     {5, 1, 8, 16, 12}, {5, 1, 4, 16, 8}, {5, 1, 8, 32, 6}, {5, 1, 12, 16, 12},
     {3, 2, 4, 8, 9}, {3, 2, 8, 8, 12}, {3, 2, 8, 8, 17},
     {5, 2, 4, 8, 11}, {5, 2, 4, 16, 6}, {5, 2, 8, 8, 19},   // the last one computes fewer pixels on b4 but measured 27 % slower
                                                              // there (52 KB of LDS, 6 MFMA tiles per wave): hence the autotuner
+    // eight-wave blocks of the small-K chunk-loop form (k_expand_dw_sk<..., NW = 8>): the 8-row tiles again, two waves per SIMD
+    // sharing one footprint; only offered to layers that take that form (ExpDwGeo::skw)
+    {3, 1, 8, 16, 10, 8}, {3, 1, 8, 32, 6, 8}, {3, 1, 8, 32, 10, 8}, {5, 1, 8, 16, 12, 8}, {5, 1, 8, 32, 6, 8},
+    {3, 2, 8, 8, 12, 8}, {3, 2, 8, 8, 17, 8}, {5, 2, 8, 8, 19, 8},
 };
 static long expdw_cost(const ExpDwShape& sh, int H, int Ho, int Wo, int pt, bool* fits) {
     const int tih = (sh.toh - 1) * sh.s + sh.k, tiw = (sh.tow - 1) * sh.s + sh.k;
@@ -2653,6 +2685,10 @@ bool expdw_shape_fits(int idx, const ExpDwGeo& g0) {
     }
     const ExpDwShape& sh = kExpDwShapes[idx % kNumExpDwShapes];
     if (sh.k != g0.k || sh.s != g0.s) return false;
+    if (sh.nw == 8) {                                     // eight-wave blocks exist for the chunk-loop small-K form only
+        static const bool off = getenv("BNHIP_NO_EXPDW_NW8") != nullptr;
+        if (off || g0.stem || !(g0.skw == 16 || g0.skw == 24 || g0.skw == 32)) return false;
+    }
     const ExpDwGeo g = expdw_oriented(idx, g0);
     bool fits;
     (void)expdw_cost(sh, g.H, g.Ho, g.Wo, g.pt, &fits);
@@ -2718,7 +2754,7 @@ bool expdw_supported(int k, int s, int Cin, int Cmid) {
 void launch_expand_dw(const float* x, const float* we, const float* be, const float* wd, const float* bd, float* y,
                       float* partial, int B, int H, int W, int Cin, int Cmid, int Ho, int Wo, int k, int s, int pt,
                       int pl, int act_e, int act_d, int shape, const StemGeom* stem, hipStream_t st, const uint16_t* wep, int prec, int out_bf16) {
-    const ExpDwGeo g0{k, s, H, W, Ho, Wo, pt, pl, stem != nullptr};
+    const ExpDwGeo g0{k, s, H, W, Ho, Wo, pt, pl, stem != nullptr, expdw_skw(Cin, act_e, stem != nullptr)};
     if (!expdw_shape_fits(shape, g0)) shape = expdw_default_shape(g0);
     if (shape < 0) return;                             // the planner only fuses layers some shape accepts
     const ExpDwShape* sh = &kExpDwShapes[shape % kNumExpDwShapes];
@@ -2756,6 +2792,20 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
 #undef ED_STEM
         return;
     }
+#define ED_CASE8(K_, S_, TH_, TW_, TR_)                                                                       \
+    if (sh->nw == 8 && sh->k == K_ && sh->s == S_ && sh->toh == TH_ && sh->tow == TW_ && sh->trh == TR_) {    \
+        if (p.Kw == 16) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 16, true, 8>), dim3(nblk), dim3(512), 0, st, p, nblk); \
+        else if (p.Kw == 24) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 24, true, 8>), dim3(nblk), dim3(512), 0, st, p, nblk); \
+        else hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 32, true, 8>), dim3(nblk), dim3(512), 0, st, p, nblk); \
+        return;                                                                                               \
+    }
+    if (sh->nw == 8) {
+        if (!sk || stem) return;                       // (expdw_shape_fits never offers these to other layers)
+        ED_CASE8(3, 1, 8, 16, 10) ED_CASE8(3, 1, 8, 32, 6) ED_CASE8(3, 1, 8, 32, 10) ED_CASE8(5, 1, 8, 16, 12) ED_CASE8(5, 1, 8, 32, 6)
+        ED_CASE8(3, 2, 8, 8, 12) ED_CASE8(3, 2, 8, 8, 17) ED_CASE8(5, 2, 8, 8, 19)
+        return;
+    }
+#undef ED_CASE8
 #define ED_CASE(K_, S_, TH_, TW_, TR_)                                                                        \
     if (sh->k == K_ && sh->s == S_ && sh->toh == TH_ && sh->tow == TW_ && sh->trh == TR_) {                   \
         if (bx) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \

@@ -338,6 +338,28 @@ def test_lanes_full_model_equal_small_batches(full_blob):
         c.close()
 
 
+def test_eight_wave_blocks_of_the_small_k_form_match(full_blob, monkeypatch):
+    """k_expand_dw_sk<..., NW = 8> (two waves per SIMD sharing one expanded footprint: shape indices 14-21) is an autotune
+    candidate of the early layers; forced onto b2 / b3 / b4 - 3 x 3 stride 2, 3 x 3 stride 1 and 5 x 5 stride 2, K widths 16 and
+    24, three and five channel chunks - it must reproduce the four-wave kernels' results to rounding and the oracle's top-1."""
+    x = sm.synth_clips(12, 144000, 48000)
+    ref_c = host.HipClassifier(full_blob, max_batch=16, autotune=False)
+    try:
+        ref = ref_c.predict_batch(x.reshape(-1), 12)
+    finally:
+        ref_c.close()
+    monkeypatch.setenv("BNHIP_EXPDW_FORCE", "b2/expand+dw=20,b3/expand+dw=16,b4/expand+dw=21")
+    c = host.HipClassifier(full_blob, max_batch=16)
+    try:
+        shapes = {s["name"]: s["shape"] for s in c.describe()["steps"] if s["kernel"] == "expand_dw"}
+        assert (shapes["b2/expand+dw"], shapes["b3/expand+dw"], shapes["b4/expand+dw"]) == (20, 16, 21), shapes
+        got = c.predict_batch(x.reshape(-1), 12)
+    finally:
+        c.close()
+    assert (got.argmax(1) == ref.argmax(1)).all()
+    assert np.abs(got - ref).max() < 2e-4 and np.abs(sig(got) - sig(ref)).max() <= 1e-5
+
+
 def test_opt_in_graph_replay_matches_eager(tiny_blob, tiny_cfg):
     """"graphs":1 replays the plan as a hipGraph from the third identical call on; results must not change (single lane and
     two lanes)."""
