@@ -592,3 +592,9 @@ class BirdNET:
     def predict_batch(self, flat, batch_size):
         conf, idx = self.classifier.predict_topk(flat, batch_size, self.TOP_K, 0, self.sensitivity)
         return [[(self.labels[i], float(c)) for c, i in zip(cr, ir)] for cr, ir in zip(conf, idx)]
+
+    def predict_pcm_batch(self, raw, bit_depth, batch_size):
+        """The windows' little-endian PCM bytes as captured (a1 runs in the kernel, process.go:479-497) -> per-window top-10."""
+        logits = self.classifier.predict_pcm(raw, bit_depth, batch_size)
+        conf, idx = self.classifier.postprocess_topk(logits, self.TOP_K, 0, self.sensitivity)
+        return [[(self.labels[i], float(c)) for c, i in zip(cr, ir)] for cr, ir in zip(conf, idx)]

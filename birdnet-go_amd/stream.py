@@ -1,0 +1,481 @@
+"""Real-time window path either side of the device call, host side.
+
+  a3  `AnalysisBuffer`      internal/audiocore/buffer/analysis.go:30-273 (+ overwrite.go)     ring -> `overlap ‖ fresh` windows
+  a4  `process_data`        internal/analysis/process.go:253-422 (+ :44-213 overrun tracker)   convert -> predict -> overrun -> enqueue
+  a5  `Orchestrator`        internal/classifier/orchestrator.go:63-68,514-572                  lock protocol + counters
+      `ModelSpec`           internal/classifier/model.go:33-56                                  window geometry (50 % overlap)
+      `BufferMonitor.tick`  internal/analysis/buffer_manager.go:388-496                         one poll of one (source, model)
+
+The reference runs one window at a time: every (source, model) pair has its own 100 ms poll loop and all of them queue on
+`inferenceMu` for a batch-1 native call.  `WindowBatcher` is the same contract turned the way the GPU wants it: one tick reads
+every buffer that has a window ready and hands all of them to ONE device call (PCM bytes go to the device as they are - the
+16/24/32-bit conversion of a1 happens in the kernel), then builds one `Results` message per window.  Per-window semantics
+(copy of the PCM bytes, overrun accounting against the model's buffer interval, drop-on-full queue) are the reference's.
+
+Byte work here is exact by construction (numpy slices); tests/test_stream.py replays the reference's own table of cases
+(analysis_test.go:23-243) and compares against the line-by-line restatement in oracle/gostream.py.
+"""
+import threading
+import time
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import results as _results
+
+# analysis.go:13-18
+OVERWRITE_WINDOW_S = 5 * 60.0
+OVERWRITE_RATE_THRESHOLD = 10
+OVERWRITE_MIN_WRITES = 50
+OVERWRITE_NOTIFY_COOLDOWN_S = 3600.0
+# process.go:34-40
+OVERRUN_REPORT_COOLDOWN_S = 3600.0
+OVERRUN_MIN_COUNT = 10
+NUM_CHANNELS, BYTES_PER_SAMPLE = 1, 2        # conf.NumChannels, conf.BytesPerSample (16-bit capture)
+
+
+class StreamError(ValueError):
+    """Validation failure (the reference's errors.CategoryValidation)."""
+
+
+class ByteRing:
+    """Byte ring in overwrite mode.  The reference uses github.com/smallnest/ringbuffer v0.1.1 (go.mod:31, absent from the
+    snapshot) with `SetOverwrite(true)` (analysis.go:120): a write never fails, the oldest unread bytes are dropped when the
+    data does not fit, and of a write longer than the ring only the last `capacity` bytes survive."""
+
+    def __init__(self, capacity):
+        self.buf = np.zeros(capacity, np.uint8)
+        self.cap, self.r, self.n = capacity, 0, 0          # read position, unread byte count
+
+    def length(self):
+        return self.n
+
+    def free(self):
+        return self.cap - self.n
+
+    def write(self, data):
+        d = np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else data.view(np.uint8).reshape(-1)
+        total = d.size
+        if total > self.cap:                                # only the newest `cap` bytes can survive
+            drop = total - self.cap
+            d = d[drop:]
+            self.r, self.n = (self.r + self.n) % self.cap, 0   # everything unread is older than what is kept
+        over = d.size - self.free()
+        if over > 0:                                        # advance the read position past the bytes being overwritten
+            self.r = (self.r + over) % self.cap
+            self.n -= over
+        w = (self.r + self.n) % self.cap
+        first = min(d.size, self.cap - w)
+        self.buf[w:w + first] = d[:first]
+        self.buf[:d.size - first] = d[first:]
+        self.n += d.size
+        return total
+
+    def read_into(self, out):
+        """Fills `out` with up to len(out) unread bytes; returns the count (ring.Read)."""
+        n = min(out.size, self.n)
+        first = min(n, self.cap - self.r)
+        out[:first] = self.buf[self.r:self.r + first]
+        out[first:n] = self.buf[:n - first]
+        self.r = (self.r + n) % self.cap
+        self.n -= n
+        return n
+
+    def reset(self):
+        self.r = self.n = 0
+
+
+class OverwriteTracker:
+    """overwrite.go: writes / overwrites within a sliding window, a warning when the rate passes the threshold."""
+
+    def __init__(self, window_s=OVERWRITE_WINDOW_S, rate_threshold=OVERWRITE_RATE_THRESHOLD, min_writes=OVERWRITE_MIN_WRITES,
+                 notify_cooldown_s=OVERWRITE_NOTIFY_COOLDOWN_S, on_warn=None, clock=time.monotonic):
+        self.mu = threading.Lock()
+        self.total_writes = self.overwrite_count = 0
+        self.clock = clock
+        self.window_start, self.last_notified = clock(), None
+        self.window_s, self.rate_threshold, self.min_writes, self.cooldown = window_s, rate_threshold, min_writes, notify_cooldown_s
+        self.on_warn = on_warn
+
+    def record_write(self):
+        with self.mu:
+            if self.window_s > 0 and self.clock() - self.window_start > self.window_s:
+                self.total_writes = self.overwrite_count = 0
+                self.window_start = self.clock()
+            self.total_writes += 1
+
+    def record_overwrite(self):
+        with self.mu:
+            self.overwrite_count += 1
+
+    def check_and_notify(self, source_id):
+        with self.mu:
+            if self.total_writes == 0 or self.total_writes < self.min_writes:
+                return False
+            rate = self.overwrite_count / self.total_writes * 100
+            if int(rate) < self.rate_threshold:
+                return False
+            now = self.clock()
+            if self.cooldown > 0 and self.last_notified is not None and now - self.last_notified < self.cooldown:
+                return False
+            self.last_notified = now
+            if self.on_warn:
+                self.on_warn(source_id, rate, self.total_writes, self.overwrite_count)
+            return True
+
+    def overwrite_rate(self):
+        with self.mu:
+            return 0.0 if self.total_writes == 0 else self.overwrite_count / self.total_writes * 100
+
+    def reset(self):
+        with self.mu:
+            self.total_writes = self.overwrite_count = 0
+            self.window_start = self.clock()
+
+
+class AnalysisBuffer:
+    """analysis.go: each `read` returns `overlap_size` bytes kept from the end of the previous window followed by
+    `read_size` fresh bytes; the very first window's prefix is zeros; `None` = try again later."""
+
+    def __init__(self, capacity, overlap_size, read_size, source_id, on_warn=None):
+        if capacity <= 0:
+            raise StreamError(f"invalid analysis buffer capacity: {capacity}, must be greater than 0")
+        if overlap_size < 0:
+            raise StreamError(f"invalid overlap size: {overlap_size}, must be >= 0")
+        if read_size <= 0:
+            raise StreamError(f"invalid read size: {read_size}, must be greater than 0")
+        if read_size < overlap_size:
+            raise StreamError(f"read size {read_size} must be >= overlap size {overlap_size}")
+        if capacity < read_size:
+            raise StreamError(f"capacity {capacity} must be >= read size {read_size}")
+        if not source_id:
+            raise StreamError("source ID must not be empty")
+        self.ring = ByteRing(capacity)
+        self.prev = None
+        self.overlap_size, self.read_size, self.window_size = overlap_size, read_size, overlap_size + read_size
+        self.source_id = source_id
+        self.tracker = OverwriteTracker(on_warn=on_warn)
+        self.mu = threading.Lock()
+
+    def write(self, data):
+        with self.mu:
+            will_overwrite = len(data) > self.ring.free()
+            self.ring.write(data)
+        self.tracker.record_write()
+        if will_overwrite:
+            self.tracker.record_overwrite()
+        self.tracker.check_and_notify(self.source_id)
+
+    def ready(self):
+        with self.mu:
+            return self.ring.length() >= self.read_size
+
+    def read(self, out=None):
+        """-> uint8[window_size] (a fresh array, or `out` filled), or None when fewer than read_size bytes are buffered."""
+        with self.mu:
+            if self.ring.length() < self.read_size:
+                return None
+            win = out if out is not None else np.empty(self.window_size, np.uint8)
+            ov = self.overlap_size
+            if ov > 0:
+                if self.prev is not None and self.prev.size == ov:
+                    win[:ov] = self.prev
+                else:
+                    win[:ov] = 0
+            n = self.ring.read_into(win[ov:ov + self.read_size])
+            if n < self.read_size:
+                win[ov + n:] = 0
+            if ov > 0:
+                if self.prev is None:
+                    self.prev = np.zeros(ov, np.uint8)
+                fresh_end = ov + n
+                if n >= ov:
+                    self.prev[:] = win[fresh_end - ov:fresh_end]
+                else:
+                    self.prev[:] = 0
+                    self.prev[ov - n:] = win[ov:fresh_end]
+            return win
+
+    def overwrite_count(self):
+        with self.tracker.mu:
+            return self.tracker.overwrite_count
+
+    def reset(self):
+        with self.mu:
+            self.ring.reset()
+            self.prev = None
+        self.tracker.reset()
+
+
+@dataclass(frozen=True)
+class ModelSpec:
+    """model.go:33-56.  `sample_rate` is what the window is sized by; `raw_sample_rate` what the model is fed at."""
+    sample_rate: int
+    clip_length_s: float
+    raw_sample_rate: int = 0
+    clip_bytes: int = 0            # test geometries whose clip is not a whole number of seconds; 0 = the reference's formula
+
+    def clip_size_bytes(self):
+        if self.clip_bytes:
+            return self.clip_bytes
+        return self.sample_rate * int(self.clip_length_s) * NUM_CHANNELS * BYTES_PER_SAMPLE
+
+    def buffer_dimensions(self):
+        clip = self.clip_size_bytes()
+        overlap = clip // 2
+        return clip, overlap, clip - overlap
+
+    def buffer_interval_s(self):
+        return self.clip_length_s / 2
+
+    def effective_sample_rate(self):
+        return self.raw_sample_rate if self.raw_sample_rate > 0 else self.sample_rate
+
+
+class OverrunTrackers:
+    """process.go:44-213: per (source, model) tumbling one-hour window of "inference took longer than the buffer interval"."""
+
+    class _T:
+        __slots__ = ("mu", "source", "model_id", "count", "window_start", "max_elapsed", "buffer_len")
+
+        def __init__(self, source, model_id):
+            self.mu = threading.Lock()
+            self.source, self.model_id = source, model_id
+            self.count, self.window_start, self.max_elapsed, self.buffer_len = 0, None, 0.0, 0.0
+
+    def __init__(self, on_report=None, clock=time.monotonic):
+        self.mu = threading.Lock()
+        self.m = {}
+        self.on_report, self.clock = on_report, clock
+
+    def get(self, source, model_id):
+        key = source + ":" + model_id
+        with self.mu:
+            t = self.m.get(key)
+            if t is None:
+                t = self.m[key] = self._T(source, model_id)
+            return t
+
+    def record(self, source, model_id, elapsed_s, buffer_len_s):
+        t = self.get(source, model_id)
+        with t.mu:
+            now = self.clock()
+            if t.window_start is None:
+                t.window_start = now
+            if now - t.window_start >= OVERRUN_REPORT_COOLDOWN_S:
+                if t.count >= OVERRUN_MIN_COUNT and self.on_report:
+                    self.on_report(t.source, t.model_id, t.count, t.max_elapsed, t.buffer_len, now - t.window_start)
+                t.count, t.max_elapsed, t.window_start = 0, 0.0, now
+            t.count += 1
+            if elapsed_s > t.max_elapsed:
+                t.max_elapsed, t.buffer_len = elapsed_s, buffer_len_s
+
+    def count(self, source, model_id):
+        t = self.get(source, model_id)
+        with t.mu:
+            return t.count
+
+    def remove_source(self, source):
+        with self.mu:
+            for k in [k for k in self.m if k.startswith(source + ":")]:
+                del self.m[k]
+
+    def cleanup(self, max_age_s):
+        now = self.clock()
+        with self.mu:
+            for k, t in list(self.m.items()):
+                with t.mu:
+                    idle = t.window_start is not None and now - t.window_start > max_age_s
+                    nothing = t.window_start is None and t.count == 0
+                if idle or nothing:
+                    del self.m[k]
+
+    def reset(self):
+        with self.mu:
+            self.m.clear()
+
+
+class OrchestratorError(RuntimeError):
+    pass
+
+
+class Orchestrator:
+    """orchestrator.go:63-68,514-572.  Lock order: models map -> `inference_mu` (one native call at a time, whatever the model)
+    -> the entry's own lock (instance lifecycle).  The map lock is dropped before the other two are taken so that unloading a
+    model never waits behind an inference.  An instance is anything with `predict_batch(flat, n)` (host.BirdNET / Perch)."""
+
+    class _Entry:
+        def __init__(self, instance, spec):
+            self.mu = threading.Lock()
+            self.instance, self.spec, self.active = instance, spec, True
+
+    def __init__(self, counters: _results.CounterMap = None):
+        self.mu = threading.Lock()
+        self.inference_mu = threading.Lock()
+        self.models = {}
+        self.counters = counters if counters is not None else _results.CounterMap()
+
+    def register(self, model_id, instance, spec: ModelSpec):
+        with self.mu:
+            self.models[model_id] = self._Entry(instance, spec)
+
+    def unload(self, model_id):
+        """Takes the map lock and the entry lock but NOT `inference_mu` (orchestrator.go:66)."""
+        with self.mu:
+            e = self.models.pop(model_id, None)
+        if e is not None:
+            with e.mu:
+                inst, e.instance = e.instance, None
+            if inst is not None and hasattr(inst, "close"):
+                inst.close()
+            self.counters.delete(model_id)
+
+    def model_spec_for(self, model_id):
+        with self.mu:
+            e = self.models.get(model_id)
+        return e.spec if e is not None else None
+
+    def set_active(self, model_id, on):
+        with self.mu:
+            e = self.models.get(model_id)
+        if e is not None:
+            e.active = bool(on)
+
+    def is_model_active(self, model_id):
+        with self.mu:
+            e = self.models.get(model_id)
+        return e is not None and e.active
+
+    def predict_model(self, model_id, call):
+        """`call(instance)` runs under the three locks; its duration goes to the per-model counters, an exception to the
+        error counter (PredictModel :553-569)."""
+        with self.mu:
+            e = self.models.get(model_id)
+        if e is None:
+            raise OrchestratorError(f"unknown model: {model_id}")
+        with self.inference_mu:
+            with e.mu:
+                if e.instance is None:
+                    raise OrchestratorError(f"model {model_id} has been closed")
+                t0 = time.perf_counter()
+                try:
+                    out = call(e.instance)
+                except Exception:
+                    self.counters.record_error(model_id)
+                    raise
+                self.counters.record_invoke(model_id, (time.perf_counter() - t0) * 1e6)
+                return out
+
+
+def _pcm_windows_predict(instance, windows, bit_depth):
+    """windows uint8 [n, window_bytes] -> per-window top-K lists.  The bytes go to the device as they are when the instance
+    can take them (`predict_pcm_batch`); otherwise they are widened here with the reference's own arithmetic (a1)."""
+    n = windows.shape[0]
+    if hasattr(instance, "predict_pcm_batch"):
+        return instance.predict_pcm_batch(windows.reshape(-1), bit_depth, n)
+    if bit_depth == 16:
+        x = windows.reshape(-1).view("<i2").astype(np.float32) / np.float32(32768.0)
+    elif bit_depth == 32:
+        x = windows.reshape(-1).view("<i4").astype(np.float32) / np.float32(2147483648.0)
+    elif bit_depth == 24:
+        b = windows.reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        v = np.where(v & 0x800000, v - (1 << 24), v)
+        x = v.astype(np.float32) / np.float32(8388608.0)
+    else:
+        raise StreamError(f"unsupported audio bit depth: {bit_depth}")
+    return instance.predict_batch(x, n)
+
+
+def process_windows(orch: Orchestrator, windows, start_times, captured_at, sources, model_id, queue: _results.ResultsQueue,
+                    overruns: OverrunTrackers, bit_depth=16, threshold=0.0):
+    """`ProcessData` for n windows of one model at once.  Returns the number of messages enqueued.
+    Elapsed time, the overrun check and the queue message are per window as in process.go:327-420; the one difference is
+    that the n windows share one device call, so each window's elapsed time is the whole call's (what a consumer waiting
+    for that window actually saw)."""
+    windows = np.ascontiguousarray(windows, np.uint8)
+    if windows.ndim == 1:
+        windows = windows[None]
+    n = windows.shape[0]
+    t0 = time.perf_counter()
+    lists = orch.predict_model(model_id, lambda inst: _pcm_windows_predict(inst, windows, bit_depth))
+    elapsed = time.perf_counter() - t0
+    spec = orch.model_spec_for(model_id)
+    interval = spec.buffer_interval_s() if spec is not None else 1.5       # fallback: BirdNET v2.4 (process.go:353)
+    sent = 0
+    for i in range(n):
+        if elapsed > interval:
+            overruns.record(sources[i], model_id, elapsed, interval)
+        dets = [_results.Detection(lbl, conf) for lbl, conf in lists[i] if conf >= threshold]
+        msg = _results.Results(start_time=float(start_times[i]), audio_captured_at=float(captured_at[i]),
+                               pcm_data=windows[i].tobytes(),            # independent copy: the window goes back to its pool
+                               results=dets, elapsed_time=elapsed, source=sources[i], model_id=model_id)
+        sent += queue.offer(msg)
+    return sent
+
+
+def process_data(orch, data, start_time, captured_at, source, model_id, queue, overruns, bit_depth=16):
+    """The reference's signature: one window."""
+    return process_windows(orch, np.frombuffer(data, np.uint8)[None], [start_time], [captured_at], [source], model_id, queue,
+                           overruns, bit_depth)
+
+
+class WindowBatcher:
+    """All (source, model) monitors of buffer_manager.go:388-496 in one object.  `tick()` is one poll: every buffer with a
+    window ready is read, windows of the same model form one batch (at most `max_batch` per device call), inactive models
+    are read and discarded exactly as the reference does (:478-480: the audio is consumed, not analysed)."""
+
+    def __init__(self, orch: Orchestrator, queue: _results.ResultsQueue = None, overruns: OverrunTrackers = None,
+                 max_batch=256, pre_capture_s=0.0, bit_depth=16, clock=time.time):
+        self.orch = orch
+        self.queue = queue if queue is not None else _results.ResultsQueue()
+        self.overruns = overruns if overruns is not None else OverrunTrackers()
+        self.max_batch, self.pre_capture_s, self.bit_depth, self.clock = max_batch, pre_capture_s, bit_depth, clock
+        self.buffers = {}                    # (source, model_id) -> AnalysisBuffer
+        self.mu = threading.Lock()
+
+    def allocate(self, source, model_id, capacity=None):
+        spec = self.orch.model_spec_for(model_id)
+        if spec is None:
+            raise OrchestratorError(f"unknown model: {model_id}")
+        clip, overlap, read = spec.buffer_dimensions()
+        ab = AnalysisBuffer(capacity if capacity is not None else 2 * clip, overlap, read, source)
+        with self.mu:
+            self.buffers[(source, model_id)] = ab
+        return ab
+
+    def remove(self, source, model_id=None):
+        with self.mu:
+            for k in [k for k in self.buffers if k[0] == source and (model_id is None or k[1] == model_id)]:
+                del self.buffers[k]
+        self.overruns.remove_source(source)
+
+    def write(self, source, data):
+        """Capture side: the same bytes go to every model's buffer of that source."""
+        with self.mu:
+            abs_ = [ab for (s, _), ab in self.buffers.items() if s == source]
+        for ab in abs_:
+            ab.write(data)
+
+    def tick(self):
+        with self.mu:
+            items = list(self.buffers.items())
+        per_model = {}
+        for (source, model_id), ab in items:
+            win = ab.read()
+            if win is None:
+                continue
+            if not self.orch.is_model_active(model_id):
+                continue
+            now = self.clock()
+            spec = self.orch.model_spec_for(model_id)
+            start = now - (self.pre_capture_s + spec.clip_length_s)       # beginTimeOffset, buffer_manager.go:490-491
+            per_model.setdefault(model_id, []).append((source, win, start, now))
+        sent = 0
+        for model_id, ws in per_model.items():
+            for lo in range(0, len(ws), self.max_batch):
+                part = ws[lo:lo + self.max_batch]
+                sent += process_windows(self.orch, np.stack([w for _, w, _, _ in part]), [s for _, _, s, _ in part],
+                                        [c for _, _, _, c in part], [src for src, _, _, _ in part], model_id, self.queue,
+                                        self.overruns, self.bit_depth)
+        return sent
