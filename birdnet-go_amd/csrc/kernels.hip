@@ -2937,24 +2937,42 @@ __global__ __launch_bounds__(1024) void k_se(SeParams p) {
     }
     __syncthreads();
     const bool v4 = (p.C & 3) == 0;
-    // FC1: one wave per output, 16-byte loads (the scalar form was ~54 dependent 4-byte loads per thread per FC)
-    for (int j = wave; j < p.Cr; j += NW) {
-        float acc = 0.f;
-        const float* wr = p.w1 + (size_t)j * p.C;
+    // FC1: one wave per output, 16-byte loads (the scalar form was ~54 dependent 4-byte loads per thread per FC).  A wave takes
+    // its outputs four at a time: the kernel is bound by round trips to the weights, so four rows' loads are in flight together
+    // (one clip: 21.7 -> 15.7 us on a 1152-channel layer, 11.9 -> 8.3 us on the first); each output's own sum keeps its order
+    // (a lane's columns ascending, then the butterfly), so no bit changes.
+    for (int j0 = wave; j0 < p.Cr; j0 += 4 * NW) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
         if (v4) {
-            const float4* w4 = reinterpret_cast<const float4*>(wr);
             const float4* m4 = reinterpret_cast<const float4*>(mean);
-#pragma unroll 5
-            for (int c = lane; c < p.C / 4; c += 64) {
-                float4 w = w4[c], mv = m4[c];
-                acc = fmaf(w.x, mv.x, acc); acc = fmaf(w.y, mv.y, acc); acc = fmaf(w.z, mv.z, acc); acc = fmaf(w.w, mv.w, acc);
+            const float4* w4 = reinterpret_cast<const float4*>(p.w1);
+            const int C4 = p.C / 4;
+#pragma unroll 2
+            for (int c = lane; c < C4; c += 64) {
+                const float4 mv = m4[c];
+                float4 w[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) w[u] = w4[(size_t)min(j0 + u * NW, p.Cr - 1) * C4 + c];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    acc[u] = fmaf(w[u].x, mv.x, acc[u]); acc[u] = fmaf(w[u].y, mv.y, acc[u]);
+                    acc[u] = fmaf(w[u].z, mv.z, acc[u]); acc[u] = fmaf(w[u].w, mv.w, acc[u]);
+                }
             }
         } else {
-#pragma unroll 4
-            for (int c = lane; c < p.C; c += 64) acc = fmaf(wr[c], mean[c], acc);
+            for (int c = lane; c < p.C; c += 64) {
+                const float mv = mean[c];
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc[u] = fmaf(p.w1[(size_t)min(j0 + u * NW, p.Cr - 1) * p.C + c], mv, acc[u]);
+            }
         }
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-        if (lane == 0) r[j] = apply_act(acc + (p.b1 ? p.b1[j] : 0.f), p.act1);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float a = acc[u];
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+            const int j = j0 + u * NW;
+            if (lane == 0 && j < p.Cr) r[j] = apply_act(a + (p.b1 ? p.b1[j] : 0.f), p.act1);
+        }
     }
     __syncthreads();
     // FC2: a thread owns 4 channels; G thread groups split the Cr range and fold through LDS in a fixed order
