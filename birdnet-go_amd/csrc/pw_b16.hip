@@ -1,0 +1,237 @@
+// gfx950 pointwise / dense GEMM of the "precision":"bf16" engines (BASELINE configs[4], Perch-style deployments):
+//   out[M,N] = act(bf16(A[M,K] (* scale[b,K])) . bf16(W[N,K])^T + bias[N]) (+ res[M,N]),   fp32 accumulate.
+// The arithmetic is exactly that of k_pw_bx3 with PwParams::prec = 1 (one v_mfma_f32_16x16x32_bf16 product per operand pair,
+// operands rounded to nearest even, slabs of 32 along K in order, the same K order inside a slab), so the two kernels agree
+// bit for bit (tests/test_perch_like.py); what differs is how the operands travel.  k_pw_bx3 is built for the six-product
+// fp32-equivalent form, where 6 MFMAs amortise each operand fragment: it stages A as fp32 through LDS and converts at the
+// fragment read.  With ONE product per fragment that traffic is the kernel (PMC, Perch bf16: 8-47 VALU per MFMA, 3-22 % of
+// the bf16 pipe busy, LDS bank conflicts on up to 90 % of LDS instructions).  Here:
+//   * A never touches LDS.  Wave w owns rows [32 w, 32 w + 32) of the block's 128-row tile and no other wave reads them, so a
+//     lane loads its own fragments straight from global memory (bf16 storage: two 8-byte loads per 16 x 32 fragment; fp32
+//     activations: two 16-byte loads), two slabs ahead; the squeeze-excite scale is multiplied in and the product rounded to
+//     bf16 in registers (4 v_cvt_pk_bf16_f32 per fragment), or - bf16 storage without scale - the loaded bits ARE the fragment.
+//   * W comes from the plan-time image k_pw_bx3 uses (hi plane = RNE bf16, already in fragment order [slab][plane][kq][row][8]):
+//     a slab's tile is a straight 16-byte-per-thread copy into LDS, double-buffered, read back conflict-free (lane = slot).
+//   * one barrier per slab (the weight buffer swap); bias / activation / residual / bf16 or fp32 store = pw_epilogue.
+// Block = 128 rows x 16 NT columns, 4 waves, accumulators [NT][2] x f32x4.
+#include "pw_common.h"
+
+#include <algorithm>
+
+namespace bnhip {
+
+typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32v4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32v2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ b16x8 b16_cvt8(const float4& a, const float4& b) {       // round to nearest even, 8 values
+    u32v4 h;
+    h[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a.x, a.y}, b16x2));
+    h[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a.z, a.w}, b16x2));
+    h[2] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){b.x, b.y}, b16x2));
+    h[3] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){b.z, b.w}, b16x2));
+    return __builtin_bit_cast(b16x8, h);
+}
+__device__ __forceinline__ float4 b16_unpack4(const u32v2& r) {
+    return make_float4(__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
+                       __uint_as_float(r[1] & 0xffff0000u));
+}
+
+// one slab's worth of a lane's A operand as loaded: k = 32 s + 4 kq .. + 3 (lo) and 32 s + 16 + 4 kq .. + 3 (hi) of its row - the
+// order of the weight image's slots, i.e. k_pw_bx3's fragment order, so that every product sits at the same position of the MFMA
+// in both kernels and their sums round alike
+template <bool ABF> struct ARaw;
+template <> struct ARaw<true> { u32v2 lo, hi; };
+template <> struct ARaw<false> { float4 lo, hi; };
+template <bool ABF, bool SCR> struct ASet { ARaw<ABF> a[2]; };
+template <bool ABF> struct ASet<ABF, true> { ARaw<ABF> a[2]; float4 slo[2], shi[2]; };
+
+// SCL: the squeeze-excite scale of a slab goes through LDS once per block ([clips of the row tile][32] floats) instead of being
+// loaded per row - possible when a 16-row MFMA tile never straddles two clips (HW % 16 == 0); otherwise each lane loads its own.
+// Loads run two slabs ahead for A (two register sets, the loop is unrolled by two) and one iteration ahead for the weight tile
+// (loaded in iteration s - 1, written to the idle LDS buffer at the top of iteration s, read in s + 1): with one slab of
+// prefetch every slab paid a memory latency (16 MFMAs = 256 cycles of cover against ~1.5 us).
+template <int NT, bool SC, bool ABF, bool SCL = false>
+__global__ __launch_bounds__(256) void k_pw_b16(PwParams p, const uint16_t* __restrict__ Wimg, int Npad, int nblk_n, unsigned nblk,
+                                                 FDiv dn, FDiv dhw) {
+    static_assert(!SCL || SC, "SCL is a form of SC");
+    constexpr bool SCR = SC && !SCL;                           // scale in registers, per lane
+    constexpr int WM = 2, BM = 64 * WM, BN = 16 * NT;
+    constexpr int WSLOTS = 4 * BN;                             // 16-byte slots of a slab's weight tile: [kq 4][row BN]
+    constexpr int WQ = (WSLOTS + 255) / 256;
+    constexpr int SCLIPS = BM / 16 + 1;                        // clips a 128-row tile can touch when HW >= 16
+    constexpr int SBUF = SCL ? SCLIPS * 32 : 0;                // floats of one scale buffer
+    constexpr int OBUF = WSLOTS * 4 + SBUF;                    // floats of one operand buffer
+    constexpr int STG = 4 * 16 * (BN + 4);                     // pw_epilogue's staging area (floats)
+    constexpr int LDSN = 2 * OBUF > STG ? 2 * OBUF : STG;
+    __shared__ __attribute__((aligned(16))) float lds[LDSN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const unsigned L = xcd_remap(blockIdx.x, nblk);
+    const int mblk = (int)fdiv(L, dn);
+    const int m0 = mblk * BM;
+    const int n0 = ((int)L - mblk * nblk_n) * BN;
+    const int K = p.K;
+    const int nslab = (K + 31) >> 5;
+
+    // element offsets of the lane's two rows (rows beyond M are clamped: their results are never stored)
+    unsigned aoff[WM], soff[SC ? WM : 1];
+    const int b_first = SCL ? (int)fdiv((unsigned)m0, dhw) : 0;                 // first clip of the row tile
+#pragma unroll
+    for (int mt = 0; mt < WM; mt++) {
+        const int m = min(m0 + 16 * WM * wave + 16 * mt + li, p.M - 1);
+        aoff[mt] = (unsigned)m * (unsigned)K + 4u * (unsigned)kq;
+        if (SC) {
+            const unsigned b = fdiv((unsigned)m, dhw);
+            soff[SC ? mt : 0] = SCL ? (unsigned)(((int)b - b_first) * 32 + 4 * kq)   // float offset inside the LDS scale buffer
+                                    : b * (unsigned)K + 4u * (unsigned)kq;
+        }
+    }
+    unsigned woff[WQ];
+#pragma unroll
+    for (int q = 0; q < WQ; q++) {
+        const int slot = min(tid + 256 * q, WSLOTS - 1);
+        const int kqs = slot / BN, r = slot - kqs * BN;
+        woff[q] = (unsigned)kqs * (unsigned)Npad + (unsigned)min(n0 + r, Npad - 1);       // 16-byte units inside plane 0 of a slab
+    }
+    const u32v4* W16 = reinterpret_cast<const u32v4*>(Wimg);
+    const uint16_t* A16 = reinterpret_cast<const uint16_t*>(p.A);
+    // scale tile loader: thread t -> clip t / 8, k quad t % 8
+    const int sclip = tid >> 3, sk4 = tid & 7;
+    const int nclips_blk = SCL ? (int)fdiv((unsigned)(min(m0 + BM, p.M) - 1), dhw) - b_first + 1 : 0;
+
+    ASet<ABF, SCR> set0, set1;
+    u32v4 wreg[WQ];
+    float4 sreg;
+    auto aload = [&](int sl, auto& st) {
+        const int k0 = sl * 32;
+        const bool inlo = k0 + 4 * kq < K, inhi = k0 + 16 + 4 * kq < K;      // K tail: columns beyond K are zeros (their weights too)
+#pragma unroll
+        for (int mt = 0; mt < WM; mt++) {
+            if constexpr (ABF) {
+                const uint16_t* ap = A16 + aoff[mt] + k0;
+                st.a[mt].lo = inlo ? *reinterpret_cast<const u32v2*>(ap) : (u32v2){0u, 0u};
+                st.a[mt].hi = inhi ? *reinterpret_cast<const u32v2*>(ap + 16) : (u32v2){0u, 0u};
+            } else {
+                const float* ap = p.A + aoff[mt] + k0;
+                st.a[mt].lo = inlo ? *reinterpret_cast<const float4*>(ap) : make_float4(0.f, 0.f, 0.f, 0.f);
+                st.a[mt].hi = inhi ? *reinterpret_cast<const float4*>(ap + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if constexpr (SCR) {
+                const float* sp = p.ascale + soff[mt] + k0;
+                st.slo[mt] = inlo ? *reinterpret_cast<const float4*>(sp) : make_float4(0.f, 0.f, 0.f, 0.f);
+                st.shi[mt] = inhi ? *reinterpret_cast<const float4*>(sp + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto wload = [&](int sl) {
+        const int k0 = sl * 32;
+        if constexpr (SCL) {
+            sreg = (sclip < nclips_blk && k0 + 4 * sk4 < K)
+                       ? *reinterpret_cast<const float4*>(p.ascale + (size_t)(b_first + sclip) * K + k0 + 4 * sk4)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const u32v4* Ws = W16 + (size_t)sl * 12 * Npad;                       // 3 planes x 4 kq x Npad slots per slab; plane 0 = hi
+#pragma unroll
+        for (int q = 0; q < WQ; q++)
+            if (tid + 256 * q < WSLOTS) wreg[q] = Ws[woff[q]];
+    };
+    auto wstore = [&](int buf) {
+        float* base = lds + buf * OBUF;
+        u32v4* Wl = reinterpret_cast<u32v4*>(base);
+#pragma unroll
+        for (int q = 0; q < WQ; q++)
+            if (tid + 256 * q < WSLOTS) Wl[tid + 256 * q] = wreg[q];
+        if constexpr (SCL) {
+            if (sclip < SCLIPS) *reinterpret_cast<float4*>(base + WSLOTS * 4 + sclip * 32 + 4 * sk4) = sreg;
+        }
+    };
+    auto afrag = [&](int mt, const auto& st, const float* sbuf) -> b16x8 {
+        if constexpr (ABF && !SC) {
+            return __builtin_bit_cast(b16x8, (u32v4){st.a[mt].lo[0], st.a[mt].lo[1], st.a[mt].hi[0], st.a[mt].hi[1]});
+        } else {
+            float4 v0, v1;
+            if constexpr (ABF) { v0 = b16_unpack4(st.a[mt].lo); v1 = b16_unpack4(st.a[mt].hi); }
+            else { v0 = st.a[mt].lo; v1 = st.a[mt].hi; }
+            if constexpr (SC) {
+                float4 s0, s1;
+                if constexpr (SCL) {
+                    s0 = *reinterpret_cast<const float4*>(sbuf + soff[mt]);
+                    s1 = *reinterpret_cast<const float4*>(sbuf + soff[mt] + 16);
+                } else { s0 = st.slo[mt]; s1 = st.shi[mt]; }
+                v0.x *= s0.x; v0.y *= s0.y; v0.z *= s0.z; v0.w *= s0.w;
+                v1.x *= s1.x; v1.y *= s1.y; v1.z *= s1.z; v1.w *= s1.w;
+            }
+            return b16_cvt8(v0, v1);
+        }
+    };
+
+    f32x4 acc[NT][WM];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int mt = 0; mt < WM; mt++) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // one slab: the weight tile of the NEXT slab (in wreg since the previous iteration) goes to the idle buffer and wreg takes the
+    // slab after it; this slab's A fragments come out of `st`, which then takes slab sl + 2
+    auto slab = [&](int sl, auto& st) {
+        if (sl + 1 < nslab) wstore((sl + 1) & 1);          // (every wave finished reading that buffer before the last barrier)
+        if (sl + 2 < nslab) wload(sl + 2);
+        const float* obuf = lds + (sl & 1) * OBUF;
+        b16x8 ah[WM];
+#pragma unroll
+        for (int mt = 0; mt < WM; mt++) ah[mt] = afrag(mt, st, obuf + WSLOTS * 4);
+        if (sl + 2 < nslab) aload(sl + 2, st);
+        const u32v4* Wl = reinterpret_cast<const u32v4*>(obuf);
+        b16x8 wf[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) wf[t] = __builtin_bit_cast(b16x8, Wl[kq * BN + 16 * t + li]);
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int mt = 0; mt < WM; mt++) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], ah[mt], acc[t][mt], 0, 0, 0);
+        __syncthreads();
+    };
+    aload(0, set0);
+    if (nslab > 1) aload(1, set1);
+    wload(0);
+    wstore(0);
+    if (nslab > 1) wload(1);
+    __syncthreads();
+    for (int sl = 0; sl < nslab; sl += 2) {
+        slab(sl, set0);
+        if (sl + 1 < nslab) slab(sl + 1, set1);
+    }
+    pw_epilogue<NT, WM>(p, acc, lds, m0, n0);
+}
+
+bool pw_b16_ok(int prec, int K) {   // (the switch is read per call - one getenv beside a 5 us launch - so that a test can flip it inside one process)
+    const char* e = getenv("BNHIP_PW_B16");
+    return prec == 1 && (K & 3) == 0 && K >= 16 && !(e && e[0] == '0');
+}
+
+bool pw_b16_forced() {
+    const char* e = getenv("BNHIP_PW_B16");
+    return e && e[0] == '2';
+}
+
+static long g_pw_b16_launches = 0;      // diagnostics (tests assert that this path, not k_pw_bx3's, ran); calls are serialised per handle
+void launch_pw_b16(const PwParams& p, const uint16_t* Wimg, int nt, int Npad, int nblk_n, unsigned nblk, hipStream_t s) {
+    g_pw_b16_launches++;
+    const FDiv dn = make_fdiv((unsigned)nblk_n), dhw = make_fdiv((unsigned)std::max(p.HW, 1));
+    const bool sc = p.ascale != nullptr, abf = p.a_bf16 != 0;
+    dim3 grid(nblk);
+    const bool scl = sc && p.HW >= 16 && (p.HW & 15) == 0;      // a 16-row tile never straddles two clips: scale through LDS
+#define B16_LAUNCH(NT_, SC_, ABF_, SCL_) hipLaunchKernelGGL((k_pw_b16<NT_, SC_, ABF_, SCL_>), grid, dim3(256), 0, s, p, Wimg, Npad, nblk_n, nblk, dn, dhw)
+#define B16_CASE(NT_) case NT_: if (scl) { if (abf) B16_LAUNCH(NT_, true, true, true); else B16_LAUNCH(NT_, true, false, true); } \
+                      else if (sc) { if (abf) B16_LAUNCH(NT_, true, true, false); else B16_LAUNCH(NT_, true, false, false); } \
+                      else { if (abf) B16_LAUNCH(NT_, false, true, false); else B16_LAUNCH(NT_, false, false, false); } break;
+    switch (nt) { B16_CASE(1) B16_CASE(2) B16_CASE(3) B16_CASE(4) B16_CASE(5) B16_CASE(6) B16_CASE(7) default: B16_CASE(8) }
+#undef B16_LAUNCH
+#undef B16_CASE
+}
+
+}  // namespace bnhip
+
+extern "C" long bnhip_debug_pw_b16_launches(void) { return bnhip::g_pw_b16_launches; }

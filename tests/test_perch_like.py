@@ -137,7 +137,7 @@ def test_expand_dw_both_orientations_vs_oracle(gpu, orient, monkeypatch):
             ed = [s for s in c.describe()["steps"] if s["kernel"] == "expand_dw" and not s["name"].startswith("stem")]
         finally:
             c.close()
-        assert ed and all((s["shape"] >= 14) == (orient == "t") for s in ed), [(s["name"], s["shape"]) for s in ed]
+        assert ed and all((s["shape"] >= 22) == (orient == "t") for s in ed), [(s["name"], s["shape"]) for s in ed]
         assert_parity(got, ref)
         assert np.abs(got - ref).max() < 1e-3
 
@@ -317,3 +317,31 @@ def test_birdnet_v3_output_rule_vs_oracle(gpu):
         c.close()
     assert got.shape == (3, 40) and emb.shape == (3, 1280)
     assert np.abs(got - outs[1]).max() < 1e-3 and np.abs(emb - outs[0]).max() < 1e-3
+
+
+@pytest.mark.gpu
+def test_bf16_gemm_kernel_equals_the_one_product_path_of_the_split_kernel(gpu, monkeypatch):
+    """k_pw_b16 (pw_b16.hip: A fragments straight from global memory, W tile through LDS in fragment order) performs exactly
+    the arithmetic of k_pw_bx3 with one product per operand pair; 64 clips so that the 128-row tiles it serves are chosen
+    (small grids shrink to 64-row tiles, which stay on k_pw_bx3).  Bit-identical logits and embeddings, squeeze-excite scaled
+    projections, fp32 and bf16-stored operands, K tails (232, 136 are not multiples of 32) included."""
+    import ctypes
+    cfg = sm.perch_config()
+    blob = sm.build_model(cfg)
+    n = 64
+    x = sm.synth_clips(n, cfg.n_samples, cfg.sample_rate, first=3)
+    lib = host.load_library()
+    lib.bnhip_debug_pw_b16_launches.restype = ctypes.c_long
+    out = {}
+    for on in ("2", "0"):                                     # 2: every 128-row tile on k_pw_b16; 0: none
+        monkeypatch.setenv("BNHIP_PW_B16", on)
+        c = host.HipClassifier(blob, max_batch=n, precision="bf16", autotune=False, lanes=1)
+        try:
+            before = lib.bnhip_debug_pw_b16_launches()
+            out[on] = [a.copy() for a in c.predict_batch(x.reshape(-1), n, want_embeddings=True)]
+            used = lib.bnhip_debug_pw_b16_launches() - before
+        finally:
+            c.close()
+        assert (used > 20) if on == "2" else (used == 0), used
+    assert np.array_equal(out["2"][0], out["0"][0]), np.abs(out["2"][0] - out["0"][0]).max()
+    assert np.array_equal(out["2"][1], out["0"][1])
