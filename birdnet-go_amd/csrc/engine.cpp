@@ -1807,7 +1807,7 @@ bool Engine::load_tuning(const char* path) {
         size_t idx = 0; Row& r = rows[i]; char name[512] = {0};
         ok = fscanf(f, "%zu %d %d %d %d %d %d %d %d %d %511[^\n]", &idx, &r.kind, &r.nt, &r.wm, &r.ntf, &r.wmf, &r.shape, &r.dwl, &r.bx, &r.S, name) == 11 &&
              idx == i && r.kind == (int)steps[i].kind && steps[i].name == name;
-        if (ok && steps[i].kind == S_PW) ok = r.nt >= 0 && r.nt <= 8 && r.ntf >= 0 && r.ntf <= 8 && r.wm >= 0 && r.wm <= 9 && r.wmf >= 0 && r.wmf <= 9 &&
+        if (ok && steps[i].kind == S_PW) ok = r.nt >= 0 && r.nt <= 8 && r.ntf >= 0 && r.ntf <= 8 && r.wm >= 0 && r.wm <= 10 && r.wmf >= 0 && r.wmf <= 10 &&
                                               ((r.wm >= 5) == (steps[i].wm >= 5) || !steps[i].wbx);       // (never switches the arithmetic family)
         if (ok && (steps[i].kind == S_EXPAND_DW || (steps[i].kind == S_DW && r.dwl))) {
             const bool st_ = steps[i].kind == S_EXPAND_DW && steps[i].mode == 1;
@@ -2053,7 +2053,7 @@ void Engine::autotune_pw() {
             if (arith_bx) {
                 // split-bf16 candidates (wm 5 / 6 = 64- / 128-row tiles, 7 / 8 the software-pipelined form): the fastest tile
                 float bbest = 1e30f; int bnt = 0, bwm = 0;
-                for (int wm = pw_b16_ok(precision, s.C) ? 9 : 8; wm >= 5; wm--)
+                for (int wm = pw_b16_ok(precision, s.C) ? (precision == 0 ? 10 : 9) : 8; wm >= 5; wm--)
                     for (int nt = 1; nt <= 8; nt++) {
                         long cols = (long)((s.Co + nt * 16 - 1) / (nt * 16)) * nt * 16;
                         if (cols * 100 > (long)((s.Co + 15) / 16 * 16) * 130) continue;

@@ -122,12 +122,12 @@ bool pw_bx3p_ok(int nt, int wm /*1 | 2*/, int K);     // PwParams::wm 7 / 8: sof
 int pw_bx3_npad(int N);
 std::vector<uint16_t> pw_bx3_image(const float* W, int N, int K);
 void launch_pw_bx3(const PwParams& p, const uint16_t* Wimg, hipStream_t s);
-// "precision":"bf16" form of the same GEMM (pw_b16.hip; PwParams::prec == 1, PwParams::wm = 9: 128-row tiles): called by
-// launch_pw_bx3, which has resolved the tile (nt = 16-column units) and the grid (a grid too small for 128-row tiles falls back
-// to k_pw_bx3's 64-row form).  BNHIP_PW_B16=0 takes the candidate away from the tuner (A/B runs, parity test).
+// The same GEMM with A streamed straight from global memory two slabs ahead (pw_b16.hip; PwParams::wm = 9 / 10: 128- / 64-row
+// tiles; one product per operand pair for "precision":"bf16" engines - 128-row tiles only - or the six-product fp32-equivalent
+// form): called by launch_pw_bx3, which has resolved the tile (nt = 16-column units) and the grid.  BNHIP_PW_B16=0 takes the candidate away from the tuner (A/B runs, parity test).
 bool pw_b16_ok(int prec, int K);
 bool pw_b16_forced();              // BNHIP_PW_B16=2: every 128-row tile of a "precision":"bf16" engine takes k_pw_b16 (parity test)
-void launch_pw_b16(const PwParams& p, const uint16_t* Wimg, int nt, int Npad, int nblk_n, unsigned nblk, hipStream_t s);
+void launch_pw_b16(const PwParams& p, const uint16_t* Wimg, int nt, int wm /*1 | 2*/, int Npad, int nblk_n, unsigned nblk, hipStream_t s);
 
 struct DwParams {
     const float* in; const float* w /*[kh][kw][C]*/; const float* bias; float* out;

@@ -1419,8 +1419,8 @@ static inline bool pw_fill_grid(int M, int N, int* nt, int* wm, unsigned* nblk, 
 }
 void launch_pw_bx3(const PwParams& p, const uint16_t* Wimg, hipStream_t s) {
     int nt = (p.nt >= 1 && p.nt <= 8) ? p.nt : pick_nt(p.M, p.N);
-    int wm = (p.wm == 5 || p.wm == 7) ? 1 : 2;             // PwParams::wm 5 / 6: 64- / 128-row tiles on the split-bf16 kernel, 7 / 8: pipelined,
-                                                           // 9: 128-row tiles on k_pw_b16 ("precision":"bf16" engines only, pw_b16_ok)
+    int wm = (p.wm == 5 || p.wm == 7 || p.wm == 10) ? 1 : 2;   // PwParams::wm 5 / 6: 64- / 128-row tiles on the split-bf16 kernel, 7 / 8: pipelined,
+                                                           // 10 / 9: 64- / 128-row tiles on k_pw_b16 (pw_b16.hip; one-product engines: 128 only)
     bool pipe = (p.wm == 7 || p.wm == 8) && pw_bx3p_ok(nt, wm, p.K);
     int bm = 64 * wm;
     int nblk_n = (p.N + nt * 16 - 1) / (nt * 16);
@@ -1430,7 +1430,10 @@ void launch_pw_bx3(const PwParams& p, const uint16_t* Wimg, hipStream_t s) {
     const int Npad = pw_bx3_npad(p.N);
     // "precision":"bf16" engines: 128-row tiles run on the kernel built for one product per operand fragment (pw_b16.hip) -
     // the same arithmetic, A straight from global memory into fragments
-    if ((p.wm == 9 || pw_b16_forced()) && wm == 2 && pw_b16_ok(p.prec, p.K)) { launch_pw_b16(p, Wimg, nt, Npad, nblk_n, nblk, s); return; }
+    if ((p.wm == 9 || p.wm == 10 || pw_b16_forced()) && (wm == 2 || p.prec == 0) && pw_b16_ok(p.prec, p.K)) {
+        launch_pw_b16(p, Wimg, nt, wm, Npad, nblk_n, nblk, s);
+        return;
+    }
     const FDiv dn = make_fdiv((unsigned)nblk_n), dhw = make_fdiv((unsigned)std::max(p.HW, 1));
     const bool sc = p.ascale != nullptr;
     dim3 grid(nblk);

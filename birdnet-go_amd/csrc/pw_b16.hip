@@ -33,6 +33,27 @@ __device__ __forceinline__ b16x8 b16_cvt8(const float4& a, const float4& b) {   
     h[3] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){b.z, b.w}, b16x2));
     return __builtin_bit_cast(b16x8, h);
 }
+// fp32 -> three bf16 pieces, exactly k_pw_bx3's decomposition (hi = RNE(x), mid = RNE(x - hi), lo = RNE(x - hi - mid); the
+// subtractions are exact and kept scalar: packed they cost ~13 cycles beside MFMAs against ~4)
+__device__ __forceinline__ float b16_sub(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void b16_split8(const float4& a, const float4& b, b16x8* hi, b16x8* mid, b16x8* lo) {
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    u32v4 h, m, l;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const f32x2 v = {x[2 * q], x[2 * q + 1]};
+        const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b16x2));
+        const f32x2 r = {b16_sub(v[0], __uint_as_float(hb << 16)), b16_sub(v[1], __uint_as_float(hb & 0xffff0000u))};
+        const unsigned mb = __builtin_bit_cast(unsigned, __builtin_convertvector(r, b16x2));
+        const f32x2 t = {b16_sub(r[0], __uint_as_float(mb << 16)), b16_sub(r[1], __uint_as_float(mb & 0xffff0000u))};
+        h[q] = hb; m[q] = mb; l[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, b16x2));
+    }
+    *hi = __builtin_bit_cast(b16x8, h); *mid = __builtin_bit_cast(b16x8, m); *lo = __builtin_bit_cast(b16x8, l);
+}
 __device__ __forceinline__ float4 b16_unpack4(const u32v2& r) {
     return make_float4(__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
                        __uint_as_float(r[1] & 0xffff0000u));
@@ -52,13 +73,18 @@ template <bool ABF> struct ASet<ABF, true> { ARaw<ABF> a[2]; float4 slo[2], shi[
 // Loads run two slabs ahead for A (two register sets, the loop is unrolled by two) and one iteration ahead for the weight tile
 // (loaded in iteration s - 1, written to the idle LDS buffer at the top of iteration s, read in s + 1): with one slab of
 // prefetch every slab paid a memory latency (16 MFMAs = 256 cycles of cover against ~1.5 us).
-template <int NT, bool SC, bool ABF, bool SCL = false>
+// SIX: the fp32-equivalent form (PwParams::prec == 0, fp32 engines): A split into three bf16 pieces in registers, all three
+// weight planes of the slab in LDS, six products per operand pair in k_pw_bx3's order.  WM: 16-row tiles per wave (rows per
+// block = 64 WM).
+template <int NT, bool SC, bool ABF, bool SCL = false, int WM = 2, bool SIX = false>
 __global__ __launch_bounds__(256) void k_pw_b16(PwParams p, const uint16_t* __restrict__ Wimg, int Npad, int nblk_n, unsigned nblk,
                                                  FDiv dn, FDiv dhw) {
     static_assert(!SCL || SC, "SCL is a form of SC");
+    static_assert(!SIX || !ABF, "fp32 engines keep fp32 activations");
     constexpr bool SCR = SC && !SCL;                           // scale in registers, per lane
-    constexpr int WM = 2, BM = 64 * WM, BN = 16 * NT;
-    constexpr int WSLOTS = 4 * BN;                             // 16-byte slots of a slab's weight tile: [kq 4][row BN]
+    constexpr int BM = 64 * WM, BN = 16 * NT;
+    constexpr int NP = SIX ? 3 : 1;                            // weight planes used (hi | hi, mid, lo)
+    constexpr int WSLOTS = NP * 4 * BN;                        // 16-byte slots of a slab's weight tile: [plane NP][kq 4][row BN]
     constexpr int WQ = (WSLOTS + 255) / 256;
     constexpr int SCLIPS = BM / 16 + 1;                        // clips a 128-row tile can touch when HW >= 16
     constexpr int SBUF = SCL ? SCLIPS * 32 : 0;                // floats of one scale buffer
@@ -92,8 +118,8 @@ __global__ __launch_bounds__(256) void k_pw_b16(PwParams p, const uint16_t* __re
 #pragma unroll
     for (int q = 0; q < WQ; q++) {
         const int slot = min(tid + 256 * q, WSLOTS - 1);
-        const int kqs = slot / BN, r = slot - kqs * BN;
-        woff[q] = (unsigned)kqs * (unsigned)Npad + (unsigned)min(n0 + r, Npad - 1);       // 16-byte units inside plane 0 of a slab
+        const int kqs = slot / BN, r = slot - kqs * BN;                                   // kqs = plane * 4 + kq
+        woff[q] = (unsigned)kqs * (unsigned)Npad + (unsigned)min(n0 + r, Npad - 1);       // 16-byte units inside a slab of the image
     }
     const u32v4* W16 = reinterpret_cast<const u32v4*>(Wimg);
     const uint16_t* A16 = reinterpret_cast<const uint16_t*>(p.A);
@@ -147,23 +173,18 @@ __global__ __launch_bounds__(256) void k_pw_b16(PwParams p, const uint16_t* __re
             if (sclip < SCLIPS) *reinterpret_cast<float4*>(base + WSLOTS * 4 + sclip * 32 + 4 * sk4) = sreg;
         }
     };
-    auto afrag = [&](int mt, const auto& st, const float* sbuf) -> b16x8 {
-        if constexpr (ABF && !SC) {
-            return __builtin_bit_cast(b16x8, (u32v4){st.a[mt].lo[0], st.a[mt].lo[1], st.a[mt].hi[0], st.a[mt].hi[1]});
-        } else {
-            float4 v0, v1;
-            if constexpr (ABF) { v0 = b16_unpack4(st.a[mt].lo); v1 = b16_unpack4(st.a[mt].hi); }
-            else { v0 = st.a[mt].lo; v1 = st.a[mt].hi; }
-            if constexpr (SC) {
-                float4 s0, s1;
-                if constexpr (SCL) {
-                    s0 = *reinterpret_cast<const float4*>(sbuf + soff[mt]);
-                    s1 = *reinterpret_cast<const float4*>(sbuf + soff[mt] + 16);
-                } else { s0 = st.slo[mt]; s1 = st.shi[mt]; }
-                v0.x *= s0.x; v0.y *= s0.y; v0.z *= s0.z; v0.w *= s0.w;
-                v1.x *= s1.x; v1.y *= s1.y; v1.z *= s1.z; v1.w *= s1.w;
-            }
-            return b16_cvt8(v0, v1);
+    // the lane's A values of one 16-row tile for this slab as fp32 (scale applied), or directly as a bf16 fragment
+    auto avals = [&](int mt, const auto& st, const float* sbuf, float4& v0, float4& v1) {
+        if constexpr (ABF) { v0 = b16_unpack4(st.a[mt].lo); v1 = b16_unpack4(st.a[mt].hi); }
+        else { v0 = st.a[mt].lo; v1 = st.a[mt].hi; }
+        if constexpr (SC) {
+            float4 s0, s1;
+            if constexpr (SCL) {
+                s0 = *reinterpret_cast<const float4*>(sbuf + soff[mt]);
+                s1 = *reinterpret_cast<const float4*>(sbuf + soff[mt] + 16);
+            } else { s0 = st.slo[mt]; s1 = st.shi[mt]; }
+            v0.x *= s0.x; v0.y *= s0.y; v0.z *= s0.z; v0.w *= s0.w;
+            v1.x *= s1.x; v1.y *= s1.y; v1.z *= s1.z; v1.w *= s1.w;
         }
     };
 
@@ -179,18 +200,55 @@ __global__ __launch_bounds__(256) void k_pw_b16(PwParams p, const uint16_t* __re
         if (sl + 1 < nslab) wstore((sl + 1) & 1);          // (every wave finished reading that buffer before the last barrier)
         if (sl + 2 < nslab) wload(sl + 2);
         const float* obuf = lds + (sl & 1) * OBUF;
-        b16x8 ah[WM];
+        b16x8 ah[WM], am[SIX ? WM : 1], al[SIX ? WM : 1];
 #pragma unroll
-        for (int mt = 0; mt < WM; mt++) ah[mt] = afrag(mt, st, obuf + WSLOTS * 4);
+        for (int mt = 0; mt < WM; mt++) {
+            if constexpr (ABF && !SC) {
+                ah[mt] = __builtin_bit_cast(b16x8, (u32v4){st.a[mt].lo[0], st.a[mt].lo[1], st.a[mt].hi[0], st.a[mt].hi[1]});
+            } else {
+                float4 v0, v1;
+                avals(mt, st, obuf + WSLOTS * 4, v0, v1);
+                if constexpr (SIX) b16_split8(v0, v1, &ah[mt], &am[SIX ? mt : 0], &al[SIX ? mt : 0]);
+                else ah[mt] = b16_cvt8(v0, v1);
+            }
+        }
         if (sl + 2 < nslab) aload(sl + 2, st);
         const u32v4* Wl = reinterpret_cast<const u32v4*>(obuf);
-        b16x8 wf[NT];
+        if constexpr (SIX) {
+            // weight fragments of tile t + 1 are requested before the MFMAs of tile t
+            u32v4 wfr[2][3];
 #pragma unroll
-        for (int t = 0; t < NT; t++) wf[t] = __builtin_bit_cast(b16x8, Wl[kq * BN + 16 * t + li]);
+            for (int pl3 = 0; pl3 < 3; pl3++) wfr[0][pl3] = Wl[(pl3 * 4 + kq) * BN + li];
 #pragma unroll
-        for (int t = 0; t < NT; t++)
+            for (int t = 0; t < NT; t++) {
+                if (t + 1 < NT) {
 #pragma unroll
-            for (int mt = 0; mt < WM; mt++) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], ah[mt], acc[t][mt], 0, 0, 0);
+                    for (int pl3 = 0; pl3 < 3; pl3++) wfr[(t + 1) & 1][pl3] = Wl[(pl3 * 4 + kq) * BN + 16 * (t + 1) + li];
+                }
+                const b16x8 wh = __builtin_bit_cast(b16x8, wfr[t & 1][0]);
+                const b16x8 wm = __builtin_bit_cast(b16x8, wfr[t & 1][1]);
+                const b16x8 wl = __builtin_bit_cast(b16x8, wfr[t & 1][2]);
+#pragma unroll
+                for (int mt = 0; mt < WM; mt++) {
+                    f32x4 c = acc[t][mt];                        // smallest terms first (k_pw_bx3's order)
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[mt], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[SIX ? mt : 0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, am[SIX ? mt : 0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, ah[mt], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, am[SIX ? mt : 0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[mt], c, 0, 0, 0);
+                    acc[t][mt] = c;
+                }
+            }
+        } else {
+            b16x8 wf[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) wf[t] = __builtin_bit_cast(b16x8, Wl[kq * BN + 16 * t + li]);
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int mt = 0; mt < WM; mt++) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], ah[mt], acc[t][mt], 0, 0, 0);
+        }
         __syncthreads();
     };
     aload(0, set0);
@@ -208,27 +266,32 @@ __global__ __launch_bounds__(256) void k_pw_b16(PwParams p, const uint16_t* __re
 
 bool pw_b16_ok(int prec, int K) {   // (the switch is read per call - one getenv beside a 5 us launch - so that a test can flip it inside one process)
     const char* e = getenv("BNHIP_PW_B16");
-    return prec == 1 && (K & 3) == 0 && K >= 16 && !(e && e[0] == '0');
+    return (prec == 0 || prec == 1) && (K & 3) == 0 && K >= 16 && !(e && e[0] == '0');
 }
-
 bool pw_b16_forced() {
     const char* e = getenv("BNHIP_PW_B16");
     return e && e[0] == '2';
 }
 
 static long g_pw_b16_launches = 0;      // diagnostics (tests assert that this path, not k_pw_bx3's, ran); calls are serialised per handle
-void launch_pw_b16(const PwParams& p, const uint16_t* Wimg, int nt, int Npad, int nblk_n, unsigned nblk, hipStream_t s) {
+// prec 1 (one product): 128-row tiles; prec 0 (six products): 64- or 128-row tiles (wm = 1 | 2)
+void launch_pw_b16(const PwParams& p, const uint16_t* Wimg, int nt, int wm, int Npad, int nblk_n, unsigned nblk, hipStream_t s) {
     g_pw_b16_launches++;
     const FDiv dn = make_fdiv((unsigned)nblk_n), dhw = make_fdiv((unsigned)std::max(p.HW, 1));
-    const bool sc = p.ascale != nullptr, abf = p.a_bf16 != 0;
-    dim3 grid(nblk);
+    const bool sc = p.ascale != nullptr, abf = p.a_bf16 != 0, six = p.prec == 0;
     const bool scl = sc && p.HW >= 16 && (p.HW & 15) == 0;      // a 16-row tile never straddles two clips: scale through LDS
-#define B16_LAUNCH(NT_, SC_, ABF_, SCL_) hipLaunchKernelGGL((k_pw_b16<NT_, SC_, ABF_, SCL_>), grid, dim3(256), 0, s, p, Wimg, Npad, nblk_n, nblk, dn, dhw)
-#define B16_CASE(NT_) case NT_: if (scl) { if (abf) B16_LAUNCH(NT_, true, true, true); else B16_LAUNCH(NT_, true, false, true); } \
-                      else if (sc) { if (abf) B16_LAUNCH(NT_, true, true, false); else B16_LAUNCH(NT_, true, false, false); } \
-                      else { if (abf) B16_LAUNCH(NT_, false, true, false); else B16_LAUNCH(NT_, false, false, false); } break;
+    dim3 grid(nblk);
+#define B16_LAUNCH(NT_, SC_, ABF_, SCL_, WM_, SIX_) hipLaunchKernelGGL((k_pw_b16<NT_, SC_, ABF_, SCL_, WM_, SIX_>), grid, dim3(256), 0, s, p, Wimg, Npad, nblk_n, nblk, dn, dhw)
+#define B16_FLAV(NT_, WM_, SIX_, ABF_) do { if (scl) B16_LAUNCH(NT_, true, ABF_, true, WM_, SIX_); else if (sc) B16_LAUNCH(NT_, true, ABF_, false, WM_, SIX_); \
+                                            else B16_LAUNCH(NT_, false, ABF_, false, WM_, SIX_); } while (0)
+#define B16_CASE(NT_) case NT_: \
+        if (six) { if (wm == 1) B16_FLAV(NT_, 1, true, false); else B16_FLAV(NT_, 2, true, false); } \
+        else if (abf) B16_FLAV(NT_, 2, false, true); \
+        else B16_FLAV(NT_, 2, false, false); \
+        break;
     switch (nt) { B16_CASE(1) B16_CASE(2) B16_CASE(3) B16_CASE(4) B16_CASE(5) B16_CASE(6) B16_CASE(7) default: B16_CASE(8) }
 #undef B16_LAUNCH
+#undef B16_FLAV
 #undef B16_CASE
 }
 

@@ -663,3 +663,24 @@ def test_range_filter_fp16_batch(built_lib):
     with pytest.raises(host.HipError, match="input size mismatch"):
         rf.predict_batch(np.zeros(7, np.float32), 2)
     rf.close()
+
+
+def test_streamed_split_gemm_equals_the_staged_one(full_blob, monkeypatch):
+    """k_pw_b16 in its six-product form (csrc/pw_b16.hip: A fragments straight from global memory two slabs ahead, the three
+    weight planes of a slab through LDS) computes what k_pw_bx3 computes - same split, same product order - so forcing every
+    split-bf16 layer onto it changes no bit: 64-row tiles (12 clips, tile shrinking) and 128-row tiles (64 clips)."""
+    import ctypes
+    lib = host.load_library()
+    lib.bnhip_debug_pw_b16_launches.restype = ctypes.c_long
+    for n in (12, 64):
+        x = sm.synth_clips(n, 144000, 48000)
+        out = {}
+        for mode in ("2", "0"):
+            monkeypatch.setenv("BNHIP_PW_B16", mode)
+            c = host.HipClassifier(full_blob, max_batch=n, autotune=False, lanes=1)
+            before = lib.bnhip_debug_pw_b16_launches()
+            out[mode] = c.predict_batch(x.reshape(-1), n).copy()
+            used = lib.bnhip_debug_pw_b16_launches() - before
+            c.close()
+            assert (used >= 15) if mode == "2" else (used == 0), (n, mode, used)
+        assert np.array_equal(out["2"], out["0"]), (n, np.abs(out["2"] - out["0"]).max())
