@@ -2235,8 +2235,13 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
 // are bound by unhidden latency at the three blocks per CU their 40-50 KB footprints allow (a wave waits two thirds of its
 // life); with the same LDS the CU then holds twice the waves, each owning half the pixel tiles in phase 1 and half the output
 // rows in phase 2 (so the registers that stay live across the chunk loop halve too).
-template <int K, int S, int TOH, int TOW, int TRH, bool STEM, int KW, bool LOOP = !STEM, int NW = 4>
-__global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, KW, !LOOP, NW)) void k_expand_dw_sk(ExpDwParams p, unsigned nblk) {
+// B16 ("precision":"bf16" engines, BASELINE configs[4] "bf16 MFMA conv"): the expand GEMM on v_mfma_f32_16x16x32_bf16 with one
+// product per operand pair - the lane's 8 input channels of the (single, zero-padded) 32-wide slab rounded to bf16 once per block,
+// the weights from plane 0 of the split image (expdw_bx_image: [Cp][3][32] bf16, natural k order): 2 MFMAs of 16 cycles per
+// 16-pixel tile and chunk where the fp32 form issues 12-16 of 32 cycles, and 4 operand registers per tile instead of 6-8.
+template <int K, int S, int TOH, int TOW, int TRH, bool STEM, int KW, bool LOOP = !STEM, int NW = 4, bool B16 = false>
+__global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, B16 ? 16 : KW, !LOOP, NW)) void k_expand_dw_sk(ExpDwParams p, unsigned nblk) {
+    static_assert(!B16 || (LOOP && !STEM && (KW == 24 || KW == 32)), "bf16 phase 1: chunk-loop form, one 32-wide slab");
     static_assert(NW == 4 || (NW == 8 && LOOP && TOH % 8 == 0), "eight-wave blocks: chunk-loop form, tile height a multiple of 8");
     static_assert(KW == 16 || KW == 24 || KW == 32, "one or two K slabs, or a slab and a half");
     static_assert(!STEM || KW == 24, "the stem's window is 3 rows x 4 columns x 2 channels");
@@ -2245,7 +2250,7 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, KW, !L
     constexpr int NPIX = TRH * TIW, NPIXP = (NPIX + 15) / 16 * 16;
     constexpr int JT = NPIXP / 16, JTW = (JT + NW - 1) / NW;
     constexpr int SW = TOW / 8;
-    constexpr int NMMA = KW / 2;                              // MFMAs per 16-pixel tile (two 16-channel halves)
+    constexpr int NMMA = B16 ? 2 : KW / 2;                    // MFMAs per 16-pixel tile (two 16-channel halves)
     __shared__ __attribute__((aligned(16))) float lds[NPIX * ED_ES + 64 * NW + K * K * 32];
     float* E = lds;
     float4* red = reinterpret_cast<float4*>(lds + NPIX * ED_ES);
@@ -2280,11 +2285,12 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, KW, !L
 
     // ---- once per block: this lane's pixel per owned tile, and its input operands for the whole K range
     bool xin[JTW];
-    f32x4 xA[JTW];                                       // k = 4 kq .. + 3 (slab 0)
-    f32x4 xB[KW == 32 ? JTW : 1];                        // k = 16 + 4 kq .. (slab 1)
-    f32x2 xH[KW == 24 ? JTW : 1];                        // k = 16 + 2 kq, + 1 (half slab)
+    f32x4 xA[B16 ? 1 : JTW];                             // k = 4 kq .. + 3 (slab 0)
+    f32x4 xB[(KW == 32 && !B16) ? JTW : 1];              // k = 16 + 4 kq .. (slab 1)
+    f32x2 xH[(KW == 24 && !B16) ? JTW : 1];              // k = 16 + 2 kq, + 1 (half slab)
+    bf16x8 xb[B16 ? JTW : 1];                            // B16: k = 8 kq .. + 7 of the one slab, as bf16
     auto load_x = [&]() {
-        const float* xb = STEM ? p.x + (size_t)b * p.Hin * p.Win * 2 : p.x;
+        const float* xbase = STEM ? p.x + (size_t)b * p.Hin * p.Win * 2 : p.x;
 #pragma unroll
         for (int a = 0; a < JTW; a++) {
             const int j = 16 * (wave + NW * a) + li;
@@ -2299,14 +2305,20 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, KW, !L
                 const int row0 = ihc * 2 - p.pts, col0 = iwc * 2 - p.pls;
                 auto tap2 = [&](int row, int col) {
                     const bool v = row >= 0 && row < p.Hin && col >= 0 && col < p.Win;
-                    const float2 u = *reinterpret_cast<const float2*>(xb + ((size_t)min(max(row, 0), p.Hin - 1) * p.Win + min(max(col, 0), p.Win - 1)) * 2);
+                    const float2 u = *reinterpret_cast<const float2*>(xbase + ((size_t)min(max(row, 0), p.Hin - 1) * p.Win + min(max(col, 0), p.Win - 1)) * 2);
                     return (f32x2){v ? u.x : 0.f, v ? u.y : 0.f};
                 };
                 const f32x2 u = tap2(row0 + (kq >> 1), col0 + (kq & 1) * 2), w = tap2(row0 + (kq >> 1), col0 + (kq & 1) * 2 + 1);
                 xA[a] = (f32x4){u[0], u[1], w[0], w[1]};
                 xH[a] = tap2(row0 + 2, col0 + kq);
+            } else if constexpr (B16) {
+                const float* xp = xbase + (size_t)((b * p.H * p.W + ihc * p.xsh + iwc * p.xsw) * Cin);
+                // K tail (Cin = 24: lane group 3): any in-bounds address - the image's weights are zero there
+                const float* xq = xp + (8 * kq < Cin ? 8 * kq : 0);
+                const float4 t0 = *reinterpret_cast<const float4*>(xq), t1 = *reinterpret_cast<const float4*>(xq + 4);
+                xb[a] = bx1_cvt8((f32x4){t0.x, t0.y, t0.z, t0.w}, (f32x4){t1.x, t1.y, t1.z, t1.w});
             } else {
-                const float* xp = xb + (size_t)((b * p.H * p.W + ihc * p.xsh + iwc * p.xsw) * Cin);
+                const float* xp = xbase + (size_t)((b * p.H * p.W + ihc * p.xsh + iwc * p.xsw) * Cin);
                 // K tail: lanes whose channels lie beyond Cin read any in-bounds address (their weights are zero)
                 const float4 t = *reinterpret_cast<const float4*>(xp + (4 * kq < Cin ? 4 * kq : 0));
                 xA[a] = (f32x4){t.x, t.y, t.z, t.w};
@@ -2327,10 +2339,11 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, KW, !L
     struct Chunk {
         f32x4 wA0, wA1, wB0, wB1;
         f32x2 wH0, wH1;
+        bf16x8 wb0, wb1;                                 // B16: rows n_base + li / + 16 + li of the image's plane 0, k = 8 kq .. + 7
         float4 bq0, bq1, bv, wd;
     };
     // (addresses as block-uniform base + 32-bit lane offset: nothing 64-bit per lane stays live across the chunk loop)
-    const unsigned wlane = (unsigned)(li * KW + 4 * kq);
+    const unsigned wlane = B16 ? (unsigned)(li * 96 + 8 * kq) : (unsigned)(li * KW + 4 * kq);      // (B16: uint16 units inside the split image)
     const int tap = tid >> 3, tsrc = p.tr ? (tap % K) * K + tap / K : tap;
     const unsigned wdlane = (unsigned)(tsrc * p.Cp + 4 * (tid & 7));
     auto fetch = [&](int cc, Chunk& q) {
@@ -2340,6 +2353,12 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, KW, !L
         // scratch - a vmcnt(0) wait right behind the prefetch it has just issued)
         unsigned wl = wlane, wdl = wdlane;
         asm volatile("" : "+v"(wl), "+v"(wdl));
+        if constexpr (B16) {
+            // image row n: 3 planes x 32 bf16 = 192 bytes; plane 0, this lane's 16 bytes
+            const uint16_t* w0 = p.wep + (size_t)n_base * 96 + wl;
+            q.wb0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(w0));
+            q.wb1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(w0 + 16 * 96));
+        } else {
         const float* w0 = p.we + (size_t)n_base * KW + wl;
         const float* w1 = w0 + 16 * KW;
         const float4 t0 = *reinterpret_cast<const float4*>(w0), t1 = *reinterpret_cast<const float4*>(w1);
@@ -2352,6 +2371,7 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, KW, !L
             const float2 u0 = *reinterpret_cast<const float2*>(w0 - 2 * kq + 16), u1 = *reinterpret_cast<const float2*>(w1 - 2 * kq + 16);
             q.wH0 = (f32x2){u0.x, u0.y}; q.wH1 = (f32x2){u1.x, u1.y};
         }
+        }
         q.bq0 = *reinterpret_cast<const float4*>(p.be + n_base + 4 * kq);
         q.bq1 = *reinterpret_cast<const float4*>(p.be + n_base + 16 + 4 * kq);
         q.bv = *reinterpret_cast<const float4*>(p.bd + n_base + 4 * c4);
@@ -2361,9 +2381,12 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, KW, !L
     q.wd = make_float4(0.f, 0.f, 0.f, 0.f);
     fetch(cc0, q);
     auto land = [&] {
+        if constexpr (B16) asm volatile("" :: "v"(q.wb0), "v"(q.wb1), "v"(q.bq0.x), "v"(q.bq1.x), "v"(q.bv.x), "v"(q.wd.x));
+        else {
         asm volatile("" :: "v"(q.wA0), "v"(q.wA1), "v"(q.bq0.x), "v"(q.bq1.x), "v"(q.bv.x), "v"(q.wd.x));
         if constexpr (KW == 32) asm volatile("" :: "v"(q.wB0), "v"(q.wB1));
         if constexpr (KW == 24) asm volatile("" :: "v"(q.wH0), "v"(q.wH1));
+        }
     };
     if constexpr (LOOP) land();     // (also on the way in: the wait at the loop head would otherwise be shared with the back edge)
 
@@ -2384,23 +2407,28 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, KW, !L
         // 144 - which then skips half of its MFMAs, activations and LDS stores; phase 2 never reads those E columns)
         auto tile_mma = [&](int a, auto hi) {
             constexpr bool HI = decltype(hi)::value;
+            if constexpr (B16) {
+                acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb0, xb[a], acc[a][0], 0, 0, 0);
+                if (HI) acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb1, xb[a], acc[a][1], 0, 0, 0);
+                return;
+            }
 #pragma unroll
             for (int sidx = 0; sidx < 4; sidx++) {
-                acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wA0[sidx], xA[a][sidx], acc[a][0], 0, 0, 0);
-                if (HI) acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wA1[sidx], xA[a][sidx], acc[a][1], 0, 0, 0);
+                acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wA0[sidx], xA[B16 ? 0 : a][sidx], acc[a][0], 0, 0, 0);
+                if (HI) acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wA1[sidx], xA[B16 ? 0 : a][sidx], acc[a][1], 0, 0, 0);
             }
             if constexpr (KW == 32) {
 #pragma unroll
                 for (int sidx = 0; sidx < 4; sidx++) {
-                    acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wB0[sidx], xB[a][sidx], acc[a][0], 0, 0, 0);
-                    if (HI) acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wB1[sidx], xB[a][sidx], acc[a][1], 0, 0, 0);
+                    acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wB0[sidx], xB[B16 ? 0 : a][sidx], acc[a][0], 0, 0, 0);
+                    if (HI) acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wB1[sidx], xB[B16 ? 0 : a][sidx], acc[a][1], 0, 0, 0);
                 }
             }
             if constexpr (KW == 24) {
 #pragma unroll
                 for (int sidx = 0; sidx < 2; sidx++) {
-                    acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wH0[sidx], xH[a][sidx], acc[a][0], 0, 0, 0);
-                    if (HI) acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wH1[sidx], xH[a][sidx], acc[a][1], 0, 0, 0);
+                    acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wH0[sidx], xH[B16 ? 0 : a][sidx], acc[a][0], 0, 0, 0);
+                    if (HI) acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wH1[sidx], xH[B16 ? 0 : a][sidx], acc[a][1], 0, 0, 0);
                 }
             }
         };
@@ -2624,6 +2652,12 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
     const bool sk = stem || (act_e == ACT_SWISH && (p.Kw == 16 || p.Kw == 24 || p.Kw == 32));
     const bool bx = wep != nullptr && !sk && expdw_bx_ok(Cin);
     if (bx) { p.wep = wep; p.Kp = expdw_kp(Cin); p.prec = prec; }
+    // ... except in "precision":"bf16" engines, where one bf16 product per pair is what was asked for: 2 MFMAs instead of 12-16
+    // per tile and chunk (k_expand_dw_sk<..., B16>; four-wave blocks, layers whose K is one 32-wide slab of the split image)
+    static const bool no_b16 = getenv("BNHIP_EXPDW_B16") && atoi(getenv("BNHIP_EXPDW_B16")) == 0;
+    const bool b16 = sk && !stem && wep != nullptr && prec == 1 && (p.Kw == 24 || p.Kw == 32) && expdw_bx_ok(Cin) &&
+                     expdw_kp(Cin) == 32 && sh->nw == 4 && !no_b16;
+    if (b16) { p.wep = wep; p.Kp = 32; p.prec = 1; }
     if (sk && !stem) {
         // small-K form: a block owns (clip, tile) and walks the channel chunks itself
         nblk = (unsigned)B * p.tiles_h * p.tiles_w;
@@ -2657,6 +2691,8 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
 #define ED_CASE(K_, S_, TH_, TW_, TR_)                                                                        \
     if (sh->k == K_ && sh->s == S_ && sh->toh == TH_ && sh->tow == TW_ && sh->trh == TR_) {                   \
         if (bx) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        else if (b16 && p.Kw == 24) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 24, true, 4, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        else if (b16) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 32, true, 4, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         else if (sk && p.Kw == 16) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 16>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         else if (sk && p.Kw == 24) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 24>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         else if (sk && p.Kw == 32) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 32>), dim3(nblk), dim3(256), 0, st, p, nblk); \
