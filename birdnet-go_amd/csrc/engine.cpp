@@ -861,6 +861,12 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                                 // (arithmetic by rule, not by timing: the split-bf16 phase 1 measured +0-0.5 % at best, so it is
                                 // used only where asked for)
                                 if (bf16x3 >= 2 || precision == 1) steps.back().bx = 1;
+                                // The small-K chunk-loop form has a six-product phase 1 as well (k_expand_dw_sk<PH = 2>: the split
+                                // is paid once per block there, not once per channel chunk).  Measured, batch 256: b2 276 -> 263 us,
+                                // b3 208 -> 208, b4 183 -> 177 alone; pipelined step 3.54-3.57 -> 3.59-3.61 ms (two A/B pairs) -
+                                // the MFMAs were not what those layers wait for.  Opt-in (BNHIP_EXPDW_SPLIT=1), read per engine.
+                                const char* sks = getenv("BNHIP_EXPDW_SPLIT");
+                                if (sks && atoi(sks) == 1 && expdw_skw(C, act, false) != 0) steps.back().bx = 1;
                             }
                             break;
                         }
@@ -1811,9 +1817,13 @@ bool Engine::load_tuning(const char* path) {
                                               ((r.wm >= 5) == (steps[i].wm >= 5) || !steps[i].wbx);       // (never switches the arithmetic family)
         if (ok && (steps[i].kind == S_EXPAND_DW || (steps[i].kind == S_DW && r.dwl))) {
             const bool st_ = steps[i].kind == S_EXPAND_DW && steps[i].mode == 1;
+            // (the same geometry the tuner and the launcher use: a layer whose phase 1 runs on the bf16 pipe has no eight-wave shapes)
+            const bool pipe16 = steps[i].kind == S_EXPAND_DW &&
+                                expdw_sk_pipe16(steps[i].C, steps[i].act, st_, precision, steps[i].bx && steps[i].wbx != nullptr && bf16x3);
             const ExpDwGeo g{steps[i].kh, steps[i].sh, steps[i].H, steps[i].W, steps[i].Ho, steps[i].Wo, steps[i].pt, steps[i].pl, st_,
-                             steps[i].kind == S_EXPAND_DW ? expdw_skw(steps[i].C, steps[i].act, st_) : 0};
-            ok = r.shape >= 0 && r.shape < expdw_num_shapes() && expdw_shape_fits(r.shape, g);
+                             (steps[i].kind == S_EXPAND_DW && !pipe16) ? expdw_skw(steps[i].C, steps[i].act, st_) : 0};
+            ok = r.shape >= 0 && r.shape < expdw_num_shapes() && expdw_shape_fits(r.shape, g) &&
+                 (steps[i].kind != S_EXPAND_DW || r.bx == steps[i].bx);            // (never switches the arithmetic)
         }
     }
     fclose(f);
@@ -1898,7 +1908,8 @@ void Engine::autotune_expdw() {
         float best = 1e30f; int best_idx = -1, best_bx = 0;
         const bool can_bx = s.wbx != nullptr && s.mode != 1 && bf16x3;
         const int bx_fixed = (can_bx && s.bx) ? 1 : 0;      // arithmetic is the planner's decision (shape rule); only the tile is timed
-        const ExpDwGeo sg0{s.kh, s.sh, s.H, s.W, s.Ho, s.Wo, s.pt, s.pl, s.mode == 1, expdw_skw(s.C, s.act, s.mode == 1)};
+        const bool pipe16 = expdw_sk_pipe16(s.C, s.act, s.mode == 1, precision, s.bx && s.wbx != nullptr && bf16x3);
+        const ExpDwGeo sg0{s.kh, s.sh, s.H, s.W, s.Ho, s.Wo, s.pt, s.pl, s.mode == 1, pipe16 ? 0 : expdw_skw(s.C, s.act, s.mode == 1)};
         // Two clocks per candidate: three launches back to back (how the layer runs inside a step: the next kernel's head
         // fills this one's tail) and the best of three isolated launches (what it costs when nothing covers its tail).  The
         // back-to-back time decides; the isolated one breaks near-ties (within 8 %), because a shape with few, long blocks can

@@ -147,6 +147,7 @@ bool expdw_supported(int k, int s, int Cin, int Cmid);
 // transposed.  `stem` layers (raw-image variant) only exist in image orientation.
 struct ExpDwGeo { int k, s, H, W, Ho, Wo, pt, pl; bool stem = false; int skw = 0; };   // skw: expdw_skw() of the layer (0: not the small-K chunk-loop form)
 int expdw_skw(int Cin, int act_e, bool stem);
+bool expdw_sk_pipe16(int Cin, int act_e, bool stem, int prec, bool have_image);   // phase 1 on the bf16 pipe (then no eight-wave shapes: pass skw = 0)
 int expdw_sum_slabs(const ExpDwGeo& g);   // slabs of the cost-model shape; 0 = no tile shape fits (do not fuse)
 int expdw_num_shapes();                   // 2n
 bool expdw_shape_fits(int idx, const ExpDwGeo& g);

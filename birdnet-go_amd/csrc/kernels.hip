@@ -2235,13 +2235,21 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
 // are bound by unhidden latency at the three blocks per CU their 40-50 KB footprints allow (a wave waits two thirds of its
 // life); with the same LDS the CU then holds twice the waves, each owning half the pixel tiles in phase 1 and half the output
 // rows in phase 2 (so the registers that stay live across the chunk loop halve too).
-// B16 ("precision":"bf16" engines, BASELINE configs[4] "bf16 MFMA conv"): the expand GEMM on v_mfma_f32_16x16x32_bf16 with one
-// product per operand pair - the lane's 8 input channels of the (single, zero-padded) 32-wide slab rounded to bf16 once per block,
-// the weights from plane 0 of the split image (expdw_bx_image: [Cp][3][32] bf16, natural k order): 2 MFMAs of 16 cycles per
-// 16-pixel tile and chunk where the fp32 form issues 12-16 of 32 cycles, and 4 operand registers per tile instead of 6-8.
-template <int K, int S, int TOH, int TOW, int TRH, bool STEM, int KW, bool LOOP = !STEM, int NW = 4, bool B16 = false>
-__global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, B16 ? 16 : KW, !LOOP, NW)) void k_expand_dw_sk(ExpDwParams p, unsigned nblk) {
-    static_assert(!B16 || (LOOP && !STEM && (KW == 24 || KW == 32)), "bf16 phase 1: chunk-loop form, one 32-wide slab");
+// PH: the pipe phase 1 runs on.  0: f32 MFMA (v_mfma_f32_16x16x4_f32).  1 ("precision":"bf16" engines, BASELINE configs[4] "bf16
+// MFMA conv"): v_mfma_f32_16x16x32_bf16 with one product per operand pair - the lane's 8 input channels of the (single,
+// zero-padded) 32-wide slab rounded to bf16 once per block, the weights from plane 0 of the split image (expdw_bx_image:
+// [Cp][3][32] bf16, natural k order): 2 MFMAs of 16 cycles per 16-pixel tile and chunk where the fp32 form issues 12-16 of 32
+// cycles (Perch b3-b6: -37...40 %).  2 (fp32 engines with bf16x3 on): the same pipe with fp32-equivalent products - the input
+// channels split once per block into three exact bf16 pieces (as k_pw_bx3 does per slab), all three weight planes, six products
+// per pair: 12 MFMAs of 16 cycles where the f32 pipe needs 8-16 of 32.  Because the block walks every channel chunk with the
+// operands resident, the split is paid once per block - in k_expand_dw's BX form it is paid per chunk, which is why that form
+// never won.
+template <int K, int S, int TOH, int TOW, int TRH, bool STEM, int KW, bool LOOP = !STEM, int NW = 4, int PH = 0>
+__global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, PH == 1 ? 16 : (PH == 2 ? 48 : KW), !LOOP, NW)) void k_expand_dw_sk(ExpDwParams p, unsigned nblk) {
+    constexpr bool B16 = PH != 0;                             // operands are bf16 fragments of one 32-wide slab
+    constexpr bool SPL = PH == 2;                             // ... three of them per value
+    static_assert(!B16 || (LOOP && !STEM), "bf16 phase 1: chunk-loop form");
+    static_assert(PH != 1 || KW == 24 || KW == 32, "one-product form: layers of the bf16 engines");
     static_assert(NW == 4 || (NW == 8 && LOOP && TOH % 8 == 0), "eight-wave blocks: chunk-loop form, tile height a multiple of 8");
     static_assert(KW == 16 || KW == 24 || KW == 32, "one or two K slabs, or a slab and a half");
     static_assert(!STEM || KW == 24, "the stem's window is 3 rows x 4 columns x 2 channels");
@@ -2250,7 +2258,7 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, B16 ? 
     constexpr int NPIX = TRH * TIW, NPIXP = (NPIX + 15) / 16 * 16;
     constexpr int JT = NPIXP / 16, JTW = (JT + NW - 1) / NW;
     constexpr int SW = TOW / 8;
-    constexpr int NMMA = B16 ? 2 : KW / 2;                    // MFMAs per 16-pixel tile (two 16-channel halves)
+    constexpr int NMMA = SPL ? 12 : (B16 ? 2 : KW / 2);       // MFMAs per 16-pixel tile (two 16-channel halves)
     __shared__ __attribute__((aligned(16))) float lds[NPIX * ED_ES + 64 * NW + K * K * 32];
     float* E = lds;
     float4* red = reinterpret_cast<float4*>(lds + NPIX * ED_ES);
@@ -2288,7 +2296,8 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, B16 ? 
     f32x4 xA[B16 ? 1 : JTW];                             // k = 4 kq .. + 3 (slab 0)
     f32x4 xB[(KW == 32 && !B16) ? JTW : 1];              // k = 16 + 4 kq .. (slab 1)
     f32x2 xH[(KW == 24 && !B16) ? JTW : 1];              // k = 16 + 2 kq, + 1 (half slab)
-    bf16x8 xb[B16 ? JTW : 1];                            // B16: k = 8 kq .. + 7 of the one slab, as bf16
+    bf16x8 xb[B16 ? JTW : 1];                            // B16: k = 8 kq .. + 7 of the one slab, as bf16 (SPL: the hi piece)
+    bf16x8 xm[SPL ? JTW : 1], xl[SPL ? JTW : 1];         // SPL: the mid and lo pieces
     auto load_x = [&]() {
         const float* xbase = STEM ? p.x + (size_t)b * p.Hin * p.Win * 2 : p.x;
 #pragma unroll
@@ -2316,7 +2325,8 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, B16 ? 
                 // K tail (Cin = 24: lane group 3): any in-bounds address - the image's weights are zero there
                 const float* xq = xp + (8 * kq < Cin ? 8 * kq : 0);
                 const float4 t0 = *reinterpret_cast<const float4*>(xq), t1 = *reinterpret_cast<const float4*>(xq + 4);
-                xb[a] = bx1_cvt8((f32x4){t0.x, t0.y, t0.z, t0.w}, (f32x4){t1.x, t1.y, t1.z, t1.w});
+                if constexpr (SPL) bx3_split8((f32x4){t0.x, t0.y, t0.z, t0.w}, (f32x4){t1.x, t1.y, t1.z, t1.w}, &xb[a], &xm[SPL ? a : 0], &xl[SPL ? a : 0]);
+                else xb[a] = bx1_cvt8((f32x4){t0.x, t0.y, t0.z, t0.w}, (f32x4){t1.x, t1.y, t1.z, t1.w});
             } else {
                 const float* xp = xbase + (size_t)((b * p.H * p.W + ihc * p.xsh + iwc * p.xsw) * Cin);
                 // K tail: lanes whose channels lie beyond Cin read any in-bounds address (their weights are zero)
@@ -2340,6 +2350,7 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, B16 ? 
         f32x4 wA0, wA1, wB0, wB1;
         f32x2 wH0, wH1;
         bf16x8 wb0, wb1;                                 // B16: rows n_base + li / + 16 + li of the image's plane 0, k = 8 kq .. + 7
+        bf16x8 wm0, wm1, wl0, wl1;                       // SPL: planes 1 and 2
         float4 bq0, bq1, bv, wd;
     };
     // (addresses as block-uniform base + 32-bit lane offset: nothing 64-bit per lane stays live across the chunk loop)
@@ -2358,6 +2369,12 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, B16 ? 
             const uint16_t* w0 = p.wep + (size_t)n_base * 96 + wl;
             q.wb0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(w0));
             q.wb1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(w0 + 16 * 96));
+            if constexpr (SPL) {
+                q.wm0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(w0 + 32));
+                q.wm1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(w0 + 16 * 96 + 32));
+                q.wl0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(w0 + 64));
+                q.wl1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(w0 + 16 * 96 + 64));
+            }
         } else {
         const float* w0 = p.we + (size_t)n_base * KW + wl;
         const float* w1 = w0 + 16 * KW;
@@ -2381,8 +2398,10 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, B16 ? 
     q.wd = make_float4(0.f, 0.f, 0.f, 0.f);
     fetch(cc0, q);
     auto land = [&] {
-        if constexpr (B16) asm volatile("" :: "v"(q.wb0), "v"(q.wb1), "v"(q.bq0.x), "v"(q.bq1.x), "v"(q.bv.x), "v"(q.wd.x));
-        else {
+        if constexpr (B16) {
+            asm volatile("" :: "v"(q.wb0), "v"(q.wb1), "v"(q.bq0.x), "v"(q.bq1.x), "v"(q.bv.x), "v"(q.wd.x));
+            if constexpr (SPL) asm volatile("" :: "v"(q.wm0), "v"(q.wm1), "v"(q.wl0), "v"(q.wl1));
+        } else {
         asm volatile("" :: "v"(q.wA0), "v"(q.wA1), "v"(q.bq0.x), "v"(q.bq1.x), "v"(q.bv.x), "v"(q.wd.x));
         if constexpr (KW == 32) asm volatile("" :: "v"(q.wB0), "v"(q.wB1));
         if constexpr (KW == 24) asm volatile("" :: "v"(q.wH0), "v"(q.wH1));
@@ -2407,7 +2426,25 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, B16 ? 
         // 144 - which then skips half of its MFMAs, activations and LDS stores; phase 2 never reads those E columns)
         auto tile_mma = [&](int a, auto hi) {
             constexpr bool HI = decltype(hi)::value;
-            if constexpr (B16) {
+            if constexpr (SPL) {
+                // six products per pair, smallest terms first (k_pw_bx3's order); the two halves are independent chains
+                const bf16x8 xh = xb[a], xmid = xm[SPL ? a : 0], xlo = xl[SPL ? a : 0];
+                f32x4 c0 = acc[a][0], c1 = acc[a][1];
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wl0, xh, c0, 0, 0, 0);
+                if (HI) c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wl1, xh, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb0, xlo, c0, 0, 0, 0);
+                if (HI) c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb1, xlo, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wm0, xmid, c0, 0, 0, 0);
+                if (HI) c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wm1, xmid, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wm0, xh, c0, 0, 0, 0);
+                if (HI) c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wm1, xh, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb0, xmid, c0, 0, 0, 0);
+                if (HI) c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb1, xmid, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb0, xh, c0, 0, 0, 0);
+                if (HI) c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb1, xh, c1, 0, 0, 0);
+                acc[a][0] = c0; acc[a][1] = c1;
+                return;
+            } else if constexpr (B16) {
                 acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb0, xb[a], acc[a][0], 0, 0, 0);
                 if (HI) acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb1, xb[a], acc[a][1], 0, 0, 0);
                 return;
@@ -2622,6 +2659,15 @@ std::vector<uint16_t> expdw_bx_image(const float* We /*[Cmid][Cin]*/, int Cmid, 
         }
     return img;
 }
+// phase 1 of the small-K chunk-loop form on the bf16 matrix pipe (k_expand_dw_sk<PH = 1 | 2>): the layer takes that form, its K
+// is one 32-wide slab of the split image, and the engine's arithmetic allows it (prec 1: one product, layers whose fp32 form
+// needs 12-16 MFMAs; prec 0 with the image on hand - bf16x3 - : six products).  BNHIP_EXPDW_B16=0: never.
+bool expdw_sk_pipe16(int Cin, int act_e, bool stem, int prec, bool have_image) {
+    static const bool off = getenv("BNHIP_EXPDW_B16") && atoi(getenv("BNHIP_EXPDW_B16")) == 0;
+    const int kw = expdw_skw(Cin, act_e, stem);
+    if (off || !have_image || kw == 0 || !expdw_bx_ok(Cin) || expdw_kp(Cin) != 32) return false;
+    return prec == 1 ? (kw == 24 || kw == 32) : prec == 0;
+}
 bool expdw_supported(int k, int s, int Cin, int Cmid) {
     // measured on MI355X at batch 256: beyond ~128 input channels the unpipelined K loop of the fused kernel loses
     // to the separate pw_gemm + dwconv pair (b13-b16 of the B0 stack: 126 us vs 176 us), so those stay unfused
@@ -2630,7 +2676,10 @@ bool expdw_supported(int k, int s, int Cin, int Cmid) {
 void launch_expand_dw(const float* x, const float* we, const float* be, const float* wd, const float* bd, float* y,
                       float* partial, int B, int H, int W, int Cin, int Cmid, int Ho, int Wo, int k, int s, int pt,
                       int pl, int act_e, int act_d, int shape, const StemGeom* stem, hipStream_t st, const uint16_t* wep, int prec, int out_bf16) {
-    const ExpDwGeo g0{k, s, H, W, Ho, Wo, pt, pl, stem != nullptr, expdw_skw(Cin, act_e, stem != nullptr)};
+    // (a layer whose phase 1 runs on the bf16 pipe never takes an eight-wave shape - those exist in the f32 form only - so that
+    // the arithmetic of a layer does not depend on which tile the tuner preferred: skw = 0 withholds them)
+    const bool pipe16 = expdw_sk_pipe16(Cin, act_e, stem != nullptr, prec, wep != nullptr);
+    const ExpDwGeo g0{k, s, H, W, Ho, Wo, pt, pl, stem != nullptr, pipe16 ? 0 : expdw_skw(Cin, act_e, stem != nullptr)};
     if (!expdw_shape_fits(shape, g0)) shape = expdw_default_shape(g0);
     if (shape < 0) return;                             // the planner only fuses layers some shape accepts
     const ExpDwShape* sh = &kExpDwShapes[shape % kNumExpDwShapes];
@@ -2652,12 +2701,10 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
     const bool sk = stem || (act_e == ACT_SWISH && (p.Kw == 16 || p.Kw == 24 || p.Kw == 32));
     const bool bx = wep != nullptr && !sk && expdw_bx_ok(Cin);
     if (bx) { p.wep = wep; p.Kp = expdw_kp(Cin); p.prec = prec; }
-    // ... except in "precision":"bf16" engines, where one bf16 product per pair is what was asked for: 2 MFMAs instead of 12-16
-    // per tile and chunk (k_expand_dw_sk<..., B16>; four-wave blocks, layers whose K is one 32-wide slab of the split image)
-    static const bool no_b16 = getenv("BNHIP_EXPDW_B16") && atoi(getenv("BNHIP_EXPDW_B16")) == 0;
-    const bool b16 = sk && !stem && wep != nullptr && prec == 1 && (p.Kw == 24 || p.Kw == 32) && expdw_bx_ok(Cin) &&
-                     expdw_kp(Cin) == 32 && sh->nw == 4 && !no_b16;
-    if (b16) { p.wep = wep; p.Kp = 32; p.prec = 1; }
+    // ... except where phase 1 runs on the bf16 pipe (expdw_sk_pipe16): one product per pair in "precision":"bf16" engines
+    // (2 MFMAs instead of 12-16 per tile and chunk), six exact products in fp32 engines that carry the split image
+    const bool b16 = pipe16 && prec == 1, spl = pipe16 && prec == 0;
+    if (pipe16) { p.wep = wep; p.Kp = 32; p.prec = prec; }
     if (sk && !stem) {
         // small-K form: a block owns (clip, tile) and walks the channel chunks itself
         nblk = (unsigned)B * p.tiles_h * p.tiles_w;
@@ -2691,8 +2738,9 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
 #define ED_CASE(K_, S_, TH_, TW_, TR_)                                                                        \
     if (sh->k == K_ && sh->s == S_ && sh->toh == TH_ && sh->tow == TW_ && sh->trh == TR_) {                   \
         if (bx) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
-        else if (b16 && p.Kw == 24) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 24, true, 4, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
-        else if (b16) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 32, true, 4, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        else if (b16 && p.Kw == 24) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 24, true, 4, 1>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        else if (b16) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 32, true, 4, 1>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        else if (spl) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 32, true, 4, 2>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         else if (sk && p.Kw == 16) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 16>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         else if (sk && p.Kw == 24) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 24>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         else if (sk && p.Kw == 32) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 32>), dim3(nblk), dim3(256), 0, st, p, nblk); \
