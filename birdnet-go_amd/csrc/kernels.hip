@@ -2244,11 +2244,15 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
 // per pair: 12 MFMAs of 16 cycles where the f32 pipe needs 8-16 of 32.  Because the block walks every channel chunk with the
 // operands resident, the split is paid once per block - in k_expand_dw's BX form it is paid per chunk, which is why that form
 // never won.
-template <int K, int S, int TOH, int TOW, int TRH, bool STEM, int KW, bool LOOP = !STEM, int NW = 4, int PH = 0>
-__global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, PH == 1 ? 16 : (PH == 2 ? 48 : KW), !LOOP, NW)) void k_expand_dw_sk(ExpDwParams p, unsigned nblk) {
-    constexpr bool B16 = PH != 0;                             // operands are bf16 fragments of one 32-wide slab
+// NS (PH = 1 only): 32-wide slabs of K the block keeps resident - a bf16 fragment is 4 registers per tile and slab, so layers
+// with up to 96 input channels fit the chunk-loop form that the f32 operands (8 registers per 32 channels) reserve for K <= 32.
+template <int K, int S, int TOH, int TOW, int TRH, bool STEM, int KW, bool LOOP = !STEM, int NW = 4, int PH = 0, int NS = 1>
+__global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, PH == 1 ? 16 * NS : (PH == 2 ? 48 : KW), !LOOP, NW)) void k_expand_dw_sk(ExpDwParams p, unsigned nblk) {
+    constexpr bool B16 = PH != 0;                             // operands are bf16 fragments of 32-wide slabs
     constexpr bool SPL = PH == 2;                             // ... three of them per value
     static_assert(!B16 || (LOOP && !STEM), "bf16 phase 1: chunk-loop form");
+    static_assert(NS == 1 || PH == 1, "several resident slabs: one-product form only");
+    constexpr int KP = 32 * NS;                               // row length of one plane of the split image (expdw_kp)
     static_assert(PH != 1 || KW == 24 || KW == 32, "one-product form: layers of the bf16 engines");
     static_assert(NW == 4 || (NW == 8 && LOOP && TOH % 8 == 0), "eight-wave blocks: chunk-loop form, tile height a multiple of 8");
     static_assert(KW == 16 || KW == 24 || KW == 32, "one or two K slabs, or a slab and a half");
@@ -2258,7 +2262,7 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, PH == 
     constexpr int NPIX = TRH * TIW, NPIXP = (NPIX + 15) / 16 * 16;
     constexpr int JT = NPIXP / 16, JTW = (JT + NW - 1) / NW;
     constexpr int SW = TOW / 8;
-    constexpr int NMMA = SPL ? 12 : (B16 ? 2 : KW / 2);       // MFMAs per 16-pixel tile (two 16-channel halves)
+    constexpr int NMMA = SPL ? 12 : (B16 ? 2 * NS : KW / 2);  // MFMAs per 16-pixel tile (two 16-channel halves)
     __shared__ __attribute__((aligned(16))) float lds[NPIX * ED_ES + 64 * NW + K * K * 32];
     float* E = lds;
     float4* red = reinterpret_cast<float4*>(lds + NPIX * ED_ES);
@@ -2296,7 +2300,7 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, PH == 
     f32x4 xA[B16 ? 1 : JTW];                             // k = 4 kq .. + 3 (slab 0)
     f32x4 xB[(KW == 32 && !B16) ? JTW : 1];              // k = 16 + 4 kq .. (slab 1)
     f32x2 xH[(KW == 24 && !B16) ? JTW : 1];              // k = 16 + 2 kq, + 1 (half slab)
-    bf16x8 xb[B16 ? JTW : 1];                            // B16: k = 8 kq .. + 7 of the one slab, as bf16 (SPL: the hi piece)
+    bf16x8 xb[B16 ? JTW : 1][NS];                        // B16: k = 32 ns + 8 kq .. + 7 of each slab, as bf16 (SPL: the hi piece)
     bf16x8 xm[SPL ? JTW : 1], xl[SPL ? JTW : 1];         // SPL: the mid and lo pieces
     auto load_x = [&]() {
         const float* xbase = STEM ? p.x + (size_t)b * p.Hin * p.Win * 2 : p.x;
@@ -2323,10 +2327,13 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, PH == 
             } else if constexpr (B16) {
                 const float* xp = xbase + (size_t)((b * p.H * p.W + ihc * p.xsh + iwc * p.xsw) * Cin);
                 // K tail (Cin = 24: lane group 3): any in-bounds address - the image's weights are zero there
-                const float* xq = xp + (8 * kq < Cin ? 8 * kq : 0);
-                const float4 t0 = *reinterpret_cast<const float4*>(xq), t1 = *reinterpret_cast<const float4*>(xq + 4);
-                if constexpr (SPL) bx3_split8((f32x4){t0.x, t0.y, t0.z, t0.w}, (f32x4){t1.x, t1.y, t1.z, t1.w}, &xb[a], &xm[SPL ? a : 0], &xl[SPL ? a : 0]);
-                else xb[a] = bx1_cvt8((f32x4){t0.x, t0.y, t0.z, t0.w}, (f32x4){t1.x, t1.y, t1.z, t1.w});
+#pragma unroll
+                for (int ns = 0; ns < NS; ns++) {
+                    const float* xq = xp + (32 * ns + 8 * kq < Cin ? 32 * ns + 8 * kq : 0);
+                    const float4 t0 = *reinterpret_cast<const float4*>(xq), t1 = *reinterpret_cast<const float4*>(xq + 4);
+                    if constexpr (SPL) bx3_split8((f32x4){t0.x, t0.y, t0.z, t0.w}, (f32x4){t1.x, t1.y, t1.z, t1.w}, &xb[a][0], &xm[SPL ? a : 0], &xl[SPL ? a : 0]);
+                    else xb[a][ns] = bx1_cvt8((f32x4){t0.x, t0.y, t0.z, t0.w}, (f32x4){t1.x, t1.y, t1.z, t1.w});
+                }
             } else {
                 const float* xp = xbase + (size_t)((b * p.H * p.W + ihc * p.xsh + iwc * p.xsw) * Cin);
                 // K tail: lanes whose channels lie beyond Cin read any in-bounds address (their weights are zero)
@@ -2349,12 +2356,12 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, PH == 
     struct Chunk {
         f32x4 wA0, wA1, wB0, wB1;
         f32x2 wH0, wH1;
-        bf16x8 wb0, wb1;                                 // B16: rows n_base + li / + 16 + li of the image's plane 0, k = 8 kq .. + 7
+        bf16x8 wb0[NS], wb1[NS];                         // B16: rows n_base + li / + 16 + li of the image's plane 0, k = 32 ns + 8 kq .. + 7
         bf16x8 wm0, wm1, wl0, wl1;                       // SPL: planes 1 and 2
         float4 bq0, bq1, bv, wd;
     };
     // (addresses as block-uniform base + 32-bit lane offset: nothing 64-bit per lane stays live across the chunk loop)
-    const unsigned wlane = B16 ? (unsigned)(li * 96 + 8 * kq) : (unsigned)(li * KW + 4 * kq);      // (B16: uint16 units inside the split image)
+    const unsigned wlane = B16 ? (unsigned)(li * 3 * KP + 8 * kq) : (unsigned)(li * KW + 4 * kq);  // (B16: uint16 units inside the split image)
     const int tap = tid >> 3, tsrc = p.tr ? (tap % K) * K + tap / K : tap;
     const unsigned wdlane = (unsigned)(tsrc * p.Cp + 4 * (tid & 7));
     auto fetch = [&](int cc, Chunk& q) {
@@ -2365,10 +2372,13 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, PH == 
         unsigned wl = wlane, wdl = wdlane;
         asm volatile("" : "+v"(wl), "+v"(wdl));
         if constexpr (B16) {
-            // image row n: 3 planes x 32 bf16 = 192 bytes; plane 0, this lane's 16 bytes
-            const uint16_t* w0 = p.wep + (size_t)n_base * 96 + wl;
-            q.wb0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(w0));
-            q.wb1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(w0 + 16 * 96));
+            // image row n: 3 planes x KP bf16; plane 0, this lane's 16 bytes of each slab
+            const uint16_t* w0 = p.wep + (size_t)n_base * (3 * KP) + wl;
+#pragma unroll
+            for (int ns = 0; ns < NS; ns++) {
+                q.wb0[ns] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(w0 + 32 * ns));
+                q.wb1[ns] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(w0 + 16 * 3 * KP + 32 * ns));
+            }
             if constexpr (SPL) {
                 q.wm0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(w0 + 32));
                 q.wm1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(w0 + 16 * 96 + 32));
@@ -2399,7 +2409,9 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, PH == 
     fetch(cc0, q);
     auto land = [&] {
         if constexpr (B16) {
-            asm volatile("" :: "v"(q.wb0), "v"(q.wb1), "v"(q.bq0.x), "v"(q.bq1.x), "v"(q.bv.x), "v"(q.wd.x));
+#pragma unroll
+            for (int ns = 0; ns < NS; ns++) asm volatile("" :: "v"(q.wb0[ns]), "v"(q.wb1[ns]));
+            asm volatile("" :: "v"(q.bq0.x), "v"(q.bq1.x), "v"(q.bv.x), "v"(q.wd.x));
             if constexpr (SPL) asm volatile("" :: "v"(q.wm0), "v"(q.wm1), "v"(q.wl0), "v"(q.wl1));
         } else {
         asm volatile("" :: "v"(q.wA0), "v"(q.wA1), "v"(q.bq0.x), "v"(q.bq1.x), "v"(q.bv.x), "v"(q.wd.x));
@@ -2428,25 +2440,28 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, PH == 
             constexpr bool HI = decltype(hi)::value;
             if constexpr (SPL) {
                 // six products per pair, smallest terms first (k_pw_bx3's order); the two halves are independent chains
-                const bf16x8 xh = xb[a], xmid = xm[SPL ? a : 0], xlo = xl[SPL ? a : 0];
+                const bf16x8 xh = xb[a][0], xmid = xm[SPL ? a : 0], xlo = xl[SPL ? a : 0];
                 f32x4 c0 = acc[a][0], c1 = acc[a][1];
                 c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wl0, xh, c0, 0, 0, 0);
                 if (HI) c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wl1, xh, c1, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb0, xlo, c0, 0, 0, 0);
-                if (HI) c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb1, xlo, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb0[0], xlo, c0, 0, 0, 0);
+                if (HI) c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb1[0], xlo, c1, 0, 0, 0);
                 c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wm0, xmid, c0, 0, 0, 0);
                 if (HI) c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wm1, xmid, c1, 0, 0, 0);
                 c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wm0, xh, c0, 0, 0, 0);
                 if (HI) c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wm1, xh, c1, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb0, xmid, c0, 0, 0, 0);
-                if (HI) c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb1, xmid, c1, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb0, xh, c0, 0, 0, 0);
-                if (HI) c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb1, xh, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb0[0], xmid, c0, 0, 0, 0);
+                if (HI) c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb1[0], xmid, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb0[0], xh, c0, 0, 0, 0);
+                if (HI) c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb1[0], xh, c1, 0, 0, 0);
                 acc[a][0] = c0; acc[a][1] = c1;
                 return;
             } else if constexpr (B16) {
-                acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb0, xb[a], acc[a][0], 0, 0, 0);
-                if (HI) acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb1, xb[a], acc[a][1], 0, 0, 0);
+#pragma unroll
+                for (int ns = 0; ns < NS; ns++) {
+                    acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb0[ns], xb[a][ns], acc[a][0], 0, 0, 0);
+                    if (HI) acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q.wb1[ns], xb[a][ns], acc[a][1], 0, 0, 0);
+                }
                 return;
             }
 #pragma unroll
@@ -2664,9 +2679,11 @@ std::vector<uint16_t> expdw_bx_image(const float* We /*[Cmid][Cin]*/, int Cmid, 
 // needs 12-16 MFMAs; prec 0 with the image on hand - bf16x3 - : six products).  BNHIP_EXPDW_B16=0: never.
 bool expdw_sk_pipe16(int Cin, int act_e, bool stem, int prec, bool have_image) {
     static const bool off = getenv("BNHIP_EXPDW_B16") && atoi(getenv("BNHIP_EXPDW_B16")) == 0;
-    const int kw = expdw_skw(Cin, act_e, stem);
-    if (off || !have_image || kw == 0 || !expdw_bx_ok(Cin) || expdw_kp(Cin) != 32) return false;
-    return prec == 1 ? (kw == 24 || kw == 32) : prec == 0;
+    static const int max_ns = getenv("BNHIP_EXPDW_B16_NS") ? atoi(getenv("BNHIP_EXPDW_B16_NS")) : 3;     // A/B switch: resident slabs allowed
+    if (off || !have_image || stem || act_e != ACT_SWISH || !expdw_bx_ok(Cin)) return false;
+    const int kw = expdw_skw(Cin, act_e, stem), ns = expdw_kp(Cin) / 32;
+    if (prec == 1) return (kw == 24 || kw == 32) || (kw == 0 && ns >= 2 && ns <= std::min(max_ns, 3));   // one product: up to three resident slabs
+    return prec == 0 && kw != 0 && ns == 1;                                                               // six products: the f32 form's layers
 }
 bool expdw_supported(int k, int s, int Cin, int Cmid) {
     // measured on MI355X at batch 256: beyond ~128 input channels the unpipelined K loop of the fused kernel loses
@@ -2698,13 +2715,13 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
     // the small-K form (f32 MFMA) also serves the bf16x3 = 2 / "precision":"bf16" engines: with one or two K slabs the MFMAs
     // are a small part of the wave either way, and the chunk loop is worth more than the cheaper products (fp32 products where
     // bf16 ones were asked for are never less accurate)
-    const bool sk = stem || (act_e == ACT_SWISH && (p.Kw == 16 || p.Kw == 24 || p.Kw == 32));
+    const bool sk = stem || pipe16 || (act_e == ACT_SWISH && (p.Kw == 16 || p.Kw == 24 || p.Kw == 32));
     const bool bx = wep != nullptr && !sk && expdw_bx_ok(Cin);
     if (bx) { p.wep = wep; p.Kp = expdw_kp(Cin); p.prec = prec; }
     // ... except where phase 1 runs on the bf16 pipe (expdw_sk_pipe16): one product per pair in "precision":"bf16" engines
     // (2 MFMAs instead of 12-16 per tile and chunk), six exact products in fp32 engines that carry the split image
     const bool b16 = pipe16 && prec == 1, spl = pipe16 && prec == 0;
-    if (pipe16) { p.wep = wep; p.Kp = 32; p.prec = prec; }
+    if (pipe16) { p.wep = wep; p.Kp = expdw_kp(Cin); p.prec = prec; }
     if (sk && !stem) {
         // small-K form: a block owns (clip, tile) and walks the channel chunks itself
         nblk = (unsigned)B * p.tiles_h * p.tiles_w;
@@ -2738,6 +2755,8 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
 #define ED_CASE(K_, S_, TH_, TW_, TR_)                                                                        \
     if (sh->k == K_ && sh->s == S_ && sh->toh == TH_ && sh->tow == TW_ && sh->trh == TR_) {                   \
         if (bx) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        else if (b16 && p.Kp == 64) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 32, true, 4, 1, 2>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        else if (b16 && p.Kp == 96) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 32, true, 4, 1, 3>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         else if (b16 && p.Kw == 24) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 24, true, 4, 1>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         else if (b16) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 32, true, 4, 1>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         else if (spl) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 32, true, 4, 2>), dim3(nblk), dim3(256), 0, st, p, nblk); \
