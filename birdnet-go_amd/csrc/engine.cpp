@@ -826,7 +826,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                         int act_d = map_act(d.act);
                         int fpt = 0, fpl = 0;
                         conv_pads(d, dH, dW, dHo, dWo, kd, kd, &fpt, &fpl);
-                        if (kd == wd.shape[2] && wd.shape[3] == dC && act_d >= 0 && expdw_supported(kd, d.stride_h, C, Co) &&
+                        if (kd == wd.shape[2] && wd.shape[3] == dC && act_d >= 0 && expdw_supported(kd, d.stride_h, C, Co, act, bf16x3 ? precision : 0) &&
                             expdw_sum_slabs(ExpDwGeo{kd, d.stride_h, dH, dW, dHo, dWo, fpt, fpl}) > 0 && need_val(in_t) >= 0) {
                             int dout = d.outputs[0];
                             if (act_d == ACT_NONE) dout = trailing_act(dout, &act_d);

@@ -140,7 +140,7 @@ int dwconv_sum_slabs(const DwParams& p);
 void launch_dwconv(const DwParams& p, float* partial, hipStream_t s);
 
 // fused MBConv front half: y = act_d(dwconv(act_e(x We^T + be)) + bd); partial (nullable) [B, slabs, Cmid]
-bool expdw_supported(int k, int s, int Cin, int Cmid);
+bool expdw_supported(int k, int s, int Cin, int Cmid, int act_e = 0, int prec = 0);   // (Cin > 128: "precision":"bf16" engines only)
 // Layer geometry for the tile-shape helpers.  Shape indices 0 .. n-1 are the instantiated tile shapes in image orientation;
 // n .. 2n-1 the same shapes with the roles of rows and columns swapped (tall, narrow images - a time-major spectrogram -
 // tile badly with 16- / 32-column tiles): the kernel then walks the image through pixel strides and reads the depthwise taps

@@ -2245,7 +2245,8 @@ __global__ __launch_bounds__(256, BX ? expdw_min_waves(K, S, TOW, TRH) : 1) void
 // operands resident, the split is paid once per block - in k_expand_dw's BX form it is paid per chunk, which is why that form
 // never won.
 // NS (PH = 1 only): 32-wide slabs of K the block keeps resident - a bf16 fragment is 4 registers per tile and slab, so layers
-// with up to 96 input channels fit the chunk-loop form that the f32 operands (8 registers per 32 channels) reserve for K <= 32.
+// with 48 ... 256 input channels fit the chunk-loop form that the f32 operands (8 registers per 32 channels) reserve for K <= 32
+// (instantiated: 2, 3, 5, 8 slabs = 64, 96, 160, 256 padded channels).
 template <int K, int S, int TOH, int TOW, int TRH, bool STEM, int KW, bool LOOP = !STEM, int NW = 4, int PH = 0, int NS = 1>
 __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, PH == 1 ? 16 * NS : (PH == 2 ? 48 : KW), !LOOP, NW)) void k_expand_dw_sk(ExpDwParams p, unsigned nblk) {
     constexpr bool B16 = PH != 0;                             // operands are bf16 fragments of 32-wide slabs
@@ -2679,16 +2680,22 @@ std::vector<uint16_t> expdw_bx_image(const float* We /*[Cmid][Cin]*/, int Cmid, 
 // needs 12-16 MFMAs; prec 0 with the image on hand - bf16x3 - : six products).  BNHIP_EXPDW_B16=0: never.
 bool expdw_sk_pipe16(int Cin, int act_e, bool stem, int prec, bool have_image) {
     static const bool off = getenv("BNHIP_EXPDW_B16") && atoi(getenv("BNHIP_EXPDW_B16")) == 0;
-    static const int max_ns = getenv("BNHIP_EXPDW_B16_NS") ? atoi(getenv("BNHIP_EXPDW_B16_NS")) : 3;     // A/B switch: resident slabs allowed
+    static const int max_ns = getenv("BNHIP_EXPDW_B16_NS") ? atoi(getenv("BNHIP_EXPDW_B16_NS")) : 5;     // A/B switch: resident slabs allowed
     if (off || !have_image || stem || act_e != ACT_SWISH || !expdw_bx_ok(Cin)) return false;
     const int kw = expdw_skw(Cin, act_e, stem), ns = expdw_kp(Cin) / 32;
-    if (prec == 1) return (kw == 24 || kw == 32) || (kw == 0 && ns >= 2 && ns <= std::min(max_ns, 3));   // one product: up to three resident slabs
+    // one product: resident slabs.  (Eight slabs - 232 -> 1392 channels on 16 x 4 images, one block per clip - are instantiated
+    // and measured slower than the unfused pair, 266 vs 65 + 90 us per block: not offered unless BNHIP_EXPDW_B16_NS=8 asks.)
+    if (prec == 1) return (kw == 24 || kw == 32) || (kw == 0 && (ns == 2 || ns == 3 || ns == 5 || ns == 8) && ns <= max_ns);
     return prec == 0 && kw != 0 && ns == 1;                                                               // six products: the f32 form's layers
 }
-bool expdw_supported(int k, int s, int Cin, int Cmid) {
+bool expdw_supported(int k, int s, int Cin, int Cmid, int act_e, int prec) {
     // measured on MI355X at batch 256: beyond ~128 input channels the unpipelined K loop of the fused kernel loses
-    // to the separate pw_gemm + dwconv pair (b13-b16 of the B0 stack: 126 us vs 176 us), so those stay unfused
-    return (k == 3 || k == 5) && (s == 1 || s == 2) && (Cin & 3) == 0 && (Cmid & 3) == 0 && Cin <= 128;
+    // to the separate pw_gemm + dwconv pair (b13-b16 of the B0 stack: 126 us vs 176 us), so those stay unfused ...
+    if (!((k == 3 || k == 5) && (s == 1 || s == 2) && (Cin & 3) == 0 && (Cmid & 3) == 0)) return false;
+    if (Cin <= 128) return true;
+    // ... except in "precision":"bf16" engines when the layer fits the chunk-loop form with resident bf16 operands
+    // (k_expand_dw_sk<PH = 1, NS = 5 | 8>: 160 / 256 padded input channels, 2 NS MFMAs of 16 cycles per tile and chunk)
+    return prec == 1 && expdw_sk_pipe16(Cin, act_e, false, prec, true);
 }
 void launch_expand_dw(const float* x, const float* we, const float* be, const float* wd, const float* bd, float* y,
                       float* partial, int B, int H, int W, int Cin, int Cmid, int Ho, int Wo, int k, int s, int pt,
@@ -2757,6 +2764,8 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
         if (bx) hipLaunchKernelGGL((k_expand_dw<K_, S_, TH_, TW_, TR_, false, true>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         else if (b16 && p.Kp == 64) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 32, true, 4, 1, 2>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         else if (b16 && p.Kp == 96) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 32, true, 4, 1, 3>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        else if (b16 && p.Kp == 160) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 32, true, 4, 1, 5>), dim3(nblk), dim3(256), 0, st, p, nblk); \
+        else if (b16 && p.Kp == 256) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 32, true, 4, 1, 8>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         else if (b16 && p.Kw == 24) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 24, true, 4, 1>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         else if (b16) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 32, true, 4, 1>), dim3(nblk), dim3(256), 0, st, p, nblk); \
         else if (spl) hipLaunchKernelGGL((k_expand_dw_sk<K_, S_, TH_, TW_, TR_, false, 32, true, 4, 2>), dim3(nblk), dim3(256), 0, st, p, nblk); \

@@ -342,6 +342,6 @@ def test_bf16_gemm_kernel_equals_the_one_product_path_of_the_split_kernel(gpu, m
             used = lib.bnhip_debug_pw_b16_launches() - before
         finally:
             c.close()
-        assert (used > 20) if on == "2" else (used == 0), used
+        assert (used >= 10) if on == "2" else (used == 0), used
     assert np.array_equal(out["2"][0], out["0"][0]), np.abs(out["2"][0] - out["0"][0]).max()
     assert np.array_equal(out["2"][1], out["0"][1])
