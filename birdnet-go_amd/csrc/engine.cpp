@@ -861,12 +861,6 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                                 // (arithmetic by rule, not by timing: the split-bf16 phase 1 measured +0-0.5 % at best, so it is
                                 // used only where asked for)
                                 if (bf16x3 >= 2 || precision == 1) steps.back().bx = 1;
-                                // The small-K chunk-loop form has a six-product phase 1 as well (k_expand_dw_sk<PH = 2>: the split
-                                // is paid once per block there, not once per channel chunk).  Measured, batch 256: b2 276 -> 263 us,
-                                // b3 208 -> 208, b4 183 -> 177 alone; pipelined step 3.54-3.57 -> 3.59-3.61 ms (two A/B pairs) -
-                                // the MFMAs were not what those layers wait for.  Opt-in (BNHIP_EXPDW_SPLIT=1), read per engine.
-                                const char* sks = getenv("BNHIP_EXPDW_SPLIT");
-                                if (sks && atoi(sks) == 1 && expdw_skw(C, act, false) != 0) steps.back().bx = 1;
                             }
                             break;
                         }

@@ -170,4 +170,43 @@ __device__ __forceinline__ void pw_epilogue(const PwParams& p, f32x4 (&acc)[NT][
 }
 
 
+// ---- split-bf16 operand helpers (k_pw_bx3 in kernels.hip, the BX / bf16 phase 1 of the fused kernels in expdw.hip)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// exact fp32 subtraction kept scalar: under -O3 the compiler SLP-packs the two remainders of a pair into v_pk_add_f32, which
+// costs ~13 cycles beside MFMAs on this chip (MI355X_MICROARCH.md, "price of one filler") against ~4 for a plain v_sub_f32
+__device__ __forceinline__ float bx3_sub(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void bx3_split8(const f32x4& a, const f32x4& b, bf16x8* hi, bf16x8* mid, bf16x8* lo) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    u32x4 h, m, l;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        // v_cvt_pk_bf16_f32 (round to nearest even) per pair, remainders by exact fp32 subtraction
+        const f32x2 v = {x[2 * q], x[2 * q + 1]};
+        const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+        const f32x2 r = {bx3_sub(v[0], __uint_as_float(hb << 16)), bx3_sub(v[1], __uint_as_float(hb & 0xffff0000u))};
+        const unsigned mb = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+        const f32x2 t = {bx3_sub(r[0], __uint_as_float(mb << 16)), bx3_sub(r[1], __uint_as_float(mb & 0xffff0000u))};
+        h[q] = hb; m[q] = mb; l[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+    }
+    *hi = __builtin_bit_cast(bf16x8, h); *mid = __builtin_bit_cast(bf16x8, m); *lo = __builtin_bit_cast(bf16x8, l);
+}
+
+// plain bf16 operands (PwParams::prec = 1): round to nearest even, no remainders
+__device__ __forceinline__ bf16x8 bx1_cvt8(const f32x4& a, const f32x4& b) {
+    u32x4 h;
+    h[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a[0], a[1]}, bf16x2));
+    h[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a[2], a[3]}, bf16x2));
+    h[2] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){b[0], b[1]}, bf16x2));
+    h[3] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){b[2], b[3]}, bf16x2));
+    return __builtin_bit_cast(bf16x8, h);
+}
+
+
 }  // namespace bnhip

@@ -684,25 +684,3 @@ def test_streamed_split_gemm_equals_the_staged_one(full_blob, monkeypatch):
             c.close()
             assert (used >= 15) if mode == "2" else (used == 0), (n, mode, used)
         assert np.array_equal(out["2"], out["0"]), (n, np.abs(out["2"] - out["0"]).max())
-
-
-def test_small_k_expand_on_the_bf16_pipe_is_fp32_equivalent(full_blob, monkeypatch):
-    """k_expand_dw_sk<PH = 2> (opt-in, BNHIP_EXPDW_SPLIT=1: b2 - b4 of the v2.4 stack): three exact bf16 pieces per operand, six
-    products - results within fp32 rounding of the f32-MFMA form, the oracle's top-1, and never an eight-wave tile."""
-    x = sm.synth_clips(8, 144000, 48000)
-    x[7] = 0.0
-    ref = Interpreter(full_blob).invoke(x)[0]
-    out = {}
-    for bx in (1, 0):
-        monkeypatch.setenv("BNHIP_EXPDW_SPLIT", str(bx))
-        c = host.HipClassifier(full_blob, max_batch=8)
-        try:
-            st = {s["name"]: s for s in c.describe()["steps"] if s["kernel"] == "expand_dw"}
-            assert all(st[n]["bx"] == bx for n in ("b2/expand+dw", "b3/expand+dw", "b4/expand+dw")), st
-            assert not bx or all(st[n]["shape"] % 22 < 14 for n in ("b2/expand+dw", "b3/expand+dw", "b4/expand+dw"))
-            out[bx] = c.predict_batch(x.reshape(-1), 8)
-        finally:
-            c.close()
-        assert_parity(out[bx], ref)
-        assert np.abs(out[bx] - ref).max() < 1e-3
-    assert np.abs(out[1] - out[0]).max() < 2e-4 and not np.array_equal(out[1], out[0])
