@@ -17,6 +17,7 @@
 #include "pw_common.h"
 
 #include <algorithm>
+#include <atomic>
 
 namespace bnhip {
 
@@ -273,10 +274,10 @@ bool pw_b16_forced() {
     return e && e[0] == '2';
 }
 
-static long g_pw_b16_launches = 0;      // diagnostics (tests assert that this path, not k_pw_bx3's, ran); calls are serialised per handle
+static std::atomic<long> g_pw_b16_launches{0};      // diagnostics (tests assert that this path, not k_pw_bx3's, ran); the workers of a multi-device handle launch concurrently
 // prec 1 (one product): 128-row tiles; prec 0 (six products): 64- or 128-row tiles (wm = 1 | 2)
 void launch_pw_b16(const PwParams& p, const uint16_t* Wimg, int nt, int wm, int Npad, int nblk_n, unsigned nblk, hipStream_t s) {
-    g_pw_b16_launches++;
+    g_pw_b16_launches.fetch_add(1, std::memory_order_relaxed);
     const FDiv dn = make_fdiv((unsigned)nblk_n), dhw = make_fdiv((unsigned)std::max(p.HW, 1));
     const bool sc = p.ascale != nullptr, abf = p.a_bf16 != 0, six = p.prec == 0;
     const bool scl = sc && p.HW >= 16 && (p.HW & 15) == 0;      // a 16-row tile never straddles two clips: scale through LDS
@@ -297,4 +298,4 @@ void launch_pw_b16(const PwParams& p, const uint16_t* Wimg, int nt, int wm, int 
 
 }  // namespace bnhip
 
-extern "C" long bnhip_debug_pw_b16_launches(void) { return bnhip::g_pw_b16_launches; }
+extern "C" long bnhip_debug_pw_b16_launches(void) { return bnhip::g_pw_b16_launches.load(std::memory_order_relaxed); }
