@@ -1537,7 +1537,10 @@ void launch_conv_igemm(const float* in, const float* w_ohwi, const float* bias, 
 // (coalesced float4), tiles row-major; blocks are XCD-remapped so vertically adjacent tiles of a clip share an
 // L2.  Optionally emits deterministic per-block channel sums for the squeeze-excite mean (no second pass over
 // the tensor, no float atomics): partial[b][tile_chunk][c].
-template <int K, int S, int TH, int TW>
+// IN16 (bf16 activation storage on the input): the thread's whole input patch - RH x RW quads of 8 bytes - is requested before
+// the first tap is applied, so a block pays one memory round trip instead of one per input row (the row loop otherwise issues
+// RW loads, waits, multiplies, and only then issues the next row's: b1 / b2 of the Perch stack ran at 2.0 / 3.2 TB/s).
+template <int K, int S, int TH, int TW, bool IN16 = false>
 __global__ __launch_bounds__(256) void k_dwconv_t(DwParams p, int CX, int PY, int tiles_w, int tiles, int tchunks,
                                                   int cchunks, unsigned nblk, float* __restrict__ partial) {
     __shared__ float red[256 * 4];
@@ -1563,6 +1566,18 @@ __global__ __launch_bounds__(256) void k_dwconv_t(DwParams p, int CX, int PY, in
         const int hi0 = th0 * S - p.pt, wi0 = tw0 * S - p.pl;
         const float4* in4 = reinterpret_cast<const float4*>(p.in) + (size_t)b * p.H * p.W * C4 + c4;
         const float4* w4 = reinterpret_cast<const float4*>(p.w) + c4;
+        uint2 raw[IN16 ? RH : 1][IN16 ? RW : 1];
+        if constexpr (IN16) {
+            const uint2* in2 = reinterpret_cast<const uint2*>(p.in) + (size_t)b * p.H * p.W * C4 + c4;
+#pragma unroll
+            for (int r = 0; r < RH; r++)
+#pragma unroll
+                for (int c = 0; c < RW; c++) {
+                    const int hi = hi0 + r, wi = wi0 + c;
+                    const bool in = hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+                    raw[r][c] = in ? in2[((size_t)hi * p.W + wi) * C4] : make_uint2(0u, 0u);
+                }
+        }
 #pragma unroll
         for (int r = 0; r < RH; r++) {
             const int hi = hi0 + r;
@@ -1571,7 +1586,10 @@ __global__ __launch_bounds__(256) void k_dwconv_t(DwParams p, int CX, int PY, in
 #pragma unroll
             for (int c = 0; c < RW; c++) {
                 int wi = wi0 + c;
-                if (!(wi >= 0 && wi < p.W)) x[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (IN16) {
+                    const uint2 rr = raw[r][c];
+                    x[c] = make_float4(__uint_as_float(rr.x << 16), __uint_as_float(rr.x & 0xffff0000u), __uint_as_float(rr.y << 16), __uint_as_float(rr.y & 0xffff0000u));
+                } else if (!(wi >= 0 && wi < p.W)) x[c] = make_float4(0.f, 0.f, 0.f, 0.f);
                 else if (p.in_bf16) x[c] = bf16x4_load(p.in, ((size_t)b * p.H * p.W + (size_t)hi * p.W + wi) * C4 + c4);
                 else x[c] = in4[((size_t)hi * p.W + wi) * C4];
             }
@@ -1712,8 +1730,11 @@ void launch_dwconv(const DwParams& p, float* partial, hipStream_t s) {
         dw_geometry(p, TH, TW, &CX, &PY, &tiles_w, &tiles, &tchunks, &cchunks);
         unsigned nblk = (unsigned)p.B * tchunks * cchunks;
         dim3 block(CX * PY < 64 ? 64 : CX * PY);
-#define DW_LAUNCH(K_, S_, TH_, TW_) hipLaunchKernelGGL((k_dwconv_t<K_, S_, TH_, TW_>), dim3(nblk), block, 0, s, p, CX, PY, \
-                                                       tiles_w, tiles, tchunks, cchunks, nblk, partial)
+        static const bool pre16 = !(getenv("BNHIP_DW_PREFETCH") && atoi(getenv("BNHIP_DW_PREFETCH")) == 0);
+#define DW_LAUNCH(K_, S_, TH_, TW_) do { if (p.in_bf16 && pre16) hipLaunchKernelGGL((k_dwconv_t<K_, S_, TH_, TW_, true>), dim3(nblk), block, 0, s, p, CX, PY, \
+                                                       tiles_w, tiles, tchunks, cchunks, nblk, partial); \
+                                         else hipLaunchKernelGGL((k_dwconv_t<K_, S_, TH_, TW_>), dim3(nblk), block, 0, s, p, CX, PY, \
+                                                       tiles_w, tiles, tchunks, cchunks, nblk, partial); } while (0)
         if (p.kh == 3 && p.sh == 1) DW_LAUNCH(3, 1, 2, 4);
         else if (p.kh == 3) DW_LAUNCH(3, 2, 2, 2);
         else if (p.sh == 1) DW_LAUNCH(5, 1, 2, 4);
