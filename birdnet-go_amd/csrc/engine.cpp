@@ -1844,6 +1844,11 @@ void Engine::mark_bf16_storage() {
     if (precision != 1 || device < 0) return;
     if (const char* e = getenv("BNHIP_BF16_ACT")) if (atoi(e) == 0) return;
     auto bx_pw = [&](const Step& s) { return s.kind == S_PW && s.bx && s.wbx && s.wm >= 5 && s.wm_full >= 5; };
+    // bf16 residual stream (BNHIP_BF16_RESID=0: block outputs stay fp32): the narrow tensors between the blocks - projection
+    // outputs, read by the next expand, by the next projection's residual add and, in ratio-1 blocks, by a depthwise kernel -
+    // are what the HBM-bound early projections of a bf16 engine mostly move
+    bool resid = true;
+    if (const char* e = getenv("BNHIP_BF16_RESID")) resid = atoi(e) != 0;
     auto dw_ok = [&](const Step& s) {
         if (s.kind != S_DW || (s.C & 3)) return false;
         DwParams p{nullptr, nullptr, nullptr, nullptr, 1, s.H, s.W, s.C, s.Ho, s.Wo, s.kh, s.kw, s.sh, s.sw, s.pt, s.pl, s.act};
@@ -1863,14 +1868,21 @@ void Engine::mark_bf16_storage() {
                     ConvParams cp{nullptr, nullptr, nullptr, nullptr, 1, s.H, s.W, s.C, s.Ho, s.Wo, s.Co, s.kh, s.kw, s.sh, s.sw, s.pt, s.pl, s.act};
                     stem_ok = conv_direct_bf16_ok(cp);
                 }
-                const bool p_ok = (bx_pw(s) && (s.Co & 3) == 0 && s.in2 < 0) || dw_ok(s) || (s.kind == S_EXPAND_DW && (s.Co & 3) == 0) || stem_ok;
+                // (a projection that adds a residual may write bf16 too - the bf16 residual stream, `resid` below)
+                const bool p_ok = (bx_pw(s) && (s.Co & 3) == 0 && (s.in2 < 0 || resid)) || dw_ok(s) || (s.kind == S_EXPAND_DW && (s.Co & 3) == 0) || stem_ok;
                 if (!p_ok) ok = false;
             }
             if (s.out2 == id) ok = false;
-            if (s.in1 == id || s.in2 == id) ok = false;
+            if (s.in1 == id) ok = false;
+            if (s.in2 == id) {                                  // residual operand of a projection: its epilogue can widen bf16
+                consumers++;
+                if (!(resid && bx_pw(s) && (s.Co & 3) == 0)) ok = false;
+            }
             if (s.in0 == id) {
                 consumers++;
-                const bool c_ok = (bx_pw(s) && (s.C & 7) == 0) || dw_ok(s);     // (the GEMM fetches 8 channels per load)
+                // (the GEMM fetches 8 channels per load; the fused kernel takes bf16 input in its bf16-pipe chunk-loop form only)
+                const bool c_ok = (bx_pw(s) && (s.C & 7) == 0) || dw_ok(s) ||
+                                  (resid && s.kind == S_EXPAND_DW && s.mode != 1 && expdw_sk_pipe16(s.C, s.act, false, precision, s.bx && s.wbx != nullptr && bf16x3));
                 if (!c_ok) ok = false;
             }
         }
@@ -1879,6 +1891,7 @@ void Engine::mark_bf16_storage() {
     // accounting: the algorithmic bytes of the steps that touch a bf16 value shrink with it
     for (Step& s : steps) {
         if (s.in0 >= 0 && vals[s.in0].half) s.bytes -= 2.0 * (double)vals[s.in0].elems;
+        if (s.kind == S_PW && s.in2 >= 0 && vals[s.in2].half) s.bytes -= 2.0 * (double)vals[s.in2].elems;
         if (s.out >= 0 && vals[s.out].half) s.bytes -= 2.0 * (double)vals[s.out].elems;
     }
 }
@@ -1917,7 +1930,8 @@ void Engine::autotune_expdw() {
             auto go = [&]() {
                 StemGeom sg{s.H2, s.W2, s.pt2, s.pl2};
                 launch_expand_dw(in0, s.w0, s.w1, s.w2, s.w3, out, out2, n, s.H, s.W, s.C, s.Co, s.Ho, s.Wo, s.kh, s.sh, s.pt, s.pl,
-                                 s.act, s.act2, idx, s.mode == 1 ? &sg : nullptr, stream, bx ? s.wbx : nullptr, precision);
+                                 s.act, s.act2, idx, s.mode == 1 ? &sg : nullptr, stream, bx ? s.wbx : nullptr, precision,
+                                 vals[s.out].half ? 1 : 0, vals[s.in0].half ? 1 : 0);          // the storage flavour the calls will run
             };
             go();
             hipEventRecord(a, stream);
@@ -2066,6 +2080,7 @@ void Engine::autotune_pw() {
                         PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, nt, wm};
                         p.prec = precision;
                         p.a_bf16 = vals[s.in0].half ? 1 : 0; p.out_bf16 = vals[s.out].half ? 1 : 0;      // the flavour the calls will run
+                        p.res_bf16 = (s.in2 >= 0 && vals[s.in2].half) ? 1 : 0;
                         launch_pw_bx3(p, s.wbx, stream);
                         hipEventRecord(a, stream);
                         for (int r = 0; r < 3; r++) launch_pw_bx3(p, s.wbx, stream);
@@ -2302,6 +2317,7 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
                            nl > 1 ? s.wm : s.wm_full};
                 p.prec = precision;
                 p.a_bf16 = vals[s.in0].half ? 1 : 0; p.out_bf16 = vals[s.out].half ? 1 : 0;
+                p.res_bf16 = (s.in2 >= 0 && vals[s.in2].half) ? 1 : 0;
                 if (p.wm >= 5 && s.wbx) launch_pw_bx3(p, s.wbx, stream);
                 else launch_pw_gemm(p, stream);
                 break;
@@ -2318,7 +2334,7 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
                     StemGeom sg{s.H2, s.W2, s.pt2, s.pl2};
                     launch_expand_dw(in0, s.w0, s.w1, s.w2, s.w3, out, out2, n, s.H, s.W, s.C, s.Co,
                                      s.Ho, s.Wo, s.kh, s.sh, s.pt, s.pl, s.act, s.act2, s.shape, s.mode == 1 ? &sg : nullptr, stream,
-                                     s.bx ? s.wbx : nullptr, precision, vals[s.out].half ? 1 : 0);
+                                     s.bx ? s.wbx : nullptr, precision, vals[s.out].half ? 1 : 0, vals[s.in0].half ? 1 : 0);
                 }
                 break;
             case S_MEAN_PARTIAL:

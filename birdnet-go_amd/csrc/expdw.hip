@@ -571,6 +571,13 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, PH == 
             } else if constexpr (B16) {
                 const float* xp = xbase + (size_t)((b * p.H * p.W + ihc * p.xsh + iwc * p.xsw) * Cin);
                 // K tail (Cin = 24: lane group 3): any in-bounds address - the image's weights are zero there
+                if (p.in_bf16) {
+                    // bf16 residual stream: the lane's 8 channels of a slab are 16 bytes that ARE the fragment
+                    const uint16_t* xh = reinterpret_cast<const uint16_t*>(xbase) + (size_t)((b * p.H * p.W + ihc * p.xsh + iwc * p.xsw) * Cin);
+#pragma unroll
+                    for (int ns = 0; ns < NS; ns++)
+                        xb[a][ns] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xh + (32 * ns + 8 * kq < Cin ? 32 * ns + 8 * kq : 0)));
+                } else
 #pragma unroll
                 for (int ns = 0; ns < NS; ns++) {
                     const float* xq = xp + (32 * ns + 8 * kq < Cin ? 32 * ns + 8 * kq : 0);
@@ -913,7 +920,8 @@ bool expdw_supported(int k, int s, int Cin, int Cmid, int act_e, int prec) {
 }
 void launch_expand_dw(const float* x, const float* we, const float* be, const float* wd, const float* bd, float* y,
                       float* partial, int B, int H, int W, int Cin, int Cmid, int Ho, int Wo, int k, int s, int pt,
-                      int pl, int act_e, int act_d, int shape, const StemGeom* stem, hipStream_t st, const uint16_t* wep, int prec, int out_bf16) {
+                      int pl, int act_e, int act_d, int shape, const StemGeom* stem, hipStream_t st, const uint16_t* wep, int prec, int out_bf16,
+                      int in_bf16) {
     // (a layer whose phase 1 runs on the bf16 pipe never takes an eight-wave shape - those exist in the f32 form only - so that
     // the arithmetic of a layer does not depend on which tile the tuner preferred: skw = 0 withholds them)
     const bool pipe16 = expdw_sk_pipe16(Cin, act_e, stem != nullptr, prec, wep != nullptr);
@@ -942,7 +950,7 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
     // ... except where phase 1 runs on the bf16 pipe (expdw_sk_pipe16: "precision":"bf16" engines, one product per pair - 2 MFMAs
     // instead of 12-16 per tile, chunk and slab)
     const bool b16 = pipe16;
-    if (pipe16) { p.wep = wep; p.Kp = expdw_kp(Cin); p.prec = prec; }
+    if (pipe16) { p.wep = wep; p.Kp = expdw_kp(Cin); p.prec = prec; p.in_bf16 = in_bf16; }     // (the planner marks x bf16 for this form only)
     if (sk && !stem) {
         // small-K form: a block owns (clip, tile) and walks the channel chunks itself
         nblk = (unsigned)B * p.tiles_h * p.tiles_w;

@@ -109,7 +109,8 @@ struct PwParams {         // pointwise conv / fully-connected as GEMM: out[M,N] 
     int prec = 0;         // k_pw_bx3 only: 0 = six bf16 products per fp32 product (fp32-equivalent), 1 = one (plain bf16 operands,
                           // fp32 accumulate: the "precision":"bf16" engines)
     int a_bf16 = 0;       // k_pw_bx3 / k_pw_bx3p only: A holds bf16 values (bf16 activation storage, K % 4 == 0)
-    int out_bf16 = 0;     // any pw kernel: out is written as bf16 (N % 4 == 0, no residual)
+    int out_bf16 = 0;     // any pw kernel: out is written as bf16 (N % 4 == 0)
+    int res_bf16 = 0;     // any pw kernel: res holds bf16 values (N % 4 == 0) - the residual stream of a "precision":"bf16" engine
 };
 void launch_pw_gemm(const PwParams& p, hipStream_t s);
 bool pw_pipe_ok(int nt, int wm, int K);   // PwParams::wm = 2 + wm selects the software-pipelined kernel (k_pw_pipe)
@@ -164,7 +165,8 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
                       const StemGeom* stem /* non-null: x is the raw image and the expand is the 3x3/2 stem (see kernels.hip) */,
                       hipStream_t st, const uint16_t* wep = nullptr /* non-null: phase 1 on the split-bf16 MFMA (expdw_bx_image) */,
                       int prec = 0 /* with wep: 1 = plain bf16 operands (one product) */,
-                      int out_bf16 = 0 /* y is written as bf16 (bf16 activation storage; Cmid % 4 == 0) */);
+                      int out_bf16 = 0 /* y is written as bf16 (bf16 activation storage; Cmid % 4 == 0) */,
+                      int in_bf16 = 0 /* x holds bf16 values (bf16 residual stream): only where expdw_sk_pipe16 holds */);
 // plain depthwise convolution through the same kernel (COPY mode: LDS-staged taps); shape as for launch_expand_dw, partial
 // (nullable) [B, expdw_shape_slabs(shape, geo), C]
 bool dwconv_lds_supported(const DwParams& p);

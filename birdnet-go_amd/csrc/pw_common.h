@@ -153,8 +153,13 @@ __device__ __forceinline__ void pw_epilogue(const PwParams& p, f32x4 (&acc)[NT][
             if (row < 16 && m < p.M && n < p.N) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * CS + 4 * c4]);
                 float* op = p.out + (size_t)m * p.N + n;
-                if (p.out_bf16) {                         // (planner: only with N % 4 == 0 and no residual)
-                    bf16x4_store(p.out, ((size_t)m * p.N + n) >> 2, make_float4(v[0], v[1], v[2], v[3]));
+                if (p.out_bf16 || p.res_bf16) {           // (planner: only with N % 4 == 0) bf16 residual stream / activation storage
+                    if (p.res) {
+                        const float4 rv = p.res_bf16 ? bf16x4_load(p.res, ((size_t)m * p.N + n) >> 2) : *reinterpret_cast<const float4*>(p.res + (size_t)m * p.N + n);
+                        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                    }
+                    if (p.out_bf16) bf16x4_store(p.out, ((size_t)m * p.N + n) >> 2, make_float4(v[0], v[1], v[2], v[3]));
+                    else *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
                 } else if (vec_ok) {
                     if (p.res) { float4 rv = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.N + n); v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
                     *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
