@@ -153,9 +153,9 @@ def test_onnx_audio_front_ends_and_crafted_files_under_asan(fuzz_bin, tmp_path):
             n_seed += 1
             corpus.append(ox)
             # the nodes and small initializers sit at the front of the graph, the big weights behind them: mutate both ends
-            corpus += _mutations(ox, rng, 60, window=6000)
+            corpus += _mutations(ox, rng, 32, window=6000)
             tail = ox[-3000:]
-            for mt in _mutations(tail, rng, 30):
+            for mt in _mutations(tail, rng, 16):
                 corpus.append(ox[:-len(tail)] + mt[:len(tail)].ljust(len(tail), b"\0"))
     crafted = _crafted_onnx() + [_crafted_empty_slice_axes()]
     corpus += crafted
