@@ -127,6 +127,9 @@ void launch_pw_bx3(const PwParams& p, const uint16_t* Wimg, hipStream_t s);
 // tiles; one product per operand pair for "precision":"bf16" engines - 128-row tiles only - or the six-product fp32-equivalent
 // form): called by launch_pw_bx3, which has resolved the tile (nt = 16-column units) and the grid.  BNHIP_PW_B16=0 takes the candidate away from the tuner (A/B runs, parity test).
 bool pw_b16_ok(int prec, int K);
+bool pw_b16s_ok(const PwParams& p);   // weights-stationary form for skinny layers (N <= 32, K <= 192) of one-product engines: PwParams::wm = 11
+bool pw_b16s_forced();
+void launch_pw_b16s(const PwParams& p, const uint16_t* Wimg, int Npad, hipStream_t s);
 bool pw_b16_forced();              // BNHIP_PW_B16=2: every 128-row tile of a "precision":"bf16" engine takes k_pw_b16 (parity test)
 void launch_pw_b16(const PwParams& p, const uint16_t* Wimg, int nt, int wm /*1 | 2*/, int Npad, int nblk_n, unsigned nblk, hipStream_t s);
 

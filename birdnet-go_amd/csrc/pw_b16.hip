@@ -265,16 +265,169 @@ __global__ __launch_bounds__(256) void k_pw_b16(PwParams p, const uint16_t* __re
     pw_epilogue<NT, WM>(p, acc, lds, m0, n0);
 }
 
+static std::atomic<long> g_pw_b16_launches{0};      // diagnostics (tests assert that this path, not k_pw_bx3's, ran); the workers of a multi-device handle launch concurrently
+
+// ---- skinny layers: weights stationary in registers
+// The early projections of an MBConv stack have K and N of a few dozen (24 -> 24, 40 -> 24, 144 -> 32, 192 -> 32) against millions of
+// rows: a 128-row tile there is one or a handful of slabs wrapped in a prologue, an LDS epilogue and barriers (Perch b2/project:
+// 458 us for 1.2 GB, 2.6 TB/s).  Here the whole weight matrix lives in a wave's registers as fragments (NS slabs x NT 16-column tiles
+// x 4 registers, at most 48), a wave walks 16-row tiles of its own row range with nothing but loads, NS x NT MFMAs and stores per
+// tile - no LDS, no barriers - the next tile's A fragments requested before this tile's MFMAs, and the epilogue goes straight from
+// the accumulators (a lane holds four consecutive channels of one row: one 8- or 16-byte access).  Same image, same K order, one
+// product per pair: bit-identical to k_pw_b16 / k_pw_bx3.  Squeeze-excite scale: per-clip fragments reloaded when the tile's clip
+// changes (HW % 16 == 0: a tile never straddles two clips).
+template <int NT, int NS, bool SC, bool ABF>
+__global__ __launch_bounds__(256) void k_pw_b16s(PwParams p, const uint16_t* __restrict__ Wimg, int Npad, int tiles_per_wave, FDiv dhw) {
+    const int lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
+    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int K = p.K, N = p.N;
+    const int ntiles = (p.M + 15) >> 4;
+    const int t0 = wave_g * tiles_per_wave, t1 = min(t0 + tiles_per_wave, ntiles);
+    if (t0 >= t1) return;
+    // weights: plane 0 of the image, slot (slab, kq, row 16 t + li)
+    const u32v4* W16 = reinterpret_cast<const u32v4*>(Wimg);
+    b16x8 wf[NS][NT];
+#pragma unroll
+    for (int ns = 0; ns < NS; ns++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) wf[ns][t] = __builtin_bit_cast(b16x8, W16[((size_t)ns * 12 + kq) * Npad + min(16 * t + li, Npad - 1)]);
+    f32x4 bias[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        bias[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int n = 16 * t + 4 * kq;
+        if (p.bias && n + 3 < N) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n); bias[t] = (f32x4){b4.x, b4.y, b4.z, b4.w}; }
+    }
+    const uint16_t* A16 = reinterpret_cast<const uint16_t*>(p.A);
+    bool inlo[NS], inhi[NS];
+#pragma unroll
+    for (int ns = 0; ns < NS; ns++) { inlo[ns] = 32 * ns + 4 * kq < K; inhi[ns] = 32 * ns + 16 + 4 * kq < K; }
+    ARaw<ABF> cur[NS], nxt[NS];
+    auto aload = [&](int tile, ARaw<ABF> (&dst)[NS]) {
+        const int m = min(16 * tile + li, p.M - 1);
+        const size_t off = (size_t)m * K + 4 * kq;
+#pragma unroll
+        for (int ns = 0; ns < NS; ns++) {
+            if constexpr (ABF) {
+                dst[ns].lo = inlo[ns] ? *reinterpret_cast<const u32v2*>(A16 + off + 32 * ns) : (u32v2){0u, 0u};
+                dst[ns].hi = inhi[ns] ? *reinterpret_cast<const u32v2*>(A16 + off + 32 * ns + 16) : (u32v2){0u, 0u};
+            } else {
+                dst[ns].lo = inlo[ns] ? *reinterpret_cast<const float4*>(p.A + off + 32 * ns) : make_float4(0.f, 0.f, 0.f, 0.f);
+                dst[ns].hi = inhi[ns] ? *reinterpret_cast<const float4*>(p.A + off + 32 * ns + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    float4 slo[SC ? NS : 1], shi[SC ? NS : 1];
+    int sclip = -1;
+    aload(t0, cur);
+    for (int tile = t0; tile < t1; tile++) {
+        if (tile + 1 < t1) aload(tile + 1, nxt);
+        if constexpr (SC) {
+            const int b = (int)fdiv((unsigned)min(16 * tile, p.M - 1), dhw);           // wave-uniform
+            if (b != sclip) {
+                sclip = b;
+                const float* sp = p.ascale + (size_t)b * K + 4 * kq;
+#pragma unroll
+                for (int ns = 0; ns < NS; ns++) {
+                    slo[ns] = inlo[ns] ? *reinterpret_cast<const float4*>(sp + 32 * ns) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    shi[ns] = inhi[ns] ? *reinterpret_cast<const float4*>(sp + 32 * ns + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ns = 0; ns < NS; ns++) {
+            b16x8 af;
+            if constexpr (ABF && !SC) {
+                af = __builtin_bit_cast(b16x8, (u32v4){cur[ns].lo[0], cur[ns].lo[1], cur[ns].hi[0], cur[ns].hi[1]});
+            } else {
+                float4 v0, v1;
+                if constexpr (ABF) { v0 = b16_unpack4(cur[ns].lo); v1 = b16_unpack4(cur[ns].hi); }
+                else { v0 = cur[ns].lo; v1 = cur[ns].hi; }
+                if constexpr (SC) {
+                    const float4 s0 = slo[ns], s1 = shi[ns];
+                    v0.x *= s0.x; v0.y *= s0.y; v0.z *= s0.z; v0.w *= s0.w;
+                    v1.x *= s1.x; v1.y *= s1.y; v1.z *= s1.z; v1.w *= s1.w;
+                }
+                af = b16_cvt8(v0, v1);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ns][t], af, acc[t], 0, 0, 0);
+        }
+        // epilogue from the accumulators: row m = 16 tile + li, channels 16 t + 4 kq .. + 3
+        const int m = 16 * tile + li;
+        if (m < p.M) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const int n = 16 * t + 4 * kq;
+                if (n + 3 < N) {                                   // (N % 4 == 0: a quad is wholly inside or outside)
+                    f32x4 v = acc[t] + bias[t];
+                    if (p.act == ACT_SWISH) v = swish4(v);
+                    else if (p.act != ACT_NONE) { v[0] = apply_act(v[0], p.act); v[1] = apply_act(v[1], p.act); v[2] = apply_act(v[2], p.act); v[3] = apply_act(v[3], p.act); }
+                    const size_t o = (size_t)m * N + n;
+                    if (p.res) {
+                        const float4 rv = p.res_bf16 ? bf16x4_load(p.res, o >> 2) : *reinterpret_cast<const float4*>(p.res + o);
+                        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                    }
+                    if (p.out_bf16) bf16x4_store(p.out, o >> 2, make_float4(v[0], v[1], v[2], v[3]));
+                    else *reinterpret_cast<float4*>(p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+        if (tile + 1 < t1) {
+#pragma unroll
+            for (int ns = 0; ns < NS; ns++) cur[ns] = nxt[ns];
+        }
+    }
+}
+
+// layers the weights-stationary kernel takes: one-product engines, N a multiple of 4 up to 32, K up to 192 (NS x NT <= 12 fragments),
+// squeeze-excite scale only when a 16-row tile cannot straddle clips
+bool pw_b16s_ok(const PwParams& p) {
+    const char* e = getenv("BNHIP_PW_B16S");              // 0: never; 2: every eligible layer whatever the tuner chose (parity test)
+    if (e && e[0] == '0') return false;
+    if (p.prec != 1 || (p.K & 3) || p.K < 16 || (p.N & 3) || p.N > 32) return false;
+    const int ns = (p.K + 31) / 32, nt = (p.N + 15) / 16;
+    if (ns * nt > 12 || ns > 6) return false;
+    if (p.ascale && !(p.HW >= 16 && (p.HW & 15) == 0)) return false;
+    return true;
+}
+void launch_pw_b16s(const PwParams& p, const uint16_t* Wimg, int Npad, hipStream_t s) {
+    g_pw_b16_launches.fetch_add(1, std::memory_order_relaxed);
+    const int ns = (p.K + 31) / 32, nt = (p.N + 15) / 16;
+    const int ntiles = (p.M + 15) / 16;
+    // enough waves to fill the chip several times over, few enough that a wave amortises its weight fragments over many tiles
+    int tpw = std::max(1, std::min(64, ntiles / (256 * 4 * 8)));
+    const int waves = (ntiles + tpw - 1) / tpw;
+    const unsigned nblk = (unsigned)((waves + 3) / 4);
+    const FDiv dhw = make_fdiv((unsigned)std::max(p.HW, 1));
+    const bool sc = p.ascale != nullptr, abf = p.a_bf16 != 0;
+#define B16S_LAUNCH(NT_, NS_, SC_, ABF_) hipLaunchKernelGGL((k_pw_b16s<NT_, NS_, SC_, ABF_>), dim3(nblk), dim3(256), 0, s, p, Wimg, Npad, tpw, dhw)
+#define B16S_FLAV(NT_, NS_) do { if (sc) { if (abf) B16S_LAUNCH(NT_, NS_, true, true); else B16S_LAUNCH(NT_, NS_, true, false); } \
+                                 else { if (abf) B16S_LAUNCH(NT_, NS_, false, true); else B16S_LAUNCH(NT_, NS_, false, false); } } while (0)
+#define B16S_NS(NT_) switch (ns) { case 1: B16S_FLAV(NT_, 1); break; case 2: B16S_FLAV(NT_, 2); break; case 3: B16S_FLAV(NT_, 3); break; \
+                                   case 4: B16S_FLAV(NT_, 4); break; case 5: B16S_FLAV(NT_, 5); break; default: B16S_FLAV(NT_, 6); break; }
+    if (nt == 1) B16S_NS(1) else B16S_NS(2)
+#undef B16S_LAUNCH
+#undef B16S_FLAV
+#undef B16S_NS
+}
+
 bool pw_b16_ok(int prec, int K) {   // (the switch is read per call - one getenv beside a 5 us launch - so that a test can flip it inside one process)
     const char* e = getenv("BNHIP_PW_B16");
     return (prec == 0 || prec == 1) && (K & 3) == 0 && K >= 16 && !(e && e[0] == '0');
+}
+bool pw_b16s_forced() {
+    const char* e = getenv("BNHIP_PW_B16S");
+    return e && e[0] == '2';
 }
 bool pw_b16_forced() {
     const char* e = getenv("BNHIP_PW_B16");
     return e && e[0] == '2';
 }
 
-static std::atomic<long> g_pw_b16_launches{0};      // diagnostics (tests assert that this path, not k_pw_bx3's, ran); the workers of a multi-device handle launch concurrently
 // prec 1 (one product): 128-row tiles; prec 0 (six products): 64- or 128-row tiles (wm = 1 | 2)
 void launch_pw_b16(const PwParams& p, const uint16_t* Wimg, int nt, int wm, int Npad, int nblk_n, unsigned nblk, hipStream_t s) {
     g_pw_b16_launches.fetch_add(1, std::memory_order_relaxed);

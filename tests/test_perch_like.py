@@ -345,3 +345,31 @@ def test_bf16_gemm_kernel_equals_the_one_product_path_of_the_split_kernel(gpu, m
         assert (used >= 10) if on == "2" else (used == 0), used
     assert np.array_equal(out["2"][0], out["0"][0]), np.abs(out["2"][0] - out["0"][0]).max()
     assert np.array_equal(out["2"][1], out["0"][1])
+
+
+@pytest.mark.gpu
+def test_weights_stationary_gemm_equals_the_tiled_kernels(gpu, monkeypatch):
+    """k_pw_b16s (pw_b16.hip: skinny projections - K, N of a few dozen - with the whole weight matrix in a wave's registers, no
+    LDS, epilogue straight from the accumulators, squeeze-excite scale reloaded per clip, bf16 residual stream) forced onto every
+    layer it accepts: same image, same K order, one product per pair - bit-identical to the tiled kernels."""
+    import ctypes
+    cfg = sm.perch_config()
+    blob = sm.build_model(cfg)
+    n = 16
+    x = sm.synth_clips(n, cfg.n_samples, cfg.sample_rate, first=5)
+    lib = host.load_library()
+    lib.bnhip_debug_pw_b16_launches.restype = ctypes.c_long
+    out = {}
+    monkeypatch.setenv("BNHIP_PW_B16", "0")                    # (so that the counter below counts k_pw_b16s launches only)
+    for on in ("2", "0"):
+        monkeypatch.setenv("BNHIP_PW_B16S", on)
+        c = host.HipClassifier(blob, max_batch=n, precision="bf16", autotune=False, lanes=1)
+        try:
+            before = lib.bnhip_debug_pw_b16_launches()
+            out[on] = [a.copy() for a in c.predict_batch(x.reshape(-1), n, want_embeddings=True)]
+            used = lib.bnhip_debug_pw_b16_launches() - before
+        finally:
+            c.close()
+        assert (used >= 5) if on == "2" else (used == 0), used
+    assert np.array_equal(out["2"][0], out["0"][0]), np.abs(out["2"][0] - out["0"][0]).max()
+    assert np.array_equal(out["2"][1], out["0"][1])
