@@ -373,3 +373,34 @@ def test_weights_stationary_gemm_equals_the_tiled_kernels(gpu, monkeypatch):
         assert (used >= 5) if on == "2" else (used == 0), used
     assert np.array_equal(out["2"][0], out["0"][0]), np.abs(out["2"][0] - out["0"][0]).max()
     assert np.array_equal(out["2"][1], out["0"][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_tuning_file_reproduces_the_plan_and_is_ignored_by_other_plans(gpu, tmp_path, monkeypatch, prec):
+    """BNHIP_TUNE_FILE (tools/profile_round.sh: one tuning for the bench, the kernel trace and every PMC pass): the first engine
+    times its candidates and writes the file, the second reads it - same tiles, same kernel flavours (incl. the streamed-operand
+    and weights-stationary GEMM codes of round 4), same bits; an engine with another plan neither uses nor overwrites it."""
+    cfg = sm.tiny_perch_config()
+    blob = sm.build_model(cfg)
+    x = sm.synth_clips(8, cfg.n_samples, cfg.sample_rate, first=2)
+    path = tmp_path / "tune.txt"
+    monkeypatch.setenv("BNHIP_TUNE_FILE", str(path))
+    plans, outs = [], []
+    for _ in range(2):
+        c = host.HipClassifier(blob, max_batch=8, precision=prec)
+        try:
+            plans.append([(s["name"], s["nt"], s["wm"], s["nt_full"], s["wm_full"], s["shape"], s["dw_lds"], s["bx"]) for s in c.describe()["steps"]])
+            outs.append(c.predict_batch(x.reshape(-1), 8).copy())
+        finally:
+            c.close()
+        assert path.exists()
+    assert plans[0] == plans[1] and np.array_equal(outs[0], outs[1])
+    text = path.read_text()
+    c = host.HipClassifier(blob, max_batch=4, precision=prec)       # another plan (batch size): tunes for itself
+    try:
+        got = c.predict_batch(x[:4].reshape(-1), 4)
+    finally:
+        c.close()
+    assert path.read_text() == text
+    assert np.abs(softmax64(got) - softmax64(outs[0][:4])).max() <= 1e-4
