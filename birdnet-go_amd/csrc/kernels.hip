@@ -1919,7 +1919,6 @@ __global__ __launch_bounds__(1024) void k_se(SeParams p) {
     }
 }
 void launch_se(const SeParams& p, hipStream_t s) {
-    size_t lds = (size_t)(p.C + p.Cr + 4096 + 16) * sizeof(float);   // mean, r, [P][C] / [G][C] scratch (<= 1024 float4)
     // Block size: 1024 threads finish a clip fastest when the kernel owns the GPU, but a 16-wave workgroup needs a whole
     // CU's worth of free wave slots and, beside another context's kernels, waited for one 5-30x its own run time
     // (rocprofv3, timed window: avg 50 us, max 330 us against 6-18 us alone) - stalling the dependent projection GEMM.
@@ -1928,6 +1927,10 @@ void launch_se(const SeParams& p, hipStream_t s) {
     int thr = env ? env : (p.threads ? p.threads : 1024);
     thr = std::max(64, std::min(1024, thr / 64 * 64));
     while (thr < 1024 && (p.C + 3) / 4 > thr) thr *= 2;              // FC2 maps one thread to a channel quad
+    // mean, r, fold scratch: [P][C] floats with P C <= threads, or [G][C / 4] float4 with G C / 4 <= threads - i.e. at most one
+    // float4 per thread.  (Sized for 1024 threads whatever the block, a 4-wave block asked for 16 KB more LDS than it can use and,
+    // beside another context's LDS-heavy kernels, waited for it: rocprofv3, Perch bf16 pipelined: avg 62 us, max 777 us.)
+    const size_t lds = (size_t)(p.C + p.Cr + 4 * thr + 16) * sizeof(float);
     hipLaunchKernelGGL(k_se, dim3(p.B), dim3(thr), lds, s, p);
 }
 
