@@ -60,6 +60,16 @@ __device__ __forceinline__ float4 b16_unpack4(const u32v2& r) {
                        __uint_as_float(r[1] & 0xffff0000u));
 }
 
+// B16_TRACE (tools/ubench/b16_trace.hip only): lane 0 of every wave of the first 64 logical blocks stamps the shader clock at the
+// phase boundaries, to see where a wave's time goes.  Compiled out of the library.
+#ifdef B16_TRACE
+__device__ long long* g_b16_trace = nullptr;      // [64 blocks][4 waves][B16_TRACE_SLOTS]
+#define B16_TRACE_SLOTS 160
+#define B16_T(i) do { if (lane == 0 && L < 64u && (i) < B16_TRACE_SLOTS) g_b16_trace[((size_t)L * 4 + wave) * B16_TRACE_SLOTS + (i)] = clock64(); } while (0)
+#else
+#define B16_T(i) do { } while (0)
+#endif
+
 // one slab's worth of a lane's A operand as loaded: k = 32 s + 4 kq .. + 3 (lo) and 32 s + 16 + 4 kq .. + 3 (hi) of its row - the
 // order of the weight image's slots, i.e. k_pw_bx3's fragment order, so that every product sits at the same position of the MFMA
 // in both kernels and their sums round alike
@@ -198,7 +208,9 @@ __global__ __launch_bounds__(256) void k_pw_b16(PwParams p, const uint16_t* __re
     // one slab: the weight tile of the NEXT slab (in wreg since the previous iteration) goes to the idle buffer and wreg takes the
     // slab after it; this slab's A fragments come out of `st`, which then takes slab sl + 2
     auto slab = [&](int sl, auto& st) {
+        B16_T(8 + 4 * sl);                                 // slab begins
         if (sl + 1 < nslab) wstore((sl + 1) & 1);          // (every wave finished reading that buffer before the last barrier)
+        B16_T(9 + 4 * sl);                                 // next weight tile in LDS (its global loads had landed)
         if (sl + 2 < nslab) wload(sl + 2);
         const float* obuf = lds + (sl & 1) * OBUF;
         b16x8 ah[WM], am[SIX ? WM : 1], al[SIX ? WM : 1];
@@ -250,19 +262,26 @@ __global__ __launch_bounds__(256) void k_pw_b16(PwParams p, const uint16_t* __re
 #pragma unroll
                 for (int mt = 0; mt < WM; mt++) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], ah[mt], acc[t][mt], 0, 0, 0);
         }
+        B16_T(10 + 4 * sl);                                // MFMAs issued
         __syncthreads();
+        B16_T(11 + 4 * sl);                                // barrier passed
     };
+    B16_T(0);
     aload(0, set0);
     if (nslab > 1) aload(1, set1);
     wload(0);
     wstore(0);
     if (nslab > 1) wload(1);
+    B16_T(1);                                              // first weight tile stored (its loads had landed)
     __syncthreads();
+    B16_T(2);
     for (int sl = 0; sl < nslab; sl += 2) {
         slab(sl, set0);
         if (sl + 1 < nslab) slab(sl + 1, set1);
     }
+    B16_T(3);
     pw_epilogue<NT, WM>(p, acc, lds, m0, n0);
+    B16_T(4);
 }
 
 static std::atomic<long> g_pw_b16_launches{0};      // diagnostics (tests assert that this path, not k_pw_bx3's, ran); the workers of a multi-device handle launch concurrently
