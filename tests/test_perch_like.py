@@ -404,3 +404,33 @@ def test_tuning_file_reproduces_the_plan_and_is_ignored_by_other_plans(gpu, tmp_
         c.close()
     assert path.read_text() == text
     assert np.abs(softmax64(got) - softmax64(outs[0][:4])).max() <= 1e-4
+
+
+@pytest.mark.gpu
+def test_bf16_residual_stream_plan_and_drift(gpu, monkeypatch):
+    """"precision":"bf16" keeps the residual stream - projection outputs, read by the next expand, the next residual add and the
+    ratio-1 blocks' depthwise kernels - as bf16 where every reader can widen it (engine.cpp mark_bf16_storage; BNHIP_BF16_RESID=0
+    keeps block outputs fp32).  The plan shows it (projections write bf16, fused expand + depthwise steps read bf16), the softmax
+    moves by less than the option's own drift against the oracle, top-1 stays."""
+    cfg = sm.perch_config()
+    blob = sm.build_model(cfg)
+    x = sm.synth_clips(3, cfg.n_samples, cfg.sample_rate, first=21)
+    ref = oracle_logits_emb(blob, x)[0]
+    out, plans = {}, {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("BNHIP_BF16_RESID", on)
+        c = host.HipClassifier(blob, max_batch=8, precision="bf16")
+        try:
+            plans[on] = {s["name"]: (s["in_bf16"], s["out_bf16"]) for s in c.describe()["steps"]}
+            out[on] = c.predict_batch(x.reshape(-1), 3)
+        finally:
+            c.close()
+    proj = [n for n in plans["1"] if n.endswith("/project")]
+    fused = [n for n in plans["1"] if n.endswith("/expand+dw")]
+    assert sum(plans["1"][n][1] for n in proj) >= 20 and sum(plans["0"][n][1] for n in proj) == 0
+    assert sum(plans["1"][n][0] for n in fused) >= 10 and sum(plans["0"][n][0] for n in fused) == 0
+    d_on = np.abs(softmax64(out["1"]) - softmax64(ref)).max()
+    d_off = np.abs(softmax64(out["0"]) - softmax64(ref)).max()
+    print(f"softmax drift vs oracle: bf16 residual stream {d_on:.2e}, fp32 residual stream {d_off:.2e}")
+    assert (out["1"].argmax(1) == ref.argmax(1)).all() and d_on <= 1e-3 and d_off <= 1e-3
+    assert np.abs(softmax64(out["1"]) - softmax64(out["0"])).max() <= 1e-3
