@@ -2287,6 +2287,12 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
                     p.logc = fs.log_compress ? 1 : 0; p.time_major = fs.time_major ? 1 : 0; p.p1 = fs.p1; p.p2 = fs.p2;
                     p.lfloor = fs.log_floor; p.lscale = fs.log_scale;
                 }
+                {
+                    static const bool f32_off = getenv("BNHIP_STFT_F32") && atoi(getenv("BNHIP_STFT_F32")) == 0;
+                    // fp32 transform: bf16 engines whose front-end compresses with a floored log (Perch-style) - a power-law
+                    // compression (v2.4: x^0.45) amplifies fp32 transform noise in near-empty bins by orders of magnitude
+                    if (precision == 1 && s.mode != 1 && fs.log_compress && !f32_off) p.f32 = 1;
+                }
                 launch_stft_bins(p, stream);
                 break;
             }

@@ -41,6 +41,7 @@ struct StftParams {
     const double* tw = nullptr;   // plan-time twiddle image (stft_build_tables)
     int pad_left = 0;             // frame f starts at sample f * hop - pad_left; samples outside [0, n_samples) are zero
     int nb_cap = 0, fpw = 0;    // set by the launcher
+    int f32 = 0;                // 1: the transform in fp32 ("precision":"bf16" engines; not with the fused mel epilogue)
     // fused mel epilogue (mel != nullptr): the wave that transformed a frame also applies the banded mel matrix and the
     // compression and writes the frame's n_mels values straight into the spectrogram image - the DFT bins never reach HBM.
     // mel = stft_mel_table(): [64 lanes][8] int32 {band A, first quad, quads, weight offset; band B ...} then the band

@@ -51,8 +51,8 @@ void launch_normalize(const float* x, const float2* mm, float* out, int n_clips,
 
 // ------------------------------------------------------------------------------------------ register FFTs
 // In-place radix-2 DIT on P complex doubles held in registers; every index is a compile-time constant after unrolling.
-template <int P>
-__device__ __forceinline__ void fft_regs(double (&re)[P], double (&im)[P]) {
+template <int P, typename R>
+__device__ __forceinline__ void fft_regs(R (&re)[P], R (&im)[P]) {
     // cos / sin of 2 pi t / 16, t = 0..7 (P <= 16 uses a stride into this table)
     constexpr double C16[8] = {1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173,
                                0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128673848};
@@ -64,7 +64,7 @@ __device__ __forceinline__ void fft_regs(double (&re)[P], double (&im)[P]) {
         int j = 0;
 #pragma unroll
         for (int bit = 0; bit < LOG; bit++) j |= ((i >> bit) & 1) << (LOG - 1 - bit);
-        if (i < j) { double t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; }
+        if (i < j) { R t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; }
     }
 #pragma unroll
     for (int len = 2; len <= P; len <<= 1) {
@@ -73,9 +73,9 @@ __device__ __forceinline__ void fft_regs(double (&re)[P], double (&im)[P]) {
         for (int i = 0; i < P; i += len) {
 #pragma unroll
             for (int k = 0; k < half; k++) {
-                const double wr = C16[k * step], wi = -S16[k * step];      // e^{-2 pi i k / len}
-                const double xr = re[i + k + half], xi = im[i + k + half];
-                const double ur = re[i + k], ui = im[i + k];
+                const R wr = (R)C16[k * step], wi = (R)-S16[k * step];      // e^{-2 pi i k / len}
+                const R xr = re[i + k + half], xi = im[i + k + half];
+                const R ur = re[i + k], ui = im[i + k];
                 if (k == 0) {                                               // w = 1
                     re[i + k] = ur + xr; im[i + k] = ui + xi; re[i + k + half] = ur - xr; im[i + k + half] = ui - xi;
                 } else if (2 * k == half) {                                 // w = -i
@@ -102,7 +102,10 @@ __device__ __forceinline__ float mel_log(float v, float lfloor, float lscale);
 // the same number of quads), applies the compression and stores the values into the spectrogram image.  Same products in
 // the same order as k_mel_banded (aligned quads of four bins, ascending): bit-identical, minus a kernel launch and the
 // bins' round trip through HBM (0.9 MB per clip).
-template <int P, int W, bool MEL = false>
+// R: the transform's arithmetic.  fp64 is what TFLite's RFFT2D computes in and what fp32 parity on near-empty bins needs (see the
+// file header); float serves the "precision":"bf16" engines, whose every later tensor is rounded to 8 significant bits anyway -
+// half the registers and LDS per wave, twice the VALU rate.
+template <int P, int W, bool MEL = false, typename R = double>
 __global__ __launch_bounds__(64 * W) void k_stft_bins(StftParams p) {
     constexpr int N2 = 64 * P;            // complex points
     constexpr int N = 2 * N2;             // real frame length (= fft length)
@@ -111,12 +114,13 @@ __global__ __launch_bounds__(64 * W) void k_stft_bins(StftParams p) {
                                           // stage 3 then spreads evenly over the bank pairs (65 left P = 8 at 2x the minimum)
     constexpr int WSZ = P * RS;           // doubles per component in a wave's slice (>= N2)
     constexpr int NPAIR = (P * P + 63) / 64;   // (k1, j') pairs per lane in the last stage (P = 4: only 16 lanes hold one)
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    double* twr = sm;                     // [P][64] Re W_{N2}^{k1 n2}
-    double* twi = twr + P * 64;
-    double* t2r = twi + P * 64;           // [Q][P]  W_64^{q j'}
-    double* t2i = t2r + Q * P;
-    double* work = t2i + Q * P;           // [W][2][WSZ]
+    extern __shared__ __attribute__((aligned(16))) unsigned char stft_sm[];
+    R* sm = reinterpret_cast<R*>(stft_sm);
+    R* twr = sm;                     // [P][64] Re W_{N2}^{k1 n2}
+    R* twi = twr + P * 64;
+    R* t2r = twi + P * 64;           // [Q][P]  W_64^{q j'}
+    R* t2i = t2r + Q * P;
+    R* work = t2i + Q * P;           // [W][2][WSZ]
     float4* melw4 = reinterpret_cast<float4*>(work + (size_t)W * 2 * WSZ);     // MEL: band weights, p.mel_quads float4s ...
     const int* binq = reinterpret_cast<const int*>(melw4 + p.mel_quads);        // ... and the bins quad each of them multiplies
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_bins(StftParams p) {
     // ---- tables (once per block): copied from the plan-time image (stft_build_tables); computing them here cost ten
     // fp64 sincos per thread and block - a sixth of the kernel at 16 frames per wave
     constexpr int NTAB = 2 * P * 64 + 2 * Q * P;
-    for (int i = tid; i < NTAB; i += blockDim.x) sm[i] = p.tw[i];
+    for (int i = tid; i < NTAB; i += blockDim.x) sm[i] = (R)p.tw[i];
     int mA = 0, loA = 0, nA = 0, wA = 0, mB = 0, loB = 0, nB = 0, wB = 0;
     if (MEL) {
         const float4* src = reinterpret_cast<const float4*>(p.mel + 64 * 8);
@@ -137,8 +141,8 @@ __global__ __launch_bounds__(64 * W) void k_stft_bins(StftParams p) {
     }
     __syncthreads();
 
-    double* wre = work + (size_t)wave * 2 * WSZ;
-    double* wim = wre + WSZ;
+    R* wre = work + (size_t)wave * 2 * WSZ;
+    R* wim = wre + WSZ;
     const float* xc = p.xn + (size_t)b * p.n_samples;
     // this lane's window taps: samples 128 n1 + 2 n2 (+1)
     float w0[P], w1[P];
@@ -152,15 +156,15 @@ __global__ __launch_bounds__(64 * W) void k_stft_bins(StftParams p) {
     // this lane's output bins (constant across frames): LDS indices of Z[k], Z[N2-k]
     constexpr int NBL = 8;                               // bins per lane held in registers (nb <= 512)
     int ka_[NBL], kb_[NBL];
-    double trr[NBL], tri[NBL];                           // W_N^k of those bins (registers: keeps the LDS for a second block)
+    R trr[NBL], tri[NBL];                           // W_N^k of those bins (registers: keeps the LDS for a second block)
 #pragma unroll
     for (int t = 0; t < NBL; t++) {
         int idx = lane + 64 * t;
         int k = idx < p.nb ? p.bins[idx] : 0;
         ka_[t] = k % N2; kb_[t] = (N2 - k % N2) % N2;
         const bool in = idx < p.nb_cap;
-        trr[t] = in ? p.tw[NTAB + idx] : 1.0;
-        tri[t] = in ? p.tw[NTAB + p.nb_cap + idx] : 0.0;
+        trr[t] = in ? (R)p.tw[NTAB + idx] : (R)1.0;
+        tri[t] = in ? (R)p.tw[NTAB + p.nb_cap + idx] : (R)0.0;
     }
 
     const int f_begin = (blockIdx.x * W + wave) * p.fpw;
@@ -192,20 +196,20 @@ __global__ __launch_bounds__(64 * W) void k_stft_bins(StftParams p) {
     };
     if (f_begin < f_end) fetch(f_begin);
     for (int f = f_begin; f < f_end; f++) {
-        double re[P], im[P];
+        R re[P], im[P];
         // ---- 1. window (fp32 product, as the graph's MUL) + P-point FFT over n1
 #pragma unroll
         for (int n1 = 0; n1 < P; n1++) {
-            re[n1] = (double)(nx[n1].x * w0[n1]);
-            im[n1] = (double)(nx[n1].y * w1[n1]);
+            re[n1] = (R)(nx[n1].x * w0[n1]);
+            im[n1] = (R)(nx[n1].y * w1[n1]);
         }
         if (f + 1 < f_end) fetch(f + 1);
-        fft_regs<P>(re, im);
+        fft_regs<P, R>(re, im);
         // ---- 2. twiddle + transpose
 #pragma unroll
         for (int k1 = 0; k1 < P; k1++) {
-            const double c = twr[k1 * 64 + lane], s = twi[k1 * 64 + lane];
-            const double r = fma(re[k1], c, -(im[k1] * s)), i2 = fma(re[k1], s, im[k1] * c);
+            const R c = twr[k1 * 64 + lane], s = twi[k1 * 64 + lane];
+            const R r = fma(re[k1], c, -(im[k1] * s)), i2 = fma(re[k1], s, im[k1] * c);
             wre[k1 * RS + lane] = r; wim[k1 * RS + lane] = i2;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -215,17 +219,17 @@ __global__ __launch_bounds__(64 * W) void k_stft_bins(StftParams p) {
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
         // ---- 3. P-point FFT over j, twiddle W_64^{q j'}, exchange, Q-point FFTs
-        fft_regs<P>(re, im);
+        fft_regs<P, R>(re, im);
 #pragma unroll
         for (int j = 0; j < P; j++) {
-            const double c = t2r[qb * P + j], s = t2i[qb * P + j];
-            const double r = fma(re[j], c, -(im[j] * s)), i2 = fma(re[j], s, im[j] * c);
+            const R c = t2r[qb * P + j], s = t2i[qb * P + j];
+            const R r = fma(re[j], c, -(im[j] * s)), i2 = fma(re[j], s, im[j] * c);
             const int slot = j * P + k1b;                 // [q][slot] layout: both sides of the exchange are conflict-free
             wre[qb * (P * P) + slot] = r; wim[qb * (P * P) + slot] = i2;   // ([slot][q] made the reads below 16-way bank conflicts)
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        double ar[NPAIR][Q], ai[NPAIR][Q];
+        R ar[NPAIR][Q], ai[NPAIR][Q];
 #pragma unroll
         for (int t = 0; t < NPAIR; t++) {
             const int slot = min(lane + 64 * t, P * P - 1);
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_bins(StftParams p) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int t = 0; t < NPAIR; t++) {
-            fft_regs<Q>(ar[t], ai[t]);
+            fft_regs<Q, R>(ar[t], ai[t]);
             const int slot = lane + 64 * t;              // = j' P + k1  ->  k = k1 + P j' + P^2 q'
             const int kbase = (slot % P) + P * (slot / P);
             if (slot < P * P) {
@@ -257,15 +261,15 @@ __global__ __launch_bounds__(64 * W) void k_stft_bins(StftParams p) {
             float o = 0.f;
             if (idx < p.nb) {
                 const int ka = ka_[t], kb = kb_[t];
-                const double zr = wre[ka], zi = wim[ka], mr = wre[kb], mi = -wim[kb];       // Z[k], conj(Z[N2-k])
-                const double er = 0.5 * (zr + mr), ei = 0.5 * (zi + mi);
-                const double dr = zr - mr, di = zi - mi;
-                const double or_ = 0.5 * di, oi = -0.5 * dr;                                 // -i/2 (Z[k] - conj(Z[N2-k]))
-                const double c = trr[t], s = tri[t];
-                const double xr = er + fma(or_, c, -(oi * s));
+                const R zr = wre[ka], zi = wim[ka], mr = wre[kb], mi = -wim[kb];       // Z[k], conj(Z[N2-k])
+                const R er = (R)0.5 * (zr + mr), ei = (R)0.5 * (zi + mi);
+                const R dr = zr - mr, di = zi - mi;
+                const R or_ = (R)0.5 * di, oi = (R)-0.5 * dr;                                 // -i/2 (Z[k] - conj(Z[N2-k]))
+                const R c = trr[t], s = tri[t];
+                const R xr = er + fma(or_, c, -(oi * s));
                 if (p.mode == 0) o = (float)xr;
                 else {
-                    const double xi = ei + fma(or_, s, oi * c);
+                    const R xi = ei + fma(or_, s, oi * c);
                     o = hypotf((float)xr, (float)xi);        // COMPLEX_ABS on complex64
                 }
             }
@@ -315,15 +319,15 @@ __global__ __launch_bounds__(64 * W) void k_stft_bins(StftParams p) {
             if (idx < p.nb) {
                 const int k = p.bins[idx];
                 const int ka = k % N2, kb = (N2 - k % N2) % N2;
-                const double zr = wre[ka], zi = wim[ka], mr = wre[kb], mi = -wim[kb];
-                const double er = 0.5 * (zr + mr), ei = 0.5 * (zi + mi);
-                const double dr = zr - mr, di = zi - mi;
-                const double or_ = 0.5 * di, oi = -0.5 * dr;
-                const double c = p.tw[NTAB + idx], s = p.tw[NTAB + p.nb_cap + idx];
-                const double xr = er + fma(or_, c, -(oi * s));
+                const R zr = wre[ka], zi = wim[ka], mr = wre[kb], mi = -wim[kb];
+                const R er = (R)0.5 * (zr + mr), ei = (R)0.5 * (zi + mi);
+                const R dr = zr - mr, di = zi - mi;
+                const R or_ = (R)0.5 * di, oi = (R)-0.5 * dr;
+                const R c = (R)p.tw[NTAB + idx], s = (R)p.tw[NTAB + p.nb_cap + idx];
+                const R xr = er + fma(or_, c, -(oi * s));
                 if (p.mode == 0) o = (float)xr;
                 else {
-                    const double xi = ei + fma(or_, s, oi * c);
+                    const R xi = ei + fma(or_, s, oi * c);
                     o = hypotf((float)xr, (float)xi);
                 }
             }
@@ -433,6 +437,16 @@ void launch_stft_bins(const StftParams& p0, hipStream_t s) {
             if (!am4) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<4, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); am4 = true; }
             hipLaunchKernelGGL((k_stft_bins<4, 8, true>), grid, dim3(64 * W), lds, s, p);
         }
+        return;
+    }
+    if (p.f32) {                                          // "precision":"bf16" engines: the transform in fp32 (half the LDS)
+        lds /= 2;
+        if (P == 4) hipLaunchKernelGGL((k_stft_bins<4, 8, false, float>), grid, dim3(64 * W), lds, s, p);
+        else if (P == 16) {
+            static bool a16f = false;
+            if (!a16f) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<16, 8, false, float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a16f = true; }
+            hipLaunchKernelGGL((k_stft_bins<16, 8, false, float>), grid, dim3(64 * W), lds, s, p);
+        } else hipLaunchKernelGGL((k_stft_bins<8, 4, false, float>), grid, dim3(64 * W), lds, s, p);
         return;
     }
     if (P == 4) {
