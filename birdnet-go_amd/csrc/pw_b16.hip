@@ -14,6 +14,8 @@
 //     a slab's tile is a straight 16-byte-per-thread copy into LDS, double-buffered, read back conflict-free (lane = slot).
 //   * one barrier per slab (the weight buffer swap); bias / activation / residual / bf16 or fp32 store = pw_epilogue.
 // Block = 128 rows x 16 NT columns, 4 waves, accumulators [NT][2] x f32x4.
+// Also in this file: the six-product (fp32-equivalent) form of the same kernel for the fp32 engines, 64- or 128-row tiles
+// (template parameters SIX, WM), and k_pw_b16s - skinny projections with the whole weight matrix in registers.
 #include "pw_common.h"
 
 #include <algorithm>
