@@ -1809,6 +1809,11 @@ bool Engine::load_tuning(const char* path) {
              idx == i && r.kind == (int)steps[i].kind && steps[i].name == name;
         if (ok && steps[i].kind == S_PW) ok = r.nt >= 0 && r.nt <= 8 && r.ntf >= 0 && r.ntf <= 8 && r.wm >= 0 && r.wm <= 11 && r.wmf >= 0 && r.wmf <= 11 &&
                                               ((r.wm >= 5) == (steps[i].wm >= 5) || !steps[i].wbx);       // (never switches the arithmetic family)
+        if (ok && steps[i].kind == S_DW) {                    // the staged form only where its tuner would have timed it
+            const Step& t = steps[i];
+            DwParams dp{nullptr, nullptr, nullptr, nullptr, 1, t.H, t.W, t.C, t.Ho, t.Wo, t.kh, t.kw, t.sh, t.sw, t.pt, t.pl, t.act};
+            ok = r.dwl == 0 || (r.dwl == 1 && dwconv_lds_supported(dp) && (t.out2 < 0 || dwconv_sum_slabs(dp) > 0));
+        }
         if (ok && (steps[i].kind == S_EXPAND_DW || (steps[i].kind == S_DW && r.dwl))) {
             const bool st_ = steps[i].kind == S_EXPAND_DW && steps[i].mode == 1;
             // (the same geometry the tuner and the launcher use: a layer whose phase 1 runs on the bf16 pipe has no eight-wave shapes)
@@ -1822,9 +1827,21 @@ bool Engine::load_tuning(const char* path) {
     }
     fclose(f);
     if (!ok) return false;
+    // A row changes what the tuners decide and nothing else; what follows from a decision (the tile count the consumers of the
+    // per-tile sums index by) is recomputed from the plan, not read: a stale or edited file can pick a slower kernel, not a wrong one.
     for (size_t i = 0; i < n; i++) {
         Step& s = steps[i]; const Row& r = rows[i];
-        s.nt = r.nt; s.wm = r.wm; s.nt_full = r.ntf; s.wm_full = r.wmf; s.shape = r.shape; s.dwl = r.dwl; s.bx = r.bx; s.S = r.S;
+        if (s.kind == S_PW) { s.nt = r.nt; s.wm = r.wm; s.nt_full = r.ntf; s.wm_full = r.wmf; }
+        const bool staged = s.kind == S_DW && r.dwl;
+        if (s.kind == S_DW) s.dwl = r.dwl;
+        if (s.kind != S_EXPAND_DW && !staged) continue;
+        s.shape = r.shape;
+        if (s.out2 < 0) continue;
+        const bool st_ = s.kind == S_EXPAND_DW && s.mode == 1;
+        const bool pipe16 = s.kind == S_EXPAND_DW && expdw_sk_pipe16(s.C, s.act, st_, precision, s.bx && s.wbx != nullptr && bf16x3);
+        const ExpDwGeo g{s.kh, s.sh, s.H, s.W, s.Ho, s.Wo, s.pt, s.pl, st_, (s.kind == S_EXPAND_DW && !pipe16) ? expdw_skw(s.C, s.act, st_) : 0};
+        s.S = expdw_shape_slabs(s.shape, g);
+        for (auto& c : steps) if (&c != &s && c.in0 == s.out2) c.S = s.S;
     }
     if (getenv("BNHIP_DEBUG")) fprintf(stderr, "[bnhip] tuning read from %s\n", path);
     return true;

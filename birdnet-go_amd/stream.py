@@ -38,6 +38,13 @@ class StreamError(ValueError):
     """Validation failure (the reference's errors.CategoryValidation)."""
 
 
+def _as_bytes(data):
+    """bytes-like or ndarray of any dtype / layout -> flat uint8 view (a copy only when the array is not contiguous)."""
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data).reshape(-1).view(np.uint8)
+    return np.frombuffer(data, np.uint8)
+
+
 class ByteRing:
     """Byte ring in overwrite mode.  The reference uses github.com/smallnest/ringbuffer v0.1.1 (go.mod:31, absent from the
     snapshot) with `SetOverwrite(true)` (analysis.go:120): a write never fails, the oldest unread bytes are dropped when the
@@ -54,7 +61,7 @@ class ByteRing:
         return self.cap - self.n
 
     def write(self, data):
-        d = np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else data.view(np.uint8).reshape(-1)
+        d = _as_bytes(data)
         total = d.size
         if total > self.cap:                                # only the newest `cap` bytes can survive
             drop = total - self.cap
@@ -119,9 +126,10 @@ class OverwriteTracker:
             if self.cooldown > 0 and self.last_notified is not None and now - self.last_notified < self.cooldown:
                 return False
             self.last_notified = now
-            if self.on_warn:
-                self.on_warn(source_id, rate, self.total_writes, self.overwrite_count)
-            return True
+            writes, overwrites = self.total_writes, self.overwrite_count
+        if self.on_warn:                                  # outside the lock: the callback may look at the tracker
+            self.on_warn(source_id, rate, writes, overwrites)
+        return True
 
     def overwrite_rate(self):
         with self.mu:
@@ -158,9 +166,10 @@ class AnalysisBuffer:
         self.mu = threading.Lock()
 
     def write(self, data):
+        d = _as_bytes(data)
         with self.mu:
-            will_overwrite = len(data) > self.ring.free()
-            self.ring.write(data)
+            will_overwrite = d.size > self.ring.free()
+            self.ring.write(d)
         self.tracker.record_write()
         if will_overwrite:
             self.tracker.record_overwrite()
@@ -426,13 +435,14 @@ class WindowBatcher:
     are read and discarded exactly as the reference does (:478-480: the audio is consumed, not analysed)."""
 
     def __init__(self, orch: Orchestrator, queue: _results.ResultsQueue = None, overruns: OverrunTrackers = None,
-                 max_batch=256, pre_capture_s=0.0, bit_depth=16, clock=time.time):
+                 max_batch=256, pre_capture_s=0.0, bit_depth=16, clock=time.time, on_error=None):
         self.orch = orch
         self.queue = queue if queue is not None else _results.ResultsQueue()
         self.overruns = overruns if overruns is not None else OverrunTrackers()
         self.max_batch, self.pre_capture_s, self.bit_depth, self.clock = max_batch, pre_capture_s, bit_depth, clock
         self.buffers = {}                    # (source, model_id) -> AnalysisBuffer
         self.mu = threading.Lock()
+        self.on_error, self.errors = on_error, 0   # a failed device call costs its own windows only (the reference logs and polls on)
 
     def allocate(self, source, model_id, capacity=None):
         spec = self.orch.model_spec_for(model_id)
@@ -465,17 +475,22 @@ class WindowBatcher:
             win = ab.read()
             if win is None:
                 continue
-            if not self.orch.is_model_active(model_id):
+            spec = self.orch.model_spec_for(model_id)
+            if spec is None or not self.orch.is_model_active(model_id):       # (unloaded since the last tick: consumed, not analysed)
                 continue
             now = self.clock()
-            spec = self.orch.model_spec_for(model_id)
             start = now - (self.pre_capture_s + spec.clip_length_s)       # beginTimeOffset, buffer_manager.go:490-491
             per_model.setdefault(model_id, []).append((source, win, start, now))
         sent = 0
         for model_id, ws in per_model.items():
             for lo in range(0, len(ws), self.max_batch):
                 part = ws[lo:lo + self.max_batch]
-                sent += process_windows(self.orch, np.stack([w for _, w, _, _ in part]), [s for _, _, s, _ in part],
-                                        [c for _, _, _, c in part], [src for src, _, _, _ in part], model_id, self.queue,
-                                        self.overruns, self.bit_depth)
+                try:
+                    sent += process_windows(self.orch, np.stack([w for _, w, _, _ in part]), [s for _, _, s, _ in part],
+                                            [c for _, _, _, c in part], [src for src, _, _, _ in part], model_id, self.queue,
+                                            self.overruns, self.bit_depth)
+                except Exception as e:                    # buffer_manager.go:494-499: the monitor logs the error and keeps polling
+                    self.errors += len(part)
+                    if self.on_error:
+                        self.on_error(model_id, [src for src, _, _, _ in part], e)
         return sent

@@ -404,6 +404,27 @@ def test_tuning_file_reproduces_the_plan_and_is_ignored_by_other_plans(gpu, tmp_
         c.close()
     assert path.read_text() == text
     assert np.abs(softmax64(got) - softmax64(outs[0][:4])).max() <= 1e-4
+    # an edited file: the derived column (tile count of the per-tile sums, mel quads) is recomputed from the plan, never read -
+    # garbage there changes nothing; a row that asks for a kernel form its layer is not eligible for makes the engine ignore
+    # the file and tune for itself.  Either way the same logits.
+    lines = text.splitlines()
+    junk = [lines[0]] + [" ".join(f[:9] + ["12345"] + f[10:]) for f in (l.split(" ") for l in lines[1:])]
+    path.write_text("\n".join(junk) + "\n")
+    c = host.HipClassifier(blob, max_batch=8, precision=prec)
+    try:
+        plan = [(s["name"], s["nt"], s["wm"], s["nt_full"], s["wm_full"], s["shape"], s["dw_lds"], s["bx"]) for s in c.describe()["steps"]]
+        again = c.predict_batch(x.reshape(-1), 8).copy()
+    finally:
+        c.close()
+    assert plan == plans[0] and np.array_equal(again, outs[0])
+    bad = [lines[0]] + [" ".join(f[:6] + ["9999"] + f[7:]) for f in (l.split(" ") for l in lines[1:])]      # no such tile shape
+    path.write_text("\n".join(bad) + "\n")
+    c = host.HipClassifier(blob, max_batch=8, precision=prec)
+    try:
+        self_tuned = c.predict_batch(x.reshape(-1), 8).copy()
+    finally:
+        c.close()
+    assert np.abs(softmax64(self_tuned) - softmax64(outs[0])).max() <= 1e-4
 
 
 @pytest.mark.gpu

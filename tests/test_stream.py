@@ -415,6 +415,63 @@ def test_batcher_inactive_model_consumes_without_analysing():
     assert wb.queue.get().pcm_data == bytes(range(8)) + bytes(range(8, 16))                 # overlap kept across the skipped window
 
 
+def test_batcher_failed_model_costs_only_its_own_windows():
+    """buffer_manager.go:494-499: a ProcessData error is logged by that monitor and polling goes on - one model's failing
+    device call must not cost the other models the windows this tick already consumed from their rings."""
+    class _Boom:
+        def predict_batch(self, flat, n):
+            raise RuntimeError("device lost")
+    o = S.Orchestrator()
+    good = _Fake()
+    o.register("bad", _Boom(), S.ModelSpec(48000, 3.0, clip_bytes=16))
+    o.register("good", good, S.ModelSpec(48000, 3.0, clip_bytes=16))
+    seen = []
+    wb = S.WindowBatcher(o, on_error=lambda model, sources, e: seen.append((model, sources, str(e))))
+    for m in ("bad", "good"):
+        wb.allocate("mic", m, capacity=256)
+    wb.write("mic", bytes(range(8)))
+    assert wb.tick() == 1 and wb.errors == 1
+    assert seen == [("bad", ["mic"], "device lost")]
+    assert wb.queue.get().model_id == "good" and len(good.calls) == 1
+    assert o.counters.peek_all()["bad"]["invoke_errors"] == 1
+
+
+def test_batcher_model_unloaded_between_ticks():
+    o = S.Orchestrator()
+    f = _Fake()
+    o.register("m", f, S.ModelSpec(48000, 3.0, clip_bytes=16))
+    wb = S.WindowBatcher(o)
+    wb.allocate("mic", "m", capacity=256)
+    wb.write("mic", bytes(range(8)))
+    o.unload("m")                                            # the buffer is still allocated: its audio is consumed, nothing raised
+    assert wb.tick() == 0 and wb.errors == 0 and not wb.buffers[("mic", "m")].ready()
+
+
+def test_analysis_buffer_takes_arrays_by_their_bytes():
+    """A capture callback that hands over int16 arrays (or strided views): the ring counts bytes, not elements."""
+    ab = S.AnalysisBuffer(16, 4, 4, "mic")
+    ab.write(np.arange(6, dtype="<i2"))                      # 12 bytes
+    ab.write(np.arange(12, dtype="<i2")[::2][:3])            # 6 bytes, not contiguous: 18 > 16 -> an overwrite
+    assert ab.overwrite_count() == 1
+    ref = GoAnalysisBuffer(16, 4, 4)
+    ref.Write(np.arange(6, dtype="<i2").tobytes())
+    ref.Write(np.ascontiguousarray(np.arange(12, dtype="<i2")[::2][:3]).tobytes())
+    assert ref.overwrites == 1
+    for _ in range(4):
+        a, b = ab.read(), ref.Read()
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert a.tobytes() == bytes(b)
+
+
+def test_overwrite_warning_callback_may_query_the_tracker():
+    """The callback runs outside the tracker's lock (it used to deadlock a callback that reads the rate back)."""
+    rates = []
+    t = S.OverwriteTracker(min_writes=1, rate_threshold=1, notify_cooldown_s=0, on_warn=lambda *a: rates.append(t.overwrite_rate()))
+    t.record_write(); t.record_overwrite()
+    assert t.check_and_notify("mic") and rates == [100.0]
+
+
 # ------------------------------------------------------------------ through the device
 @pytest.mark.gpu
 def test_batcher_streams_through_the_device(tiny_cfg, tiny_blob):
