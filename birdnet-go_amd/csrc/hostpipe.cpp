@@ -319,6 +319,19 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
         for (int k = 0, left = mid; k < nm; k++) { const int c = (left + (nm - k) - 1) / (nm - k); csize.push_back(c); left -= c; }
         csize.push_back(t1); csize.push_back(t2);
     }
+    if (const char* cc = getenv("BNHIP_HOST_CHUNKS")) {    // experiments: an explicit schedule "32,64,96,64" (read per call; must add up)
+        std::vector<int> want;
+        long sum = 0;
+        for (const char* q = cc; *q;) {
+            char* end = nullptr;
+            const long v = strtol(q, &end, 10);
+            if (end == q || v < 1 || v > e.max_batch) { want.clear(); break; }
+            want.push_back((int)v); sum += v;
+            q = *end == ',' ? end + 1 : end;
+            if (*end && *end != ',') { want.clear(); break; }
+        }
+        if (!want.empty() && sum == j.n_clips) csize = want;
+    }
     const int nch = (int)csize.size();
     std::vector<int> cfirst(nch + 1, 0);
     for (int c = 0; c < nch; c++) cfirst[c + 1] = cfirst[c] + csize[c];
