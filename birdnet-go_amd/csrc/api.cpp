@@ -24,6 +24,7 @@
 #include "hostpipe.h"
 #include "model_onnx.h"
 #include "tflite_model.h"
+#include "windows.h"
 
 using namespace bnhip;
 
@@ -437,6 +438,130 @@ int bnhip_host_free(void* p) {
     if (e != hipSuccess) { (void)hipGetLastError(); return set_err(BNHIP_E_INVALID, std::string("bnhip_host_free: not a bnhip_host_alloc pointer: ") + hipGetErrorString(e)); }
     return BNHIP_OK;
     BN_GUARD_END((void)0)
+}
+
+// ---------------------------------------------------------------------------------------------- window assembler (row a3)
+struct bnhip_windows {
+    std::unique_ptr<bnhip::WindowAssembler> a;
+    uint8_t* batch = nullptr;
+    bool pinned = false;
+};
+
+static void windows_free(bnhip_windows* w) {
+    if (!w) return;
+    if (w->batch) {
+        if (w->pinned) { if (hipHostFree(w->batch) != hipSuccess) (void)hipGetLastError(); }
+        else std::free(w->batch);
+    }
+    delete w;
+}
+
+int bnhip_windows_create(size_t overlap_bytes, size_t read_bytes, int max_batch, bnhip_windows** out) {
+    if (!out) return set_err(BNHIP_E_INVALID, "out is NULL");
+    *out = nullptr;
+    // NewAnalysisBuffer's checks (analysis.go:65-90); the capacity ones are per source (bnhip_windows_add_source)
+    if (read_bytes == 0) return set_err(BNHIP_E_INVALID, "invalid read size: 0, must be greater than 0");
+    if (read_bytes < overlap_bytes) return set_err(BNHIP_E_INVALID, "read size must be >= overlap size");
+    if (max_batch < 1) return set_err(BNHIP_E_INVALID, "max_batch must be positive");
+    const size_t wb = overlap_bytes + read_bytes;
+    if (wb < read_bytes || wb > ((size_t)1 << 40) / (size_t)max_batch) return set_err(BNHIP_E_INVALID, "window batch too large");
+    bnhip_windows* w = nullptr;
+    BN_GUARD_BEGIN
+    w = new bnhip_windows();
+    w->a = std::make_unique<bnhip::WindowAssembler>(overlap_bytes, read_bytes, max_batch);
+    const size_t bytes = wb * (size_t)max_batch;
+    // page-locked when there is a device to read it (the host pipeline then copies straight out of it); plain memory
+    // otherwise, so that the byte work can be used and tested on a box without one
+    int ndev = 0;
+    if (bnhip_init(&ndev) == BNHIP_OK && ndev > 0) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, bytes, hipHostMallocPortable) == hipSuccess) { w->batch = static_cast<uint8_t*>(p); w->pinned = true; }
+        else (void)hipGetLastError();
+    }
+    if (!w->batch) {
+        w->batch = static_cast<uint8_t*>(std::malloc(bytes));
+        if (!w->batch) { windows_free(w); w = nullptr; return set_err(BNHIP_E_NOMEM, "out of host memory"); }
+    }
+    *out = w;
+    return BNHIP_OK;
+    BN_GUARD_END(windows_free(w))
+}
+
+int bnhip_windows_info(const bnhip_windows* w, size_t* window_bytes, int* max_batch, int* pinned, int* n_sources) {
+    if (!w) return set_err(BNHIP_E_INVALID, "NULL argument");
+    BN_GUARD_BEGIN
+    if (window_bytes) *window_bytes = w->a->window_bytes();
+    if (max_batch) *max_batch = w->a->max_batch();
+    if (pinned) *pinned = w->pinned ? 1 : 0;
+    if (n_sources) *n_sources = w->a->n_sources();
+    return BNHIP_OK;
+    BN_GUARD_END((void)0)
+}
+
+int bnhip_windows_add_source(bnhip_windows* w, const char* source_id, size_t capacity_bytes, int* out_source) {
+    if (!w || !out_source) return set_err(BNHIP_E_INVALID, "NULL argument");
+    *out_source = -1;
+    if (!source_id || !*source_id) return set_err(BNHIP_E_INVALID, "source ID must not be empty");
+    if (capacity_bytes == 0) return set_err(BNHIP_E_INVALID, "invalid analysis buffer capacity: 0, must be greater than 0");
+    if (capacity_bytes < w->a->read_bytes()) return set_err(BNHIP_E_INVALID, "capacity must be >= read size");
+    if (capacity_bytes > ((size_t)1 << 40)) return set_err(BNHIP_E_INVALID, "capacity too large");
+    BN_GUARD_BEGIN
+    const int idx = w->a->add_source(source_id, capacity_bytes);
+    if (idx < 0) return set_err(BNHIP_E_INVALID, "capacity must be >= read size");
+    *out_source = idx;
+    return BNHIP_OK;
+    BN_GUARD_END((void)0)
+}
+
+int bnhip_windows_remove_source(bnhip_windows* w, int source) {
+    if (!w) return set_err(BNHIP_E_INVALID, "NULL argument");
+    BN_GUARD_BEGIN
+    return w->a->remove_source(source) ? BNHIP_OK : set_err(BNHIP_E_INVALID, "no such source");
+    BN_GUARD_END((void)0)
+}
+
+int bnhip_windows_write(bnhip_windows* w, int source, const void* data, size_t n_bytes) {
+    if (!w || (!data && n_bytes)) return set_err(BNHIP_E_INVALID, "NULL argument");
+    BN_GUARD_BEGIN
+    return w->a->write(source, data, n_bytes) ? BNHIP_OK : set_err(BNHIP_E_INVALID, "no such source");
+    BN_GUARD_END((void)0)
+}
+
+int bnhip_windows_collect(bnhip_windows* w, int cap, int* sources, int* n_windows, const void** batch) {
+    if (!w || !sources || !n_windows) return set_err(BNHIP_E_INVALID, "NULL argument");
+    *n_windows = 0;
+    if (batch) *batch = w->batch;
+    if (cap < 0) return set_err(BNHIP_E_INVALID, "cap must not be negative");
+    BN_GUARD_BEGIN
+    *n_windows = w->a->collect(w->batch, cap, sources);
+    return BNHIP_OK;
+    BN_GUARD_END((void)0)
+}
+
+int bnhip_windows_ready(const bnhip_windows* w, int* n_ready) {
+    if (!w || !n_ready) return set_err(BNHIP_E_INVALID, "NULL argument");
+    BN_GUARD_BEGIN
+    *n_ready = w->a->ready();
+    return BNHIP_OK;
+    BN_GUARD_END((void)0)
+}
+
+int bnhip_windows_stats(const bnhip_windows* w, int source, uint64_t* writes, uint64_t* overwrites, size_t* buffered_bytes) {
+    if (!w) return set_err(BNHIP_E_INVALID, "NULL argument");
+    BN_GUARD_BEGIN
+    return w->a->stats(source, writes, overwrites, buffered_bytes) ? BNHIP_OK : set_err(BNHIP_E_INVALID, "no such source");
+    BN_GUARD_END((void)0)
+}
+
+int bnhip_windows_reset(bnhip_windows* w, int source) {
+    if (!w) return set_err(BNHIP_E_INVALID, "NULL argument");
+    BN_GUARD_BEGIN
+    return w->a->reset(source) ? BNHIP_OK : set_err(BNHIP_E_INVALID, "no such source");
+    BN_GUARD_END((void)0)
+}
+
+void bnhip_windows_destroy(bnhip_windows* w) {
+    try { windows_free(w); } catch (...) {}
 }
 
 void bnhip_shutdown(void) {

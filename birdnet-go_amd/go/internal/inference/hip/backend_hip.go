@@ -43,6 +43,16 @@ typedef int  (*fn_rs_flush_pcm16)(bnhip_resampler*, int16_t*, int, int*);
 typedef void (*fn_rs_destroy)(bnhip_resampler*);
 typedef int  (*fn_host_alloc)(size_t, void**);
 typedef int  (*fn_host_free)(void*);
+typedef struct bnhip_windows bnhip_windows;
+typedef int  (*fn_win_create)(size_t, size_t, int, bnhip_windows**);
+typedef int  (*fn_win_info)(const bnhip_windows*, size_t*, int*, int*, int*);
+typedef int  (*fn_win_add_source)(bnhip_windows*, const char*, size_t, int*);
+typedef int  (*fn_win_remove_source)(bnhip_windows*, int);
+typedef int  (*fn_win_write)(bnhip_windows*, int, const void*, size_t);
+typedef int  (*fn_win_collect)(bnhip_windows*, int, int*, int*, const void**);
+typedef int  (*fn_win_stats)(const bnhip_windows*, int, uint64_t*, uint64_t*, size_t*);
+typedef int  (*fn_win_reset)(bnhip_windows*, int);
+typedef void (*fn_win_destroy)(bnhip_windows*);
 
 typedef struct {
     void* handle;
@@ -52,6 +62,8 @@ typedef struct {
     fn_rs_create rs_create; fn_rs_estimate rs_estimate; fn_rs_process_pcm16 rs_process_pcm16; fn_rs_flush_pcm16 rs_flush_pcm16;
     fn_rs_destroy rs_destroy;
     fn_host_alloc host_alloc; fn_host_free host_free;
+    fn_win_create win_create; fn_win_info win_info; fn_win_add_source win_add_source; fn_win_remove_source win_remove_source;
+    fn_win_write win_write; fn_win_collect win_collect; fn_win_stats win_stats; fn_win_reset win_reset; fn_win_destroy win_destroy;
 } bnbind_t;
 static bnbind_t BN;
 static char bnbind_errbuf[256];
@@ -80,6 +92,11 @@ static const char* bnbind_load(const char* path) {
     BN_RESOLVE(rs_process_pcm16, "bnhip_resampler_process_pcm16"); BN_RESOLVE(rs_flush_pcm16, "bnhip_resampler_flush_pcm16");
     BN_RESOLVE(rs_destroy, "bnhip_resampler_destroy");
     BN_RESOLVE(host_alloc, "bnhip_host_alloc"); BN_RESOLVE(host_free, "bnhip_host_free");
+    BN_RESOLVE(win_create, "bnhip_windows_create"); BN_RESOLVE(win_info, "bnhip_windows_info");
+    BN_RESOLVE(win_add_source, "bnhip_windows_add_source"); BN_RESOLVE(win_remove_source, "bnhip_windows_remove_source");
+    BN_RESOLVE(win_write, "bnhip_windows_write"); BN_RESOLVE(win_collect, "bnhip_windows_collect");
+    BN_RESOLVE(win_stats, "bnhip_windows_stats"); BN_RESOLVE(win_reset, "bnhip_windows_reset");
+    BN_RESOLVE(win_destroy, "bnhip_windows_destroy");
     return NULL;
 }
 static void bnbind_unload(void) {
@@ -110,6 +127,15 @@ static int bnbind_rs_flush_pcm16(bnhip_resampler* r, int16_t* out, int cap, int*
 static void bnbind_rs_destroy(bnhip_resampler* r) { BN.rs_destroy(r); }
 static int bnbind_host_alloc(size_t n, void** p) { return BN.host_alloc(n, p); }
 static int bnbind_host_free(void* p) { return BN.host_free ? BN.host_free(p) : 0; }
+static int bnbind_win_create(size_t ov, size_t rd, int mb, bnhip_windows** w) { return BN.win_create(ov, rd, mb, w); }
+static int bnbind_win_info(const bnhip_windows* w, size_t* wb, int* mb, int* pinned, int* ns) { return BN.win_info(w, wb, mb, pinned, ns); }
+static int bnbind_win_add_source(bnhip_windows* w, const char* id, size_t cap, int* out) { return BN.win_add_source(w, id, cap, out); }
+static int bnbind_win_remove_source(bnhip_windows* w, int s) { return BN.win_remove_source(w, s); }
+static int bnbind_win_write(bnhip_windows* w, int s, const void* d, size_t n) { return BN.win_write(w, s, d, n); }
+static int bnbind_win_collect(bnhip_windows* w, int cap, int* src, int* n, const void** batch) { return BN.win_collect(w, cap, src, n, batch); }
+static int bnbind_win_stats(const bnhip_windows* w, int s, uint64_t* wr, uint64_t* ov, size_t* buffered) { return BN.win_stats(w, s, wr, ov, buffered); }
+static int bnbind_win_reset(bnhip_windows* w, int s) { return BN.win_reset(w, s); }
+static void bnbind_win_destroy(bnhip_windows* w) { if (BN.win_destroy) BN.win_destroy(w); }
 */
 import "C"
 
@@ -421,6 +447,172 @@ func (c *Classifier) PredictPCM16(pcm []byte, batchSize int) ([]float32, error) 
 		return nil, fmt.Errorf("hip: predict_pcm16 failed (%d): %s", int(rc), lastError())
 	}
 	return out, nil
+}
+
+// WindowAssembler holds the analysis buffers of every audio source of ONE model in the library (bnhip_windows): per source the
+// ring in overwrite mode and the overlap tail of buffer.AnalysisBuffer (internal/audiocore/buffer/analysis.go:30-276), per tick
+// the Read() of all of that model's poll loops (internal/analysis/buffer_manager.go:388-496) in one pass - every source with a
+// window ready lands in a row of one page-locked batch buffer, which PredictWindows hands to the device as it is.  Where the
+// reference queues one batch-1 Predict per window behind Orchestrator.inferenceMu (internal/classifier/orchestrator.go:531),
+// a tick is one device call.  Write may be called from any capture goroutine; Collect / PredictWindows from one at a time.
+type WindowAssembler struct {
+	h           *C.bnhip_windows
+	windowBytes int
+	maxBatch    int
+	pinned      bool
+	sources     []C.int // scratch of Collect
+}
+
+// NewWindowAssembler: overlapBytes + readBytes = the model's clip in bytes (ModelSpec.BufferDimensions, model.go:33-56).
+func NewWindowAssembler(overlapBytes, readBytes, maxBatch int) (*WindowAssembler, error) {
+	if overlapBytes < 0 || readBytes <= 0 || maxBatch <= 0 {
+		return nil, fmt.Errorf("hip: invalid window geometry: overlap %d, read %d, max batch %d", overlapBytes, readBytes, maxBatch)
+	}
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	var h *C.bnhip_windows
+	if rc := C.bnbind_win_create(C.size_t(overlapBytes), C.size_t(readBytes), C.int(maxBatch), &h); rc != 0 {
+		return nil, fmt.Errorf("hip: windows_create failed (%d): %s", int(rc), lastError())
+	}
+	var wb C.size_t
+	var mb, pin C.int
+	C.bnbind_win_info(h, &wb, &mb, &pin, nil)
+	return &WindowAssembler{h: h, windowBytes: int(wb), maxBatch: int(mb), pinned: pin != 0, sources: make([]C.int, int(mb))}, nil
+}
+
+// AddSource = NewAnalysisBuffer(capacity, overlap, read, sourceID) for one more source; the index names it from then on.
+func (w *WindowAssembler) AddSource(sourceID string, capacity int) (int, error) {
+	if w.h == nil {
+		return -1, errors.New("hip: window assembler is closed")
+	}
+	id := C.CString(sourceID)
+	defer C.free(unsafe.Pointer(id))
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	var idx C.int
+	if capacity < 0 {
+		capacity = 0
+	}
+	if rc := C.bnbind_win_add_source(w.h, id, C.size_t(capacity), &idx); rc != 0 {
+		return -1, fmt.Errorf("hip: windows_add_source failed (%d): %s", int(rc), lastError())
+	}
+	return int(idx), nil
+}
+
+func (w *WindowAssembler) RemoveSource(source int) error {
+	if w.h == nil {
+		return nil
+	}
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	if rc := C.bnbind_win_remove_source(w.h, C.int(source)); rc != 0 {
+		return fmt.Errorf("hip: windows_remove_source failed (%d): %s", int(rc), lastError())
+	}
+	return nil
+}
+
+// Write = AnalysisBuffer.Write (analysis.go:152-175): never blocks on the consumer, the oldest unread bytes go when the ring
+// is full.  The bytes are copied before it returns.
+func (w *WindowAssembler) Write(source int, data []byte) error {
+	if w.h == nil {
+		return errors.New("hip: window assembler is closed")
+	}
+	if len(data) == 0 {
+		return nil
+	}
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	if rc := C.bnbind_win_write(w.h, C.int(source), unsafe.Pointer(&data[0]), C.size_t(len(data))); rc != 0 {
+		return fmt.Errorf("hip: windows_write failed (%d): %s", int(rc), lastError())
+	}
+	return nil
+}
+
+// Collect reads every source that has a window ready (at most maxBatch; the next call resumes behind the last source looked
+// at).  windows is a view of the library's batch buffer - row k belongs to sources[k] - valid until the next Collect.
+func (w *WindowAssembler) Collect() (sources []int, windows []byte, err error) {
+	if w.h == nil {
+		return nil, nil, errors.New("hip: window assembler is closed")
+	}
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	var n C.int
+	var batch unsafe.Pointer
+	if rc := C.bnbind_win_collect(w.h, C.int(w.maxBatch), &w.sources[0], &n, &batch); rc != 0 {
+		return nil, nil, fmt.Errorf("hip: windows_collect failed (%d): %s", int(rc), lastError())
+	}
+	if n == 0 {
+		return nil, nil, nil
+	}
+	sources = make([]int, int(n))
+	for i := range sources {
+		sources[i] = int(w.sources[i])
+	}
+	return sources, unsafe.Slice((*byte)(batch), int(n)*w.windowBytes), nil
+}
+
+// OverwriteStats: the OverwriteTracker's inputs for one source (buffer/overwrite.go) - writes and overwriting writes since
+// creation or Reset.  The rate window and the notification policy stay with the caller.
+func (w *WindowAssembler) OverwriteStats(source int) (writes, overwrites uint64, err error) {
+	if w.h == nil {
+		return 0, 0, errors.New("hip: window assembler is closed")
+	}
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	var wr, ov C.uint64_t
+	if rc := C.bnbind_win_stats(w.h, C.int(source), &wr, &ov, nil); rc != 0 {
+		return 0, 0, fmt.Errorf("hip: windows_stats failed (%d): %s", int(rc), lastError())
+	}
+	return uint64(wr), uint64(ov), nil
+}
+
+// Reset = AnalysisBuffer.Reset (analysis.go:270-276) for one source.
+func (w *WindowAssembler) Reset(source int) error {
+	if w.h == nil {
+		return nil
+	}
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	if rc := C.bnbind_win_reset(w.h, C.int(source)); rc != 0 {
+		return fmt.Errorf("hip: windows_reset failed (%d): %s", int(rc), lastError())
+	}
+	return nil
+}
+
+func (w *WindowAssembler) WindowBytes() int { return w.windowBytes }
+func (w *WindowAssembler) Pinned() bool     { return w.pinned }
+
+func (w *WindowAssembler) Close() {
+	if w.h != nil {
+		C.bnbind_win_destroy(w.h)
+		w.h = nil
+	}
+}
+
+// PredictWindows is one tick of the real-time path for this classifier's model: Collect, then one device call over all ready
+// windows straight from the assembler's batch buffer (16-bit capture, conf.BytesPerSample; the /32768 conversion of
+// process.go:479-497 runs on the device).  Returns the source of each row and flat [len(sources)*nClasses] logits; nothing
+// ready = (nil, nil, nil), the reference's "try again later".  The caller builds one Results message per row, as ProcessData
+// does per window (process.go:327-420); windows is the PCM it must copy into the message before the next tick.
+func (c *Classifier) PredictWindows(w *WindowAssembler) (sources []int, windows []byte, logits []float32, err error) {
+	if c.h == nil {
+		return nil, nil, nil, errors.New("hip: classifier is closed")
+	}
+	if w.windowBytes != c.nSamples*2 {
+		return nil, nil, nil, fmt.Errorf("window size mismatch: assembler %d bytes, model clip %d bytes", w.windowBytes, c.nSamples*2)
+	}
+	sources, windows, err = w.Collect()
+	if err != nil || len(sources) == 0 {
+		return nil, nil, nil, err
+	}
+	logits = make([]float32, len(sources)*c.nClasses)
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	if rc := C.bnbind_predict_pcm16(c.h, (*C.int16_t)(unsafe.Pointer(&windows[0])), C.int(len(sources)),
+		(*C.float)(unsafe.Pointer(&logits[0])), nil); rc != 0 {
+		return nil, nil, nil, fmt.Errorf("hip: predict_pcm16 failed (%d): %s", int(rc), lastError())
+	}
+	return sources, windows, logits, nil
 }
 
 // CustomClassifier implements inference.CustomClassifier (internal/inference/backend.go:31-53) for a dense head file - the

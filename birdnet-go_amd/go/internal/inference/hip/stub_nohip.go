@@ -39,6 +39,22 @@ func (*Classifier) PredictTopKSoftmax([]float32, int, int) ([]float32, []int32, 
 	return nil, nil, ErrHIPUnavailable
 }
 
+type WindowAssembler struct{}
+
+func NewWindowAssembler(int, int, int) (*WindowAssembler, error)             { return nil, ErrHIPUnavailable }
+func (*WindowAssembler) AddSource(string, int) (int, error)                  { return -1, ErrHIPUnavailable }
+func (*WindowAssembler) RemoveSource(int) error                              { return nil }
+func (*WindowAssembler) Write(int, []byte) error                             { return ErrHIPUnavailable }
+func (*WindowAssembler) Collect() ([]int, []byte, error)                     { return nil, nil, ErrHIPUnavailable }
+func (*WindowAssembler) OverwriteStats(int) (uint64, uint64, error)          { return 0, 0, ErrHIPUnavailable }
+func (*WindowAssembler) Reset(int) error                                     { return nil }
+func (*WindowAssembler) WindowBytes() int                                    { return 0 }
+func (*WindowAssembler) Pinned() bool                                        { return false }
+func (*WindowAssembler) Close()                                              {}
+func (*Classifier) PredictWindows(*WindowAssembler) ([]int, []byte, []float32, error) {
+	return nil, nil, nil, ErrHIPUnavailable
+}
+
 type CustomClassifier struct{}
 
 func NewCustomClassifier([]byte, []string, ...int) (*CustomClassifier, error) { return nil, ErrHIPUnavailable }

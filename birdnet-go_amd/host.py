@@ -32,7 +32,9 @@ SYMBOLS = ["bnhip_init", "bnhip_shutdown", "bnhip_model_create", "bnhip_model_in
            "bnhip_resampler_create", "bnhip_resampler_estimate", "bnhip_resampler_process_pcm16",
            "bnhip_resampler_process_f32", "bnhip_resampler_flush_pcm16", "bnhip_resampler_flush_f32",
            "bnhip_resampler_destroy", "bnhip_us_frame_cv_device", "bnhip_profile_steps", "bnhip_profile_steps_read",
-           "bnhip_host_alloc", "bnhip_host_free"]
+           "bnhip_host_alloc", "bnhip_host_free", "bnhip_windows_create", "bnhip_windows_info", "bnhip_windows_add_source",
+           "bnhip_windows_remove_source", "bnhip_windows_write", "bnhip_windows_collect", "bnhip_windows_ready",
+           "bnhip_windows_stats", "bnhip_windows_reset", "bnhip_windows_destroy"]
 
 
 class HipError(RuntimeError):

@@ -12,15 +12,23 @@ every buffer that has a window ready and hands all of them to ONE device call (P
 16/24/32-bit conversion of a1 happens in the kernel), then builds one `Results` message per window.  Per-window semantics
 (copy of the PCM bytes, overrun accounting against the model's buffer interval, drop-on-full queue) are the reference's.
 
+Two holders of the rings: `AnalysisBuffer` below mirrors the reference's type one to one (its tests are the reference's
+table); `NativeWindows` is the library's window assembler behind the C ABI (`bnhip_windows_*`, csrc/windows.cpp) - the form a
+Go host binds - which reads every ready source into consecutive rows of one page-locked batch buffer, so that the device call
+copies the windows from where they were assembled.  `WindowBatcher` uses the native one unless told otherwise; both are held
+to the same oracle.
+
 Byte work here is exact by construction (numpy slices); tests/test_stream.py replays the reference's own table of cases
 (analysis_test.go:23-243) and compares against the line-by-line restatement in oracle/gostream.py.
 """
+import ctypes as C
 import threading
 import time
 from dataclasses import dataclass
 
 import numpy as np
 
+from . import host as _host
 from . import results as _results
 
 # analysis.go:13-18
@@ -214,6 +222,121 @@ class AnalysisBuffer:
             self.ring.reset()
             self.prev = None
         self.tracker.reset()
+
+
+class NativeWindows:
+    """`bnhip_windows` (include/bnhip.h): per-source rings + overlap tails in the library, every ready window collected into one
+    batch buffer (page-locked when a device is present).  One assembler per window geometry, i.e. per model."""
+
+    _proto_done = False
+
+    def __init__(self, overlap_bytes, read_bytes, max_batch=256):
+        lib = self._lib = _host.load_library()
+        if not NativeWindows._proto_done:
+            vp, sz, ci = C.c_void_p, C.c_size_t, C.c_int
+            lib.bnhip_windows_create.argtypes = [sz, sz, ci, C.POINTER(vp)]
+            lib.bnhip_windows_info.argtypes = [vp, C.POINTER(sz), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+            lib.bnhip_windows_add_source.argtypes = [vp, C.c_char_p, sz, C.POINTER(ci)]
+            lib.bnhip_windows_remove_source.argtypes = [vp, ci]
+            lib.bnhip_windows_write.argtypes = [vp, ci, vp, sz]
+            lib.bnhip_windows_collect.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(vp)]
+            lib.bnhip_windows_ready.argtypes = [vp, C.POINTER(ci)]
+            lib.bnhip_windows_stats.argtypes = [vp, ci, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(sz)]
+            lib.bnhip_windows_reset.argtypes = [vp, ci]
+            lib.bnhip_windows_destroy.argtypes = [vp]
+            lib.bnhip_windows_destroy.restype = None
+            NativeWindows._proto_done = True
+        if overlap_bytes < 0 or read_bytes < 0:
+            raise StreamError(f"invalid window geometry: overlap {overlap_bytes}, read {read_bytes}")
+        h = C.c_void_p()
+        self._h = None
+        self._check(lib.bnhip_windows_create(overlap_bytes, read_bytes, max_batch, C.byref(h)))
+        self._h = h
+        wb, mb, pin = C.c_size_t(), C.c_int(), C.c_int()
+        self._check(lib.bnhip_windows_info(h, C.byref(wb), C.byref(mb), C.byref(pin), None))
+        self.window_bytes, self.max_batch, self.pinned = wb.value, mb.value, bool(pin.value)
+        self.overlap_size, self.read_size = overlap_bytes, read_bytes
+        self._sources = (C.c_int * self.max_batch)()
+        self._rows = None                               # uint8 [max_batch, window_bytes] over the library's batch buffer
+
+    def _check(self, rc):
+        if rc != _host.BNHIP_OK:
+            msg = (self._lib.bnhip_last_error() or b"").decode("utf-8", "replace")
+            if rc == _host.E_INVALID:
+                raise StreamError(msg)
+            raise _host.HipError(rc, msg)
+
+    def _alive(self):
+        if self._h is None:
+            raise StreamError("window assembler is closed")
+        return self._h
+
+    def add_source(self, source_id, capacity):
+        idx = C.c_int(-1)
+        self._check(self._lib.bnhip_windows_add_source(self._alive(), source_id.encode(), max(0, capacity), C.byref(idx)))
+        return idx.value
+
+    def remove_source(self, source):
+        self._check(self._lib.bnhip_windows_remove_source(self._alive(), source))
+
+    def write(self, source, data):
+        d = _as_bytes(data)
+        self._check(self._lib.bnhip_windows_write(self._alive(), source, d.ctypes.data, d.size))
+
+    def collect(self, cap=None):
+        """-> (source indices, uint8 [n, window_bytes] VIEW of the batch buffer, valid until the next collect)."""
+        n, p = C.c_int(0), C.c_void_p()
+        cap = self.max_batch if cap is None else min(cap, self.max_batch)
+        self._check(self._lib.bnhip_windows_collect(self._alive(), cap, self._sources, C.byref(n), C.byref(p)))
+        if self._rows is None:
+            buf = (C.c_uint8 * (self.max_batch * self.window_bytes)).from_address(p.value)
+            self._rows = np.frombuffer(buf, np.uint8).reshape(self.max_batch, self.window_bytes)
+        return list(self._sources[:n.value]), self._rows[:n.value]
+
+    def ready(self):
+        n = C.c_int(0)
+        self._check(self._lib.bnhip_windows_ready(self._alive(), C.byref(n)))
+        return n.value
+
+    def stats(self, source):
+        w, o, b = C.c_uint64(), C.c_uint64(), C.c_size_t()
+        self._check(self._lib.bnhip_windows_stats(self._alive(), source, C.byref(w), C.byref(o), C.byref(b)))
+        return w.value, o.value, b.value
+
+    def reset(self, source):
+        self._check(self._lib.bnhip_windows_reset(self._alive(), source))
+
+    def close(self):
+        if self._h is not None:
+            self._rows = None
+            self._lib.bnhip_windows_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _NativeSource:
+    """One source of a NativeWindows with the AnalysisBuffer's surface (write / ready / overwrite_count / reset)."""
+
+    def __init__(self, win: NativeWindows, index, source_id):
+        self.win, self.index, self.source_id = win, index, source_id
+        self.read_size, self.overlap_size, self.window_size = win.read_size, win.overlap_size, win.window_bytes
+
+    def write(self, data):
+        self.win.write(self.index, data)
+
+    def ready(self):
+        return self.win.stats(self.index)[2] >= self.read_size
+
+    def overwrite_count(self):
+        return self.win.stats(self.index)[1]
+
+    def reset(self):
+        self.win.reset(self.index)
 
 
 @dataclass(frozen=True)
@@ -435,12 +558,14 @@ class WindowBatcher:
     are read and discarded exactly as the reference does (:478-480: the audio is consumed, not analysed)."""
 
     def __init__(self, orch: Orchestrator, queue: _results.ResultsQueue = None, overruns: OverrunTrackers = None,
-                 max_batch=256, pre_capture_s=0.0, bit_depth=16, clock=time.time, on_error=None):
+                 max_batch=256, pre_capture_s=0.0, bit_depth=16, clock=time.time, on_error=None, native=True):
         self.orch = orch
         self.queue = queue if queue is not None else _results.ResultsQueue()
         self.overruns = overruns if overruns is not None else OverrunTrackers()
         self.max_batch, self.pre_capture_s, self.bit_depth, self.clock = max_batch, pre_capture_s, bit_depth, clock
-        self.buffers = {}                    # (source, model_id) -> AnalysisBuffer
+        self.buffers = {}                    # (source, model_id) -> AnalysisBuffer | _NativeSource
+        self.native = native                 # rings in the library, windows collected into its page-locked batch buffer
+        self.assemblers = {}                 # native: model_id -> NativeWindows
         self.mu = threading.Lock()
         self.on_error, self.errors = on_error, 0   # a failed device call costs its own windows only (the reference logs and polls on)
 
@@ -449,15 +574,32 @@ class WindowBatcher:
         if spec is None:
             raise OrchestratorError(f"unknown model: {model_id}")
         clip, overlap, read = spec.buffer_dimensions()
-        ab = AnalysisBuffer(capacity if capacity is not None else 2 * clip, overlap, read, source)
+        capacity = capacity if capacity is not None else 2 * clip
+        if not self.native:
+            ab = AnalysisBuffer(capacity, overlap, read, source)
+            with self.mu:
+                self.buffers[(source, model_id)] = ab
+            return ab
         with self.mu:
-            self.buffers[(source, model_id)] = ab
+            win = self.assemblers.get(model_id)
+            if win is None or (win.overlap_size, win.read_size) != (overlap, read):
+                if win is not None:                       # the model was re-registered with another geometry
+                    for k in [k for k in self.buffers if k[1] == model_id]:
+                        del self.buffers[k]
+                    win.close()
+                win = self.assemblers[model_id] = NativeWindows(overlap, read, self.max_batch)
+            old = self.buffers.pop((source, model_id), None)
+            if old is not None:
+                win.remove_source(old.index)
+            ab = self.buffers[(source, model_id)] = _NativeSource(win, win.add_source(source, capacity), source)
         return ab
 
     def remove(self, source, model_id=None):
         with self.mu:
             for k in [k for k in self.buffers if k[0] == source and (model_id is None or k[1] == model_id)]:
-                del self.buffers[k]
+                ab = self.buffers.pop(k)
+                if isinstance(ab, _NativeSource):
+                    ab.win.remove_source(ab.index)
         self.overruns.remove_source(source)
 
     def write(self, source, data):
@@ -467,7 +609,42 @@ class WindowBatcher:
         for ab in abs_:
             ab.write(data)
 
+    def _tick_native(self):
+        with self.mu:
+            wins = list(self.assemblers.items())
+            names = {(id(ab.win), ab.index): src for (src, _), ab in self.buffers.items() if isinstance(ab, _NativeSource)}
+        sent = 0
+        for model_id, win in wins:
+            while True:
+                idxs, rows = win.collect(self.max_batch)          # rows: a view of the library's batch buffer
+                if not idxs:
+                    break
+                spec = self.orch.model_spec_for(model_id)
+                if spec is not None and self.orch.is_model_active(model_id):
+                    now = self.clock()
+                    start = now - (self.pre_capture_s + spec.clip_length_s)
+                    sources = [names.get((id(win), i), f"source#{i}") for i in idxs]
+                    try:
+                        sent += process_windows(self.orch, rows, [start] * len(idxs), [now] * len(idxs), sources, model_id,
+                                                self.queue, self.overruns, self.bit_depth)
+                    except Exception as e:
+                        self.errors += len(idxs)
+                        if self.on_error:
+                            self.on_error(model_id, sources, e)
+                if len(idxs) < min(self.max_batch, win.max_batch):
+                    break
+        return sent
+
+    def close(self):
+        with self.mu:
+            for win in self.assemblers.values():
+                win.close()
+            self.assemblers.clear()
+            self.buffers.clear()
+
     def tick(self):
+        if self.native:
+            return self._tick_native()
         with self.mu:
             items = list(self.buffers.items())
         per_model = {}

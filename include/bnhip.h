@@ -111,6 +111,39 @@ int bnhip_predict_pcm16(bnhip_model* m, const int16_t* pcm, int n_clips, float* 
  * bits_per_sample / 8 bytes each.  Any other depth is BNHIP_E_INVALID (pcm.go:215-222 "supported_bit_depths 16,24,32"). */
 int bnhip_predict_pcm(bnhip_model* m, const void* pcm, int bits_per_sample, int n_clips, float* logits, float* emb);
 
+/* Window assembler: the real-time path's analysis buffers, one per audio source, read in one pass.
+ * Replaces, per source, buffer.AnalysisBuffer (internal/audiocore/buffer/analysis.go:30-276: NewAnalysisBuffer :55-145, Write
+ * :152-175, Read :187-252, Reset :270-276) and, per tick, the Read() of every (source, model) poll loop
+ * (internal/analysis/buffer_manager.go:388-496) - the reference then makes one batch-1 Predict per window behind
+ * Orchestrator.inferenceMu (internal/classifier/orchestrator.go:531); here all windows that are ready land in consecutive rows of
+ * ONE batch buffer, which is what bnhip_predict_pcm takes (bits_per_sample as captured, n_clips = *n_windows).  The buffer is
+ * page-locked when a device is present (*pinned), so the copy engines read the rows in place: a window's bytes move once
+ * between the capture callback and the device.
+ *   geometry  one assembler per model: overlap_bytes + read_bytes = the model's clip in bytes, overlap = clip / 2
+ *             (internal/classifier/model.go:33-56); read_bytes >= overlap_bytes >= 0, read_bytes > 0 (analysis.go:65-90)
+ *   write     any thread, any chunk size; overwrite mode - the oldest unread bytes are dropped when the data does not fit
+ *             (analysis.go:119 SetOverwrite(true)), the write is counted as an overwrite when len(data) > free bytes (:154)
+ *   collect   one thread at a time (writers may run beside it): every source with >= read_bytes buffered yields
+ *             `previous tail (zeros the first time) || read_bytes fresh bytes`; at most min(cap, max_batch) windows per call,
+ *             the next call resumes behind the last source looked at; sources[k] = source of row k; *batch = the rows, valid
+ *             until the next collect / destroy.  A model that is inactive still collects (the audio is consumed, not analysed:
+ *             buffer_manager.go:478-481) and simply skips the predict.
+ * Needs no device and no bnhip_model. */
+typedef struct bnhip_windows bnhip_windows;
+int bnhip_windows_create(size_t overlap_bytes, size_t read_bytes, int max_batch, bnhip_windows** out);
+int bnhip_windows_info(const bnhip_windows* w, size_t* window_bytes, int* max_batch, int* pinned, int* n_sources);
+/* capacity_bytes >= read_bytes (analysis.go:56-64,91-100); source_id non-empty (:101-109).  Slots of removed sources are reused. */
+int bnhip_windows_add_source(bnhip_windows* w, const char* source_id, size_t capacity_bytes, int* out_source);
+int bnhip_windows_remove_source(bnhip_windows* w, int source);
+int bnhip_windows_write(bnhip_windows* w, int source, const void* data, size_t n_bytes);
+int bnhip_windows_collect(bnhip_windows* w, int cap, int* sources, int* n_windows, const void** batch);
+int bnhip_windows_ready(const bnhip_windows* w, int* n_ready);
+/* writes / overwrites since creation or reset (the OverwriteTracker's inputs, buffer/overwrite.go; the rate window and the
+ * notification policy stay with the host), bytes currently buffered.  Any output may be NULL. */
+int bnhip_windows_stats(const bnhip_windows* w, int source, uint64_t* writes, uint64_t* overwrites, size_t* buffered_bytes);
+int bnhip_windows_reset(bnhip_windows* w, int source);
+void bnhip_windows_destroy(bnhip_windows* w);
+
 /* Page-locked host buffers for the host-pointer entries above.  The reference's accelerator shim keeps a C-allocated input
  * buffer per classifier so that the native side reads memory the Go GC cannot move (backend_openvino.go:673-680); here the same
  * buffer is page-locked as well: when `samples` / `pcm` (and `logits`, `emb`) of a bnhip_predict* call lie in memory from

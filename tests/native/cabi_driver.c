@@ -98,6 +98,56 @@ int main(int argc, char** argv) {
             rc = bnbind_us_frame_cv(0, sm, 1, 64, 48000, 32, 16, 30000, &cv, &ok);
             CHECK(rc == 0 && ok == 0, "us_frame_cv: split above Nyquist must be (0, false)");
         }
+        /* WindowAssembler (bnhip_windows_*): byte work, no device needed.  Geometry checks of NewAnalysisBuffer
+         * (analysis.go:55-109), two sources, first window = zero prefix + fresh bytes, second = previous tail + fresh bytes
+         * (TestAnalysisBuffer_Read_ContentParity, analysis_test.go:203-243), overwrite accounting, cap + resume */
+        {
+            bnhip_windows* w = (bnhip_windows*)1;
+            rc = bnbind_win_create(64, 32, 4, &w);
+            CHECK(rc == -1 && w == NULL && strstr(bnbind_last_error(), "overlap"), "read < overlap must be invalid (rc %d)", rc);
+            rc = bnbind_win_create(8, 0, 4, &w);
+            CHECK(rc == -1 && w == NULL, "read size 0 must be invalid (rc %d)", rc);
+            rc = bnbind_win_create(4, 8, 2, &w);
+            CHECK(rc == 0 && w, "windows_create: %s", bnbind_last_error());
+            size_t wb = 0; int mb = 0, pinned = -1, nsrc = -1;
+            CHECK(bnbind_win_info(w, &wb, &mb, &pinned, &nsrc) == 0 && wb == 12 && mb == 2 && nsrc == 0 && (pinned == 0 || pinned == 1), "windows_info");
+            int a = -1, b = -1, c = -1;
+            CHECK(bnbind_win_add_source(w, "", 64, &a) == -1 && a == -1, "empty source id must be invalid");
+            CHECK(bnbind_win_add_source(w, "mic-a", 4, &a) == -1 && a == -1, "capacity below the read size must be invalid");
+            CHECK(bnbind_win_add_source(w, "mic-a", 16, &a) == 0 && a == 0, "add_source a: %s", bnbind_last_error());
+            CHECK(bnbind_win_add_source(w, "mic-b", 16, &b) == 0 && b == 1, "add_source b");
+            CHECK(bnbind_win_add_source(w, "mic-c", 16, &c) == 0 && c == 2, "add_source c");
+            unsigned char st[32];
+            for (int i = 0; i < 32; i++) st[i] = (unsigned char)(i + 1);
+            int src[4] = {-1, -1, -1, -1}, n = -1;
+            const void* batch = NULL;
+            CHECK(bnbind_win_write(w, a, st, 7) == 0, "write");
+            CHECK(bnbind_win_collect(w, 4, src, &n, &batch) == 0 && n == 0 && batch, "7 of 8 bytes: try again later");
+            CHECK(bnbind_win_write(w, a, st + 7, 9) == 0 && bnbind_win_write(w, b, st + 16, 8) == 0 && bnbind_win_write(w, c, st, 8) == 0, "write");
+            CHECK(bnbind_win_write(w, 7, st, 1) == -1, "write to an unknown source must be invalid");
+            /* three sources ready, max_batch 2: a and b now, c (and a's second window) on the next call */
+            CHECK(bnbind_win_collect(w, 4, src, &n, &batch) == 0 && n == 2 && src[0] == a && src[1] == b, "collect 1: n %d", n);
+            const unsigned char* r = batch;
+            unsigned char want0[12] = {0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8}, want1[12] = {0, 0, 0, 0, 17, 18, 19, 20, 21, 22, 23, 24};
+            CHECK(memcmp(r, want0, 12) == 0 && memcmp(r + 12, want1, 12) == 0, "first windows: zero prefix + fresh bytes");
+            CHECK(bnbind_win_collect(w, 4, src, &n, &batch) == 0 && n == 2 && src[0] == c && src[1] == a, "collect 2: n %d src %d %d", n, src[0], src[1]);
+            unsigned char want2[12] = {5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+            r = batch;
+            CHECK(memcmp(r + 12, want2, 12) == 0, "second window of a: previous tail + fresh bytes");
+            /* overwrite mode: 24 bytes into a 16-byte ring keep the newest 16 and count one overwriting write */
+            CHECK(bnbind_win_write(w, b, st, 24) == 0, "long write");
+            uint64_t wr = 0, ov = 0; size_t buffered = 0;
+            CHECK(bnbind_win_stats(w, b, &wr, &ov, &buffered) == 0 && wr == 2 && ov == 1 && buffered == 16, "stats: %llu %llu %zu",
+                  (unsigned long long)wr, (unsigned long long)ov, buffered);
+            CHECK(bnbind_win_collect(w, 1, src, &n, &batch) == 0 && n == 1 && src[0] == b, "collect 3");
+            unsigned char want3[12] = {21, 22, 23, 24, 9, 10, 11, 12, 13, 14, 15, 16};
+            CHECK(memcmp(batch, want3, 12) == 0, "after the overwrite: tail of b's first window + the oldest surviving bytes");
+            CHECK(bnbind_win_reset(w, b) == 0 && bnbind_win_stats(w, b, &wr, &ov, &buffered) == 0 && wr == 0 && ov == 0 && buffered == 0, "reset");
+            CHECK(bnbind_win_remove_source(w, c) == 0 && bnbind_win_remove_source(w, c) == -1, "remove_source");
+            CHECK(bnbind_win_add_source(w, "mic-d", 32, &c) == 0 && c == 2, "a removed source's slot is reused");
+            bnbind_win_destroy(w);
+            bnbind_win_destroy(NULL);
+        }
         /* without a GPU Init reports "unavailable" (-2) and the message names the reason; with one it succeeds */
         int n = -1;
         rc = bnbind_init(&n);
@@ -220,6 +270,51 @@ int main(int argc, char** argv) {
         CHECK(nb2 == na && memcmp(ya, yb, (size_t)na * 2) == 0, "chunked resampling differs from one call (%d vs %d samples)", nb2, na);
         bnbind_rs_destroy(ra); bnbind_rs_destroy(rb);
         free(x); free(ya); free(yb);
+    }
+    /* Classifier.PredictWindows: every source's PCM through the window assembler, one device call per tick straight from its
+     * page-locked batch buffer == PredictPCM16 on the same windows cut by hand (zero prefix, then 50 % overlap) */
+    if (ns >= 1000 && (ns & 1) == 0) {
+        const size_t clip_b = (size_t)ns * 2, ovb = clip_b / 2, rdb = clip_b - ovb;
+        bnhip_windows* w = NULL;
+        CHECK(bnbind_win_create(ovb, rdb, 256, &w) == 0 && w, "windows_create: %s", bnbind_last_error());
+        size_t wb = 0; int pinned = 0;
+        CHECK(bnbind_win_info(w, &wb, NULL, &pinned, NULL) == 0 && wb == clip_b && pinned == 1, "the batch buffer must be page-locked on a GPU box");
+        int16_t* pcm = malloc((size_t)n_clips * clip_b);
+        for (size_t i = 0; i < (size_t)n_clips * ns; i++) {
+            float v = in[i] < -1.f ? -1.f : (in[i] > 1.f ? 1.f : in[i]);
+            pcm[i] = (int16_t)(v * 32767.f);
+        }
+        int* srcs = malloc((size_t)n_clips * sizeof(int));
+        for (int c = 0; c < n_clips; c++) {
+            char id[32]; snprintf(id, sizeof id, "mic-%d", c);
+            int idx = -1;
+            CHECK(bnbind_win_add_source(w, id, 2 * clip_b, &idx) == 0 && idx == c, "add_source");
+            /* a source's stream = its clip, written in ragged pieces */
+            const unsigned char* p = (const unsigned char*)(pcm + (size_t)c * ns);
+            for (size_t off = 0, step = 1000 + 37 * (size_t)c; off < clip_b; off += step)
+                CHECK(bnbind_win_write(w, idx, p + off, off + step <= clip_b ? step : clip_b - off) == 0, "write");
+        }
+        int16_t* hand = calloc((size_t)n_clips * ns, 2);
+        float* o1 = malloc((size_t)n_clips * nc * 4); float* o2 = malloc((size_t)n_clips * nc * 4);
+        for (int tick = 0; tick < 2; tick++) {             /* each clip holds two reads: two windows per source */
+            int n = 0; const void* batch = NULL;
+            CHECK(bnbind_win_collect(w, n_clips, srcs, &n, &batch) == 0 && n == n_clips, "collect: n %d", n);
+            for (int c = 0; c < n_clips; c++) {
+                CHECK(srcs[c] == c, "source order");
+                unsigned char* hw = (unsigned char*)(hand + (size_t)c * ns);
+                const unsigned char* p = (const unsigned char*)(pcm + (size_t)c * ns);
+                if (tick == 0) { memset(hw, 0, ovb); memcpy(hw + ovb, p, rdb); }
+                else { memcpy(hw, p + rdb - ovb, ovb); memcpy(hw + ovb, p + rdb, rdb); }
+            }
+            CHECK(memcmp(batch, hand, (size_t)n_clips * clip_b) == 0, "tick %d: assembled windows differ from the hand-cut ones", tick);
+            CHECK(bnbind_predict_pcm16(h, (const int16_t*)batch, n, o1, NULL) == 0, "predict_pcm16 (windows): %s", bnbind_last_error());
+            CHECK(bnbind_predict_pcm16(h, hand, n, o2, NULL) == 0, "predict_pcm16 (hand): %s", bnbind_last_error());
+            CHECK(memcmp(o1, o2, (size_t)n * nc * 4) == 0, "tick %d: logits from the assembler's buffer differ", tick);
+        }
+        int n = -1; const void* batch = NULL;
+        CHECK(bnbind_win_collect(w, n_clips, srcs, &n, &batch) == 0 && n == 0, "nothing left: try again later");
+        bnbind_win_destroy(w);
+        free(pcm); free(srcs); free(hand); free(o1); free(o2);
     }
     FILE* fo = fopen(argv[5], "wb");
     CHECK(fo && fwrite(out, 4, (size_t)n_clips * nc, fo) == (size_t)n_clips * nc, "write %s", argv[5]);

@@ -113,7 +113,8 @@ def test_go_shim_pins_the_os_thread_around_error_fetch():
     # every exported entry that can fail fetches the thread-local error text: each must hold the OS thread
     for fn in ("func Init(", "func NewClassifierWithOptions(", "func (c *Classifier) predict(", "func (c *Classifier) PredictBatch(",
                "func (c *Classifier) predictTopK(", "func (c *Classifier) PredictPCM16(", "func ComputeUSFrameCV(", "func NewResampler(",
-               "func (r *Resampler) ResampleTo(", "func (r *Resampler) Flush("):
+               "func (r *Resampler) ResampleTo(", "func (r *Resampler) Flush(", "func NewWindowAssembler(", "func (w *WindowAssembler) AddSource(",
+               "func (w *WindowAssembler) Write(", "func (w *WindowAssembler) Collect(", "func (c *Classifier) PredictWindows("):
         body = src[src.index(fn):]
         body = body[:body.index("\n}\n")]
         assert "runtime.LockOSThread()" in body and "defer runtime.UnlockOSThread()" in body, fn
@@ -160,6 +161,12 @@ def test_go_shim_implements_every_backend_interface():
     assert "func NewResampler(fromRate, toRate int" in src and "func ResampleBytes(pcm []byte, fromRate, toRate int" in src
     assert "func ComputeUSFrameCV(samples []float64, sampleRate int, cfg USFilterConfig" in src
     assert "StrictF32 bool" in src and '`,"bf16x3":0`' in src
+    # the real-time window path (rows a3 / a4): the assembler's methods, and the same surface in the no-tag stub
+    stub = open(os.path.join(os.path.dirname(GO_SHIM), "stub_nohip.go")).read()
+    for m in ("AddSource(", "RemoveSource(", "Write(", "Collect(", "OverwriteStats(", "Reset(", "WindowBytes(", "Pinned(", "Close("):
+        assert f"func (w *WindowAssembler) {m}" in src and f"func (*WindowAssembler) {m}" in stub, m
+    assert "func (c *Classifier) PredictWindows(w *WindowAssembler) (sources []int, windows []byte, logits []float32, err error)" in src
+    assert "func (*Classifier) PredictWindows(*WindowAssembler) ([]int, []byte, []float32, error)" in stub
 
 
 @pytest.mark.gpu

@@ -1,7 +1,8 @@
 """analysis-window assembly, ProcessData, Orchestrator.
 
 The first block replays the reference's own cases (internal/audiocore/buffer/analysis_test.go:23-243) against
-birdnet_go_amd.stream AND the byte-at-a-time oracle (oracle/gostream.py), so the oracle is pinned by the same table.
+birdnet_go_amd.stream, against the library's window assembler behind the C ABI (bnhip_windows_*, one source) AND against the
+byte-at-a-time oracle (oracle/gostream.py), so the oracle is pinned by the same table.
 """
 import threading
 import time
@@ -40,7 +41,29 @@ def _product(capacity, overlap, read, source="test-source"):
     return S.AnalysisBuffer(capacity, overlap, read, source)
 
 
-IMPLS = [pytest.param(_product, id="product"), pytest.param(_OracleAB, id="oracle")]
+class _NativeAB:
+    """One source of a `bnhip_windows` assembler behind the product's method names."""
+
+    def __init__(self, capacity, overlap, read, source="test-source"):
+        self.w = S.NativeWindows(overlap, read, max_batch=4)
+        self.i = self.w.add_source(source, capacity)
+
+    def write(self, data):
+        self.w.write(self.i, data)
+
+    def read(self):
+        idxs, rows = self.w.collect()
+        assert idxs in ([], [self.i])
+        return rows[0].copy() if idxs else None
+
+    def overwrite_count(self):
+        return self.w.stats(self.i)[1]
+
+    def reset(self):
+        self.w.reset(self.i)
+
+
+IMPLS = [pytest.param(_product, id="product"), pytest.param(_NativeAB, id="native"), pytest.param(_OracleAB, id="oracle")]
 
 
 @pytest.mark.parametrize("make", IMPLS)
@@ -102,6 +125,32 @@ def test_overlap_read(make):                                 # TestAnalysisBuffe
             assert bytes(second[:ov]) == first[rd:]
             return
     pytest.fail("second read did not return data in time")
+
+
+def test_native_validation_messages():                       # analysis.go:55-108 through the C ABI
+    with pytest.raises(S.StreamError, match="read size must be >= overlap size"):
+        S.NativeWindows(1024, 512)
+    with pytest.raises(S.StreamError, match="invalid read size: 0"):
+        S.NativeWindows(0, 0)
+    with pytest.raises(S.StreamError, match="max_batch must be positive"):
+        S.NativeWindows(0, 8, max_batch=0)
+    w = S.NativeWindows(4, 16, max_batch=2)
+    with pytest.raises(S.StreamError, match="capacity must be >= read size"):
+        w.add_source("mic", 8)
+    with pytest.raises(S.StreamError, match="invalid analysis buffer capacity: 0"):
+        w.add_source("mic", 0)
+    with pytest.raises(S.StreamError, match="source ID must not be empty"):
+        w.add_source("", 64)
+    with pytest.raises(S.StreamError, match="no such source"):
+        w.write(3, b"abcd")
+    i = w.add_source("mic", 64)
+    w.remove_source(i)
+    with pytest.raises(S.StreamError, match="no such source"):
+        w.write(i, b"abcd")
+    assert w.add_source("mic2", 64) == i                     # the slot is reused
+    w.close()
+    with pytest.raises(S.StreamError, match="closed"):
+        w.ready()
 
 
 def test_overwrite_tracker_rate():                           # TestOverwriteTracker_RateCalculation :169-197
@@ -173,6 +222,109 @@ def test_product_equals_oracle_on_random_traffic(seed):
         assert p.ring.length() == o.ring.Length()
     assert p.overwrite_count() <= o.overwrites               # a tracker reset (Reset()) zeroes the product's count only
     assert n_windows > 20
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_native_assembler_equals_oracle_on_random_traffic(seed):
+    """Several sources behind one `bnhip_windows`: random writes (some longer than the ring), collects with random caps,
+    resets, a source removed and another added mid-stream.  Every collected row must be the window the byte-at-a-time oracle
+    of that source returns next, sources served round-robin from behind the last one looked at, nothing ready left behind
+    when the cap was not hit."""
+    rng = np.random.default_rng(100 + seed)
+    ov = int(rng.integers(0, 40))
+    rd = int(rng.integers(max(ov, 1), 90))
+    nsrc = int(rng.integers(2, 7))
+    mb = int(rng.integers(1, nsrc + 2))
+    w = S.NativeWindows(ov, rd, max_batch=mb)
+    assert w.window_bytes == ov + rd and w.max_batch == mb
+    caps = [int(rng.integers(rd, 4 * rd + 7)) for _ in range(nsrc)]
+    idx = [w.add_source(f"s{k}", caps[k]) for k in range(nsrc)]
+    assert idx == list(range(nsrc))
+    ora = {i: GoAnalysisBuffer(caps[i], ov, rd) for i in idx}
+    n_windows, nxt = 0, 0
+    for step in range(600):
+        op = rng.random()
+        live = sorted(ora)
+        if op < 0.6:
+            i = int(rng.choice(live))
+            cap = caps[i]
+            n = int(rng.integers(0, 2 * cap + 3)) if rng.random() < 0.1 else int(rng.integers(0, rd + 5))
+            data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+            w.write(i, data)
+            ora[i].Write(data)
+        elif op < 0.93:
+            cap = int(rng.integers(1, mb + 2))
+            n_ready = sum(o.ring.Length() >= rd for o in ora.values())
+            assert w.ready() == n_ready
+            got, rows = w.collect(cap)
+            assert len(got) == min(n_ready, cap, mb) and len(set(got)) == len(got), step
+            # round-robin: the table is walked from `nxt`, wrapping once
+            nslots = len(caps)
+            order = [(nxt + k) % nslots for k in range(nslots)]
+            want = [i for i in order if i in ora and ora[i].ring.Length() >= rd][:min(cap, mb)]
+            assert got == want, step
+            if len(got) == min(cap, mb):                     # stopped at the cap: the next pass starts behind the last source
+                nxt = (nxt + order.index(got[-1]) + 1) % nslots      # served (otherwise the whole table was looked at)
+            for k, i in enumerate(got):
+                assert bytes(rows[k]) == ora[i].Read(), (step, i)
+                n_windows += 1
+        elif op < 0.96:
+            i = int(rng.choice(live))
+            w.reset(i)
+            ora[i].Reset()
+        elif op < 0.98 and len(live) > 1:
+            i = int(rng.choice(live))
+            w.remove_source(i)
+            del ora[i]
+        else:
+            c = int(rng.integers(rd, 4 * rd + 7))
+            i = w.add_source(f"n{step}", c)
+            assert i not in ora
+            if i == len(caps):
+                caps.append(c)
+            else:
+                caps[i] = c
+            ora[i] = GoAnalysisBuffer(c, ov, rd)
+        for i, o in ora.items():
+            assert w.stats(i)[2] == o.ring.Length()
+    assert n_windows > 30
+    w.close()
+
+
+def test_native_assembler_concurrent_writers_lose_nothing():
+    """Capture threads write while the consumer collects (analysis.go: "Write is safe for concurrent use"): rings large enough
+    never to overwrite, so the fresh halves of each source's windows, concatenated, must be exactly what its thread wrote."""
+    ov, rd, nsrc = 16, 64, 4
+    w = S.NativeWindows(ov, rd, max_batch=3)
+    total = 64 * 200
+    idx = [w.add_source(f"t{k}", total) for k in range(nsrc)]
+    data = [np.random.default_rng(k).integers(0, 256, total, dtype=np.uint8).tobytes() for k in range(nsrc)]
+
+    def writer(k):
+        rng = np.random.default_rng(50 + k)
+        pos = 0
+        while pos < total:
+            n = int(rng.integers(1, 200))
+            w.write(idx[k], data[k][pos:pos + n])
+            pos += n
+
+    ts = [threading.Thread(target=writer, args=(k,)) for k in range(nsrc)]
+    for t in ts:
+        t.start()
+    fresh = {i: bytearray() for i in idx}
+    tails = {i: bytes(ov) for i in idx}
+    while any(t.is_alive() for t in ts) or w.ready():
+        got, rows = w.collect()
+        for k, i in enumerate(got):
+            row = bytes(rows[k])
+            assert row[:ov] == tails[i]
+            fresh[i] += row[ov:]
+            tails[i] = row[-ov:]
+    for t in ts:
+        t.join()
+    for k, i in enumerate(idx):
+        assert bytes(fresh[i]) == data[k] and w.stats(i)[1] == 0
+    w.close()
 
 
 def test_ring_wraps_and_keeps_newest_bytes():
@@ -364,12 +516,13 @@ def _reference_windows(stream_bytes, overlap, read):
     return out
 
 
-def test_batcher_equals_per_source_monitors():
+@pytest.mark.parametrize("native", [True, False], ids=["native", "python"])
+def test_batcher_equals_per_source_monitors(native):
     o = S.Orchestrator()
     f = _Fake()
     spec = S.ModelSpec(48000, 3.0, clip_bytes=64)            # 32-sample windows, 16 overlap
     o.register("m", f, spec)
-    wb = S.WindowBatcher(o, R.ResultsQueue(size=1000), max_batch=3, clock=lambda: 100.0)
+    wb = S.WindowBatcher(o, R.ResultsQueue(size=1000), max_batch=3, clock=lambda: 100.0, native=native)
     rng = np.random.default_rng(5)
     streams = {f"src{i}": rng.integers(-32768, 32767, 16 * 37, dtype=np.int16).tobytes() for i in range(5)}
     for s in streams:
@@ -400,11 +553,12 @@ def test_batcher_equals_per_source_monitors():
     assert o.counters.peek_all()["m"]["invoke_count"] == len(f.calls)
 
 
-def test_batcher_inactive_model_consumes_without_analysing():
+@pytest.mark.parametrize("native", [True, False], ids=["native", "python"])
+def test_batcher_inactive_model_consumes_without_analysing(native):
     o = S.Orchestrator()
     f = _Fake()
     o.register("bat", f, S.ModelSpec(48000, 3.0, clip_bytes=16))
-    wb = S.WindowBatcher(o)
+    wb = S.WindowBatcher(o, native=native)
     wb.allocate("mic", "bat", capacity=256)
     o.set_active("bat", False)
     wb.write("mic", bytes(range(8)))
@@ -415,7 +569,8 @@ def test_batcher_inactive_model_consumes_without_analysing():
     assert wb.queue.get().pcm_data == bytes(range(8)) + bytes(range(8, 16))                 # overlap kept across the skipped window
 
 
-def test_batcher_failed_model_costs_only_its_own_windows():
+@pytest.mark.parametrize("native", [True, False], ids=["native", "python"])
+def test_batcher_failed_model_costs_only_its_own_windows(native):
     """buffer_manager.go:494-499: a ProcessData error is logged by that monitor and polling goes on - one model's failing
     device call must not cost the other models the windows this tick already consumed from their rings."""
     class _Boom:
@@ -426,7 +581,7 @@ def test_batcher_failed_model_costs_only_its_own_windows():
     o.register("bad", _Boom(), S.ModelSpec(48000, 3.0, clip_bytes=16))
     o.register("good", good, S.ModelSpec(48000, 3.0, clip_bytes=16))
     seen = []
-    wb = S.WindowBatcher(o, on_error=lambda model, sources, e: seen.append((model, sources, str(e))))
+    wb = S.WindowBatcher(o, on_error=lambda model, sources, e: seen.append((model, sources, str(e))), native=native)
     for m in ("bad", "good"):
         wb.allocate("mic", m, capacity=256)
     wb.write("mic", bytes(range(8)))
@@ -436,11 +591,12 @@ def test_batcher_failed_model_costs_only_its_own_windows():
     assert o.counters.peek_all()["bad"]["invoke_errors"] == 1
 
 
-def test_batcher_model_unloaded_between_ticks():
+@pytest.mark.parametrize("native", [True, False], ids=["native", "python"])
+def test_batcher_model_unloaded_between_ticks(native):
     o = S.Orchestrator()
     f = _Fake()
     o.register("m", f, S.ModelSpec(48000, 3.0, clip_bytes=16))
-    wb = S.WindowBatcher(o)
+    wb = S.WindowBatcher(o, native=native)
     wb.allocate("mic", "m", capacity=256)
     wb.write("mic", bytes(range(8)))
     o.unload("m")                                            # the buffer is still allocated: its audio is consumed, nothing raised
@@ -474,9 +630,11 @@ def test_overwrite_warning_callback_may_query_the_tracker():
 
 # ------------------------------------------------------------------ through the device
 @pytest.mark.gpu
-def test_batcher_streams_through_the_device(tiny_cfg, tiny_blob):
+@pytest.mark.parametrize("native", [True, False], ids=["native", "python"])
+def test_batcher_streams_through_the_device(tiny_cfg, tiny_blob, native):
     """Five sources streaming 16-bit PCM in ragged chunks through WindowBatcher + host.BirdNET == the same windows cut by hand
-    and sent through predict_pcm16 one call at a time (the reference's one-window-per-call pattern)."""
+    and sent through predict_pcm16 one call at a time (the reference's one-window-per-call pattern).  native: the rings live in
+    the library and the device call reads the windows out of its page-locked batch buffer."""
     from birdnet_go_amd import host
     clf = host.HipClassifier(tiny_blob, device=0, max_batch=8)
     labels = [f"sp{i}" for i in range(clf.num_species())]
@@ -485,7 +643,7 @@ def test_batcher_streams_through_the_device(tiny_cfg, tiny_blob):
     spec = S.ModelSpec(tiny_cfg.sample_rate, 3.0, clip_bytes=clip_bytes)
     o = S.Orchestrator()
     o.register("tiny", bn, spec)
-    wb = S.WindowBatcher(o, R.ResultsQueue(size=1000), max_batch=8)
+    wb = S.WindowBatcher(o, R.ResultsQueue(size=1000), max_batch=8, native=native)
     rng = np.random.default_rng(11)
     n_src, n_win = 5, 4
     t = np.arange(tiny_cfg.n_samples // 2 * (n_win + 1)) / tiny_cfg.sample_rate
@@ -516,4 +674,38 @@ def test_batcher_streams_through_the_device(tiny_cfg, tiny_blob):
             assert [d.species for d in m.results] == [lbl for lbl, _ in one]
             np.testing.assert_allclose([d.confidence for d in m.results], [c for _, c in one], rtol=0, atol=2e-6)
     assert o.counters.peek_all()["tiny"]["invoke_count"] >= n_win
+    if native:
+        assert wb.assemblers["tiny"].pinned and wb.assemblers["tiny"].window_bytes == clip_bytes
+    wb.close()
+    clf.close()
+
+
+@pytest.mark.gpu
+def test_native_windows_feed_the_host_pipeline_in_place(tiny_cfg, tiny_blob):
+    """140 sources ready in one tick: the call is large enough for the chunked host pipeline (>= 128 clips), which detects that
+    the library's batch buffer is page-locked and lets the copy engines read the windows where they were assembled
+    (csrc/hostpipe.cpp is_pinned).  Same logits, bit for bit, as the same windows passed from pageable memory."""
+    from birdnet_go_amd import host
+    clf = host.HipClassifier(tiny_blob, device=0, max_batch=256)
+    clip_bytes = tiny_cfg.n_samples * 2
+    overlap, read = clip_bytes // 2, clip_bytes - clip_bytes // 2
+    w = S.NativeWindows(overlap, read, max_batch=256)
+    assert w.pinned
+    rng = np.random.default_rng(3)
+    n_src = 140
+    pcm = (rng.normal(0, 0.2, (n_src, 2 * read // 2)).clip(-1, 1) * 32767).astype("<i2")
+    for k in range(n_src):
+        assert w.add_source(f"mic{k}", 2 * clip_bytes) == k
+        w.write(k, pcm[k])                                    # two reads' worth: two windows per source
+    for rnd in range(2):
+        idxs, rows = w.collect()
+        assert idxs == list(range(n_src))
+        got = clf.predict_pcm(rows.reshape(-1), 16, n_src)                 # the library's buffer, in place
+        want = clf.predict_pcm(rows.copy().reshape(-1), 16, n_src)         # pageable copy of the same bytes
+        assert np.array_equal(got, want)
+        b = pcm.view(np.uint8).reshape(n_src, -1)
+        prefix = np.zeros((n_src, overlap), np.uint8) if rnd == 0 else b[:, read - overlap:read]
+        assert np.array_equal(rows, np.concatenate([prefix, b[:, rnd * read:(rnd + 1) * read]], axis=1))
+    assert w.collect()[0] == []
+    w.close()
     clf.close()
