@@ -811,22 +811,39 @@ int bnhip_postprocess_topk(bnhip_model* m, const float* logits, int n_clips, int
     BN_GUARD_END((void)0)
 }
 
-int bnhip_predict_topk(bnhip_model* m, const float* samples, int n_clips, int activation, double sensitivity, int k,
-                       float* out_conf, int32_t* out_idx) {
-    if (!m || !samples || !out_conf || !out_idx) return set_err(BNHIP_E_INVALID, "NULL argument");
-    BN_GUARD_BEGIN
+// pcm_bits as in predict_host
+static int predict_topk_host(bnhip_model* m, const void* src, int pcm_bits, int n_clips, int activation, double sensitivity, int k,
+                             float* out_conf, int32_t* out_idx) {
+    if (!m || !src || !out_conf || !out_idx) return set_err(BNHIP_E_INVALID, "NULL argument");
     Engine& e = m->eng();
     if (n_clips <= 0 || k <= 0) return set_err(BNHIP_E_INVALID, "n_clips and k must be positive");
     if (activation < 0 || activation > 2) return set_err(BNHIP_E_INVALID, "unknown activation");
     if ((size_t)e.n_classes * 4 > 150 * 1024) return set_err(BNHIP_E_UNSUPPORTED, "too many classes for the LDS top-k");
     if (e.device < 0) return set_err(BNHIP_E_INVALID, "plan-only model cannot run");
-    const int kk = std::min(k, e.n_classes), ns = e.n_samples;
+    const int kk = std::min(k, e.n_classes);
+    const size_t in_stride = (size_t)e.n_samples * (pcm_bits ? (size_t)pcm_bits / 8 : 4);
     return shard_run(m, n_clips, [=](Engine& en, int off, int cnt, std::string& err) {
         HostJob j;
-        j.src = samples + (size_t)off * ns; j.n_clips = cnt; j.topk = k; j.activation = activation; j.sensitivity = sensitivity;
+        j.src = (const char*)src + (size_t)off * in_stride; j.pcm_bits = pcm_bits; j.n_clips = cnt;
+        j.topk = k; j.activation = activation; j.sensitivity = sensitivity;
         j.out_conf = out_conf + (size_t)off * kk; j.out_idx = out_idx + (size_t)off * kk;
         return host_run(en, j, err);
     });
+}
+
+int bnhip_predict_topk(bnhip_model* m, const float* samples, int n_clips, int activation, double sensitivity, int k,
+                       float* out_conf, int32_t* out_idx) {
+    BN_GUARD_BEGIN
+    return predict_topk_host(m, samples, 0, n_clips, activation, sensitivity, k, out_conf, out_idx);
+    BN_GUARD_END((void)0)
+}
+
+int bnhip_predict_pcm_topk(bnhip_model* m, const void* pcm, int bits_per_sample, int n_clips, int activation, double sensitivity,
+                           int k, float* out_conf, int32_t* out_idx) {
+    BN_GUARD_BEGIN
+    if (bits_per_sample != 16 && bits_per_sample != 24 && bits_per_sample != 32)
+        return set_err(BNHIP_E_INVALID, "unsupported bit depth: " + std::to_string(bits_per_sample) + " (supported: 16, 24, 32)");
+    return predict_topk_host(m, pcm, bits_per_sample, n_clips, activation, sensitivity, k, out_conf, out_idx);
     BN_GUARD_END((void)0)
 }
 

@@ -43,6 +43,7 @@ typedef int  (*fn_rs_flush_pcm16)(bnhip_resampler*, int16_t*, int, int*);
 typedef void (*fn_rs_destroy)(bnhip_resampler*);
 typedef int  (*fn_host_alloc)(size_t, void**);
 typedef int  (*fn_host_free)(void*);
+typedef int  (*fn_predict_pcm_topk)(bnhip_model*, const void*, int, int, int, double, int, float*, int32_t*);
 typedef struct bnhip_windows bnhip_windows;
 typedef int  (*fn_win_create)(size_t, size_t, int, bnhip_windows**);
 typedef int  (*fn_win_info)(const bnhip_windows*, size_t*, int*, int*, int*);
@@ -64,6 +65,7 @@ typedef struct {
     fn_host_alloc host_alloc; fn_host_free host_free;
     fn_win_create win_create; fn_win_info win_info; fn_win_add_source win_add_source; fn_win_remove_source win_remove_source;
     fn_win_write win_write; fn_win_collect win_collect; fn_win_stats win_stats; fn_win_reset win_reset; fn_win_destroy win_destroy;
+    fn_predict_pcm_topk predict_pcm_topk;
 } bnbind_t;
 static bnbind_t BN;
 static char bnbind_errbuf[256];
@@ -97,6 +99,7 @@ static const char* bnbind_load(const char* path) {
     BN_RESOLVE(win_write, "bnhip_windows_write"); BN_RESOLVE(win_collect, "bnhip_windows_collect");
     BN_RESOLVE(win_stats, "bnhip_windows_stats"); BN_RESOLVE(win_reset, "bnhip_windows_reset");
     BN_RESOLVE(win_destroy, "bnhip_windows_destroy");
+    BN_RESOLVE(predict_pcm_topk, "bnhip_predict_pcm_topk");
     return NULL;
 }
 static void bnbind_unload(void) {
@@ -136,6 +139,9 @@ static int bnbind_win_collect(bnhip_windows* w, int cap, int* src, int* n, const
 static int bnbind_win_stats(const bnhip_windows* w, int s, uint64_t* wr, uint64_t* ov, size_t* buffered) { return BN.win_stats(w, s, wr, ov, buffered); }
 static int bnbind_win_reset(bnhip_windows* w, int s) { return BN.win_reset(w, s); }
 static void bnbind_win_destroy(bnhip_windows* w) { if (BN.win_destroy) BN.win_destroy(w); }
+static int bnbind_predict_pcm_topk(bnhip_model* m, const void* pcm, int bits, int n, int act, double sens, int k, float* c, int32_t* i) {
+    return BN.predict_pcm_topk(m, pcm, bits, n, act, sens, k, c, i);
+}
 */
 import "C"
 
@@ -613,6 +619,38 @@ func (c *Classifier) PredictWindows(w *WindowAssembler) (sources []int, windows 
 		return nil, nil, nil, fmt.Errorf("hip: predict_pcm16 failed (%d): %s", int(rc), lastError())
 	}
 	return sources, windows, logits, nil
+}
+
+// PredictWindowsTopK is PredictWindows with (*BirdNET).Predict's post-processing on the device as well: per ready window the
+// k best confidences float32(1/(1+exp(-sensitivity*float64(x)))) and their label indices, descending (analyze.go:113-115,
+// 197-208, 220-301) - the logits never reach the host.  conf / idx are flat [len(sources)*min(k, nClasses)].
+func (c *Classifier) PredictWindowsTopK(w *WindowAssembler, k int, sensitivity float64) (sources []int, windows []byte, conf []float32, idx []int32, err error) {
+	if c.h == nil {
+		return nil, nil, nil, nil, errors.New("hip: classifier is closed")
+	}
+	if w.windowBytes != c.nSamples*2 {
+		return nil, nil, nil, nil, fmt.Errorf("window size mismatch: assembler %d bytes, model clip %d bytes", w.windowBytes, c.nSamples*2)
+	}
+	if k <= 0 {
+		return nil, nil, nil, nil, errors.New("hip: k must be positive")
+	}
+	sources, windows, err = w.Collect()
+	if err != nil || len(sources) == 0 {
+		return nil, nil, nil, nil, err
+	}
+	kk := k
+	if kk > c.nClasses {
+		kk = c.nClasses
+	}
+	conf = make([]float32, len(sources)*kk)
+	idx = make([]int32, len(sources)*kk)
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	if rc := C.bnbind_predict_pcm_topk(c.h, unsafe.Pointer(&windows[0]), 16, C.int(len(sources)), 0, C.double(sensitivity), C.int(k),
+		(*C.float)(unsafe.Pointer(&conf[0])), (*C.int32_t)(unsafe.Pointer(&idx[0]))); rc != 0 {
+		return nil, nil, nil, nil, fmt.Errorf("hip: predict_pcm_topk failed (%d): %s", int(rc), lastError())
+	}
+	return sources, windows, conf, idx, nil
 }
 
 // CustomClassifier implements inference.CustomClassifier (internal/inference/backend.go:31-53) for a dense head file - the

@@ -55,6 +55,10 @@ func (*Classifier) PredictWindows(*WindowAssembler) ([]int, []byte, []float32, e
 	return nil, nil, nil, ErrHIPUnavailable
 }
 
+func (*Classifier) PredictWindowsTopK(*WindowAssembler, int, float64) ([]int, []byte, []float32, []int32, error) {
+	return nil, nil, nil, nil, ErrHIPUnavailable
+}
+
 type CustomClassifier struct{}
 
 func NewCustomClassifier([]byte, []string, ...int) (*CustomClassifier, error) { return nil, ErrHIPUnavailable }

@@ -34,7 +34,7 @@ SYMBOLS = ["bnhip_init", "bnhip_shutdown", "bnhip_model_create", "bnhip_model_in
            "bnhip_resampler_destroy", "bnhip_us_frame_cv_device", "bnhip_profile_steps", "bnhip_profile_steps_read",
            "bnhip_host_alloc", "bnhip_host_free", "bnhip_windows_create", "bnhip_windows_info", "bnhip_windows_add_source",
            "bnhip_windows_remove_source", "bnhip_windows_write", "bnhip_windows_collect", "bnhip_windows_ready",
-           "bnhip_windows_stats", "bnhip_windows_reset", "bnhip_windows_destroy"]
+           "bnhip_windows_stats", "bnhip_windows_reset", "bnhip_windows_destroy", "bnhip_predict_pcm_topk"]
 
 
 class HipError(RuntimeError):
@@ -71,6 +71,8 @@ def load_library(path=None):
                                            C.c_void_p, C.c_void_p]
     lib.bnhip_predict_topk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p,
                                        C.c_void_p]
+    lib.bnhip_predict_pcm_topk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p,
+                                           C.c_void_p]
     lib.bnhip_us_frame_cv.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p]
     lib.bnhip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
@@ -264,6 +266,23 @@ class HipClassifier:
         idx = np.empty((batch_size, kk), np.int32)
         _check(self._lib, self._lib.bnhip_predict_topk(self._h, x.ctypes.data, batch_size, activation, sensitivity, k,
                                                        conf.ctypes.data, idx.ctypes.data))
+        return conf, idx
+
+    def predict_pcm_topk(self, raw, bit_depth, batch_size, k=10, activation=0, sensitivity=1.0):
+        """predict_pcm + postprocess_topk in one call (bnhip_predict_pcm_topk): the windows' PCM bytes in, top-k out; neither the
+        float samples nor the logits exist on the host."""
+        self._alive()
+        if bit_depth not in (16, 24, 32):
+            raise HipError(E_INVALID, f"unsupported bit depth: {bit_depth} (supported: 16, 24, 32)")
+        x = np.frombuffer(raw, np.uint8)
+        if x.size != batch_size * self.n_samples * (bit_depth // 8):
+            raise HipError(E_INVALID, f"input size mismatch: expected {batch_size * self.n_samples} samples of "
+                                      f"{bit_depth // 8} bytes, got {x.size} bytes")
+        kk = min(k, self._n_classes)
+        conf = np.empty((batch_size, kk), np.float32)
+        idx = np.empty((batch_size, kk), np.int32)
+        _check(self._lib, self._lib.bnhip_predict_pcm_topk(self._h, x.ctypes.data, bit_depth, batch_size, activation, sensitivity, k,
+                                                           conf.ctypes.data, idx.ctypes.data))
         return conf, idx
 
     # ---- plumbing
@@ -597,6 +616,5 @@ class BirdNET:
 
     def predict_pcm_batch(self, raw, bit_depth, batch_size):
         """The windows' little-endian PCM bytes as captured (a1 runs in the kernel, process.go:479-497) -> per-window top-10."""
-        logits = self.classifier.predict_pcm(raw, bit_depth, batch_size)
-        conf, idx = self.classifier.postprocess_topk(logits, self.TOP_K, 0, self.sensitivity)
+        conf, idx = self.classifier.predict_pcm_topk(raw, bit_depth, batch_size, self.TOP_K, 0, self.sensitivity)
         return [[(self.labels[i], float(c)) for c, i in zip(cr, ir)] for cr, ir in zip(conf, idx)]

@@ -170,6 +170,13 @@ int bnhip_postprocess_topk(bnhip_model* m, const float* logits, int n_clips, int
 int bnhip_predict_topk(bnhip_model* m, const float* samples, int n_clips, int activation, double sensitivity,
                        int k, float* out_conf, int32_t* out_idx);
 
+/* The same from PCM bytes as captured (bits_per_sample 16 / 24 / 32 as in bnhip_predict_pcm): what (*BirdNET).Predict does for
+ * one analysis window - convert (internal/analysis/process.go:479-497) -> classifier -> sigmoid(sensitivity) -> top-10
+ * (internal/classifier/analyze.go:25-110) - for n_clips windows in one call; with the rows of bnhip_windows_collect as `pcm`
+ * this is one tick of the real-time path.  Neither the float samples nor the logits exist on the host. */
+int bnhip_predict_pcm_topk(bnhip_model* m, const void* pcm, int bits_per_sample, int n_clips, int activation,
+                           double sensitivity, int k, float* out_conf, int32_t* out_idx);
+
 /* Ultrasonic frame-CV filter (internal/audiocore/ultrasonic/filter.go:20-66), float64 throughout.
  * samples: host float64 [n_clips * n] (int16/32768 as float64, convert/pcm.go:108-113).
  * cv/ok: [n_clips]. device: HIP device ordinal. */

@@ -310,6 +310,22 @@ int main(int argc, char** argv) {
             CHECK(bnbind_predict_pcm16(h, (const int16_t*)batch, n, o1, NULL) == 0, "predict_pcm16 (windows): %s", bnbind_last_error());
             CHECK(bnbind_predict_pcm16(h, hand, n, o2, NULL) == 0, "predict_pcm16 (hand): %s", bnbind_last_error());
             CHECK(memcmp(o1, o2, (size_t)n * nc * 4) == 0, "tick %d: logits from the assembler's buffer differ", tick);
+            /* PredictWindowsTopK: the tick's post-processing on the device too - top-1 = argmax of those logits, descending */
+            {
+                const int kk = nc < 10 ? nc : 10;
+                float* tc = malloc((size_t)n * kk * 4); int32_t* ti = malloc((size_t)n * kk * 4);
+                CHECK(bnbind_predict_pcm_topk(h, batch, 16, n, 0, 1.0, 10, tc, ti) == 0, "predict_pcm_topk: %s", bnbind_last_error());
+                CHECK(bnbind_predict_pcm_topk(h, batch, 12, n, 0, 1.0, 10, tc, ti) == -1, "12-bit PCM must be invalid");
+                for (int c = 0; c < n; c++) {
+                    int am = 0;
+                    for (int i = 1; i < nc; i++) if (o1[(size_t)c * nc + i] > o1[(size_t)c * nc + am]) am = i;
+                    CHECK(ti[c * kk] == am, "window %d: top-1 %d != argmax %d", c, ti[c * kk], am);
+                    const double want = 1.0 / (1.0 + exp(-(double)o1[(size_t)c * nc + am]));
+                    CHECK(fabs((double)tc[c * kk] - want) < 1e-6, "window %d: confidence %g vs %g", c, tc[c * kk], want);
+                    for (int j = 1; j < kk; j++) CHECK(tc[c * kk + j] <= tc[c * kk + j - 1], "confidences not descending");
+                }
+                free(tc); free(ti);
+            }
         }
         int n = -1; const void* batch = NULL;
         CHECK(bnbind_win_collect(w, n_clips, srcs, &n, &batch) == 0 && n == 0, "nothing left: try again later");

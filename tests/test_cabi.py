@@ -114,7 +114,7 @@ def test_go_shim_pins_the_os_thread_around_error_fetch():
     for fn in ("func Init(", "func NewClassifierWithOptions(", "func (c *Classifier) predict(", "func (c *Classifier) PredictBatch(",
                "func (c *Classifier) predictTopK(", "func (c *Classifier) PredictPCM16(", "func ComputeUSFrameCV(", "func NewResampler(",
                "func (r *Resampler) ResampleTo(", "func (r *Resampler) Flush(", "func NewWindowAssembler(", "func (w *WindowAssembler) AddSource(",
-               "func (w *WindowAssembler) Write(", "func (w *WindowAssembler) Collect(", "func (c *Classifier) PredictWindows("):
+               "func (w *WindowAssembler) Write(", "func (w *WindowAssembler) Collect(", "func (c *Classifier) PredictWindows(", "func (c *Classifier) PredictWindowsTopK("):
         body = src[src.index(fn):]
         body = body[:body.index("\n}\n")]
         assert "runtime.LockOSThread()" in body and "defer runtime.UnlockOSThread()" in body, fn
@@ -167,6 +167,8 @@ def test_go_shim_implements_every_backend_interface():
         assert f"func (w *WindowAssembler) {m}" in src and f"func (*WindowAssembler) {m}" in stub, m
     assert "func (c *Classifier) PredictWindows(w *WindowAssembler) (sources []int, windows []byte, logits []float32, err error)" in src
     assert "func (*Classifier) PredictWindows(*WindowAssembler) ([]int, []byte, []float32, error)" in stub
+    assert "func (c *Classifier) PredictWindowsTopK(w *WindowAssembler, k int, sensitivity float64)" in src
+    assert "func (*Classifier) PredictWindowsTopK(*WindowAssembler, int, float64) ([]int, []byte, []float32, []int32, error)" in stub
 
 
 @pytest.mark.gpu

@@ -427,6 +427,27 @@ def test_pcm24_pcm32_paths_match_float_path(full_clf):
         full_clf.predict_pcm(bytes(2 * 144000), 8, 2)
 
 
+def test_pcm_topk_in_one_call_equals_the_two_step_path(full_clf):
+    """bnhip_predict_pcm_topk (one analysis window's whole (*BirdNET).Predict: convert -> classifier -> sigmoid(sensitivity) ->
+    top-10, analyze.go:25-110) == bnhip_predict_pcm followed by bnhip_postprocess_topk, bit for bit, at every bit depth and for
+    the softmax / plain-sigmoid activations; an unsupported depth is rejected."""
+    x = sm.synth_clips(3, 144000, 48000, first=3)
+    i16 = np.clip(np.round(x * 32767), -32768, 32767).astype("<i2")
+    i32 = np.clip(np.round(x.astype(np.float64) * 2147483647), -2147483648, 2147483647).astype("<i4")
+    i24 = (i32 >> 8).astype("<i4").view(np.uint8).reshape(-1, 4)[:, :3].tobytes()
+    for raw, bits in ((i16.tobytes(), 16), (i24, 24), (i32.tobytes(), 32)):
+        logits = full_clf.predict_pcm(raw, bits, 3)
+        for act, sens in ((0, 1.0), (0, 1.35), (1, 1.0), (2, 1.0)):
+            conf, idx = full_clf.predict_pcm_topk(raw, bits, 3, 10, act, sens)
+            c2, i2 = full_clf.postprocess_topk(logits, 10, act, sens)
+            assert np.array_equal(conf, c2) and np.array_equal(idx, i2), (bits, act, sens)
+            assert (idx[:, 0] == logits.argmax(1)).all() and (np.diff(conf, axis=1) <= 0).all()
+    with pytest.raises(host.HipError, match="unsupported bit depth"):
+        full_clf.predict_pcm_topk(bytes(3 * 144000), 8, 3)
+    with pytest.raises(host.HipError, match="size mismatch"):
+        full_clf.predict_pcm_topk(bytes(10), 16, 3)
+
+
 def test_banded_mel_matches_gemm_mel(built_lib, full_blob):
     """The fused banded mel + pow + store kernel against the dense mel GEMM + finish pair it replaces (same products, other
     summation order), and both against the oracle."""
