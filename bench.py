@@ -275,9 +275,40 @@ def host_pointer_rates(clf, x, reps_small=100, reps_mid=12, reps_big=5):
         dt = t(lambda: clf.predict_pcm16(pp.array.reshape(-1), 256, out=po.array), reps_mid)
         res["pcm16_256_pinned"] = {"ms": dt * 1e3, "clips_per_s": 256 / dt}
         res["pinned_bit_identical_to_pageable"] = same
+    # one tick of the real-time window path at 256 sources: every source's capture bytes written into the
+    # library's window assembler (bnhip_windows_write), one collect into its page-locked batch buffer, one bnhip_predict_pcm_topk
+    # over the rows - where the reference runs 256 batch-1 Predict calls behind inferenceMu (orchestrator.go:531)
+    from birdnet_go_amd import stream as _stream
+    clip_b = x.shape[1] * 2
+    ovb, rdb = clip_b // 2, clip_b - clip_b // 2
+    win = _stream.NativeWindows(ovb, rdb, 256)
+    try:
+        ids = [win.add_source(f"src{i}", 2 * clip_b) for i in range(256)]
+        fresh = pcm.view(np.uint8).reshape(256, -1)[:, :rdb]
+        parts = {"write": [], "collect": [], "predict": []}
+
+        def tick():
+            t0 = time.perf_counter()
+            for i in ids:
+                win.write(i, fresh[i])
+            t1 = time.perf_counter()
+            idxs, rows = win.collect()
+            t2 = time.perf_counter()
+            conf, idx = clf.predict_pcm_topk(rows.reshape(-1), 16, len(idxs), 10, 0, 1.0)
+            t3 = time.perf_counter()
+            parts["write"].append(t1 - t0); parts["collect"].append(t2 - t1); parts["predict"].append(t3 - t2)
+            return len(idxs)
+        assert tick() == 256
+        dt = t(tick, reps_mid)
+        med = {k: sorted(v[-reps_mid:])[reps_mid // 2] * 1e3 for k, v in parts.items()}
+        res["realtime_tick_256"] = {"ms": dt * 1e3, "windows_per_s": 256 / dt, "write_ms": med["write"], "collect_ms": med["collect"],
+                                    "predict_pcm_topk_ms": med["predict"], "batch_buffer_pinned": win.pinned}
+    finally:
+        win.close()
     res["note"] = ("blocking C-ABI entries bnhip_predict / bnhip_predict_pcm16, outputs complete on return; calls of >= 128 clips run as chunks "
                    "on two contexts (csrc/hostpipe.cpp): pageable caller memory is staged through the library's pinned slots by copy threads, "
-                   "`_pinned` legs pass bnhip_host_alloc memory, which the copy engines read and write directly; median of the calls")
+                   "`_pinned` legs pass bnhip_host_alloc memory, which the copy engines read and write directly; median of the calls; "
+                   "realtime_tick_256: 256 sources through bnhip_windows_write / _collect and one bnhip_predict_pcm_topk over the assembler's rows")
     return res
 
 

@@ -2,7 +2,12 @@
 #include "windows.h"
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <thread>
 
 namespace bnhip {
 
@@ -86,6 +91,73 @@ bool WindowAssembler::read_window(Source& s, uint8_t* win) {
     return true;
 }
 
+// A window is three copies of half a clip each (tail -> row, ring -> row, row -> tail): 256 windows of BirdNET v2.4 are 110 MB of
+// memcpy, 3.4 ms on one thread - as long as the device needs for the batch.  The rows are independent, so a few helper threads
+// take them (process-wide, started on first use, never joined: a destructor joining threads at dlclose time can deadlock
+// under the loader lock, and a Go host exits without static destructors anyway).  BNHIP_COPY_THREADS as for the host pipeline.
+namespace {
+
+class RowPool {
+  public:
+    RowPool() {
+        int n = 0;
+        if (const char* e = getenv("BNHIP_COPY_THREADS")) n = atoi(e);
+        else n = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 4));
+        n = std::max(0, std::min(n, 64));
+        for (int i = 0; i < n; i++) std::thread([this] { loop(); }).detach();
+    }
+    // fn(i) for i in [0, n): the caller works too; returns when all are done
+    void run(int n, const std::function<void(int)>& fn) {
+        if (n <= 0) return;
+        Job job{&fn, n};
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            jobs_.push_back(&job);
+        }
+        cv_.notify_all();
+        work(job);
+        std::unique_lock<std::mutex> lk(mu_);
+        jobs_.erase(std::find(jobs_.begin(), jobs_.end(), &job));         // no new helper may pick it up ...
+        done_.wait(lk, [&] { return job.active == 0; });                  // ... and the ones inside have left
+    }
+
+  private:
+    struct Job {
+        const std::function<void(int)>* fn;
+        int n;
+        std::atomic<int> next{0};
+        int active = 0;                                      // helpers inside work(); under mu_
+    };
+    static void work(Job& j) {
+        for (int i; (i = j.next.fetch_add(1, std::memory_order_relaxed)) < j.n;) (*j.fn)(i);
+    }
+    void loop() {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            Job* j = nullptr;
+            cv_.wait(lk, [&] {
+                for (Job* c : jobs_) if (c->next.load(std::memory_order_relaxed) < c->n) { j = c; return true; }
+                return false;
+            });
+            j->active++;
+            lk.unlock();
+            work(*j);
+            lk.lock();
+            if (--j->active == 0) done_.notify_all();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    std::vector<Job*> jobs_;
+};
+
+RowPool& row_pool() {
+    static RowPool* p = new RowPool();
+    return *p;
+}
+
+}  // namespace
+
 int WindowAssembler::collect(uint8_t* batch, int cap, int* sources) {
     std::lock_guard<std::mutex> cg(collect_mu_);
     std::shared_lock<std::shared_mutex> lk(table_mu_);
@@ -93,16 +165,29 @@ int WindowAssembler::collect(uint8_t* batch, int cap, int* sources) {
     if (!ns || cap <= 0) return 0;
     cap = std::min(cap, max_batch_);
     const size_t wb = window_bytes();
+    // pass 1: who is ready (only this thread consumes, so a ready source stays ready unless it is reset in between)
     int k = 0;
     size_t i = 0;
     const size_t start = next_ % ns;
     for (; i < ns && k < cap; i++) {
         const size_t idx = (start + i) % ns;
         if (!src_[idx]) continue;
-        if (read_window(*src_[idx], batch + (size_t)k * wb)) sources[k++] = (int)idx;
+        std::lock_guard<std::mutex> g(src_[idx]->mu);
+        if (src_[idx]->n >= read_) sources[k++] = (int)idx;
     }
     next_ = (start + i) % ns;                                // behind the last source looked at
-    return k;
+    // pass 2: row r <- source sources[r]
+    std::vector<char> ok((size_t)k, 1);
+    auto fill = [&](int r) { ok[r] = read_window(*src_[sources[r]], batch + (size_t)r * wb) ? 1 : 0; };
+    if ((size_t)k * wb >= ((size_t)4 << 20) && k > 1) row_pool().run(k, fill);
+    else for (int r = 0; r < k; r++) fill(r);
+    int out = 0;                                             // (a source reset between the passes: close the gap)
+    for (int r = 0; r < k; r++) {
+        if (!ok[r]) continue;
+        if (out != r) { std::memmove(batch + (size_t)out * wb, batch + (size_t)r * wb, wb); sources[out] = sources[r]; }
+        out++;
+    }
+    return out;
 }
 
 int WindowAssembler::ready() const {

@@ -17,7 +17,9 @@ if __name__ == "__main__":
     res = host_pointer_rates(clf, x, reps_small=200, reps_mid=20, reps_big=8)
     for k, v in res.items():
         if isinstance(v, dict):
-            print(f"{k:12s} {v['ms']:9.3f} ms  {v['clips_per_s']:9.0f} clips/s")
+            rate = v.get("clips_per_s", v.get("windows_per_s", 0.0))
+            extra = "  ".join(f"{kk} {vv:.3f}" for kk, vv in v.items() if kk.endswith("_ms"))
+            print(f"{k:18s} {v['ms']:9.3f} ms  {rate:9.0f} /s  {extra}")
     if "--json" in sys.argv:
         with open(sys.argv[sys.argv.index("--json") + 1], "w") as fh:
             json.dump(res, fh, indent=1)
