@@ -847,6 +847,60 @@ int bnhip_predict_pcm_topk(bnhip_model* m, const void* pcm, int bits_per_sample,
     BN_GUARD_END((void)0)
 }
 
+// One tick: who is ready -> rows filled chunk by chunk under the device's work on the previous chunks -> top-k.
+int bnhip_windows_predict_topk(bnhip_windows* w, bnhip_model* m, int bits_per_sample, int activation, double sensitivity, int k,
+                               int* sources, int* n_windows, float* out_conf, int32_t* out_idx, const void** batch) {
+    if (!w || !m || !sources || !n_windows || !out_conf || !out_idx) return set_err(BNHIP_E_INVALID, "NULL argument");
+    *n_windows = 0;
+    if (batch) *batch = w->batch;
+    if (bits_per_sample != 16 && bits_per_sample != 24 && bits_per_sample != 32)
+        return set_err(BNHIP_E_INVALID, "unsupported bit depth: " + std::to_string(bits_per_sample) + " (supported: 16, 24, 32)");
+    if (k <= 0) return set_err(BNHIP_E_INVALID, "n_clips and k must be positive");
+    if (activation < 0 || activation > 2) return set_err(BNHIP_E_INVALID, "unknown activation");
+    bool begun = false;
+    BN_GUARD_BEGIN
+    Engine& e = m->eng();
+    if (e.device < 0) return set_err(BNHIP_E_INVALID, "plan-only model cannot run");
+    if ((size_t)e.n_classes * 4 > 150 * 1024) return set_err(BNHIP_E_UNSUPPORTED, "too many classes for the LDS top-k");
+    const size_t clip_bytes = (size_t)e.n_samples * (size_t)(bits_per_sample / 8);
+    if (w->a->window_bytes() != clip_bytes)
+        return set_err(BNHIP_E_INVALID, "window size mismatch: assembler " + std::to_string(w->a->window_bytes()) + " bytes, model clip " +
+                                        std::to_string(clip_bytes) + " bytes");
+    bnhip::WindowAssembler& a = *w->a;
+    const int n = a.collect_begin(a.max_batch(), sources);
+    begun = true;
+    if (n == 0) { a.collect_end(); return BNHIP_OK; }       // "try again later"
+    // every listed source gives up exactly one read, whatever happens to the device call: ranges the pipeline did not get to
+    // (an error on the way) are consumed afterwards, as the reference's monitor has consumed its window before ProcessData fails
+    std::vector<char> filled((size_t)n, 0);
+    uint8_t* rows = w->batch;
+    auto fill = [&a, &filled, rows, sources](int first, int cnt) {
+        a.collect_rows(rows, sources, first, cnt);
+        for (int r = first; r < first + cnt; r++) filled[(size_t)r] = 1;
+    };
+    const int kk = std::min(k, e.n_classes);
+    int rc = shard_run(m, n, [=](Engine& en, int off, int cnt, std::string& err) {
+        HostJob j;
+        j.src = rows + (size_t)off * clip_bytes; j.pcm_bits = bits_per_sample; j.n_clips = cnt;
+        j.topk = k; j.activation = activation; j.sensitivity = sensitivity;
+        j.out_conf = out_conf + (size_t)off * kk; j.out_idx = out_idx + (size_t)off * kk;
+        j.prepare = [=](int first, int c) { fill(off + first, c); };
+        return host_run(en, j, err);
+    });
+    for (int r = 0; r < n;) {
+        if (filled[(size_t)r]) { r++; continue; }
+        int q = r;
+        while (q < n && !filled[(size_t)q]) q++;
+        fill(r, q - r);
+        r = q;
+    }
+    a.collect_end();
+    begun = false;
+    *n_windows = n;
+    return rc;
+    BN_GUARD_END(if (begun) w->a->collect_end())
+}
+
 int bnhip_us_frame_cv(int device, const double* samples, int n_clips, int n, int sample_rate, int fft_size, int hop,
                       int split_hz, double* cv, int32_t* ok) {
     if (!samples || !cv || !ok || n_clips <= 0) return set_err(BNHIP_E_INVALID, "NULL/empty argument");

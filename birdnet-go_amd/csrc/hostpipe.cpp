@@ -261,6 +261,7 @@ int small_run(Engine& e, const HostJob& j, std::string& err) {
         const int n = std::min(e.max_batch, j.n_clips - off);
         const size_t cnt = (size_t)n * e.n_samples;
         const char* src = (const char*)j.src + (size_t)off * e.n_samples * bps;
+        if (j.prepare) j.prepare(off, n);
         if (j.pcm_bits) {
             HP_TRY(hipMemcpyAsync(e.d_stage_pcm, src, cnt * bps, hipMemcpyHostToDevice, e.stream), "H2D copy");
             launch_pcm_to_f32(e.d_stage_pcm, j.pcm_bits, e.d_stage_in, cnt, e.stream);
@@ -382,6 +383,7 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
         hipError_t he = finish(s);                       // the slot's previous chunk (c - K) must have left it
         if (he != hipSuccess) return he;
         s.chunk = c;
+        if (j.prepare) j.prepare(cfirst[c], chunk_n(c));   // (the producer's own threads; returns with the clips in place)
         if (!src_pinned) pool().submit(s.h_in, (const char*)j.src + (size_t)cfirst[c] * clip_bytes, (size_t)chunk_n(c) * clip_bytes, &s.fill);
         return hipSuccess;
     };

@@ -9,6 +9,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <string>
 
 namespace bnhip {
@@ -26,6 +27,10 @@ struct HostJob {
     double sensitivity = 1.0;
     float* out_conf = nullptr;
     int32_t* out_idx = nullptr;
+    // Optional producer of the input: when set, clips [first, first + n) of `src` do not exist until prepare(first, n) has
+    // returned.  The pipeline calls it once per chunk, in order, where it would otherwise start staging that chunk - i.e. while
+    // the previous chunks are on the device (bnhip_windows_predict_topk: the window assembler fills the rows then).
+    std::function<void(int first, int n)> prepare;
 };
 
 // Runs the job on one engine (one shard of a multi-device call).  Returns a BNHIP_* code; err carries the message.

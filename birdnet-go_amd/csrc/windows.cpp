@@ -158,14 +158,13 @@ RowPool& row_pool() {
 
 }  // namespace
 
-int WindowAssembler::collect(uint8_t* batch, int cap, int* sources) {
-    std::lock_guard<std::mutex> cg(collect_mu_);
-    std::shared_lock<std::shared_mutex> lk(table_mu_);
+int WindowAssembler::collect_begin(int cap, int* sources) {
+    collect_mu_.lock();
+    table_mu_.lock_shared();
     const size_t ns = src_.size();
     if (!ns || cap <= 0) return 0;
     cap = std::min(cap, max_batch_);
-    const size_t wb = window_bytes();
-    // pass 1: who is ready (only this thread consumes, so a ready source stays ready unless it is reset in between)
+    // who is ready (only the collecting thread consumes, so a ready source stays ready unless it is reset in between)
     int k = 0;
     size_t i = 0;
     const size_t start = next_ % ns;
@@ -176,17 +175,36 @@ int WindowAssembler::collect(uint8_t* batch, int cap, int* sources) {
         if (src_[idx]->n >= read_) sources[k++] = (int)idx;
     }
     next_ = (start + i) % ns;                                // behind the last source looked at
-    // pass 2: row r <- source sources[r]
-    std::vector<char> ok((size_t)k, 1);
-    auto fill = [&](int r) { ok[r] = read_window(*src_[sources[r]], batch + (size_t)r * wb) ? 1 : 0; };
-    if ((size_t)k * wb >= ((size_t)4 << 20) && k > 1) row_pool().run(k, fill);
-    else for (int r = 0; r < k; r++) fill(r);
+    return k;
+}
+
+void WindowAssembler::collect_rows(uint8_t* batch, int* sources, int first, int n) {
+    const size_t wb = window_bytes();
+    auto fill = [&](int q) {
+        const int r = first + q;
+        uint8_t* row = batch + (size_t)r * wb;
+        if (sources[r] < 0 || !read_window(*src_[sources[r]], row)) { std::memset(row, 0, wb); sources[r] = -1; }
+    };
+    if ((size_t)n * wb >= ((size_t)4 << 20) && n > 1) row_pool().run(n, fill);
+    else for (int q = 0; q < n; q++) fill(q);
+}
+
+void WindowAssembler::collect_end() {
+    table_mu_.unlock_shared();
+    collect_mu_.unlock();
+}
+
+int WindowAssembler::collect(uint8_t* batch, int cap, int* sources) {
+    const int k = collect_begin(cap, sources);
+    collect_rows(batch, sources, 0, k);
+    const size_t wb = window_bytes();
     int out = 0;                                             // (a source reset between the passes: close the gap)
     for (int r = 0; r < k; r++) {
-        if (!ok[r]) continue;
+        if (sources[r] < 0) continue;
         if (out != r) { std::memmove(batch + (size_t)out * wb, batch + (size_t)r * wb, wb); sources[out] = sources[r]; }
         out++;
     }
+    collect_end();
     return out;
 }
 

@@ -39,6 +39,13 @@ class WindowAssembler {
     // Every source with at least read_bytes buffered, starting behind the last source served (a tick that hits `cap` does not
     // starve the sources at the end of the table): window k goes to batch + k * window_bytes(), its source index to sources[k].
     int collect(uint8_t* batch, int cap, int* sources);
+    // The same in steps, for a consumer that overlaps the copies with something else (api.cpp bnhip_windows_predict_topk: the
+    // host pipeline fills chunk c + 1's rows while chunk c is on the device).  begin: who is ready (row r <- sources[r]); holds
+    // the collect and table locks until end, which the same thread must call.  rows: fills rows [first, first + n) - callable
+    // from several threads on disjoint ranges; a source that was reset since begin yields a row of zeros and sources[r] = -1.
+    int collect_begin(int cap, int* sources);
+    void collect_rows(uint8_t* batch, int* sources, int first, int n);
+    void collect_end();
     int ready() const;
     bool stats(int source, uint64_t* writes, uint64_t* overwrites, size_t* buffered) const;
     bool reset(int source);                                  // analysis.go:270-276

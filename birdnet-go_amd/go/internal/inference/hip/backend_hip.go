@@ -54,6 +54,7 @@ typedef int  (*fn_win_collect)(bnhip_windows*, int, int*, int*, const void**);
 typedef int  (*fn_win_stats)(const bnhip_windows*, int, uint64_t*, uint64_t*, size_t*);
 typedef int  (*fn_win_reset)(bnhip_windows*, int);
 typedef void (*fn_win_destroy)(bnhip_windows*);
+typedef int  (*fn_win_predict_topk)(bnhip_windows*, bnhip_model*, int, int, double, int, int*, int*, float*, int32_t*, const void**);
 
 typedef struct {
     void* handle;
@@ -65,7 +66,7 @@ typedef struct {
     fn_host_alloc host_alloc; fn_host_free host_free;
     fn_win_create win_create; fn_win_info win_info; fn_win_add_source win_add_source; fn_win_remove_source win_remove_source;
     fn_win_write win_write; fn_win_collect win_collect; fn_win_stats win_stats; fn_win_reset win_reset; fn_win_destroy win_destroy;
-    fn_predict_pcm_topk predict_pcm_topk;
+    fn_predict_pcm_topk predict_pcm_topk; fn_win_predict_topk win_predict_topk;
 } bnbind_t;
 static bnbind_t BN;
 static char bnbind_errbuf[256];
@@ -99,13 +100,17 @@ static const char* bnbind_load(const char* path) {
     BN_RESOLVE(win_write, "bnhip_windows_write"); BN_RESOLVE(win_collect, "bnhip_windows_collect");
     BN_RESOLVE(win_stats, "bnhip_windows_stats"); BN_RESOLVE(win_reset, "bnhip_windows_reset");
     BN_RESOLVE(win_destroy, "bnhip_windows_destroy");
-    BN_RESOLVE(predict_pcm_topk, "bnhip_predict_pcm_topk");
+    BN_RESOLVE(predict_pcm_topk, "bnhip_predict_pcm_topk"); BN_RESOLVE(win_predict_topk, "bnhip_windows_predict_topk");
     return NULL;
 }
 static void bnbind_unload(void) {
     if (BN.shutdown) BN.shutdown();
     if (BN.handle) dlclose(BN.handle);
     memset(&BN, 0, sizeof BN);
+}
+static int bnbind_win_predict_topk(bnhip_windows* w, bnhip_model* m, int bits, int act, double sens, int k, int* src, int* n,
+                                   float* c, int32_t* i, const void** batch) {
+    return BN.win_predict_topk(w, m, bits, act, sens, k, src, n, c, i, batch);
 }
 // fixed-arity wrappers (cgo cannot call function pointers directly)
 static int bnbind_init(int* n) { return BN.init(n); }
@@ -628,29 +633,36 @@ func (c *Classifier) PredictWindowsTopK(w *WindowAssembler, k int, sensitivity f
 	if c.h == nil {
 		return nil, nil, nil, nil, errors.New("hip: classifier is closed")
 	}
-	if w.windowBytes != c.nSamples*2 {
-		return nil, nil, nil, nil, fmt.Errorf("window size mismatch: assembler %d bytes, model clip %d bytes", w.windowBytes, c.nSamples*2)
+	if w.h == nil {
+		return nil, nil, nil, nil, errors.New("hip: window assembler is closed")
 	}
 	if k <= 0 {
 		return nil, nil, nil, nil, errors.New("hip: k must be positive")
-	}
-	sources, windows, err = w.Collect()
-	if err != nil || len(sources) == 0 {
-		return nil, nil, nil, nil, err
 	}
 	kk := k
 	if kk > c.nClasses {
 		kk = c.nClasses
 	}
-	conf = make([]float32, len(sources)*kk)
-	idx = make([]int32, len(sources)*kk)
+	// one call: readiness pass, then the rows of chunk i+1 are assembled while chunk i is on the device
+	cbuf := make([]float32, w.maxBatch*kk)
+	ibuf := make([]int32, w.maxBatch*kk)
 	runtime.LockOSThread()
 	defer runtime.UnlockOSThread()
-	if rc := C.bnbind_predict_pcm_topk(c.h, unsafe.Pointer(&windows[0]), 16, C.int(len(sources)), 0, C.double(sensitivity), C.int(k),
-		(*C.float)(unsafe.Pointer(&conf[0])), (*C.int32_t)(unsafe.Pointer(&idx[0]))); rc != 0 {
-		return nil, nil, nil, nil, fmt.Errorf("hip: predict_pcm_topk failed (%d): %s", int(rc), lastError())
+	var n C.int
+	var batch unsafe.Pointer
+	if rc := C.bnbind_win_predict_topk(w.h, c.h, 16, 0, C.double(sensitivity), C.int(k), &w.sources[0], &n,
+		(*C.float)(unsafe.Pointer(&cbuf[0])), (*C.int32_t)(unsafe.Pointer(&ibuf[0])), &batch); rc != 0 {
+		// (the n listed sources have given up their window all the same, buffer_manager.go:494-499)
+		return nil, nil, nil, nil, fmt.Errorf("hip: windows_predict_topk failed (%d): %s", int(rc), lastError())
 	}
-	return sources, windows, conf, idx, nil
+	if n == 0 {
+		return nil, nil, nil, nil, nil
+	}
+	sources = make([]int, int(n))
+	for i := range sources {
+		sources[i] = int(w.sources[i]) // -1: the source was reset under the tick, skip the row
+	}
+	return sources, unsafe.Slice((*byte)(batch), int(n)*w.windowBytes), cbuf[:int(n)*kk], ibuf[:int(n)*kk], nil
 }
 
 // CustomClassifier implements inference.CustomClassifier (internal/inference/backend.go:31-53) for a dense head file - the

@@ -34,7 +34,8 @@ SYMBOLS = ["bnhip_init", "bnhip_shutdown", "bnhip_model_create", "bnhip_model_in
            "bnhip_resampler_destroy", "bnhip_us_frame_cv_device", "bnhip_profile_steps", "bnhip_profile_steps_read",
            "bnhip_host_alloc", "bnhip_host_free", "bnhip_windows_create", "bnhip_windows_info", "bnhip_windows_add_source",
            "bnhip_windows_remove_source", "bnhip_windows_write", "bnhip_windows_collect", "bnhip_windows_ready",
-           "bnhip_windows_stats", "bnhip_windows_reset", "bnhip_windows_destroy", "bnhip_predict_pcm_topk"]
+           "bnhip_windows_stats", "bnhip_windows_reset", "bnhip_windows_destroy", "bnhip_predict_pcm_topk",
+           "bnhip_windows_predict_topk"]
 
 
 class HipError(RuntimeError):
@@ -613,6 +614,13 @@ class BirdNET:
     def predict_batch(self, flat, batch_size):
         conf, idx = self.classifier.predict_topk(flat, batch_size, self.TOP_K, 0, self.sensitivity)
         return [[(self.labels[i], float(c)) for c, i in zip(cr, ir)] for cr, ir in zip(conf, idx)]
+
+    def predict_windows(self, win, bit_depth=16):
+        """One tick for this model: every ready window of the assembler `win` (stream.NativeWindows) through one device call, the
+        rows assembled under the device's work on the previous chunk (bnhip_windows_predict_topk).
+        -> (source indices, uint8 rows view, per-window top-10 lists); a source index of -1 marks a row to skip."""
+        idxs, rows, conf, idx = win.predict_topk(self.classifier, bit_depth, self.TOP_K, 0, self.sensitivity)
+        return idxs, rows, [[(self.labels[i], float(c)) for c, i in zip(cr, ir)] for cr, ir in zip(conf, idx)]
 
     def predict_pcm_batch(self, raw, bit_depth, batch_size):
         """The windows' little-endian PCM bytes as captured (a1 runs in the kernel, process.go:479-497) -> per-window top-10."""

@@ -244,6 +244,8 @@ class NativeWindows:
             lib.bnhip_windows_stats.argtypes = [vp, ci, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(sz)]
             lib.bnhip_windows_reset.argtypes = [vp, ci]
             lib.bnhip_windows_destroy.argtypes = [vp]
+            lib.bnhip_windows_predict_topk.argtypes = [vp, vp, ci, ci, C.c_double, ci, C.POINTER(ci), C.POINTER(ci), vp, vp,
+                                                       C.POINTER(vp)]
             lib.bnhip_windows_destroy.restype = None
             NativeWindows._proto_done = True
         if overlap_bytes < 0 or read_bytes < 0:
@@ -288,10 +290,34 @@ class NativeWindows:
         n, p = C.c_int(0), C.c_void_p()
         cap = self.max_batch if cap is None else min(cap, self.max_batch)
         self._check(self._lib.bnhip_windows_collect(self._alive(), cap, self._sources, C.byref(n), C.byref(p)))
+        return list(self._sources[:n.value]), self._view(p)[:n.value]
+
+    def _view(self, p):
         if self._rows is None:
             buf = (C.c_uint8 * (self.max_batch * self.window_bytes)).from_address(p.value)
             self._rows = np.frombuffer(buf, np.uint8).reshape(self.max_batch, self.window_bytes)
-        return list(self._sources[:n.value]), self._rows[:n.value]
+        return self._rows
+
+    def predict_topk(self, clf, bit_depth=16, k=10, activation=0, sensitivity=1.0):
+        """collect + device call in one (bnhip_windows_predict_topk): the rows of chunk c + 1 are assembled while chunk c is on
+        the device.  clf: host.HipClassifier.  -> (source indices, rows view, conf [n, kk], idx [n, kk]); on a device error the
+        exception carries `.sources` - those windows are consumed all the same."""
+        clf._alive()
+        kk = min(k, clf.num_species())
+        if getattr(self, "_tk", None) is None or self._tk[0].shape[1] != kk:
+            self._tk = (np.empty((self.max_batch, kk), np.float32), np.empty((self.max_batch, kk), np.int32))
+        conf, idx = self._tk
+        n, p = C.c_int(0), C.c_void_p()
+        rc = self._lib.bnhip_windows_predict_topk(self._alive(), clf._h, bit_depth, activation, sensitivity, k, self._sources,
+                                                  C.byref(n), conf.ctypes.data, idx.ctypes.data, C.byref(p))
+        srcs = list(self._sources[:n.value])
+        if rc != _host.BNHIP_OK:
+            try:
+                self._check(rc)
+            except Exception as e:
+                e.sources = srcs
+                raise
+        return srcs, self._view(p)[:n.value], conf[:n.value].copy(), idx[:n.value].copy()
 
     def ready(self):
         n = C.c_int(0)
@@ -528,14 +554,20 @@ def process_windows(orch: Orchestrator, windows, start_times, captured_at, sourc
     windows = np.ascontiguousarray(windows, np.uint8)
     if windows.ndim == 1:
         windows = windows[None]
-    n = windows.shape[0]
     t0 = time.perf_counter()
     lists = orch.predict_model(model_id, lambda inst: _pcm_windows_predict(inst, windows, bit_depth))
     elapsed = time.perf_counter() - t0
+    return _emit_results(orch, windows, lists, elapsed, start_times, captured_at, sources, model_id, queue, overruns, threshold)
+
+
+def _emit_results(orch, windows, lists, elapsed, start_times, captured_at, sources, model_id, queue, overruns, threshold=0.0):
+    """ProcessData's tail per window (process.go:327-420): overrun check, PCM copy, enqueue-or-drop.  sources[i] None = skip."""
     spec = orch.model_spec_for(model_id)
     interval = spec.buffer_interval_s() if spec is not None else 1.5       # fallback: BirdNET v2.4 (process.go:353)
     sent = 0
-    for i in range(n):
+    for i in range(windows.shape[0]):
+        if sources[i] is None:
+            continue
         if elapsed > interval:
             overruns.record(sources[i], model_id, elapsed, interval)
         dets = [_results.Detection(lbl, conf) for lbl, conf in lists[i] if conf >= threshold]
@@ -614,23 +646,47 @@ class WindowBatcher:
             wins = list(self.assemblers.items())
             names = {(id(ab.win), ab.index): src for (src, _), ab in self.buffers.items() if isinstance(ab, _NativeSource)}
         sent = 0
+        def name(win, i):
+            return None if i < 0 else names.get((id(win), i), f"source#{i}")
+
+        def one_tick(inst, win):
+            # an instance that can run the whole tick in the library does (rows assembled under the device's work on the
+            # previous chunk); anything else gets the collected rows
+            if hasattr(inst, "predict_windows"):
+                return inst.predict_windows(win, self.bit_depth)
+            idxs, rows = win.collect(self.max_batch)
+            try:
+                return idxs, rows, (_pcm_windows_predict(inst, rows, self.bit_depth) if idxs else [])
+            except Exception as e:
+                e.sources = idxs                              # (consumed all the same)
+                raise
+
         for model_id, win in wins:
             while True:
-                idxs, rows = win.collect(self.max_batch)          # rows: a view of the library's batch buffer
+                spec = self.orch.model_spec_for(model_id)
+                if spec is None or not self.orch.is_model_active(model_id):   # consumed, not analysed (buffer_manager.go:478-481)
+                    idxs, _ = win.collect(self.max_batch)
+                    if len(idxs) < min(self.max_batch, win.max_batch):
+                        break
+                    continue
+                if not win.ready():                               # nothing to do: no inference lock, no invoke counted
+                    break
+                now = self.clock()
+                start = now - (self.pre_capture_s + spec.clip_length_s)
+                t0 = time.perf_counter()
+                try:
+                    idxs, rows, lists = self.orch.predict_model(model_id, lambda inst: one_tick(inst, win))
+                except Exception as e:
+                    lost = [name(win, i) for i in getattr(e, "sources", [])]
+                    self.errors += max(1, len(lost))
+                    if self.on_error:
+                        self.on_error(model_id, lost, e)
+                    break
                 if not idxs:
                     break
-                spec = self.orch.model_spec_for(model_id)
-                if spec is not None and self.orch.is_model_active(model_id):
-                    now = self.clock()
-                    start = now - (self.pre_capture_s + spec.clip_length_s)
-                    sources = [names.get((id(win), i), f"source#{i}") for i in idxs]
-                    try:
-                        sent += process_windows(self.orch, rows, [start] * len(idxs), [now] * len(idxs), sources, model_id,
-                                                self.queue, self.overruns, self.bit_depth)
-                    except Exception as e:
-                        self.errors += len(idxs)
-                        if self.on_error:
-                            self.on_error(model_id, sources, e)
+                sources = [name(win, i) for i in idxs]
+                sent += _emit_results(self.orch, rows, lists, time.perf_counter() - t0, [start] * len(idxs), [now] * len(idxs), sources,
+                                      model_id, self.queue, self.overruns)
                 if len(idxs) < min(self.max_batch, win.max_batch):
                     break
         return sent

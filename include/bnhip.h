@@ -142,6 +142,15 @@ int bnhip_windows_ready(const bnhip_windows* w, int* n_ready);
  * notification policy stay with the host), bytes currently buffered.  Any output may be NULL. */
 int bnhip_windows_stats(const bnhip_windows* w, int source, uint64_t* writes, uint64_t* overwrites, size_t* buffered_bytes);
 int bnhip_windows_reset(bnhip_windows* w, int source);
+/* One tick of the real-time path in one call: bnhip_windows_collect + bnhip_predict_pcm_topk, with the rows of chunk c + 1
+ * assembled while chunk c is on the device (the host pipeline asks for them where it would otherwise stage caller memory).
+ * sources: at least max_batch ints; *n_windows rows were taken (0 = "try again later", nothing is run); out_conf / out_idx:
+ * at least max_batch * min(k, n_classes).  overlap_bytes + read_bytes must equal the model's clip at bits_per_sample.  A source
+ * that was reset between the readiness pass and its row has sources[r] = -1 and a row of zeros: skip it.  On a device error
+ * the listed sources have still given up their window, as the reference's monitor has consumed its window by the time
+ * ProcessData fails (buffer_manager.go:494-499). */
+int bnhip_windows_predict_topk(bnhip_windows* w, bnhip_model* m, int bits_per_sample, int activation, double sensitivity,
+                               int k, int* sources, int* n_windows, float* out_conf, int32_t* out_idx, const void** batch);
 void bnhip_windows_destroy(bnhip_windows* w);
 
 /* Page-locked host buffers for the host-pointer entries above.  The reference's accelerator shim keeps a C-allocated input

@@ -329,6 +329,33 @@ int main(int argc, char** argv) {
         }
         int n = -1; const void* batch = NULL;
         CHECK(bnbind_win_collect(w, n_clips, srcs, &n, &batch) == 0 && n == 0, "nothing left: try again later");
+        /* the whole tick in one call (bnhip_windows_predict_topk): same streams again, top-k == collect + predict_pcm_topk */
+        {
+            const int kk = nc < 10 ? nc : 10;
+            float* ta = malloc((size_t)256 * kk * 4); int32_t* ia = malloc((size_t)256 * kk * 4);
+            float* tb = malloc((size_t)256 * kk * 4); int32_t* ib = malloc((size_t)256 * kk * 4);
+            int* s2 = malloc(256 * sizeof(int));
+            CHECK(bnbind_win_predict_topk(w, h, 16, 0, 1.0, 10, s2, &n, ta, ia, &batch) == 0 && n == 0, "tick with nothing ready: rc/n %d", n);
+            CHECK(bnbind_win_predict_topk(w, h, 24, 0, 1.0, 10, s2, &n, ta, ia, &batch) == -1, "a bit depth that does not match the window size must be invalid");
+            for (int c = 0; c < n_clips; c++) {
+                CHECK(bnbind_win_reset(w, c) == 0, "reset");   /* back to the first-window state (zero prefix) */
+                CHECK(bnbind_win_write(w, c, pcm + (size_t)c * ns, clip_b) == 0, "write");
+            }
+            for (int tick = 0; tick < 2; tick++) {
+                CHECK(bnbind_win_predict_topk(w, h, 16, 0, 1.0, 10, s2, &n, ta, ia, &batch) == 0 && n == n_clips, "tick: %s (n %d)", bnbind_last_error(), n);
+                for (int c = 0; c < n_clips; c++) {
+                    CHECK(s2[c] == c, "source order");
+                    unsigned char* hw = (unsigned char*)(hand + (size_t)c * ns);
+                    const unsigned char* p = (const unsigned char*)(pcm + (size_t)c * ns);
+                    if (tick == 0) { memset(hw, 0, ovb); memcpy(hw + ovb, p, rdb); }
+                    else { memcpy(hw, p + rdb - ovb, ovb); memcpy(hw + ovb, p + rdb, rdb); }
+                }
+                CHECK(memcmp(batch, hand, (size_t)n_clips * clip_b) == 0, "tick %d: rows differ from the hand-cut windows", tick);
+                CHECK(bnbind_predict_pcm_topk(h, hand, 16, n_clips, 0, 1.0, 10, tb, ib) == 0, "predict_pcm_topk: %s", bnbind_last_error());
+                CHECK(memcmp(ta, tb, (size_t)n_clips * kk * 4) == 0 && memcmp(ia, ib, (size_t)n_clips * kk * 4) == 0, "tick %d: top-k differs", tick);
+            }
+            free(ta); free(ia); free(tb); free(ib); free(s2);
+        }
         bnbind_win_destroy(w);
         free(pcm); free(srcs); free(hand); free(o1); free(o2);
     }

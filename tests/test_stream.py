@@ -762,5 +762,21 @@ def test_native_windows_feed_the_host_pipeline_in_place(tiny_cfg, tiny_blob):
         prefix = np.zeros((n_src, overlap), np.uint8) if rnd == 0 else b[:, read - overlap:read]
         assert np.array_equal(rows, np.concatenate([prefix, b[:, rnd * read:(rnd + 1) * read]], axis=1))
     assert w.collect()[0] == []
+    # the whole tick in one call: the pipeline asks the assembler for chunk c + 1's rows while chunk c is on the device
+    # (bnhip_windows_predict_topk; 140 windows = three chunks on two contexts).  Same rows, same top-k as the two-step path.
+    for k in range(n_src):
+        w.reset(k)
+        w.write(k, pcm[k])
+    for rnd in range(2):
+        idxs, rows, conf, idx = w.predict_topk(clf, 16, 10, 0, 1.25)
+        assert idxs == list(range(n_src))
+        prefix = np.zeros((n_src, overlap), np.uint8) if rnd == 0 else b[:, read - overlap:read]
+        want_rows = np.concatenate([prefix, b[:, rnd * read:(rnd + 1) * read]], axis=1)
+        assert np.array_equal(rows, want_rows)
+        c2, i2 = clf.predict_pcm_topk(want_rows.reshape(-1), 16, n_src, 10, 0, 1.25)
+        assert np.array_equal(conf, c2) and np.array_equal(idx, i2)
+    assert w.predict_topk(clf)[0] == []
+    with pytest.raises(S.StreamError, match="window size mismatch"):
+        w.predict_topk(clf, 32)
     w.close()
     clf.close()
