@@ -285,30 +285,37 @@ def host_pointer_rates(clf, x, reps_small=100, reps_mid=12, reps_big=5):
     try:
         ids = [win.add_source(f"src{i}", 2 * clip_b) for i in range(256)]
         fresh = pcm.view(np.uint8).reshape(256, -1)[:, :rdb]
-        parts = {"write": [], "collect": [], "predict": []}
+        parts = {"write": [], "collect": [], "predict": [], "one_call": []}
 
-        def tick():
+        def tick(one_call):
             t0 = time.perf_counter()
             for i in ids:
                 win.write(i, fresh[i])
             t1 = time.perf_counter()
-            idxs, rows = win.collect()
-            t2 = time.perf_counter()
-            conf, idx = clf.predict_pcm_topk(rows.reshape(-1), 16, len(idxs), 10, 0, 1.0)
-            t3 = time.perf_counter()
-            parts["write"].append(t1 - t0); parts["collect"].append(t2 - t1); parts["predict"].append(t3 - t2)
+            parts["write"].append(t1 - t0)
+            if one_call:                                      # bnhip_windows_predict_topk: rows assembled under the device's work
+                idxs = win.predict_topk(clf, 16, 10, 0, 1.0)[0]
+                parts["one_call"].append(time.perf_counter() - t1)
+            else:
+                idxs, rows = win.collect()
+                t2 = time.perf_counter()
+                clf.predict_pcm_topk(rows.reshape(-1), 16, len(idxs), 10, 0, 1.0)
+                parts["collect"].append(t2 - t1); parts["predict"].append(time.perf_counter() - t2)
             return len(idxs)
-        assert tick() == 256
-        dt = t(tick, reps_mid)
+        assert tick(False) == 256 and tick(True) == 256
+        for _ in range(reps_mid):
+            tick(False); tick(True)
         med = {k: sorted(v[-reps_mid:])[reps_mid // 2] * 1e3 for k, v in parts.items()}
-        res["realtime_tick_256"] = {"ms": dt * 1e3, "windows_per_s": 256 / dt, "write_ms": med["write"], "collect_ms": med["collect"],
-                                    "predict_pcm_topk_ms": med["predict"], "batch_buffer_pinned": win.pinned}
+        res["realtime_tick_256"] = {"ms": med["one_call"], "windows_per_s": 256 / (med["one_call"] * 1e-3),
+                                    "two_step_collect_ms": med["collect"], "two_step_predict_pcm_topk_ms": med["predict"],
+                                    "capture_side_write_ms": med["write"], "batch_buffer_pinned": win.pinned}
     finally:
         win.close()
     res["note"] = ("blocking C-ABI entries bnhip_predict / bnhip_predict_pcm16, outputs complete on return; calls of >= 128 clips run as chunks "
                    "on two contexts (csrc/hostpipe.cpp): pageable caller memory is staged through the library's pinned slots by copy threads, "
                    "`_pinned` legs pass bnhip_host_alloc memory, which the copy engines read and write directly; median of the calls; "
-                   "realtime_tick_256: 256 sources through bnhip_windows_write / _collect and one bnhip_predict_pcm_topk over the assembler's rows")
+                   "realtime_tick_256: 256 sources written into the window assembler, then ONE bnhip_windows_predict_topk (ms = that call; the two-step "
+                   "collect + bnhip_predict_pcm_topk beside it)")
     return res
 
 
