@@ -128,7 +128,8 @@ int bnhip_predict_pcm(bnhip_model* m, const void* pcm, int bits_per_sample, int 
  *             the next call resumes behind the last source looked at; sources[k] = source of row k; *batch = the rows, valid
  *             until the next collect / destroy.  A model that is inactive still collects (the audio is consumed, not analysed:
  *             buffer_manager.go:478-481) and simply skips the predict.
- * Needs no device and no bnhip_model. */
+ * Needs no device and no bnhip_model.  bnhip_windows_destroy must not run beside any other call on the same assembler (stop the
+ * capture callbacks first, as the reference stops its monitors first, RemoveMonitor / RemoveAllMonitors buffer_manager.go:255-292). */
 typedef struct bnhip_windows bnhip_windows;
 int bnhip_windows_create(size_t overlap_bytes, size_t read_bytes, int max_batch, bnhip_windows** out);
 int bnhip_windows_info(const bnhip_windows* w, size_t* window_bytes, int* max_batch, int* pinned, int* n_sources);

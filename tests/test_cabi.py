@@ -59,6 +59,50 @@ def test_invalid_arguments(built_lib):
     lib.bnhip_model_destroy(None)   # idempotent / NULL-safe like Close()
 
 
+def test_window_entries_reject_null_and_nonsense(built_lib, tiny_blob):
+    """Every bnhip_windows_* entry with NULL handles / outputs, negative or unknown sources, a negative cap; the tick entry with a
+    plan-only model, a bit depth it does not know and a window size that is not the model's clip - all BNHIP_E_INVALID with a
+    message, nothing crashes, nothing is consumed."""
+    from birdnet_go_amd import stream as S
+    lib = host.load_library()
+    w = S.NativeWindows(4, 8, max_batch=2)                  # (sets the prototypes)
+    h = w._h
+    vp, ci = C.c_void_p, C.c_int
+    n, src, p = ci(7), (ci * 4)(), vp()
+    assert lib.bnhip_windows_create(4, 8, 2, None) == host.E_INVALID
+    assert lib.bnhip_windows_info(None, None, None, None, None) == host.E_INVALID
+    assert lib.bnhip_windows_info(h, None, None, None, None) == host.BNHIP_OK       # every output is optional
+    assert lib.bnhip_windows_add_source(None, b"mic", 64, C.byref(n)) == host.E_INVALID
+    assert lib.bnhip_windows_add_source(h, b"mic", 64, None) == host.E_INVALID
+    assert lib.bnhip_windows_add_source(h, None, 64, C.byref(n)) == host.E_INVALID and n.value == -1
+    assert lib.bnhip_windows_write(None, 0, b"ab", 2) == host.E_INVALID
+    assert lib.bnhip_windows_write(h, -1, b"ab", 2) == host.E_INVALID
+    assert lib.bnhip_windows_write(h, 0, None, 2) == host.E_INVALID
+    assert lib.bnhip_windows_remove_source(h, -3) == host.E_INVALID and lib.bnhip_windows_reset(h, 9) == host.E_INVALID
+    assert lib.bnhip_windows_stats(h, 0, None, None, None) == host.E_INVALID           # no such source yet
+    assert lib.bnhip_windows_collect(h, -1, src, C.byref(n), C.byref(p)) == host.E_INVALID and n.value == 0
+    assert lib.bnhip_windows_collect(h, 2, None, C.byref(n), None) == host.E_INVALID
+    assert lib.bnhip_windows_collect(None, 2, src, C.byref(n), None) == host.E_INVALID
+    assert lib.bnhip_windows_ready(h, None) == host.E_INVALID
+    i = w.add_source("mic", 32)
+    w.write(i, bytes(range(8)))
+    assert lib.bnhip_windows_write(h, i, None, 0) == host.BNHIP_OK                   # an empty write is a write (counted)
+    assert w.stats(i) == (2, 0, 8)
+    # the tick entry: arguments are checked before anything is read from the rings
+    conf, idx = (C.c_float * 20)(), (C.c_int32 * 20)()
+    m = host.HipClassifier(tiny_blob, plan_only=True)
+    args = lambda bits, k=10: (h, m._h, bits, 0, 1.0, k, src, C.byref(n), conf, idx, None)
+    assert lib.bnhip_windows_predict_topk(None, m._h, 16, 0, 1.0, 10, src, C.byref(n), conf, idx, None) == host.E_INVALID
+    assert lib.bnhip_windows_predict_topk(h, None, 16, 0, 1.0, 10, src, C.byref(n), conf, idx, None) == host.E_INVALID
+    assert lib.bnhip_windows_predict_topk(*args(12)) == host.E_INVALID and b"bit depth" in lib.bnhip_last_error()
+    assert lib.bnhip_windows_predict_topk(*args(16, 0)) == host.E_INVALID
+    assert lib.bnhip_windows_predict_topk(*args(16)) == host.E_INVALID and b"plan-only" in lib.bnhip_last_error()
+    assert w.stats(i) == (2, 0, 8) and w.ready() == 1                               # still there
+    m.close()
+    lib.bnhip_windows_destroy(None)
+    w.close()
+
+
 def test_us_guards_need_no_gpu(built_lib):
     # the reference's guard clauses (filter.go:21-37) answer before any device work
     cv, ok = host.us_frame_cv(np.zeros((2, 100)), 256000)
