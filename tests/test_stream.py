@@ -780,3 +780,36 @@ def test_native_windows_feed_the_host_pipeline_in_place(tiny_cfg, tiny_blob):
         w.predict_topk(clf, 32)
     w.close()
     clf.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [24, 32])
+def test_tick_at_the_other_capture_depths(tiny_cfg, tiny_blob, bits):
+    """The reference captures 16-bit (conf.BytesPerSample); the boundary takes the three depths of ConvertToFloat32
+    (convert/pcm.go:206-268).  A tick over 24- / 32-bit windows == bnhip_predict_pcm_topk on the same windows cut by hand."""
+    from birdnet_go_amd import host
+    clf = host.HipClassifier(tiny_blob, device=0, max_batch=8)
+    bps = bits // 8
+    clip_b = tiny_cfg.n_samples * bps
+    ov = (tiny_cfg.n_samples // 2) * bps                      # whole samples on either side of the cut
+    rd = clip_b - ov
+    w = S.NativeWindows(ov, rd, max_batch=8)
+    rng = np.random.default_rng(bits)
+    x = rng.normal(0, 0.2, (3, 2 * rd // bps)).clip(-1, 1)
+    i32 = np.round(x * (2 ** 31 - 1)).astype("<i4")
+    raw = i32.view(np.uint8).reshape(3, -1, 4)[:, :, 4 - bps:].reshape(3, -1)     # top `bps` bytes of each sample, little-endian
+    for k in range(3):
+        assert w.add_source(f"mic{k}", 2 * clip_b) == k
+        w.write(k, raw[k])
+    for rnd in range(2):
+        idxs, rows, conf, idx = w.predict_topk(clf, bits, 5, 0, 1.0)
+        assert idxs == [0, 1, 2]
+        prefix = np.zeros((3, ov), np.uint8) if rnd == 0 else raw[:, rd - ov:rd]
+        want = np.concatenate([prefix, raw[:, rnd * rd:(rnd + 1) * rd]], axis=1)
+        assert np.array_equal(rows, want)
+        c2, i2 = clf.predict_pcm_topk(want.reshape(-1), bits, 3, 5, 0, 1.0)
+        assert np.array_equal(conf, c2) and np.array_equal(idx, i2)
+    with pytest.raises(S.StreamError, match="window size mismatch"):
+        w.predict_topk(clf, 16)
+    w.close()
+    clf.close()
