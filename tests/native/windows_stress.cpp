@@ -1,6 +1,7 @@
 // Test infrastructure: csrc/windows.cpp under ThreadSanitizer (tests/test_stream.py builds it with g++ -fsanitize=thread).
 // Writers on every source, two assemblers collecting at once through the shared row pool, resets and source churn beside
 // them; every collected row is checked against the stream it was cut from.
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -80,12 +81,57 @@ static int run_one(int seed, size_t ov, size_t rd, int nsrc, int ticks) {
     return bad;
 }
 
+// Rings barely larger than one read, writes of every size up to three rings' worth: the overwrite paths (read position pushed
+// forward, writes longer than the ring) under the sanitizers.  What can be said about the content: a window's fresh half is a
+// run of consecutive stream positions only when nothing was dropped inside it, so the check is on the accounting instead -
+// buffered bytes never exceed the capacity, overwriting writes are counted, every row is fully written (no poison left).
+static int run_overwrite(int seed) {
+    const size_t ov = 24, rd = 40, cap = 47;
+    const int nsrc = 6;
+    WindowAssembler w(ov, rd, 4);
+    std::vector<int> ids;
+    for (int k = 0; k < nsrc; k++) ids.push_back(w.add_source("o" + std::to_string(k), cap + (size_t)k));
+    std::atomic<bool> stop{false};
+    std::vector<std::thread> th;
+    for (int k = 0; k < nsrc; k++)
+        th.emplace_back([&, k] {
+            std::vector<uint8_t> buf(3 * (cap + 8), (uint8_t)(k + 1));
+            unsigned step = (unsigned)seed * 7919u + (unsigned)k;
+            while (!stop) {
+                step = step * 1103515245u + 12345u;
+                w.write(ids[k], buf.data(), (step >> 8) % buf.size());
+            }
+        });
+    int bad = 0;
+    std::vector<uint8_t> batch(4 * (ov + rd));
+    int src[4];
+    for (int it = 0; it < 20000; it++) {
+        std::fill(batch.begin(), batch.end(), (uint8_t)0xEE);
+        const int n = w.collect(batch.data(), 1 + it % 5, src);
+        if (n < 0 || n > 4) bad++;
+        for (int r = 0; r < n; r++) {
+            const int k = (int)(std::find(ids.begin(), ids.end(), src[r]) - ids.begin());
+            const uint8_t* row = batch.data() + (size_t)r * (ov + rd);
+            for (size_t i = 0; i < ov + rd; i++) if (row[i] != (uint8_t)(k + 1) && !(i < ov && row[i] == 0)) bad++;   // own bytes, or the zero prefix
+        }
+        if (it % 997 == 0) w.reset(ids[(size_t)it % nsrc]);
+    }
+    stop = true;
+    for (auto& t : th) t.join();
+    for (int k = 0; k < nsrc; k++) {
+        uint64_t wr = 0, ovw = 0; size_t buffered = 0;
+        w.stats(ids[k], &wr, &ovw, &buffered);
+        if (buffered > cap + (size_t)k || ovw > wr || ovw == 0) bad++;
+    }
+    return bad;
+}
+
 int main() {
     std::atomic<int> bad{0};
     std::thread a([&] { bad += run_one(1, 256 * 1024, 256 * 1024, 12, 4); });     // 6 MB batches: the row pool
     std::thread b([&] { bad += run_one(2, 192 * 1024, 320 * 1024, 10, 3); });     // a second assembler beside it
     a.join(); b.join();
-    const int c = run_one(3, 8, 24, 5, 50);                                        // small rows: the serial path
+    const int c = run_one(3, 8, 24, 5, 50) + run_overwrite(4);                     // small rows: the serial path; overwrite mode
     printf("windows stress: %d mismatches\n", bad + c);
     return bad + c ? 1 : 0;
 }
