@@ -1807,7 +1807,7 @@ bool Engine::load_tuning(const char* path) {
         size_t idx = 0; Row& r = rows[i]; char name[512] = {0};
         ok = fscanf(f, "%zu %d %d %d %d %d %d %d %d %d %511[^\n]", &idx, &r.kind, &r.nt, &r.wm, &r.ntf, &r.wmf, &r.shape, &r.dwl, &r.bx, &r.S, name) == 11 &&
              idx == i && r.kind == (int)steps[i].kind && steps[i].name == name;
-        if (ok && steps[i].kind == S_PW) ok = r.nt >= 0 && r.nt <= 8 && r.ntf >= 0 && r.ntf <= 8 && r.wm >= 0 && r.wm <= 11 && r.wmf >= 0 && r.wmf <= 11 &&
+        if (ok && steps[i].kind == S_PW) ok = r.nt >= 0 && r.nt <= 8 && r.ntf >= 0 && r.ntf <= 8 && r.wm >= 0 && r.wm <= 12 && r.wmf >= 0 && r.wmf <= 12 &&
                                               ((r.wm >= 5) == (steps[i].wm >= 5) || !steps[i].wbx);       // (never switches the arithmetic family)
         if (ok && steps[i].kind == S_DW) {                    // the staged form only where its tuner would have timed it
             const Step& t = steps[i];
@@ -2089,8 +2089,9 @@ void Engine::autotune_pw() {
             if (arith_bx) {
                 // split-bf16 candidates (wm 5 / 6 = 64- / 128-row tiles, 7 / 8 the software-pipelined form): the fastest tile
                 float bbest = 1e30f; int bnt = 0, bwm = 0;
-                for (int wm = precision == 1 ? 11 : (pw_b16_ok(precision, s.C) ? 10 : 8); wm >= 5; wm--)
+                for (int wm = pw_ws_candidate() ? 12 : (precision == 1 ? 11 : (pw_b16_ok(precision, s.C) ? 10 : 8)); wm >= 5; wm--)
                     for (int nt = 1; nt <= 8; nt++) {
+                        if (wm == 11 && precision != 1) continue;
                         long cols = (long)((s.Co + nt * 16 - 1) / (nt * 16)) * nt * 16;
                         if (cols * 100 > (long)((s.Co + 15) / 16 * 16) * 130) continue;
                         if (wm >= 7 && wm <= 8 && !pw_bx3p_ok(nt, wm - 6, s.C)) continue;
@@ -2104,6 +2105,11 @@ void Engine::autotune_pw() {
                             if (!pw_b16s_ok(q)) continue;
                         }
                         p.a_bf16 = vals[s.in0].half ? 1 : 0; p.out_bf16 = vals[s.out].half ? 1 : 0;      // the flavour the calls will run
+                        if (wm == 12) {                                        // weight columns in LDS: 64- or 128-column blocks
+                            if (nt != 4 && nt != 8) continue;
+                            PwParams q = p; q.ascale = in1;
+                            if (!pw_ws_ok(q)) continue;
+                        }
                         p.res_bf16 = (s.in2 >= 0 && vals[s.in2].half) ? 1 : 0;
                         launch_pw_bx3(p, s.wbx, stream);
                         hipEventRecord(a, stream);

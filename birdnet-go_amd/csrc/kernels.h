@@ -131,6 +131,12 @@ bool pw_b16_ok(int prec, int K);
 bool pw_b16s_ok(const PwParams& p);   // weights-stationary form for skinny layers (N <= 32, K <= 192) of one-product engines: PwParams::wm = 11
 bool pw_b16s_forced();
 void launch_pw_b16s(const PwParams& p, const uint16_t* Wimg, int Npad, hipStream_t s);
+// experimental (BNHIP_PW_WS = 1: tuner candidate, 2: forced): weight columns stationary in LDS, blocks persistent over row tiles, for
+// K of 65 .. 192 and N >= 64 without a squeeze-excite scale (the 6x expands): PwParams::wm = 12, nt = 4 | 8 (64 / 128 columns)
+bool pw_ws_ok(const PwParams& p);
+bool pw_ws_candidate();
+bool pw_ws_forced();
+void launch_pw_ws(const PwParams& p, const uint16_t* Wimg, int Npad, hipStream_t s);
 bool pw_b16_forced();              // BNHIP_PW_B16=2: every 128-row tile of a "precision":"bf16" engine takes k_pw_b16 (parity test)
 void launch_pw_b16(const PwParams& p, const uint16_t* Wimg, int nt, int wm /*1 | 2*/, int Npad, int nblk_n, unsigned nblk, hipStream_t s);
 

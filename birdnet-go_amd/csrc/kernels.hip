@@ -1382,6 +1382,7 @@ static inline bool pw_fill_grid(int M, int N, int* nt, int* wm, unsigned* nblk, 
 }
 void launch_pw_bx3(const PwParams& p, const uint16_t* Wimg, hipStream_t s) {
     if ((p.wm == 11 || pw_b16s_forced()) && pw_b16s_ok(p)) { launch_pw_b16s(p, Wimg, pw_bx3_npad(p.N), s); return; }   // skinny layers: weights in registers
+    if ((p.wm == 12 || pw_ws_forced()) && pw_ws_ok(p)) { launch_pw_ws(p, Wimg, pw_bx3_npad(p.N), s); return; }       // short K, wide N: weight columns in LDS (experimental)
     int nt = (p.nt >= 1 && p.nt <= 8) ? p.nt : pick_nt(p.M, p.N);
     int wm = (p.wm == 5 || p.wm == 7 || p.wm == 10) ? 1 : 2;   // PwParams::wm 5 / 6: 64- / 128-row tiles on the split-bf16 kernel, 7 / 8: pipelined,
                                                            // 10 / 9: 64- / 128-row tiles on k_pw_b16 (pw_b16.hip; one-product engines: 128 only)
