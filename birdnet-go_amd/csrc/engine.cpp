@@ -381,9 +381,19 @@ Engine::~Engine() {
     release_streams();
 }
 
+int pw_switches_from_env() {
+    auto sw = [](const char* name, int off, int force) {
+        const char* e = getenv(name);
+        return !e ? 0 : e[0] == '0' ? off : e[0] == '2' ? force : 0;
+    };
+    return sw("BNHIP_PW_B16", PW_SW_B16_OFF, PW_SW_B16_FORCE) | sw("BNHIP_PW_B16S", PW_SW_B16S_OFF, PW_SW_B16S_FORCE) |
+           sw("BNHIP_PW_WS", PW_SW_WS_OFF, PW_SW_WS_FORCE);
+}
+
 bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* err, int* code) {
     device = dev;
     max_batch = maxb;
+    pw_sw = pw_switches_from_env();      // (tests flip these between engines of one process; nothing reads them after this line)
     *code = BNHIP_E_UNSUPPORTED;
     // graph rewrites first (float16 constants behind DEQUANTIZE, unfolded batch norm, PAD + VALID convolutions): the
     // patterns below then see one canonical form whatever the exporter emitted
@@ -1808,7 +1818,7 @@ bool Engine::load_tuning(const char* path) {
         ok = fscanf(f, "%zu %d %d %d %d %d %d %d %d %d %511[^\n]", &idx, &r.kind, &r.nt, &r.wm, &r.ntf, &r.wmf, &r.shape, &r.dwl, &r.bx, &r.S, name) == 11 &&
              idx == i && r.kind == (int)steps[i].kind && steps[i].name == name;
         if (ok && steps[i].kind == S_PW) ok = r.nt >= 0 && r.nt <= 8 && r.ntf >= 0 && r.ntf <= 8 && r.wm >= 0 && r.wm <= 12 && r.wmf >= 0 && r.wmf <= 12 &&
-                                              ((r.wm >= 5) == (steps[i].wm >= 5) || !steps[i].wbx);       // (never switches the arithmetic family)
+                                              (((r.wm >= 5) == (steps[i].wm >= 5) && (r.wmf >= 5) == (steps[i].wm_full >= 5)) || !steps[i].wbx);       // (never switches the arithmetic family: bf16 storage was decided from it)
         if (ok && steps[i].kind == S_DW) {                    // the staged form only where its tuner would have timed it
             const Step& t = steps[i];
             DwParams dp{nullptr, nullptr, nullptr, nullptr, 1, t.H, t.W, t.C, t.Ho, t.Wo, t.kh, t.kw, t.sh, t.sw, t.pt, t.pl, t.act};
@@ -2089,26 +2099,23 @@ void Engine::autotune_pw() {
             if (arith_bx) {
                 // split-bf16 candidates (wm 5 / 6 = 64- / 128-row tiles, 7 / 8 the software-pipelined form): the fastest tile
                 float bbest = 1e30f; int bnt = 0, bwm = 0;
-                for (int wm = pw_ws_candidate() ? 12 : (precision == 1 ? 11 : (pw_b16_ok(precision, s.C) ? 10 : 8)); wm >= 5; wm--)
+                for (int wm = 12; wm >= 5; wm--)
                     for (int nt = 1; nt <= 8; nt++) {
                         if (wm == 11 && precision != 1) continue;
                         long cols = (long)((s.Co + nt * 16 - 1) / (nt * 16)) * nt * 16;
-                        if (cols * 100 > (long)((s.Co + 15) / 16 * 16) * 130) continue;
+                        if (wm != 12 && cols * 100 > (long)((s.Co + 15) / 16 * 16) * 130) continue;
                         if (wm >= 7 && wm <= 8 && !pw_bx3p_ok(nt, wm - 6, s.C)) continue;
-                        if ((wm == 9 || wm == 10) && !pw_b16_ok(precision, s.C)) continue;
+                        if ((wm == 9 || wm == 10) && !pw_b16_ok(precision, s.C, pw_sw)) continue;
                         if (wm == 10 && precision != 0) continue;              // (64-row tiles of k_pw_b16: six-product form only)
                         PwParams p{in0, s.w0, s.w1, in1, in2, out, n * s.H * s.W, s.Co, s.C, s.H * s.W, s.act, nt, wm};
-                        p.prec = precision;
-                        if (wm == 11) {                                        // weights-stationary form: no tile to choose
-                            if (nt != 1) continue;
-                            PwParams q = p; q.ascale = in1;
-                            if (!pw_b16s_ok(q)) continue;
-                        }
+                        p.prec = precision; p.sw = pw_sw;
                         p.a_bf16 = vals[s.in0].half ? 1 : 0; p.out_bf16 = vals[s.out].half ? 1 : 0;      // the flavour the calls will run
-                        if (wm == 12) {                                        // weight columns in LDS: 64- or 128-column blocks
-                            if (nt != 4 && nt != 8) continue;
-                            PwParams q = p; q.ascale = in1;
-                            if (!pw_ws_ok(q)) continue;
+                        if (wm == 11) {                                        // weights-stationary form: no tile to choose
+                            if (nt != 1 || !pw_b16s_ok(p)) continue;
+                        }
+                        if (wm == 12) {                                        // weight columns in LDS: 64-, 96- or 128-column blocks
+                            if ((nt != 4 && nt != 6 && nt != 8) || !pw_ws_ok(p) || !pw_ws_fills(p)) continue;
+                            if (precision == 1 && nt != 4) continue;
                         }
                         p.res_bf16 = (s.in2 >= 0 && vals[s.in2].half) ? 1 : 0;
                         launch_pw_bx3(p, s.wbx, stream);
@@ -2354,6 +2361,7 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
                 p.prec = precision;
                 p.a_bf16 = vals[s.in0].half ? 1 : 0; p.out_bf16 = vals[s.out].half ? 1 : 0;
                 p.res_bf16 = (s.in2 >= 0 && vals[s.in2].half) ? 1 : 0;
+                p.sw = pw_sw;
                 if (p.wm >= 5 && s.wbx) launch_pw_bx3(p, s.wbx, stream);
                 else launch_pw_gemm(p, stream);
                 break;

@@ -104,6 +104,7 @@ class Engine {
                                         // layers round their operands to bf16 (one product, fp32 accumulate) - Perch-style deployments
     int bf16x3 = 0;                     // split-bf16 MFMA path for pointwise / dense layers (k_pw_bx3): 0 off, 1 per layer where the
                                         // create-time autotuner measures it faster, 2 every eligible layer (parity tests)
+    int pw_sw = 0;                      // PW_SW_* switch bits of the split-bf16 GEMM family: the environment read ONCE in build(), carried in every PwParams
     bool use_graphs = false;            // opt-in: replay the plan as a hipGraph once a (pointers, n) combination repeats (measured: no gain on ROCm 7.2)
     void drop_graphs();
     void autotune_expdw();

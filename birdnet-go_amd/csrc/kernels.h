@@ -112,7 +112,11 @@ struct PwParams {         // pointwise conv / fully-connected as GEMM: out[M,N] 
     int a_bf16 = 0;       // k_pw_bx3 / k_pw_bx3p only: A holds bf16 values (bf16 activation storage, K % 4 == 0)
     int out_bf16 = 0;     // any pw kernel: out is written as bf16 (N % 4 == 0)
     int res_bf16 = 0;     // any pw kernel: res holds bf16 values (N % 4 == 0) - the residual stream of a "precision":"bf16" engine
+    int sw = 0;           // PW_SW_* bits: experiment / test switches of the split-bf16 kernel family, read from the environment ONCE per
+                          // engine (Engine::build) and carried here - no getenv on the launch path
 };
+enum { PW_SW_B16_OFF = 1, PW_SW_B16_FORCE = 2, PW_SW_B16S_OFF = 4, PW_SW_B16S_FORCE = 8, PW_SW_WS_OFF = 16, PW_SW_WS_FORCE = 32 };
+int pw_switches_from_env();       // BNHIP_PW_B16 / _B16S / _WS: "0" = never, "2" = wherever the kernel accepts the layer (parity tests)
 void launch_pw_gemm(const PwParams& p, hipStream_t s);
 bool pw_pipe_ok(int nt, int wm, int K);   // PwParams::wm = 2 + wm selects the software-pipelined kernel (k_pw_pipe)
 int pw_default_nt(int M, int N);
@@ -126,19 +130,19 @@ std::vector<uint16_t> pw_bx3_image(const float* W, int N, int K);
 void launch_pw_bx3(const PwParams& p, const uint16_t* Wimg, hipStream_t s);
 // The same GEMM with A streamed straight from global memory two slabs ahead (pw_b16.hip; PwParams::wm = 9 / 10: 128- / 64-row
 // tiles; one product per operand pair for "precision":"bf16" engines - 128-row tiles only - or the six-product fp32-equivalent
-// form): called by launch_pw_bx3, which has resolved the tile (nt = 16-column units) and the grid.  BNHIP_PW_B16=0 takes the candidate away from the tuner (A/B runs, parity test).
-bool pw_b16_ok(int prec, int K);
+// form): called by launch_pw_bx3, which has resolved the tile (nt = 16-column units) and the grid.
+bool pw_b16_ok(int prec, int K, int sw);
 bool pw_b16s_ok(const PwParams& p);   // weights-stationary form for skinny layers (N <= 32, K <= 192) of one-product engines: PwParams::wm = 11
-bool pw_b16s_forced();
 void launch_pw_b16s(const PwParams& p, const uint16_t* Wimg, int Npad, hipStream_t s);
-// experimental (BNHIP_PW_WS = 1: tuner candidate, 2: forced): weight columns stationary in LDS, blocks persistent over row tiles, for
-// K of 65 .. 192 and N >= 64 without a squeeze-excite scale (the 6x expands): PwParams::wm = 12, nt = 4 | 8 (64 / 128 columns)
-bool pw_ws_ok(const PwParams& p);
-bool pw_ws_candidate();
-bool pw_ws_forced();
-void launch_pw_ws(const PwParams& p, const uint16_t* Wimg, int Npad, hipStream_t s);
-bool pw_b16_forced();              // BNHIP_PW_B16=2: every 128-row tile of a "precision":"bf16" engine takes k_pw_b16 (parity test)
 void launch_pw_b16(const PwParams& p, const uint16_t* Wimg, int nt, int wm /*1 | 2*/, int Npad, int nblk_n, unsigned nblk, hipStream_t s);
+// pw_ws.hip - k_pw_ws (PwParams::wm = 12, nt = 4 | 6 | 8: 16-column units of a column block; same image, same K order, same
+// product order per accumulator: bit-identical to k_pw_bx3): short K, wide N without a squeeze-excite scale (the 6x expands, the
+// layer in front of the pooling): a block's weight columns stay in LDS, its waves walk 32-row tile pairs with A streamed from
+// global memory through a register ring several slabs ahead, epilogue straight from the accumulators.  A call too small for it
+// (pw_ws_ok) takes a tiled kernel - same bits.
+bool pw_ws_ok(const PwParams& p);
+bool pw_ws_fills(const PwParams& p);      // the call is large enough to put blocks on half of the chip
+void launch_pw_ws(const PwParams& p, const uint16_t* Wimg, int Npad, hipStream_t s);
 
 struct DwParams {
     const float* in; const float* w /*[kh][kw][C]*/; const float* bias; float* out;

@@ -1381,8 +1381,9 @@ static inline bool pw_fill_grid(int M, int N, int* nt, int* wm, unsigned* nblk, 
     return changed;
 }
 void launch_pw_bx3(const PwParams& p, const uint16_t* Wimg, hipStream_t s) {
-    if ((p.wm == 11 || pw_b16s_forced()) && pw_b16s_ok(p)) { launch_pw_b16s(p, Wimg, pw_bx3_npad(p.N), s); return; }   // skinny layers: weights in registers
-    if ((p.wm == 12 || pw_ws_forced()) && pw_ws_ok(p)) { launch_pw_ws(p, Wimg, pw_bx3_npad(p.N), s); return; }       // short K, wide N: weight columns in LDS (experimental)
+    if ((p.wm == 11 || (p.sw & PW_SW_B16S_FORCE)) && pw_b16s_ok(p)) { launch_pw_b16s(p, Wimg, pw_bx3_npad(p.N), s); return; }   // skinny layers: weights in registers
+    if (((p.wm == 12 && pw_ws_fills(p)) || (p.sw & PW_SW_WS_FORCE)) && pw_ws_ok(p)) { launch_pw_ws(p, Wimg, pw_bx3_npad(p.N), s); return; }   // short K, wide N: weight columns in LDS
+    // (a layer tuned onto one of those forms whose call is too small for it - a few clips - takes a tiled kernel: same bits)
     int nt = (p.nt >= 1 && p.nt <= 8) ? p.nt : pick_nt(p.M, p.N);
     int wm = (p.wm == 5 || p.wm == 7 || p.wm == 10) ? 1 : 2;   // PwParams::wm 5 / 6: 64- / 128-row tiles on the split-bf16 kernel, 7 / 8: pipelined,
                                                            // 10 / 9: 64- / 128-row tiles on k_pw_b16 (pw_b16.hip; one-product engines: 128 only)
@@ -1395,7 +1396,7 @@ void launch_pw_bx3(const PwParams& p, const uint16_t* Wimg, hipStream_t s) {
     const int Npad = pw_bx3_npad(p.N);
     // "precision":"bf16" engines: 128-row tiles run on the kernel built for one product per operand fragment (pw_b16.hip) -
     // the same arithmetic, A straight from global memory into fragments
-    if ((p.wm == 9 || p.wm == 10 || pw_b16_forced()) && (wm == 2 || p.prec == 0) && pw_b16_ok(p.prec, p.K)) {
+    if ((p.wm == 9 || p.wm == 10 || (p.sw & PW_SW_B16_FORCE)) && (wm == 2 || p.prec == 0) && pw_b16_ok(p.prec, p.K, p.sw)) {
         launch_pw_b16(p, Wimg, nt, wm, Npad, nblk_n, nblk, s);
         return;
     }

@@ -16,51 +16,12 @@
 // Block = 128 rows x 16 NT columns, 4 waves, accumulators [NT][2] x f32x4.
 // Also in this file: the six-product (fp32-equivalent) form of the same kernel for the fp32 engines, 64- or 128-row tiles
 // (template parameters SIX, WM), and k_pw_b16s - skinny projections with the whole weight matrix in registers.
-#include "pw_common.h"
+#include "pw_split.h"
 
 #include <algorithm>
 #include <atomic>
 
 namespace bnhip {
-
-typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32v4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32v2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ b16x8 b16_cvt8(const float4& a, const float4& b) {       // round to nearest even, 8 values
-    u32v4 h;
-    h[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a.x, a.y}, b16x2));
-    h[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a.z, a.w}, b16x2));
-    h[2] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){b.x, b.y}, b16x2));
-    h[3] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){b.z, b.w}, b16x2));
-    return __builtin_bit_cast(b16x8, h);
-}
-// fp32 -> three bf16 pieces, exactly k_pw_bx3's decomposition (hi = RNE(x), mid = RNE(x - hi), lo = RNE(x - hi - mid); the
-// subtractions are exact and kept scalar: packed they cost ~13 cycles beside MFMAs against ~4)
-__device__ __forceinline__ float b16_sub(float a, float b) {
-    float r;
-    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ void b16_split8(const float4& a, const float4& b, b16x8* hi, b16x8* mid, b16x8* lo) {
-    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    u32v4 h, m, l;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const f32x2 v = {x[2 * q], x[2 * q + 1]};
-        const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b16x2));
-        const f32x2 r = {b16_sub(v[0], __uint_as_float(hb << 16)), b16_sub(v[1], __uint_as_float(hb & 0xffff0000u))};
-        const unsigned mb = __builtin_bit_cast(unsigned, __builtin_convertvector(r, b16x2));
-        const f32x2 t = {b16_sub(r[0], __uint_as_float(mb << 16)), b16_sub(r[1], __uint_as_float(mb & 0xffff0000u))};
-        h[q] = hb; m[q] = mb; l[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, b16x2));
-    }
-    *hi = __builtin_bit_cast(b16x8, h); *mid = __builtin_bit_cast(b16x8, m); *lo = __builtin_bit_cast(b16x8, l);
-}
-__device__ __forceinline__ float4 b16_unpack4(const u32v2& r) {
-    return make_float4(__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
-                       __uint_as_float(r[1] & 0xffff0000u));
-}
 
 // B16_TRACE (tools/ubench/b16_trace.hip only): lane 0 of every wave of the first 64 logical blocks stamps the shader clock at the
 // phase boundaries, to see where a wave's time goes.  Compiled out of the library.
@@ -72,12 +33,6 @@ __device__ long long* g_b16_trace = nullptr;      // [64 blocks][4 waves][B16_TR
 #define B16_T(i) do { } while (0)
 #endif
 
-// one slab's worth of a lane's A operand as loaded: k = 32 s + 4 kq .. + 3 (lo) and 32 s + 16 + 4 kq .. + 3 (hi) of its row - the
-// order of the weight image's slots, i.e. k_pw_bx3's fragment order, so that every product sits at the same position of the MFMA
-// in both kernels and their sums round alike
-template <bool ABF> struct ARaw;
-template <> struct ARaw<true> { u32v2 lo, hi; };
-template <> struct ARaw<false> { float4 lo, hi; };
 template <bool ABF, bool SCR> struct ASet { ARaw<ABF> a[2]; };
 template <bool ABF> struct ASet<ABF, true> { ARaw<ABF> a[2]; float4 slo[2], shi[2]; };
 
@@ -407,8 +362,7 @@ __global__ __launch_bounds__(256) void k_pw_b16s(PwParams p, const uint16_t* __r
 // layers the weights-stationary kernel takes: one-product engines, N a multiple of 4 up to 32, K up to 192 (NS x NT <= 12 fragments),
 // squeeze-excite scale only when a 16-row tile cannot straddle clips
 bool pw_b16s_ok(const PwParams& p) {
-    const char* e = getenv("BNHIP_PW_B16S");              // 0: never; 2: every eligible layer whatever the tuner chose (parity test)
-    if (e && e[0] == '0') return false;
+    if (p.sw & PW_SW_B16S_OFF) return false;
     if (p.prec != 1 || (p.K & 3) || p.K < 16 || (p.N & 3) || p.N > 32) return false;
     const int ns = (p.K + 31) / 32, nt = (p.N + 15) / 16;
     if (ns * nt > 12 || ns > 6) return false;
@@ -436,182 +390,8 @@ void launch_pw_b16s(const PwParams& p, const uint16_t* Wimg, int Npad, hipStream
 #undef B16S_NS
 }
 
-// ---- short contractions with wide outputs (the 6x expands of the late blocks): weight columns stationary in LDS
-// Where a k_pw_bx3 / k_pw_b16 block spends its LDS pipe: per slab and CU, 16 waves x 9 fragment reads (ds_read_b128, 4 cycles) = 576
-// cycles plus 4 blocks x 9 KB of weight-tile writes at ~79 B/clk = 470 - against 1 152 MFMA cycles per SIMD (64 x 48 tiles), with a
-// barrier per slab on top.  For K <= 192 a block's whole column range fits: NS slabs x 3 planes x 16 NT columns x 64 B = 74 KB
-// (64 columns) or 147 KB (128).  So: load it once, then every wave walks 16-row tiles of the block's row range with A streamed from
-// global memory one tile ahead (as k_pw_b16s does) - no tile writes, no barrier after the first, the epilogue straight from the
-// accumulators.  Eight waves per block (two per SIMD: one's loads and epilogue under the other's MFMAs).  Same image, same K
-// order, same product order per accumulator as k_pw_bx3: bit-identical.
-// EXPERIMENTAL (written at the end of round 4 without GPU time left to measure it): never chosen unless BNHIP_PW_WS is set
-// (1: a tuner candidate, 2: forced onto every layer it accepts - the parity test).
-template <int NT, int NS, bool SIX, bool ABF>
-__global__ __launch_bounds__(512) void k_pw_ws(PwParams p, const uint16_t* __restrict__ Wimg, int Npad, int nblk_n, unsigned nblk,
-                                                int tiles_per_block, FDiv dn) {
-    static_assert(!SIX || !ABF, "fp32 engines keep fp32 activations");
-    constexpr int BN = 16 * NT, NP = SIX ? 3 : 1;
-    constexpr int WSLOTS = NS * NP * 4 * BN;                 // 16-byte slots: [slab][plane][kq][column]
-    extern __shared__ __attribute__((aligned(16))) unsigned char ws_lds[];
-    u32v4* Wl = reinterpret_cast<u32v4*>(ws_lds);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
-    const unsigned L = xcd_remap(blockIdx.x, nblk);          // consecutive L: the column blocks of one row range, on one XCD (they share A)
-    const int g = (int)fdiv(L, dn);
-    const int n0 = ((int)L - g * nblk_n) * BN;
-    const int K = p.K, N = p.N;
-    const u32v4* W16 = reinterpret_cast<const u32v4*>(Wimg);
-    for (int slot = tid; slot < WSLOTS; slot += 512) {
-        const int r = slot % BN, q = slot / BN;              // q = (slab * NP + plane) * 4 + kq
-        const int kqs = q & 3, pl = (q >> 2) % NP, sl = (q >> 2) / NP;
-        Wl[slot] = W16[((size_t)sl * 12 + pl * 4 + kqs) * Npad + min(n0 + r, Npad - 1)];
-    }
-    __syncthreads();
-
-    const int mtiles = (p.M + 15) >> 4;
-    const int t_begin = g * tiles_per_block, t_end = min(t_begin + tiles_per_block, mtiles);
-    const uint16_t* A16 = reinterpret_cast<const uint16_t*>(p.A);
-    bool inlo[NS], inhi[NS];
-#pragma unroll
-    for (int ns = 0; ns < NS; ns++) { inlo[ns] = 32 * ns + 4 * kq < K; inhi[ns] = 32 * ns + 16 + 4 * kq < K; }
-    ARaw<ABF> cur[NS], nxt[NS];
-    auto aload = [&](int tile, ARaw<ABF> (&dst)[NS]) {
-        const int m = min(16 * tile + li, p.M - 1);
-        const size_t off = (size_t)m * K + 4 * kq;
-#pragma unroll
-        for (int ns = 0; ns < NS; ns++) {
-            if constexpr (ABF) {
-                dst[ns].lo = inlo[ns] ? *reinterpret_cast<const u32v2*>(A16 + off + 32 * ns) : (u32v2){0u, 0u};
-                dst[ns].hi = inhi[ns] ? *reinterpret_cast<const u32v2*>(A16 + off + 32 * ns + 16) : (u32v2){0u, 0u};
-            } else {
-                dst[ns].lo = inlo[ns] ? *reinterpret_cast<const float4*>(p.A + off + 32 * ns) : make_float4(0.f, 0.f, 0.f, 0.f);
-                dst[ns].hi = inhi[ns] ? *reinterpret_cast<const float4*>(p.A + off + 32 * ns + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    };
-    auto wfrag = [&](int idx, u32v4 (&dst)[NP]) {            // step idx = slab * NT + column tile
-        const int ns = idx / NT, t = idx - ns * NT;
-#pragma unroll
-        for (int pl = 0; pl < NP; pl++) dst[pl] = Wl[((ns * NP + pl) * 4 + kq) * BN + 16 * t + li];
-    };
-    int tile = t_begin + wave;
-    if (tile < t_end) aload(tile, cur);
-    for (; tile < t_end; tile += 8) {
-        if (tile + 8 < t_end) aload(tile + 8, nxt);
-        f32x4 acc[NT];
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        u32v4 wfr[2][NP];
-        wfrag(0, wfr[0]);
-#pragma unroll
-        for (int ns = 0; ns < NS; ns++) {
-            b16x8 ah, am, al;
-            if constexpr (ABF) {
-                ah = __builtin_bit_cast(b16x8, (u32v4){cur[ns].lo[0], cur[ns].lo[1], cur[ns].hi[0], cur[ns].hi[1]});
-            } else if constexpr (SIX) {
-                b16_split8(cur[ns].lo, cur[ns].hi, &ah, &am, &al);
-            } else {
-                ah = b16_cvt8(cur[ns].lo, cur[ns].hi);
-            }
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const int idx = ns * NT + t;
-                if (idx + 1 < NS * NT) wfrag(idx + 1, wfr[(idx + 1) & 1]);
-                const b16x8 wh = __builtin_bit_cast(b16x8, wfr[idx & 1][0]);
-                f32x4 c = acc[t];
-                if constexpr (SIX) {                         // smallest terms first (k_pw_bx3's order)
-                    const b16x8 wm = __builtin_bit_cast(b16x8, wfr[idx & 1][NP - 2]);
-                    const b16x8 wl = __builtin_bit_cast(b16x8, wfr[idx & 1][NP - 1]);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, am, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, ah, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, am, c, 0, 0, 0);
-                }
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah, c, 0, 0, 0);
-            }
-        }
-        // epilogue from the accumulators: row m = 16 tile + li, channels n0 + 16 t + 4 kq .. + 3
-        const int m = 16 * tile + li;
-        if (m < p.M) {
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const int n = n0 + 16 * t + 4 * kq;
-                if (n + 3 < N) {                                   // (N % 4 == 0: a quad is wholly inside or outside)
-                    f32x4 v = acc[t];
-                    if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n); v += (f32x4){b4.x, b4.y, b4.z, b4.w}; }
-                    if (p.act == ACT_SWISH) v = swish4(v);
-                    else if (p.act != ACT_NONE) { v[0] = apply_act(v[0], p.act); v[1] = apply_act(v[1], p.act); v[2] = apply_act(v[2], p.act); v[3] = apply_act(v[3], p.act); }
-                    const size_t o = (size_t)m * N + n;
-                    if (p.res) {
-                        const float4 rv = p.res_bf16 ? bf16x4_load(p.res, o >> 2) : *reinterpret_cast<const float4*>(p.res + o);
-                        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-                    }
-                    if (p.out_bf16) bf16x4_store(p.out, o >> 2, make_float4(v[0], v[1], v[2], v[3]));
-                    else *reinterpret_cast<float4*>(p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            }
-        }
-        if (tile + 8 < t_end) {
-#pragma unroll
-            for (int ns = 0; ns < NS; ns++) cur[ns] = nxt[ns];
-        }
-    }
-}
-
-static int pw_ws_env() {                                  // read per call, as the other switches: a test flips it inside one process
-    const char* e = getenv("BNHIP_PW_WS");
-    return e ? atoi(e) : 0;
-}
-bool pw_ws_candidate() { return pw_ws_env() >= 1; }
-bool pw_ws_forced() { return pw_ws_env() == 2; }
-// layers it takes: K of 65 .. 192 (3 .. 6 slabs), N >= 64, no squeeze-excite scale on A (the expands have none)
-bool pw_ws_ok(const PwParams& p) {
-    if (pw_ws_env() < 1) return false;
-    if (p.prec != 0 && p.prec != 1) return false;
-    if ((p.K & 3) || p.K < 65 || p.K > 192 || (p.N & 3) || p.N < 64 || p.ascale) return false;
-    if (p.a_bf16 && p.prec != 1) return false;
-    return true;
-}
-void launch_pw_ws(const PwParams& p, const uint16_t* Wimg, int Npad, hipStream_t s) {
-    g_pw_b16_launches.fetch_add(1, std::memory_order_relaxed);
-    const int ns = (p.K + 31) / 32;
-    const bool six = p.prec == 0, abf = p.a_bf16 != 0;
-    // (one-product steps are a single MFMA: the compiler requests every fragment ahead and the 128-column form spills - 64 there)
-    const int nt = !six ? 4 : ((p.nt == 4 || p.nt == 8) ? p.nt : (p.N >= 128 ? 8 : 4));
-    const int BN = 16 * nt, np = six ? 3 : 1;
-    const size_t lds = (size_t)ns * np * 4 * BN * 16;
-    const int nblk_n = (p.N + BN - 1) / BN, mtiles = (p.M + 15) / 16;
-    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
-    int G = std::max(1, 256 * per_cu / nblk_n);              // one resident generation of blocks: each loads its columns once
-    G = std::min(G, std::max(1, mtiles / 8));                // (at least one tile per wave)
-    const int tpb = (mtiles + G - 1) / G;
-    G = (mtiles + tpb - 1) / tpb;
-    const unsigned nblk = (unsigned)G * (unsigned)nblk_n;
-    const FDiv dn = make_fdiv((unsigned)nblk_n);
-#define WS_LAUNCH(NT_, NS_, SIX_, ABF_) do { \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_ws<NT_, NS_, SIX_, ABF_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((k_pw_ws<NT_, NS_, SIX_, ABF_>), dim3(nblk), dim3(512), lds, s, p, Wimg, Npad, nblk_n, nblk, tpb, dn); } while (0)
-#define WS_NS(NT_, SIX_, ABF_) switch (ns) { case 3: WS_LAUNCH(NT_, 3, SIX_, ABF_); break; case 4: WS_LAUNCH(NT_, 4, SIX_, ABF_); break; \
-                                             case 5: WS_LAUNCH(NT_, 5, SIX_, ABF_); break; default: WS_LAUNCH(NT_, 6, SIX_, ABF_); break; }
-    if (six) { if (nt == 4) WS_NS(4, true, false) else WS_NS(8, true, false) }
-    else if (abf) WS_NS(4, false, true)
-    else WS_NS(4, false, false)
-#undef WS_LAUNCH
-#undef WS_NS
-}
-
-bool pw_b16_ok(int prec, int K) {   // (the switch is read per call - one getenv beside a 5 us launch - so that a test can flip it inside one process)
-    const char* e = getenv("BNHIP_PW_B16");
-    return (prec == 0 || prec == 1) && (K & 3) == 0 && K >= 16 && !(e && e[0] == '0');
-}
-bool pw_b16s_forced() {
-    const char* e = getenv("BNHIP_PW_B16S");
-    return e && e[0] == '2';
-}
-bool pw_b16_forced() {
-    const char* e = getenv("BNHIP_PW_B16");
-    return e && e[0] == '2';
-}
+// the switches (BNHIP_PW_B16 / BNHIP_PW_B16S: 0 = candidate taken away, 2 = forced) are read once per engine and travel in PwParams::sw
+bool pw_b16_ok(int prec, int K, int sw) { return (prec == 0 || prec == 1) && (K & 3) == 0 && K >= 16 && !(sw & PW_SW_B16_OFF); }
 
 // prec 1 (one product): 128-row tiles; prec 0 (six products): 64- or 128-row tiles (wm = 1 | 2)
 void launch_pw_b16(const PwParams& p, const uint16_t* Wimg, int nt, int wm, int Npad, int nblk_n, unsigned nblk, hipStream_t s) {

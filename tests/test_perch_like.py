@@ -378,28 +378,28 @@ def test_weights_stationary_gemm_equals_the_tiled_kernels(gpu, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("model,prec", [("perch", "f32"), ("v24", "f32"), ("v24", "bf16")])
 def test_weights_in_lds_gemm_equals_the_tiled_kernels(gpu, monkeypatch, model, prec):
-    """k_pw_ws (pw_b16.hip, experimental, opt-in through BNHIP_PW_WS): the 6x expands with K <= 192 keep their weight columns in
-    LDS for the life of a block, which walks 16-row tiles with A streamed from global memory - no tile writes, one barrier.
-    Forced onto every layer it accepts: same image, same K order, same product order per accumulator - bit-identical to the
-    tiled kernels, in the six-product form of the fp32 engines (Perch dimensions: K = 136, five slabs, 128-column blocks with a
-    ragged last one; v2.4: K = 192, six slabs, 147 KB of LDS) and the one-product form of the bf16 ones (64-column blocks)."""
+    """k_pw_ws (pw_ws.hip; a tuner candidate by default, BNHIP_PW_WS=0 takes it away, 2 forces it): the 6x expands keep their
+    weight columns in LDS for the life of a block, whose waves walk 16-row tile pairs with A streamed from global memory through
+    a register ring - no tile writes, one barrier.  Forced onto every layer it accepts: same image, same K order, same product
+    order per accumulator - bit-identical to the tiled kernels, in the six-product form of the fp32 engines (Perch dimensions:
+    K = 136, five slabs with a K tail, ring depth 1; v2.4: K = 192, six slabs, ring depth 3, and K = 320, ten slabs, ring depth 5)
+    and the one-product form of the bf16 ones (64-column blocks, bf16 A fragments as loaded).  The row counts here give waves
+    odd and even tile counts, single-tile tails and the staggered second half of every block."""
     import ctypes
     cfg = sm.perch_config() if model == "perch" else sm.SynthConfig()
     blob = sm.build_model(cfg)
     n = 16 if model == "perch" else 24
     x = sm.synth_clips(n, cfg.n_samples, cfg.sample_rate, first=9)
     lib = host.load_library()
-    lib.bnhip_debug_pw_b16_launches.restype = ctypes.c_long
+    lib.bnhip_debug_pw_ws_launches.restype = ctypes.c_long
     out = {}
-    monkeypatch.setenv("BNHIP_PW_B16", "0")                    # (the counter then counts k_pw_ws launches only)
-    monkeypatch.setenv("BNHIP_PW_B16S", "0")
     for on in ("2", "0"):
         monkeypatch.setenv("BNHIP_PW_WS", on)
         c = host.HipClassifier(blob, max_batch=n, precision=prec, autotune=False, lanes=1)
         try:
-            before = lib.bnhip_debug_pw_b16_launches()
+            before = lib.bnhip_debug_pw_ws_launches()
             out[on] = c.predict_batch(x.reshape(-1), n).copy()
-            used = lib.bnhip_debug_pw_b16_launches() - before
+            used = lib.bnhip_debug_pw_ws_launches() - before
         finally:
             c.close()
         assert (used >= 3) if on == "2" else (used == 0), used

@@ -1,0 +1,116 @@
+// Late-layer GEMM lab: every split-bf16 kernel form of the library on the v2.4 stack's pointwise shapes at batch 256, through
+// the library's own dispatcher (launch_pw_bx3) - bitwise comparison against the tiled k_pw_bx3 and two clocks per candidate
+// (ten launches back to back, best of five isolated launches).  Links the built library; no model, no Python.
+//   hipcc --offload-arch=gfx950 -O2 -std=c++17 -I birdnet-go_amd/csrc -o tools/ubench/bin/pw_lab tools/ubench/pw_lab.cpp \
+//         -L birdnet-go_amd/lib -lbnhip -Wl,-rpath,'$ORIGIN/../../../birdnet-go_amd/lib'
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+using namespace bnhip;
+
+struct Shape { const char* name; int M, N, K, HW, act; bool scale, res; };
+struct Cand { int wm, nt; };
+
+static float* dev_f(const std::vector<float>& h) {
+    float* d; (void)hipMalloc(&d, h.size() * 4); (void)hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice); return d;
+}
+
+int main(int argc, char** argv) {
+    const char* only = argc > 1 ? argv[1] : nullptr;
+    const int only_wm = argc > 3 ? atoi(argv[2]) : 0, only_nt = argc > 3 ? atoi(argv[3]) : 0;      // pw_lab <shape> <wm> <nt>: one candidate
+    const Shape shapes[] = {
+        {"b13/expand", 12288, 1152, 192, 48, ACT_SWISH, false, false},
+        {"top", 12288, 1024, 320, 48, ACT_SWISH, false, false},
+        {"b13/project", 12288, 192, 1152, 48, ACT_NONE, true, true},
+        {"b16/project", 12288, 320, 1152, 48, ACT_NONE, true, false},
+        {"b12/project", 12288, 192, 672, 48, ACT_NONE, true, false},
+        {"b10/project", 49152, 112, 672, 192, ACT_NONE, true, true},
+        {"b9/project", 49152, 112, 480, 192, ACT_NONE, true, false},
+        {"b8/project", 49152, 80, 480, 192, ACT_NONE, true, true},
+        {"b6/project", 49152, 80, 240, 192, ACT_NONE, true, false},
+        {"b5/project", 196608, 40, 240, 768, ACT_NONE, true, true},
+        {"b4/project", 196608, 40, 144, 768, ACT_NONE, true, false},
+        {"dense", 256, 6522, 1024, 1, ACT_NONE, false, false},
+    };
+    const Cand cands[] = {{6, 4}, {6, 3}, {6, 6}, {6, 8}, {5, 3}, {5, 5}, {5, 7}, {8, 4}, {9, 4}, {9, 6}, {10, 3}, {10, 5}, {10, 7},
+                          {12, 4}, {12, 6}, {12, 8}};
+    std::mt19937 rng(1234);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (const Shape& sh : shapes) {
+        if (only && !strstr(sh.name, only)) continue;
+        const int M = sh.M, N = sh.N, K = sh.K, B = (M + sh.HW - 1) / sh.HW;
+        std::vector<float> A((size_t)M * K), W((size_t)N * K), bias(N), sc((size_t)B * K), res((size_t)M * N);
+        for (auto& v : A) v = nd(rng);
+        for (auto& v : W) v = nd(rng) * 0.05f;
+        for (auto& v : bias) v = nd(rng) * 0.1f;
+        for (auto& v : sc) v = 0.5f + 0.5f * std::fabs(nd(rng)) * 0.3f;
+        for (auto& v : res) v = nd(rng);
+        const std::vector<uint16_t> img = pw_bx3_image(W.data(), N, K);
+        uint16_t* dimg; (void)hipMalloc(&dimg, img.size() * 2); (void)hipMemcpy(dimg, img.data(), img.size() * 2, hipMemcpyHostToDevice);
+        float *dA = dev_f(A), *dW = dev_f(W), *db = dev_f(bias), *ds = sh.scale ? dev_f(sc) : nullptr, *dr = sh.res ? dev_f(res) : nullptr;
+        float *dref, *dout;
+        (void)hipMalloc(&dref, (size_t)M * N * 4); (void)hipMalloc(&dout, (size_t)M * N * 4);
+        auto params = [&](int wm, int nt, float* out) {
+            PwParams p{dA, dW, db, ds, dr, out, M, N, K, sh.HW, sh.act, nt, wm};
+            p.prec = 0;
+            return p;
+        };
+        { PwParams p = params(6, 4, dref); launch_pw_bx3(p, dimg, 0); (void)hipDeviceSynchronize(); }
+        std::vector<float> href((size_t)M * N), hout((size_t)M * N);
+        (void)hipMemcpy(href.data(), dref, href.size() * 4, hipMemcpyDeviceToHost);
+        // sanity of the reference itself against a double-precision dot product on a few outputs
+        double worst = 0;
+        for (int t = 0; t < 64; t++) {
+            const int m = (int)(rng() % M), n = (int)(rng() % N);
+            double acc = 0;
+            for (int k = 0; k < K; k++) acc += (double)(A[(size_t)m * K + k] * (sh.scale ? sc[(size_t)(m / sh.HW) * K + k] : 1.f)) * W[(size_t)n * K + k];
+            acc += bias[n];
+            if (sh.act == ACT_SWISH) acc = acc / (1.0 + std::exp(-acc));
+            if (sh.res) acc += res[(size_t)m * N + n];
+            worst = std::max(worst, std::fabs(acc - href[(size_t)m * N + n]));
+        }
+        printf("== %-12s M=%d N=%d K=%d HW=%d scale=%d res=%d  (reference k_pw_bx3 128x64 vs fp64 on 64 outputs: max |d| %.2e)\n", sh.name, M, N, K, sh.HW,
+               (int)sh.scale, (int)sh.res, worst);
+        for (const Cand& c : cands) {
+            if (only_wm && (c.wm != only_wm || c.nt != only_nt)) continue;
+            PwParams p = params(c.wm, c.nt, dout);
+            if (c.wm == 12 && !pw_ws_ok(p)) continue;
+            if (c.wm == 8 && !pw_bx3p_ok(c.nt, 2, K)) continue;
+            if (c.wm != 12 && c.nt * 16 > (N + 15) / 16 * 16 * 13 / 10 && c.nt > 1) continue;
+            (void)hipMemset(dout, 0xff, (size_t)M * N * 4);
+            launch_pw_bx3(p, dimg, 0);
+            hipError_t err = hipDeviceSynchronize();
+            if (err != hipSuccess) { printf("   wm=%2d nt=%d: LAUNCH FAILED %s\n", c.wm, c.nt, hipGetErrorString(err)); (void)hipGetLastError(); continue; }
+            (void)hipMemcpy(hout.data(), dout, hout.size() * 4, hipMemcpyDeviceToHost);
+            size_t bad = 0, first = 0;
+            for (size_t i = 0; i < hout.size(); i++)
+                if (memcmp(&hout[i], &href[i], 4)) { if (!bad) first = i; bad++; }
+            launch_pw_bx3(p, dimg, 0);
+            (void)hipEventRecord(e0, 0);
+            for (int r = 0; r < 10; r++) launch_pw_bx3(p, dimg, 0);
+            (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+            float b2b; (void)hipEventElapsedTime(&b2b, e0, e1);
+            float iso = 1e30f;
+            for (int r = 0; r < 5; r++) {
+                (void)hipEventRecord(e0, 0); launch_pw_bx3(p, dimg, 0); (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+                float t; (void)hipEventElapsedTime(&t, e0, e1); iso = std::min(iso, t);
+            }
+            printf("   wm=%2d nt=%d: %7.1f us b2b  %7.1f us iso  %6.1f TF   %s", c.wm, c.nt, b2b * 100, iso * 1e3, 2.0 * M * N * K / (b2b * 1e-4) / 1e12,
+                   bad ? "MISMATCH" : "bit-identical");
+            if (bad) printf(" (%zu of %zu, first at row %zu col %zu: %g vs %g)", bad, hout.size(), first / N, first % N, hout[first], href[first]);
+            printf("\n");
+            fflush(stdout);
+        }
+        hipFree(dimg); hipFree(dA); hipFree(dW); hipFree(db); if (ds) hipFree(ds); if (dr) hipFree(dr); hipFree(dref); hipFree(dout);
+    }
+    return 0;
+}
