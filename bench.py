@@ -55,21 +55,60 @@ def parse():
     return ap.parse_args()
 
 
-def pmc_traffic(kclass, workload="birdnet"):
-    """HBM bytes per launch of a kernel class from the newest committed PMC pass (profiles/rNN_traffic.json, produced by
-    tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same bench; FETCH_SIZE
-    doubled per the gfx950 correction in MI355X_MICROARCH.md).  PMC cannot be collected inside the timed run itself."""
+def lib_digest():
+    """Content digest of the loaded library's sources + flags (birdnet-go_amd/build.py writes it beside the .so)."""
+    try:
+        from birdnet_go_amd import host
+        return open(os.path.join(os.path.dirname(host.LIB_PATH), ".build_digest")).read().strip()
+    except Exception:
+        return None
+
+
+def plan_signature(desc):
+    """What the create-time tuners decided, as one hash: per step (name, tiles, kernel flavour, fused-kernel shape, staged depthwise,
+    split-bf16 phase 1) - the same decisions a BNHIP_TUNE_FILE records."""
+    import hashlib
+    h = hashlib.sha256()
+    for s_ in desc["steps"]:
+        h.update(repr((s_["name"], s_["nt"], s_["wm"], s_["nt_full"], s_["wm_full"], s_["shape"], s_["dw_lds"], s_["bx"])).encode())
+    return h.hexdigest()[:16]
+
+
+def _bound_evidence(pattern, workload, cur_digest, cur_plan):
+    """Newest committed counter file of a kind, IF it was collected on the library that is loaded now (tools/profile_round.sh stamps
+    every counter file with the library digest, the tune file's hash and the plan signature of its passes).  Counters cannot be
+    collected inside the timed run, so the line quotes them from a file - a file from another build would put stale counters under a
+    fresh headline, so it is dropped with a note instead."""
     import glob
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", pattern))
                    if ("perch" in os.path.basename(f)) == (workload == "perch"))
     if not files:
-        return None
+        return None, None, {"dropped": "no committed counter file"}
+    path = files[-1]
+    data = json.load(open(path))
+    bind = data.get("_binding")
+    rel = os.path.relpath(path, ROOT)
+    if not bind or not bind.get("lib_digest"):
+        return None, rel, {"dropped": f"{rel} carries no library digest (collected before round 5): not quoted"}
+    if not cur_digest or bind["lib_digest"] != cur_digest:
+        return None, rel, {"dropped": f"{rel} was collected on library {str(bind['lib_digest'])[:12]}, this run loaded {str(cur_digest)[:12]}: not quoted"}
+    note = {"lib_digest": cur_digest[:16], "tune_sha256": (bind.get("tune_sha256") or "")[:16], "plan_signature_of_the_passes": bind.get("plan_signature"),
+            "plan_matches_this_run": bind.get("plan_signature") == cur_plan}
+    return data, rel, note
+
+
+def pmc_traffic(kclass, workload="birdnet", cur_digest=None, cur_plan=None):
+    """HBM bytes per launch of a kernel class from the newest committed PMC pass (profiles/rNN_traffic.json, produced by
+    tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same bench; FETCH_SIZE
+    doubled per the gfx950 correction in MI355X_MICROARCH.md), bound to the loaded library (see _bound_evidence)."""
     names = {"expand_dw": "k_expand_dw", "pw_gemm": "k_pw_", "frontend": "k_frontend", "dwconv": "k_dwconv",
              "conv_direct": "k_conv_direct", "se": "k_se", "stft": "k_stft"}
     pref = names.get(kclass)
     if not pref:
         return None
-    data = json.load(open(files[-1]))
+    data, rel, note = _bound_evidence("r*_traffic.json", workload, cur_digest, cur_plan)
+    if data is None:
+        return {"bytes_per_launch": None, "source": rel, "binding": note}
     tot = n = 0
     for k, v in data.items():
         if k.startswith(pref):
@@ -77,21 +116,19 @@ def pmc_traffic(kclass, workload="birdnet"):
             n += v["dispatches"]
     if not n:
         return None
-    return {"bytes_per_launch": tot / n, "source": os.path.relpath(files[-1], ROOT)}
+    return {"bytes_per_launch": tot / n, "source": rel, "binding": note}
 
 
-def pmc_mfma_util(workload="birdnet"):
+def pmc_mfma_util(workload="birdnet", cur_digest=None, cur_plan=None):
     """BASELINE.md section 4's figure: MFMA-pipe utilisation of the pointwise-conv + dense kernels over THEIR OWN time, from the
     newest committed PMC pass (profiles/rNN_mfma_util.json, tools/pmc_summary.py): SQ_VALU_MFMA_BUSY_CYCLES summed over the
-    class's dispatches / (their summed durations x 2.4 GHz x 1024 SIMDs).  Counters cannot be collected inside the timed run."""
-    import glob
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_util.json"))
-                   if ("perch" in os.path.basename(f)) == (workload == "perch"))
-    if not files:
-        return None
-    d = json.load(open(files[-1]))
+    class's dispatches / (their summed durations x 2.4 GHz x 1024 SIMDs), bound to the loaded library (see _bound_evidence)."""
+    d, rel, note = _bound_evidence("r*_mfma_util.json", workload, cur_digest, cur_plan)
+    if d is None:
+        return {"source": rel, "binding": note, "pointwise_and_dense": None, "expand_dw": None,
+                "target": ">= 0.40 over the pointwise + dense kernels' own time (BASELINE.md section 4)"}
     cls = d.get("classes", {})
-    out = {"source": os.path.relpath(files[-1], ROOT), "numerator": d.get("numerator"), "denominator": d.get("denominator"),
+    out = {"source": rel, "binding": note, "numerator": d.get("numerator"), "denominator": d.get("denominator"),
            "pointwise_and_dense": cls.get("pw_gemm", {}).get("mfma_util"), "expand_dw": cls.get("expand_dw", {}).get("mfma_util"),
            "valu_per_mfma": {k: v.get("valu_per_mfma") for k, v in cls.items() if v.get("valu_per_mfma")},
            "target": ">= 0.40 over the pointwise + dense kernels' own time (BASELINE.md section 4)"}
@@ -648,6 +685,8 @@ def run_model(args):
                                    if perch else
                                    "BASELINE configs[1]: BirdNET v2.4 fp32, batch 256 x 3 s @ 48 kHz per GPU, "
                                    "mel front-end + CNN + head on device, raw logits out",
+                       "inputs": "device-resident (device-only): the clips are in HBM when the timed region starts; rates through the "
+                                 "blocking host-pointer entries (PCIe-inclusive) are in `host_pointer`",
                        "batch_per_gpu": B, "n_samples": cfg.n_samples, "n_classes": clf.num_species(),
                        "sharding": f"clips index-contiguous over {world} rank(s); weights broadcast once",
                        "pipeline_depth": depth, "input_sets": NSETS},
@@ -698,10 +737,12 @@ def run_model(args):
             roof["flop_per_byte"] = intensity
             if pipe_note:
                 roof["pipes"] = pipe_note
-            tr = pmc_traffic(dom["kernel"], args.workload)
+            cur_dig, cur_plan = lib_digest(), plan_signature(clf.describe())
+            tr = pmc_traffic(dom["kernel"], args.workload, cur_dig, cur_plan)
             if tr:
                 roof["traffic"] = tr["bytes_per_launch"]
                 roof["traffic_source"] = tr["source"]
+                roof["traffic_binding"] = tr["binding"]
             roof["launches"] = dom["launches"]
             roof["avg_launch_ms"] = per_launch_ms
             desc = clf.describe()
@@ -728,9 +769,11 @@ def run_model(args):
                     roof["exclusive"] = {"achieved": ex, "frac": ex / roof["peak"], "avg_launch_ms": w["ms"] / w["launches"],
                                          "launches": w["launches"]}
             out["roofline"] = roof
-            mu = pmc_mfma_util(args.workload)
+            mu = pmc_mfma_util(args.workload, cur_dig, cur_plan)
             if mu:
                 out["mfma_util"] = mu
+            out["evidence"] = {"lib_digest": cur_dig, "plan_signature": cur_plan, "tune_file": os.environ.get("BNHIP_TUNE_FILE") or None,
+                               "note": "counter files under profiles/ are quoted only when they were collected on this library digest"}
             wsum = sum(r["ms"] for r in warm_prof) or 1.0
             roof["share_of_kernel_time"] = next((r["ms"] for r in warm_prof if r["kernel"] == dom["kernel"]), 0.0) / wsum
             out["kernels_warmup_pass"] = [{"kernel": r["kernel"], "ms_per_step": r["ms"], "launches_per_step": r["launches"],

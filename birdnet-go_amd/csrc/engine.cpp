@@ -1793,11 +1793,24 @@ void Engine::tune_or_load() {
 }
 
 // One line per step: what the three create-time tuners decide (tile shapes, kernel flavour, LDS-staged depthwise, slab counts).
-static const char* kTuneMagic = "bnhip-tuning-1";
+static const char* kTuneMagic = "bnhip-tuning-2";
+// what a tuning was made FOR, beyond the step names: every step's geometry, the clip length and the device architecture
+// (the header of version 1 carried none of them)
+static unsigned long long tune_plan_hash(const Engine& e) {
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&](long long v) { for (int b = 0; b < 8; b++) { h ^= (unsigned long long)(v >> (8 * b)) & 0xff; h *= 1099511628211ull; } };
+    mix(e.n_samples); mix(e.n_classes);
+    for (const Step& s : e.steps) { mix((int)s.kind); mix(s.H); mix(s.W); mix(s.C); mix(s.Co); mix(s.Ho); mix(s.Wo); mix(s.kh); mix(s.kw); mix(s.sh); mix(s.sw); mix(s.act); }
+    hipDeviceProp_t pr{};
+    if (e.device >= 0 && hipGetDeviceProperties(&pr, e.device) == hipSuccess)
+        for (const char* c = pr.gcnArchName; *c && *c != ':'; c++) mix(*c);
+    else (void)hipGetLastError();
+    return h;
+}
 bool Engine::save_tuning(const char* path) const {
     FILE* f = fopen(path, "w");
     if (!f) return false;
-    fprintf(f, "%s %zu %d %d %d %d %d\n", kTuneMagic, steps.size(), max_batch, depth, host_depth, precision, bf16x3);
+    fprintf(f, "%s %zu %d %d %d %d %d %llx\n", kTuneMagic, steps.size(), max_batch, depth, host_depth, precision, bf16x3, tune_plan_hash(*this));
     for (size_t i = 0; i < steps.size(); i++) {
         const Step& s = steps[i];
         fprintf(f, "%zu %d %d %d %d %d %d %d %d %d %s\n", i, (int)s.kind, s.nt, s.wm, s.nt_full, s.wm_full, s.shape, s.dwl, s.bx, s.S, s.name.c_str());
@@ -1808,9 +1821,9 @@ bool Engine::save_tuning(const char* path) const {
 bool Engine::load_tuning(const char* path) {
     FILE* f = fopen(path, "r");
     if (!f) return false;
-    char magic[32] = {0}; size_t n = 0; int mb = 0, dp = 0, hd = 0, pr = 0, bx = 0;
-    bool ok = fscanf(f, "%31s %zu %d %d %d %d %d", magic, &n, &mb, &dp, &hd, &pr, &bx) == 7 && !strcmp(magic, kTuneMagic) && n == steps.size() &&
-              mb == max_batch && dp == depth && hd == host_depth && pr == precision && bx == bf16x3;
+    char magic[32] = {0}; size_t n = 0; int mb = 0, dp = 0, hd = 0, pr = 0, bx = 0; unsigned long long ph = 0;
+    bool ok = fscanf(f, "%31s %zu %d %d %d %d %d %llx", magic, &n, &mb, &dp, &hd, &pr, &bx, &ph) == 8 && !strcmp(magic, kTuneMagic) && n == steps.size() &&
+              mb == max_batch && dp == depth && hd == host_depth && pr == precision && bx == bf16x3 && ph == tune_plan_hash(*this);
     struct Row { int kind, nt, wm, ntf, wmf, shape, dwl, bx, S; };
     std::vector<Row> rows(ok ? n : 0);
     for (size_t i = 0; ok && i < n; i++) {

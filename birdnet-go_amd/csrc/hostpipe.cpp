@@ -3,6 +3,8 @@
 // the caller's slice is only read before the entry returns).
 #include "hostpipe.h"
 
+#include <cstdint>
+
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -222,14 +224,27 @@ int ensure_pipe(Engine& e, const HostJob& j, size_t chunk_bytes, std::string& er
 // Is [p, p + bytes) page-locked host memory the runtime knows (bnhip_host_alloc / hipHostMalloc / hipHostRegister)?  Then the
 // copy engines can read / write it directly and the staging pass through the pinned slots is skipped: the reference's own
 // accelerator shim keeps a C-allocated input buffer for the same reason (backend_openvino.go:673-680).
+static std::atomic<long> g_pinned_inputs{0};      // diagnostics: pipelined calls whose input was recognised as page-locked (a test asserts the path is taken)
+// The whole range must lie inside ONE allocation: two pinned allocations with pageable pages between them would pass a probe of
+// the first and last byte.  hipMemGetAddressRange gives the allocation's base and size where the runtime answers it
+// for host allocations; where it does not, the two probes must at least map to device addresses exactly bytes - 1 apart with the
+// same owner and flags - anything else takes the staging path, which is always correct.
 bool is_pinned(const void* p, size_t bytes) {
     if (!p || !bytes) return false;
     hipPointerAttribute_t a{};
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
     if (a.type != hipMemoryTypeHost) return false;
+    void* base = nullptr; size_t size = 0;
+    if (hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t*>(&base), &size, const_cast<void*>(p)) == hipSuccess && base && size) {
+        const uintptr_t lo = reinterpret_cast<uintptr_t>(base), q = reinterpret_cast<uintptr_t>(p);
+        return q >= lo && bytes <= size && q - lo <= size - bytes;
+    }
+    (void)hipGetLastError();
     hipPointerAttribute_t b{};
     if (hipPointerGetAttributes(&b, (const char*)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return b.type == hipMemoryTypeHost;
+    if (b.type != hipMemoryTypeHost || b.device != a.device || b.allocationFlags != a.allocationFlags) return false;
+    if (!a.devicePointer || !b.devicePointer) return false;
+    return reinterpret_cast<uintptr_t>(b.devicePointer) - reinterpret_cast<uintptr_t>(a.devicePointer) == bytes - 1;
 }
 
 int ensure_small_topk(Engine& e, int k, std::string& err) {
@@ -353,6 +368,7 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
     for (int c = 0; c < Engine::kMaxDepth; c++) if (e.ctx_stream[c]) hipStreamSynchronize(e.ctx_stream[c]);
 
     const bool src_pinned = is_pinned(j.src, (size_t)j.n_clips * clip_bytes);
+    if (src_pinned) g_pinned_inputs.fetch_add(1, std::memory_order_relaxed);
     const bool logits_pinned = j.logits && is_pinned(j.logits, (size_t)j.n_clips * e.n_classes * 4);
     const bool emb_pinned = j.emb && is_pinned(j.emb, (size_t)j.n_clips * e.emb_dim * 4);
     auto chunk_n = [&](int c) { return csize[c]; };
@@ -475,3 +491,5 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
 }
 
 }  // namespace bnhip
+
+extern "C" long bnhip_debug_pinned_inputs(void) { return bnhip::g_pinned_inputs.load(std::memory_order_relaxed); }

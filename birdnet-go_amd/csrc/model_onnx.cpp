@@ -287,7 +287,18 @@ bool fold_node(const ONode& nd, const std::vector<CT>& in, const std::vector<boo
     if (op == "Cast" && has(0)) {
         const int64_t to = nd.ai("to", 0);
         *out = in[0];
-        if (to == 7 || to == 6) { if (!in[0].is_int) { out->is_int = true; out->iv.resize(in[0].fv.size()); for (size_t k = 0; k < in[0].fv.size(); k++) out->iv[k] = (int64_t)in[0].fv[k]; out->fv.clear(); } return true; }
+        if (to == 7 || to == 6) {
+            if (!in[0].is_int) {
+                // (float -> integer of a NaN, an infinity or a value beyond the target's range is undefined behaviour in C++ and
+                // implementation-defined in ONNX: such a node is not folded - the graph then fails planning instead of silently folding garbage)
+                const float lim = to == 6 ? 2147483520.f : 9.2233715e18f;
+                for (float v : in[0].fv) if (!(v > -lim && v < lim)) return false;
+                out->is_int = true; out->iv.resize(in[0].fv.size());
+                for (size_t k = 0; k < in[0].fv.size(); k++) out->iv[k] = (int64_t)in[0].fv[k];
+                out->fv.clear();
+            }
+            return true;
+        }
         if (to == 1) { if (in[0].is_int) { out->is_int = false; out->fv.resize(in[0].iv.size()); for (size_t k = 0; k < in[0].iv.size(); k++) out->fv[k] = (float)in[0].iv[k]; out->iv.clear(); } return true; }
         return false;
     }
@@ -303,7 +314,10 @@ bool fold_node(const ONode& nd, const std::vector<CT>& in, const std::vector<boo
         if (v.is_int) out->iv.assign(n, v.iv[0]); else out->fv.assign(n, v.fv[0]);
         return true;
     }
-    if (op == "Shape" && has(0)) { out->is_int = true; out->dims = {(int64_t)in[0].dims.size()}; out->iv = in[0].dims; return true; }
+    if (op == "Shape" && has(0)) {
+        if (nd.attr("start") || nd.attr("end")) return false;          // (opset 15's sliced Shape: not folded - the full shape would be wrong)
+        out->is_int = true; out->dims = {(int64_t)in[0].dims.size()}; out->iv = in[0].dims; return true;
+    }
     if (op == "Concat") {
         if (in.empty()) return false;
         for (size_t k = 0; k < in.size(); k++) if (!present[k] || in[k].is_int != in[0].is_int || in[k].dims.size() != in[0].dims.size()) return false;
@@ -391,6 +405,9 @@ bool fold_node(const ONode& nd, const std::vector<CT>& in, const std::vector<boo
             int64_t ax = axes[k]; if (ax < 0) ax += r;
             if (ax < 0 || ax >= r || steps[k] == 0) return false;
             const int64_t n = in[0].dims[ax];
+            // (a step beyond the axis length selects what a step of n + 1 selects; clamping keeps the count arithmetic below away from
+            // INT64 overflow - steps come from the model file)
+            steps[k] = std::min<int64_t>(std::max<int64_t>(steps[k], -(n + 1)), n + 1);
             int64_t a = in[1].iv[k], b = in[2].iv[k];
             if (steps[k] > 0) {
                 if (a < 0) a += n; if (b < 0) b += n;
@@ -439,8 +456,10 @@ bool fold_node(const ONode& nd, const std::vector<CT>& in, const std::vector<boo
         out->is_int = true; out->dims = a.size() >= b.size() ? a.dims : b.dims; out->iv.resize(n);
         for (size_t k = 0; k < n; k++) {
             const int64_t x = a.iv[a.size() == 1 ? 0 : k], y = b.iv[b.size() == 1 ? 0 : k];
-            if (op == "Div" && y == 0) return false;
-            out->iv[k] = op == "Add" ? x + y : op == "Sub" ? x - y : op == "Mul" ? x * y : x / y;
+            if (op == "Div" && (y == 0 || (y == -1 && x == INT64_MIN))) return false;
+            // (values come from the model file: wrap like two's-complement hardware instead of signed-overflow UB)
+            const uint64_t ux = (uint64_t)x, uy = (uint64_t)y;
+            out->iv[k] = op == "Add" ? (int64_t)(ux + uy) : op == "Sub" ? (int64_t)(ux - uy) : op == "Mul" ? (int64_t)(ux * uy) : x / y;
         }
         return true;
     }

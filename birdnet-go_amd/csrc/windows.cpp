@@ -16,7 +16,7 @@ WindowAssembler::WindowAssembler(size_t overlap_bytes, size_t read_bytes, int ma
 
 int WindowAssembler::add_source(const std::string& id, size_t capacity) {
     if (capacity < read_ || capacity == 0) return -1;       // analysis.go:91-100 (capacity must hold one read)
-    auto s = std::make_unique<Source>();
+    auto s = std::make_shared<Source>();
     s->id = id;
     s->ring.assign(capacity, 0);
     s->prev.assign(overlap_, 0);
@@ -30,6 +30,7 @@ int WindowAssembler::add_source(const std::string& id, size_t capacity) {
 bool WindowAssembler::remove_source(int source) {
     std::unique_lock<std::shared_mutex> lk(table_mu_);
     if (source < 0 || (size_t)source >= src_.size() || !src_[source]) return false;
+    { std::lock_guard<std::mutex> g(src_[source]->mu); src_[source]->removed = true; }     // (a collect in flight may still hold it)
     src_[source].reset();
     return true;
 }
@@ -70,7 +71,7 @@ bool WindowAssembler::write(int source, const void* data, size_t n) {
 // window's last `overlap` bytes (zeros the first time), then `read` fresh bytes; the new tail is the window's last `overlap` bytes.
 bool WindowAssembler::read_window(Source& s, uint8_t* win) {
     std::lock_guard<std::mutex> g(s.mu);
-    if (s.n < read_) return false;
+    if (s.removed || s.n < read_) return false;
     if (overlap_) {
         if (s.have_prev) std::memcpy(win, s.prev.data(), overlap_);
         else std::memset(win, 0, overlap_);
@@ -160,11 +161,12 @@ RowPool& row_pool() {
 
 int WindowAssembler::collect_begin(int cap, int* sources) {
     collect_mu_.lock();
-    table_mu_.lock_shared();
+    held_.clear();
+    std::shared_lock<std::shared_mutex> lk(table_mu_);      // released on return: the rows' sources are held by reference
     const size_t ns = src_.size();
     if (!ns || cap <= 0) return 0;
     cap = std::min(cap, max_batch_);
-    // who is ready (only the collecting thread consumes, so a ready source stays ready unless it is reset in between)
+    // who is ready (only the collecting thread consumes, so a ready source stays ready unless it is reset or removed in between)
     int k = 0;
     size_t i = 0;
     const size_t start = next_ % ns;
@@ -172,7 +174,7 @@ int WindowAssembler::collect_begin(int cap, int* sources) {
         const size_t idx = (start + i) % ns;
         if (!src_[idx]) continue;
         std::lock_guard<std::mutex> g(src_[idx]->mu);
-        if (src_[idx]->n >= read_) sources[k++] = (int)idx;
+        if (src_[idx]->n >= read_) { sources[k++] = (int)idx; held_.push_back(src_[idx]); }
     }
     next_ = (start + i) % ns;                                // behind the last source looked at
     return k;
@@ -183,14 +185,14 @@ void WindowAssembler::collect_rows(uint8_t* batch, int* sources, int first, int 
     auto fill = [&](int q) {
         const int r = first + q;
         uint8_t* row = batch + (size_t)r * wb;
-        if (sources[r] < 0 || !read_window(*src_[sources[r]], row)) { std::memset(row, 0, wb); sources[r] = -1; }
+        if (sources[r] < 0 || (size_t)r >= held_.size() || !read_window(*held_[r], row)) { std::memset(row, 0, wb); sources[r] = -1; }
     };
     if ((size_t)n * wb >= ((size_t)4 << 20) && n > 1) row_pool().run(n, fill);
     else for (int q = 0; q < n; q++) fill(q);
 }
 
 void WindowAssembler::collect_end() {
-    table_mu_.unlock_shared();
+    held_.clear();
     collect_mu_.unlock();
 }
 

@@ -41,8 +41,11 @@ class WindowAssembler {
     int collect(uint8_t* batch, int cap, int* sources);
     // The same in steps, for a consumer that overlaps the copies with something else (api.cpp bnhip_windows_predict_topk: the
     // host pipeline fills chunk c + 1's rows while chunk c is on the device).  begin: who is ready (row r <- sources[r]); holds
-    // the collect and table locks until end, which the same thread must call.  rows: fills rows [first, first + n) - callable
-    // from several threads on disjoint ranges; a source that was reset since begin yields a row of zeros and sources[r] = -1.
+    // the COLLECT lock until end, which the same thread must call - the table lock is released before begin returns (the ready
+    // sources are pinned by reference for the duration), so add_source / remove_source / write never wait for a device call
+    // (on a writer-preferring shared mutex a pending remove_source stalled every capture thread until the call
+    // ended).  rows: fills rows [first, first + n) - callable from several threads on disjoint ranges; a source that was reset
+    // or removed since begin yields a row of zeros and sources[r] = -1.
     int collect_begin(int cap, int* sources);
     void collect_rows(uint8_t* batch, int* sources, int first, int n);
     void collect_end();
@@ -58,6 +61,7 @@ class WindowAssembler {
         std::vector<uint8_t> ring, prev;
         size_t r = 0, n = 0;                                 // read position, unread bytes
         bool have_prev = false;
+        bool removed = false;                                // remove_source() ran: a collect that still holds a reference reads nothing
         uint64_t writes = 0, overwrites = 0;
     };
     bool read_window(Source& s, uint8_t* win);
@@ -65,8 +69,9 @@ class WindowAssembler {
     const size_t overlap_, read_;
     const int max_batch_;
     mutable std::shared_mutex table_mu_;                     // the table; a source's bytes are under its own mutex
-    std::vector<std::unique_ptr<Source>> src_;               // nullptr = free slot
+    std::vector<std::shared_ptr<Source>> src_;               // nullptr = free slot
     std::mutex collect_mu_;                                  // one collect() at a time (writers run beside it)
+    std::vector<std::shared_ptr<Source>> held_;              // collect_begin .. collect_end: the sources of the rows, under collect_mu_
     size_t next_ = 0;                                        // where the next collect() starts
 };
 

@@ -412,7 +412,8 @@ func (c *Classifier) Close() {
 
 // PinnedF32 is a float32 slice over page-locked memory (bnhip_host_alloc) for batch callers: fill Data, pass it to PredictBatch /
 // PredictTopK - the library recognises pinned memory per call and lets the copy engines read it directly instead of staging it.
-// The memory is C-owned: Free it, do not let the slice outlive Free.
+// The memory is C-owned: Free it, do not let the slice (or a sub-slice of it) outlive Free, and do not Free it while a Predict
+// call that was handed the slice is still running - nothing on the Go side tracks either.
 type PinnedF32 struct {
 	Data []float32
 	p    unsafe.Pointer
@@ -466,12 +467,19 @@ func (c *Classifier) PredictPCM16(pcm []byte, batchSize int) ([]float32, error) 
 // window ready lands in a row of one page-locked batch buffer, which PredictWindows hands to the device as it is.  Where the
 // reference queues one batch-1 Predict per window behind Orchestrator.inferenceMu (internal/classifier/orchestrator.go:531),
 // a tick is one device call.  Write may be called from any capture goroutine; Collect / PredictWindows from one at a time.
+//
+// Lifetimes: every `windows` slice handed out below is a VIEW of the library's batch buffer (C memory): the next tick
+// overwrites it and Close frees it.  Copy what must outlive the tick (the reference copies the PCM into its Results message
+// too, process.go:364-372).  Close waits for a tick or a Write in flight (life) and ticks exclude each other (tick), so a
+// Close racing a poll loop can neither free the buffer under a device call nor hand the C side a dead handle.
 type WindowAssembler struct {
 	h           *C.bnhip_windows
 	windowBytes int
 	maxBatch    int
 	pinned      bool
-	sources     []C.int // scratch of Collect
+	sources     []C.int      // scratch of Collect
+	tick        sync.Mutex   // one Collect / PredictWindows* at a time
+	life        sync.RWMutex // readers: every call that uses h; writer: Close
 }
 
 // NewWindowAssembler: overlapBytes + readBytes = the model's clip in bytes (ModelSpec.BufferDimensions, model.go:33-56).
@@ -493,6 +501,8 @@ func NewWindowAssembler(overlapBytes, readBytes, maxBatch int) (*WindowAssembler
 
 // AddSource = NewAnalysisBuffer(capacity, overlap, read, sourceID) for one more source; the index names it from then on.
 func (w *WindowAssembler) AddSource(sourceID string, capacity int) (int, error) {
+	w.life.RLock()
+	defer w.life.RUnlock()
 	if w.h == nil {
 		return -1, errors.New("hip: window assembler is closed")
 	}
@@ -511,6 +521,8 @@ func (w *WindowAssembler) AddSource(sourceID string, capacity int) (int, error) 
 }
 
 func (w *WindowAssembler) RemoveSource(source int) error {
+	w.life.RLock()
+	defer w.life.RUnlock()
 	if w.h == nil {
 		return nil
 	}
@@ -525,6 +537,8 @@ func (w *WindowAssembler) RemoveSource(source int) error {
 // Write = AnalysisBuffer.Write (analysis.go:152-175): never blocks on the consumer, the oldest unread bytes go when the ring
 // is full.  The bytes are copied before it returns.
 func (w *WindowAssembler) Write(source int, data []byte) error {
+	w.life.RLock()
+	defer w.life.RUnlock()
 	if w.h == nil {
 		return errors.New("hip: window assembler is closed")
 	}
@@ -542,6 +556,15 @@ func (w *WindowAssembler) Write(source int, data []byte) error {
 // Collect reads every source that has a window ready (at most maxBatch; the next call resumes behind the last source looked
 // at).  windows is a view of the library's batch buffer - row k belongs to sources[k] - valid until the next Collect.
 func (w *WindowAssembler) Collect() (sources []int, windows []byte, err error) {
+	w.tick.Lock()
+	defer w.tick.Unlock()
+	w.life.RLock()
+	defer w.life.RUnlock()
+	return w.collectLocked()
+}
+
+// collectLocked: the caller holds tick and life.
+func (w *WindowAssembler) collectLocked() (sources []int, windows []byte, err error) {
 	if w.h == nil {
 		return nil, nil, errors.New("hip: window assembler is closed")
 	}
@@ -565,6 +588,8 @@ func (w *WindowAssembler) Collect() (sources []int, windows []byte, err error) {
 // OverwriteStats: the OverwriteTracker's inputs for one source (buffer/overwrite.go) - writes and overwriting writes since
 // creation or Reset.  The rate window and the notification policy stay with the caller.
 func (w *WindowAssembler) OverwriteStats(source int) (writes, overwrites uint64, err error) {
+	w.life.RLock()
+	defer w.life.RUnlock()
 	if w.h == nil {
 		return 0, 0, errors.New("hip: window assembler is closed")
 	}
@@ -579,6 +604,8 @@ func (w *WindowAssembler) OverwriteStats(source int) (writes, overwrites uint64,
 
 // Reset = AnalysisBuffer.Reset (analysis.go:270-276) for one source.
 func (w *WindowAssembler) Reset(source int) error {
+	w.life.RLock()
+	defer w.life.RUnlock()
 	if w.h == nil {
 		return nil
 	}
@@ -593,7 +620,12 @@ func (w *WindowAssembler) Reset(source int) error {
 func (w *WindowAssembler) WindowBytes() int { return w.windowBytes }
 func (w *WindowAssembler) Pinned() bool     { return w.pinned }
 
+// Close frees the rings and the batch buffer; every slice a tick handed out dangles from here on.  Waits for calls in flight.
 func (w *WindowAssembler) Close() {
+	w.tick.Lock()
+	defer w.tick.Unlock()
+	w.life.Lock()
+	defer w.life.Unlock()
 	if w.h != nil {
 		C.bnbind_win_destroy(w.h)
 		w.h = nil
@@ -604,7 +636,8 @@ func (w *WindowAssembler) Close() {
 // windows straight from the assembler's batch buffer (16-bit capture, conf.BytesPerSample; the /32768 conversion of
 // process.go:479-497 runs on the device).  Returns the source of each row and flat [len(sources)*nClasses] logits; nothing
 // ready = (nil, nil, nil), the reference's "try again later".  The caller builds one Results message per row, as ProcessData
-// does per window (process.go:327-420); windows is the PCM it must copy into the message before the next tick.
+// does per window (process.go:327-420); windows is the PCM it must copy into the message before the next tick (a view of C
+// memory: the next tick overwrites it, Close frees it).  On a failed device call sources still lists who gave up a window.
 func (c *Classifier) PredictWindows(w *WindowAssembler) (sources []int, windows []byte, logits []float32, err error) {
 	if c.h == nil {
 		return nil, nil, nil, errors.New("hip: classifier is closed")
@@ -612,7 +645,11 @@ func (c *Classifier) PredictWindows(w *WindowAssembler) (sources []int, windows 
 	if w.windowBytes != c.nSamples*2 {
 		return nil, nil, nil, fmt.Errorf("window size mismatch: assembler %d bytes, model clip %d bytes", w.windowBytes, c.nSamples*2)
 	}
-	sources, windows, err = w.Collect()
+	w.tick.Lock()
+	defer w.tick.Unlock()
+	w.life.RLock()
+	defer w.life.RUnlock()
+	sources, windows, err = w.collectLocked()
 	if err != nil || len(sources) == 0 {
 		return nil, nil, nil, err
 	}
@@ -621,23 +658,30 @@ func (c *Classifier) PredictWindows(w *WindowAssembler) (sources []int, windows 
 	defer runtime.UnlockOSThread()
 	if rc := C.bnbind_predict_pcm16(c.h, (*C.int16_t)(unsafe.Pointer(&windows[0])), C.int(len(sources)),
 		(*C.float)(unsafe.Pointer(&logits[0])), nil); rc != 0 {
-		return nil, nil, nil, fmt.Errorf("hip: predict_pcm16 failed (%d): %s", int(rc), lastError())
+		// the listed sources have given up their window all the same (their overlap tails advanced): the caller gets the list
+		// with the error, as the reference's monitor has consumed its window before ProcessData fails (buffer_manager.go:494-499)
+		return sources, nil, nil, fmt.Errorf("hip: predict_pcm16 failed (%d): %s", int(rc), lastError())
 	}
 	return sources, windows, logits, nil
 }
 
 // PredictWindowsTopK is PredictWindows with (*BirdNET).Predict's post-processing on the device as well: per ready window the
 // k best confidences float32(1/(1+exp(-sensitivity*float64(x)))) and their label indices, descending (analyze.go:113-115,
-// 197-208, 220-301) - the logits never reach the host.  conf / idx are flat [len(sources)*min(k, nClasses)].
+// 197-208, 220-301) - the logits never reach the host.  conf / idx are flat [len(sources)*min(k, nClasses)].  On a failed device
+// call sources still lists who gave up a window (everything else nil); windows is a view valid until the next tick or Close.
 func (c *Classifier) PredictWindowsTopK(w *WindowAssembler, k int, sensitivity float64) (sources []int, windows []byte, conf []float32, idx []int32, err error) {
 	if c.h == nil {
 		return nil, nil, nil, nil, errors.New("hip: classifier is closed")
 	}
-	if w.h == nil {
-		return nil, nil, nil, nil, errors.New("hip: window assembler is closed")
-	}
 	if k <= 0 {
 		return nil, nil, nil, nil, errors.New("hip: k must be positive")
+	}
+	w.tick.Lock()
+	defer w.tick.Unlock()
+	w.life.RLock()
+	defer w.life.RUnlock()
+	if w.h == nil {
+		return nil, nil, nil, nil, errors.New("hip: window assembler is closed")
 	}
 	kk := k
 	if kk > c.nClasses {
@@ -652,8 +696,16 @@ func (c *Classifier) PredictWindowsTopK(w *WindowAssembler, k int, sensitivity f
 	var batch unsafe.Pointer
 	if rc := C.bnbind_win_predict_topk(w.h, c.h, 16, 0, C.double(sensitivity), C.int(k), &w.sources[0], &n,
 		(*C.float)(unsafe.Pointer(&cbuf[0])), (*C.int32_t)(unsafe.Pointer(&ibuf[0])), &batch); rc != 0 {
-		// (the n listed sources have given up their window all the same, buffer_manager.go:494-499)
-		return nil, nil, nil, nil, fmt.Errorf("hip: windows_predict_topk failed (%d): %s", int(rc), lastError())
+		// the n listed sources have given up their window all the same (buffer_manager.go:494-499; the C call reports them
+		// on failure too): the caller gets the list with the error and knows which sources lost a window
+		err = fmt.Errorf("hip: windows_predict_topk failed (%d): %s", int(rc), lastError())
+		if n > 0 {
+			sources = make([]int, int(n))
+			for i := range sources {
+				sources[i] = int(w.sources[i])
+			}
+		}
+		return sources, nil, nil, nil, err
 	}
 	if n == 0 {
 		return nil, nil, nil, nil, nil

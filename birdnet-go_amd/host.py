@@ -106,7 +106,8 @@ def init():
 class PinnedArray:
     """A numpy array over page-locked memory from bnhip_host_alloc (the reference's shim keeps a C-allocated input buffer per
     classifier, backend_openvino.go:673-680): bnhip_predict* read / write such buffers by DMA, without the staging copy.
-    `.array` is the view; free() (or the with-statement) releases it."""
+    `.array` is the view; free() (or the with-statement) releases it.  The memory is C-owned: views or slices of `.array` taken
+    before free() dangle afterwards (numpy cannot know) - copy what must outlive it, and never free() during a predict call."""
 
     def __init__(self, shape, dtype=np.float32):
         self._lib = load_library()

@@ -158,11 +158,22 @@ def test_go_shim_pins_the_os_thread_around_error_fetch():
     for fn in ("func Init(", "func NewClassifierWithOptions(", "func (c *Classifier) predict(", "func (c *Classifier) PredictBatch(",
                "func (c *Classifier) predictTopK(", "func (c *Classifier) PredictPCM16(", "func ComputeUSFrameCV(", "func NewResampler(",
                "func (r *Resampler) ResampleTo(", "func (r *Resampler) Flush(", "func NewWindowAssembler(", "func (w *WindowAssembler) AddSource(",
-               "func (w *WindowAssembler) Write(", "func (w *WindowAssembler) Collect(", "func (c *Classifier) PredictWindows(", "func (c *Classifier) PredictWindowsTopK("):
+               "func (w *WindowAssembler) Write(", "func (w *WindowAssembler) collectLocked(", "func (c *Classifier) PredictWindows(", "func (c *Classifier) PredictWindowsTopK("):
         body = src[src.index(fn):]
         body = body[:body.index("\n}\n")]
         assert "runtime.LockOSThread()" in body and "defer runtime.UnlockOSThread()" in body, fn
     assert src.index("#include <stdio.h>") < src.index("snprintf")
+    # a tick cannot race Close (ticks exclude each other, Close waits for calls in flight), and a failed device call
+    # still tells the host which sources gave up a window
+    close_body = src[src.index("func (w *WindowAssembler) Close("):]
+    close_body = close_body[:close_body.index("\n}\n")]
+    assert "w.tick.Lock()" in close_body and "w.life.Lock()" in close_body
+    for fn in ("func (w *WindowAssembler) Collect(", "func (c *Classifier) PredictWindows(", "func (c *Classifier) PredictWindowsTopK("):
+        body = src[src.index(fn):]
+        body = body[:body.index("\n}\n")]
+        assert "w.tick.Lock()" in body and "w.life.RLock()" in body, fn
+    topk = src[src.index("func (c *Classifier) PredictWindowsTopK("):]
+    assert "return sources, nil, nil, nil, err" in topk[:topk.index("\n}\n")]
 
 
 @pytest.mark.gpu

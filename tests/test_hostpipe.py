@@ -182,8 +182,15 @@ def test_pinned_caller_buffers_are_bit_identical_and_skip_the_staging(gpu, full_
                 host.PinnedArray((n, clf.num_species()), np.float32) as po:
             pi.array[:] = x; pp.array[:] = pcm
             po.array[:] = np.nan
+            import ctypes
+            lib = host.load_library()
+            lib.bnhip_debug_pinned_inputs.restype = ctypes.c_long
+            before = lib.bnhip_debug_pinned_inputs()
             got = clf.predict_batch(pi.array.reshape(-1), n, out=po.array)
             assert got.ctypes.data == po.array.ctypes.data and np.array_equal(got, ref)
+            assert lib.bnhip_debug_pinned_inputs() == before + 1          # recognised (whole range inside one allocation), not staged
+            # pageable input is not counted (it goes through the pinned staging slots)
+            assert np.array_equal(clf.predict_batch(x.reshape(-1), n), ref) and lib.bnhip_debug_pinned_inputs() == before + 1
             assert np.array_equal(clf.predict_batch(pi.array.reshape(-1), n), ref)             # pinned in, pageable out
             po.array[:] = np.nan
             assert np.array_equal(clf.predict_batch(x.reshape(-1), n, out=po.array), ref)      # pageable in, pinned out

@@ -114,6 +114,38 @@ def _crafted_onnx():
     return out
 
 
+def _crafted_fold_arithmetic():
+    """constant folding on values taken from the file - Slice steps of INT64_MAX / INT64_MIN (signed overflow in the
+    count arithmetic), an opset-15 Shape with `start` (the full shape is not its value), Cast of NaN / inf / 1e30 to int64, and
+    integer Div / Mul at the ends of the range.  Valid or not, none may trip UBSan."""
+    from birdnet_go_amd.onnx_build import OnnxBuilder
+    out = []
+    i64 = lambda *v: np.asarray(v, np.int64)
+    for step, a, e in ((2 ** 63 - 1, 0, 8), (-(2 ** 63), 7, -(2 ** 62)), (-(2 ** 63) + 1, 7, -9)):
+        b = OnnxBuilder()
+        x = b.input("x", ["N", 8])
+        c = b.init(np.arange(8, dtype=np.float32))
+        sl = b.node("Slice", [c, b.init(i64(a)), b.init(i64(e)), b.init(i64(0)), b.init(i64(step))])
+        b.output(b.node("Add", [x, sl]), ["N", 8])
+        out.append(b.finish())
+    b = OnnxBuilder()
+    x = b.input("x", ["N", 8])
+    sh = b.node("Shape", [b.init(np.zeros((2, 4), np.float32))], start=1)
+    b.output(b.node("Reshape", [x, b.node("Concat", [b.init(i64(-1)), sh], axis=0)]), ["N", 4])
+    out.append(b.finish())
+    b = OnnxBuilder()
+    x = b.input("x", ["N", 8])
+    k = b.node("Cast", [b.init(np.asarray([np.nan, np.inf, 1e30], np.float32))], to=7)
+    b.output(b.node("Reshape", [x, k]), ["N", 8])
+    out.append(b.finish())
+    for op, u, v in (("Div", -(2 ** 63), -1), ("Mul", 2 ** 62, 4), ("Add", 2 ** 63 - 1, 2 ** 63 - 1), ("Sub", -(2 ** 63), 1)):
+        b = OnnxBuilder()
+        x = b.input("x", ["N", 8])
+        b.output(b.node("Reshape", [x, b.node(op, [b.init(i64(u)), b.init(i64(v))])]), ["N", 8])
+        out.append(b.finish())
+    return out
+
+
 def _crafted_empty_slice_axes():
     """the reverse `Slice` behind the mel MatMul with an EMPTY `axes` initializer (dims=[0]): tail_ok() indexed
     ax[0] of an empty vector.  Written by the audio transcriber with the Slice's axes operand swapped for an empty one."""
@@ -159,6 +191,7 @@ def test_onnx_audio_front_ends_and_crafted_files_under_asan(fuzz_bin, tmp_path):
                 corpus.append(ox[:-len(tail)] + mt[:len(tail)].ljust(len(tail), b"\0"))
     crafted = _crafted_onnx() + [_crafted_empty_slice_axes()]
     corpus += crafted
+    corpus += _crafted_fold_arithmetic()          # (may be accepted - some are valid ONNX; UBSan must stay silent)
     path = tmp_path / "corpus_audio.bin"
     with open(path, "wb") as f:
         for b in corpus:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-kernel PMC averages from rocprofv3 rocpd databases (one db per --pmc pass).
-Usage: python tools/pmc_summary.py [--traffic-json OUT] [--mfma-json OUT] [--window SKIP:COUNT] <db> [<db> ...]
+Usage: python tools/pmc_summary.py [--traffic-json OUT] [--mfma-json OUT] [--binding FILE] [--window SKIP:COUNT] <db> [<db> ...]
   --window: only COUNT consecutive engine dispatches ending SKIP before the last (e.g. the timed steps: skips the create-time
     autotune launches, which would otherwise pollute the per-kernel averages with other layers' shapes)
   -> CSV on stdout: kernel, dispatches, avg_us, then every counter as an average PER DISPATCH OF THE PASS THAT COLLECTED IT.
@@ -8,6 +8,8 @@ Usage: python tools/pmc_summary.py [--traffic-json OUT] [--mfma-json OUT] [--win
      a kernel missing from a pass is an error, not a silent zero.
   --traffic-json: {kernel: {dispatches, hbm_bytes_per_launch, fetch_kib_raw, write_kib}},
     hbm bytes = FETCH_SIZE[KiB] * 1024 * 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE[KiB] * 1024.
+  --binding: a JSON object ({lib_digest, tune_sha256, plan_signature}: what the passes ran on) copied into both JSON outputs as
+    "_binding"; bench.py quotes a counter file only when its lib_digest is the loaded library's.
   --mfma-json: MFMA-pipe utilisation per kernel and per kernel class:
     SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the chip) / (kernel time * 2.4 GHz * 1024 SIMDs), kernel time taken from the
     pass that collected the counter; plus VALU : MFMA instruction ratio."""
@@ -59,11 +61,14 @@ def main():
     argv = sys.argv[1:]
     tj = mj = None
     window = None
-    while argv and argv[0] in ("--traffic-json", "--mfma-json", "--window"):
+    binding = None
+    while argv and argv[0] in ("--traffic-json", "--mfma-json", "--window", "--binding"):
         if argv[0] == "--traffic-json":
             tj = argv[1]
         elif argv[0] == "--mfma-json":
             mj = argv[1]
+        elif argv[0] == "--binding":
+            binding = json.load(open(argv[1]))
         else:
             window = tuple(int(v) for v in argv[1].split(":"))
         argv = argv[2:]
@@ -105,6 +110,8 @@ def main():
             fs, fn, _ = per["FETCH_SIZE"][k]; ws, wn, _ = per["WRITE_SIZE"][k]
             f, w = fs / max(fn, 1), ws / max(wn, 1)
             out[k] = {"dispatches": cnt0[k], "hbm_bytes_per_launch": f * 1024 * 2 + w * 1024, "fetch_kib_raw": f, "write_kib": w}
+        if binding:
+            out["_binding"] = binding
         json.dump(out, open(tj, "w"), indent=1)
     if mj and "SQ_VALU_MFMA_BUSY_CYCLES" in per:
         ker, cls = {}, defaultdict(lambda: [0.0, 0.0, 0.0, 0.0])
@@ -120,7 +127,7 @@ def main():
         json.dump({"denominator": f"kernel time (the PMC pass's own dispatch durations) x {CLK_GHZ} GHz x {N_SIMD} SIMDs",
                    "numerator": "SQ_VALU_MFMA_BUSY_CYCLES summed over the class's dispatches",
                    "classes": {c: {"mfma_util": v[0] / v[1] if v[1] else 0.0, "valu_per_mfma": (v[2] / v[3]) if v[3] else None} for c, v in cls.items()},
-                   "kernels": ker}, open(mj, "w"), indent=1)
+                   "kernels": ker, **({"_binding": binding} if binding else {})}, open(mj, "w"), indent=1)
     sys.exit(2 if odd else 0)
 
 

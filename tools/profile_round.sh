@@ -17,6 +17,15 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 export BNHIP_TUNE_FILE=$OUT/${TAG}_tune.txt
 rm -f $BNHIP_TUNE_FILE
 python bench.py $WL --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/${TAG}_bench_default.json 2> /dev/null
+# what every later pass runs on: the library's source digest, the tune file's hash, the plan signature of the bench line -
+# stamped into the counter files so that bench.py quotes them only beside the library they were collected on
+python - <<PY
+import hashlib, json
+line = json.loads(open("$OUT/${TAG}_bench_default.json").read().strip().splitlines()[-1])
+ev = line.get("evidence") or {}
+json.dump({"lib_digest": ev.get("lib_digest"), "tune_sha256": hashlib.sha256(open("$BNHIP_TUNE_FILE", "rb").read()).hexdigest(),
+           "plan_signature": ev.get("plan_signature"), "tag": "$TAG"}, open("$OUT/${TAG}_binding.json", "w"))
+PY
 BENCH="python bench.py $WL --steps 20 --warmup 3 --no-cpu-baseline --no-fp32-run --no-oracle-check --no-host-pointer --no-secondary --no-distribution"
 rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- $BENCH > $OUT/${TAG}_bench_under_rocprof.json 2> /tmp/kt.err
 DB=$(find /tmp/kt -name "*.db" | head -1)
@@ -37,7 +46,7 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU
   rocprofv3 --pmc $c -d /tmp/pmc$i -o p -- $PB > /dev/null 2>&1
   DBS="$DBS $(find /tmp/pmc$i -name '*.db' | head -1)"
 done
-python tools/pmc_summary.py --traffic-json $OUT/${TAG}_traffic.json --mfma-json $OUT/${TAG}_mfma_util.json --window $NL:$((5 * NL)) $DBS > $OUT/${TAG}_pmc.csv 2> $OUT/${TAG}_pmc_errors.txt
+python tools/pmc_summary.py --traffic-json $OUT/${TAG}_traffic.json --mfma-json $OUT/${TAG}_mfma_util.json --binding $OUT/${TAG}_binding.json --window $NL:$((5 * NL)) $DBS > $OUT/${TAG}_pmc.csv 2> $OUT/${TAG}_pmc_errors.txt
 # (the serial detail run is a depth-1 engine: its own tuning, not the pipelined one)
 BNHIP_TUNE_FILE= python bench.py $WL --depth 1 --detail --steps 5 --warmup 3 --no-cpu-baseline --no-fp32-run --no-oracle-check --no-host-pointer --no-secondary --no-distribution > /dev/null 2> $OUT/${TAG}_step_detail_depth1.txt
 echo done
