@@ -605,6 +605,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
                 size_t o_win = wpush(wfull.data(), wfull.size()), o_bins = wpush(binsf.data(), binsf.size());
                 size_t o_mel = wpush(melw.data(), melw.size());
                 std::vector<double> twt = stft_build_tables(fm.Lfft, bins.data(), fs.nb);
+                fs.stft_zmask = stft_zmask(fm.Lfft, bins.data(), fs.nb);
                 size_t o_tw = wpush(reinterpret_cast<const float*>(twt.data()), twt.size() * 2);   // fp64 image, 256-B aligned
                 specs.push_back(fs);
                 const int si = (int)specs.size() - 1;
@@ -2325,6 +2326,7 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
             case S_STFT: {
                 const FrontSpec& fs = specs[s.spec];
                 StftParams p{in0, fs.window_full, fs.bins, out, n_samples, fs.Lfft, fs.L, fs.hop, fs.F, fs.nb, fs.nbp, fs.mode, n, fs.stft_tw, fs.pad_left};
+                p.zmask = fs.stft_zmask;
                 if (s.mode == 1) {                           // fused mel epilogue: `out` is the spectrogram image
                     p.out = nullptr; p.img = out; p.mel = s.w3; p.mel_quads = s.S; p.n_mels = fs.n_mels; p.Ctot = C_spec; p.c0 = fs.c;
                     p.logc = fs.log_compress ? 1 : 0; p.time_major = fs.time_major ? 1 : 0; p.p1 = fs.p1; p.p2 = fs.p2;

@@ -72,6 +72,7 @@ struct FrontSpec {
     int nb = 0, nbp = 0, mode = 0;   // needed bins, padded to 4; 0 = real part, 1 = magnitude
     const float* window_full = nullptr;
     const double* stft_tw = nullptr;   // twiddle image of the STFT step (stft_build_tables)
+    unsigned stft_zmask = 0xffffffffu; // which outputs of the closing FFT stage the needed bins read (stft_zmask)
     const int* bins = nullptr;
     // front-end variants beyond the v2.4 MelSpec layer (Perch-style log-mel): see FrontendMatch
     bool normalize = true, log_compress = false, time_major = false;

@@ -42,6 +42,8 @@ struct StftParams {
     int pad_left = 0;             // frame f starts at sample f * hop - pad_left; samples outside [0, n_samples) are zero
     int nb_cap = 0, fpw = 0;    // set by the launcher
     int f32 = 0;                // 1: the transform in fp32 ("precision":"bf16" engines; not with the fused mel epilogue)
+    unsigned zmask = 0xffffffffu; // output pruning of the last FFT stage (stft_zmask): which of the Q outputs of the closing Q-point transforms any
+                                // needed bin reads, four bits per pass of that stage (wave-uniform); all ones = compute everything
     // fused mel epilogue (mel != nullptr): the wave that transformed a frame also applies the banded mel matrix and the
     // compression and writes the frame's n_mels values straight into the spectrogram image - the DFT bins never reach HBM.
     // mel = stft_mel_table(): [64 lanes][8] int32 {band A, first quad, quads, weight offset; band B ...} then the band
@@ -52,6 +54,7 @@ struct StftParams {
     float* img = nullptr;       // [B, n_mels, F, Ctot] (or [B, F, n_mels, Ctot] when time_major)
 };
 std::vector<double> stft_build_tables(int Lfft, const int* bins, int nb);
+unsigned stft_zmask(int Lfft, const int* bins, int nb);     // plan time: StftParams::zmask for a needed-bin list
 // Fused-mel table for launch_stft_bins: melw [n_mels][nbp] (zero outside each row's band), span [2 n_mels] = [lo, hi) per row.
 // Empty when the front-end cannot take the fused form (more than 512 bins, more than 128 bands, table too large for LDS).
 std::vector<float> stft_mel_table(int Lfft, const float* melw, const int* span, int n_mels, int nb, int nbp, int* quads);

@@ -344,6 +344,11 @@ void launch_pw_ws(const PwParams& p, const uint16_t* Wimg, int Npad, hipStream_t
 #undef WS_ONE
 }
 
+// (k_pw_f32s - the fp32 twin of k_pw_b16s for the HBM-bound early projections 32 -> 16, 96 -> 24, 144 -> 24: the whole weight matrix
+// as f32-MFMA operands in a wave's registers, 16-byte loads, MFMAs and 16-byte stores, no LDS, no barrier, bit-identical to
+// k_pw_gemm - was built and measured in round 5: 128 / 92 / 151 us against 104 / 81 / 137 us for the tiled kernel, whatever the
+// number of waves; those layers already move 4.4-5.4 TB/s.  Removed: profiles/r05_pw_lab_f32_family.txt)
+
 }  // namespace bnhip
 
 extern "C" long bnhip_debug_pw_ws_launches(void) { return bnhip::g_pw_ws_launches.load(std::memory_order_relaxed); }

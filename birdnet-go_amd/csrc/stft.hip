@@ -240,9 +240,29 @@ __global__ __launch_bounds__(64 * W) void k_stft_bins(StftParams p) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int t = 0; t < NPAIR; t++) {
-            fft_regs<Q, R>(ar[t], ai[t]);
             const int slot = lane + 64 * t;              // = j' P + k1  ->  k = k1 + P j' + P^2 q'
             const int kbase = (slot % P) + P * (slot / P);
+            // Output pruning (2048-point transform, Q = 4): the mel bank reads a fraction of the bins (v2.4: 129 of 1 025), so
+            // most Z[k1 + P j' + P^2 q'] are never read - pass t of this stage only computes and stores the q' some needed bin
+            // reads (p.zmask, wave-uniform, from the plan).  Each kept output is formed by the same additions in the same order
+            // as the full radix-2 transform below: same bits.
+            const unsigned zm = Q == 4 ? (p.zmask >> (4 * t)) & 15u : 15u;
+            if (Q == 4 && zm != 15u) {
+                if (slot < P * P) {
+                    if (zm & 5u) {                       // q' = 0, 2: (x0 + x2) +- (x1 + x3)
+                        const R a_r = ar[t][0] + ar[t][2], a_i = ai[t][0] + ai[t][2], c_r = ar[t][1] + ar[t][3], c_i = ai[t][1] + ai[t][3];
+                        if (zm & 1u) { wre[kbase] = a_r + c_r; wim[kbase] = a_i + c_i; }
+                        if (zm & 4u) { wre[kbase + 2 * P * P] = a_r - c_r; wim[kbase + 2 * P * P] = a_i - c_i; }
+                    }
+                    if (zm & 10u) {                      // q' = 1, 3: (x0 - x2) -+ i (x1 - x3)
+                        const R b_r = ar[t][0] - ar[t][2], b_i = ai[t][0] - ai[t][2], d_r = ar[t][1] - ar[t][3], d_i = ai[t][1] - ai[t][3];
+                        if (zm & 2u) { wre[kbase + P * P] = b_r + d_i; wim[kbase + P * P] = b_i - d_r; }
+                        if (zm & 8u) { wre[kbase + 3 * P * P] = b_r - d_i; wim[kbase + 3 * P * P] = b_i + d_r; }
+                    }
+                }
+                continue;
+            }
+            fft_regs<Q, R>(ar[t], ai[t]);
             if (slot < P * P) {
 #pragma unroll
                 for (int q = 0; q < Q; q++) { wre[kbase + P * P * q] = ar[t][q]; wim[kbase + P * P * q] = ai[t][q]; }
@@ -364,6 +384,20 @@ std::vector<double> stft_build_tables(int Lfft, const int* bins, int nb) {
         trr[i] = std::cos(a); tri[i] = std::sin(a);
     }
     return t;
+}
+// Which outputs of the closing Q-point transforms does the real-input split of the needed bins read?  Bin k reads Z[k mod N2] and
+// Z[(N2 - k) mod N2]; Z[k1 + P j' + P^2 q'] is produced in pass t = (j' P + k1) / 64 as output q'.  Four bits per pass; only the
+// Q = 4 kernel (2048-point frames) prunes, everything else gets all ones.  BNHIP_STFT_PRUNE=0: all ones (A/B runs).
+unsigned stft_zmask(int Lfft, const int* bins, int nb) {
+    const char* e = getenv("BNHIP_STFT_PRUNE");           // (plan time only - never on the launch path)
+    const bool off = e && atoi(e) == 0;
+    const int P = Lfft / 128;
+    if (P != 16 || off || nb <= 0) return 0xffffffffu;
+    const int N2 = 64 * P;
+    unsigned m = 0;
+    auto need = [&](int z) { const int qp = z / (P * P), slot = ((z % (P * P)) / P) * P + z % P; m |= 1u << (4 * (slot / 64) + qp); };
+    for (int i = 0; i < nb; i++) { const int k = bins[i] % N2; need(k); need((N2 - k) % N2); }
+    return m | 0xffff0000u;
 }
 static int stft_waves(int P) { return P == 8 ? 4 : 8; }
 size_t stft_lds_bytes(int P, int nb_cap) {

@@ -113,3 +113,25 @@ def test_fused_mel_epilogue_vs_the_separate_banded_kernel(gpu, full_blob):
                 assert (got.argmax(1) == ref.argmax(1)).all() and np.abs(got - ref).max() < 1e-3
         finally:
             fused.close(); plain.close()
+
+
+@pytest.mark.gpu
+def test_output_pruned_stft_is_bit_identical_to_the_full_transform(gpu, full_blob, monkeypatch):
+    """VERDICT r4 #3, the output-pruned STFT: the mel bank of the v2.4 front-end reads 129 of the 2048-point transform's 1 025 bins,
+    so the closing 4-point stage of k_stft_bins<16> computes and stores only the outputs a needed bin reads (StftParams::zmask, from
+    the plan).  Every kept output is the same chain of additions as in the full stage: the logits must not move by one bit - on
+    material, on silence (the case the fp64 transform exists for) and with the fused mel epilogue."""
+    from birdnet_go_amd import host, synth_model as sm
+    x = sm.synth_clips(6, 144000, 48000, first=31)
+    x[2] = 0.0
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("BNHIP_FUSE_MEL", fuse)
+        out = {}
+        for prune in ("1", "0"):
+            monkeypatch.setenv("BNHIP_STFT_PRUNE", prune)
+            c = host.HipClassifier(full_blob, max_batch=8, autotune=False)
+            try:
+                out[prune] = c.predict_batch(x.reshape(-1), 6).copy()
+            finally:
+                c.close()
+        assert np.isfinite(out["1"]).all() and np.array_equal(out["1"], out["0"]), np.abs(out["1"] - out["0"]).max()

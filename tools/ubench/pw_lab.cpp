@@ -16,7 +16,7 @@
 #include "kernels.h"
 using namespace bnhip;
 
-struct Shape { const char* name; int M, N, K, HW, act; bool scale, res; };
+struct Shape { const char* name; int M, N, K, HW, act; bool scale, res; bool f32 = false; };
 struct Cand { int wm, nt; };
 
 static float* dev_f(const std::vector<float>& h) {
@@ -39,7 +39,12 @@ int main(int argc, char** argv) {
         {"b5/project", 196608, 40, 240, 768, ACT_NONE, true, true},
         {"b4/project", 196608, 40, 144, 768, ACT_NONE, true, false},
         {"dense", 256, 6522, 1024, 1, ACT_NONE, false, false},
+        // the f32-MFMA family (HBM-bound early projections): wm 1 / 2 k_pw_gemm 64- / 128-row tiles, 3 / 4 k_pw_pipe
+        {"b1/project", 3145728, 16, 32, 12288, ACT_NONE, true, false, true},
+        {"b2/project", 786432, 24, 96, 3072, ACT_NONE, true, false, true},
+        {"b3/project", 786432, 24, 144, 3072, ACT_NONE, true, true, true},
     };
+    const Cand cands32[] = {{1, 1}, {1, 2}, {2, 1}, {2, 2}, {3, 2}, {4, 2}};
     const Cand cands[] = {{6, 4}, {6, 3}, {6, 6}, {6, 8}, {5, 3}, {5, 5}, {5, 7}, {8, 4}, {9, 4}, {9, 6}, {10, 3}, {10, 5}, {10, 7},
                           {12, 4}, {12, 6}, {12, 8}};
     std::mt19937 rng(1234);
@@ -64,7 +69,8 @@ int main(int argc, char** argv) {
             p.prec = 0;
             return p;
         };
-        { PwParams p = params(6, 4, dref); launch_pw_bx3(p, dimg, 0); (void)hipDeviceSynchronize(); }
+        auto launch = [&](const PwParams& p) { if (sh.f32) launch_pw_gemm(p, 0); else launch_pw_bx3(p, dimg, 0); };
+        { PwParams p = sh.f32 ? params(1, 2, dref) : params(6, 4, dref); launch(p); (void)hipDeviceSynchronize(); }
         std::vector<float> href((size_t)M * N), hout((size_t)M * N);
         (void)hipMemcpy(href.data(), dref, href.size() * 4, hipMemcpyDeviceToHost);
         // sanity of the reference itself against a double-precision dot product on a few outputs
@@ -78,30 +84,34 @@ int main(int argc, char** argv) {
             if (sh.res) acc += res[(size_t)m * N + n];
             worst = std::max(worst, std::fabs(acc - href[(size_t)m * N + n]));
         }
-        printf("== %-12s M=%d N=%d K=%d HW=%d scale=%d res=%d  (reference k_pw_bx3 128x64 vs fp64 on 64 outputs: max |d| %.2e)\n", sh.name, M, N, K, sh.HW,
+        printf("== %-12s M=%d N=%d K=%d HW=%d scale=%d res=%d  (reference tiled kernel vs fp64 on 64 outputs: max |d| %.2e)\n", sh.name, M, N, K, sh.HW,
                (int)sh.scale, (int)sh.res, worst);
-        for (const Cand& c : cands) {
+        std::vector<Cand> cl;
+        if (sh.f32) cl.assign(std::begin(cands32), std::end(cands32)); else cl.assign(std::begin(cands), std::end(cands));
+        for (const Cand& c : cl) {
             if (only_wm && (c.wm != only_wm || c.nt != only_nt)) continue;
             PwParams p = params(c.wm, c.nt, dout);
-            if (c.wm == 12 && !pw_ws_ok(p)) continue;
-            if (c.wm == 8 && !pw_bx3p_ok(c.nt, 2, K)) continue;
-            if (c.wm != 12 && c.nt * 16 > (N + 15) / 16 * 16 * 13 / 10 && c.nt > 1) continue;
+            if (sh.f32 && c.nt <= 8 && c.nt * 16 > (N + 15) / 16 * 16) continue;
+            if (sh.f32 && c.wm > 2 && !pw_pipe_ok(c.nt, c.wm - 2, K)) continue;
+            if (!sh.f32 && c.wm == 12 && !pw_ws_ok(p)) continue;
+            if (!sh.f32 && c.wm == 8 && !pw_bx3p_ok(c.nt, 2, K)) continue;
+            if (!sh.f32 && c.wm != 12 && c.nt * 16 > (N + 15) / 16 * 16 * 13 / 10 && c.nt > 1) continue;
             (void)hipMemset(dout, 0xff, (size_t)M * N * 4);
-            launch_pw_bx3(p, dimg, 0);
+            launch(p);
             hipError_t err = hipDeviceSynchronize();
             if (err != hipSuccess) { printf("   wm=%2d nt=%d: LAUNCH FAILED %s\n", c.wm, c.nt, hipGetErrorString(err)); (void)hipGetLastError(); continue; }
             (void)hipMemcpy(hout.data(), dout, hout.size() * 4, hipMemcpyDeviceToHost);
             size_t bad = 0, first = 0;
             for (size_t i = 0; i < hout.size(); i++)
                 if (memcmp(&hout[i], &href[i], 4)) { if (!bad) first = i; bad++; }
-            launch_pw_bx3(p, dimg, 0);
+            launch(p);
             (void)hipEventRecord(e0, 0);
-            for (int r = 0; r < 10; r++) launch_pw_bx3(p, dimg, 0);
+            for (int r = 0; r < 10; r++) launch(p);
             (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
             float b2b; (void)hipEventElapsedTime(&b2b, e0, e1);
             float iso = 1e30f;
             for (int r = 0; r < 5; r++) {
-                (void)hipEventRecord(e0, 0); launch_pw_bx3(p, dimg, 0); (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+                (void)hipEventRecord(e0, 0); launch(p); (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
                 float t; (void)hipEventElapsedTime(&t, e0, e1); iso = std::min(iso, t);
             }
             printf("   wm=%2d nt=%d: %7.1f us b2b  %7.1f us iso  %6.1f TF   %s", c.wm, c.nt, b2b * 100, iso * 1e3, 2.0 * M * N * K / (b2b * 1e-4) / 1e12,
