@@ -30,6 +30,9 @@ for name, kw in (("one_engine", {}), ("devices_0_0_peer", {"devices": [0, 0], "r
         res[name] = {"ms_per_512_clip_call": dt * 1e3, "clips_per_s": 512 / dt, "devices": d.get("devices"), "weight_replication": d.get("weight_replication")}
     finally:
         clf.close()
-res["same_logits"] = bool(np.array_equal(outs["one_engine"], outs["devices_0_0_peer"]))
+# (the two handles run different call geometries - 2 x 256-clip shards against one 512-clip pipelined call - and each engine times its
+# own tile candidates: another grouping of the squeeze-excite partial sums, i.e. another fp32 summation order; tests/test_multi_device.py
+# holds the difference to 1e-4)
+res["max_abs_logit_diff"] = float(np.abs(outs["one_engine"] - outs["devices_0_0_peer"]).max())
 res["ratio"] = res["devices_0_0_peer"]["clips_per_s"] / res["one_engine"]["clips_per_s"]
 print(json.dumps(res))

@@ -41,9 +41,7 @@ echo "launches per step: $NL" > $OUT/${TAG}_profile_notes.txt
 PB="python bench.py $WL --steps 5 --warmup 2 --no-cpu-baseline --no-fp32-run --no-oracle-check --no-profile --no-host-pointer --no-secondary --no-distribution"
 DBS=""
 i=0
-# (GRBM_GUI_ACTIVE in a pass of its own: busy cycles of the chip during a dispatch = the shader clock the kernel actually ran at -
-# MFMA-heavy kernels run near 1.95 GHz, not at the 2.4 GHz the utilisation figure's stated denominator uses; a pass that fails only loses that column)
-for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY" "GRBM_GUI_ACTIVE"; do
+for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
   i=$((i + 1)); rm -rf /tmp/pmc$i
   rocprofv3 --pmc $c -d /tmp/pmc$i -o p -- $PB > /dev/null 2>&1
   DB1=$(find /tmp/pmc$i -name '*.db' | head -1)
