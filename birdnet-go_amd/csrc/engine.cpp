@@ -366,6 +366,7 @@ Engine::~Engine() {
     for (auto& e : prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto e : ev_pool) hipEventDestroy(e);
     for (auto& p : step_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    if (mm_scratch) hipFree(mm_scratch);
     for (void* p : {(void*)act_arena, (void*)w_arena, (void*)d_stage_in, (void*)d_stage_logits, (void*)d_stage_emb,
                     (void*)d_stage_pcm, (void*)d_post_conf, (void*)d_topk_conf, (void*)d_topk_idx})
         if (p) hipFree(p);
@@ -387,7 +388,7 @@ int pw_switches_from_env() {
         return !e ? 0 : e[0] == '0' ? off : e[0] == '2' ? force : 0;
     };
     return sw("BNHIP_PW_B16", PW_SW_B16_OFF, PW_SW_B16_FORCE) | sw("BNHIP_PW_B16S", PW_SW_B16S_OFF, PW_SW_B16S_FORCE) |
-           sw("BNHIP_PW_WS", PW_SW_WS_OFF, PW_SW_WS_FORCE);
+           sw("BNHIP_PW_WS", PW_SW_WS_OFF, PW_SW_WS_FORCE) | sw("BNHIP_PW_LAT", PW_SW_LAT_OFF, 0);
 }
 
 bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* err, int* code) {
@@ -1670,6 +1671,8 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
     HIPCHK(hipMalloc((void**)&w_arena, std::max<size_t>(w_bytes, 256)));
     if (!defer_weights) HIPCHK(hipMemcpy(w_arena, wimg.data(), w_bytes, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&act_arena, std::max<size_t>(act_bytes, 256)));
+    HIPCHK(hipMalloc((void**)&mm_scratch, (size_t)kMaxDepth * kMaxLanes * kMinMaxScratch * sizeof(float)));
+    HIPCHK(hipMemset(mm_scratch, 0, (size_t)kMaxDepth * kMaxLanes * kMinMaxScratch * sizeof(float)));      // (arrival counters start at zero and reset themselves)
     depth = std::max(1, std::min(depth, kMaxDepth));
     host_depth = std::max(1, std::min(host_depth, kMaxDepth));
     if (depth > 1 && !ensure_contexts(depth, err)) return false;
@@ -2204,7 +2207,9 @@ bool Engine::run_on_context(int c, hipStream_t st, const float* d_in, int n, flo
     call_idx++;                                  // a later unsplit run() orders itself behind the contexts
     cur_arena = ctx_arena[c];
     cur_stream = st;
+    cur_ctx = c;                                 // (the context's own min/max scratch)
     bool ok = run_eager(d_in, n, d_logits, d_emb, err);
+    cur_ctx = -1;
     cur_arena = nullptr;
     cur_stream = nullptr;
     return ok;
@@ -2308,7 +2313,10 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
         if (prof_this) { pe.a = get_event(); pe.b = get_event(); pe.step = si; pe.n = n; hipEventRecord(pe.a, stream); }
         switch (s.kind) {
             case S_MINMAX:
-                launch_clip_minmax(in0, n, n_samples, specs[0].eps, reinterpret_cast<float2*>(out), stream);
+                // (scratch of the small-call form: a buffer of its own per context and lane - the arena's full and lane layouts
+                // share memory, a counter kept there would be overwritten by the other layout's activations between calls)
+                launch_clip_minmax(in0, n, n_samples, specs[0].eps, reinterpret_cast<float2*>(out),
+                                   mm_scratch ? mm_scratch + ((size_t)std::max(cur_ctx, 0) * kMaxLanes + (size_t)li) * kMinMaxScratch : nullptr, stream);
                 break;
             case S_FRONTEND: {
                 const FrontSpec& fs = specs[s.spec];

@@ -118,6 +118,8 @@ class Engine {
     int depth = 1;
     hipStream_t ctx_stream[kMaxDepth] = {nullptr, nullptr, nullptr};
     char* ctx_arena[kMaxDepth] = {nullptr, nullptr, nullptr};
+    static constexpr int kMinMaxScratch = 16 * (2 * kMinMaxParts + 2);   // floats: 16 clips x (parts + counter) of k_clip_minmax_parts
+    float* mm_scratch = nullptr;        // [context][lane][kMinMaxScratch]: outside the arenas (their layouts overlap), zeroed once
     hipEvent_t ev_ctx_fork = nullptr, ev_ctx_done[kMaxDepth] = {nullptr, nullptr, nullptr};
     unsigned call_idx = 0;
     bool run_pipelined(const float* d_in, int n, float* d_logits, float* d_emb, std::string* err);

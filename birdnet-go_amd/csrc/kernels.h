@@ -14,7 +14,8 @@ void launch_pcm_to_f32(const void* pcm, int bits /*16, 24, 32*/, float* out, siz
 
 // ---- front-end
 // per-clip (min, max(x-min)+eps) as TFLite's REDUCE_MIN/SUB/REDUCE_MAX/ADD chain produces them
-void launch_clip_minmax(const float* x, int n_clips, int n_samples, float eps, float2* mm, hipStream_t s);
+constexpr int kMinMaxParts = 16;      // blocks per clip of the small-call form; scratch = [clip][2 * kMinMaxParts + 2] floats, zero before first use
+void launch_clip_minmax(const float* x, int n_clips, int n_samples, float eps, float2* mm, float* scratch /*nullable*/, hipStream_t s);
 
 struct FrontendParams {
     const float* x;        // [B, n_samples] raw clip
@@ -118,8 +119,8 @@ struct PwParams {         // pointwise conv / fully-connected as GEMM: out[M,N] 
     int sw = 0;           // PW_SW_* bits: experiment / test switches of the split-bf16 kernel family, read from the environment ONCE per
                           // engine (Engine::build) and carried here - no getenv on the launch path
 };
-enum { PW_SW_B16_OFF = 1, PW_SW_B16_FORCE = 2, PW_SW_B16S_OFF = 4, PW_SW_B16S_FORCE = 8, PW_SW_WS_OFF = 16, PW_SW_WS_FORCE = 32 };
-int pw_switches_from_env();       // BNHIP_PW_B16 / _B16S / _WS: "0" = never, "2" = wherever the kernel accepts the layer (parity tests)
+enum { PW_SW_B16_OFF = 1, PW_SW_B16_FORCE = 2, PW_SW_B16S_OFF = 4, PW_SW_B16S_FORCE = 8, PW_SW_WS_OFF = 16, PW_SW_WS_FORCE = 32, PW_SW_LAT_OFF = 64 };
+int pw_switches_from_env();       // BNHIP_PW_B16 / _B16S / _WS / _LAT (0 only): "0" = never, "2" = wherever the kernel accepts the layer (parity tests)
 void launch_pw_gemm(const PwParams& p, hipStream_t s);
 bool pw_pipe_ok(int nt, int wm, int K);   // PwParams::wm = 2 + wm selects the software-pipelined kernel (k_pw_pipe)
 int pw_default_nt(int M, int N);
@@ -143,6 +144,11 @@ void launch_pw_b16(const PwParams& p, const uint16_t* Wimg, int nt, int wm /*1 |
 // layer in front of the pooling): a block's weight columns stay in LDS, its waves walk 32-row tile pairs with A streamed from
 // global memory through a register ring several slabs ahead, epilogue straight from the accumulators.  A call too small for it
 // (pw_ws_ok) takes a tiled kernel - same bits.
+// pw_ws.hip - k_pw_lat: the long-K layers (K >= 256) of SMALL calls (one to a few clips: <= 2048 16 x 16 output tiles): one wave per
+// (row tile, column group), operands from global memory into a register ring several slabs ahead, no LDS, no barrier; bit-identical to
+// k_pw_bx3.  Taken by launch_pw_bx3 for every call it accepts, whatever the tuned tile.
+bool pw_lat_ok(const PwParams& p);
+void launch_pw_lat(const PwParams& p, const uint16_t* Wimg, int Npad, hipStream_t s);
 bool pw_ws_ok(const PwParams& p);
 bool pw_ws_fills(const PwParams& p);      // the call is large enough to put blocks on half of the chip
 void launch_pw_ws(const PwParams& p, const uint16_t* Wimg, int Npad, hipStream_t s);

@@ -349,6 +349,143 @@ void launch_pw_ws(const PwParams& p, const uint16_t* Wimg, int Npad, hipStream_t
 // k_pw_gemm - was built and measured in round 5: 128 / 92 / 151 us against 104 / 81 / 137 us for the tiled kernel, whatever the
 // number of waves; those layers already move 4.4-5.4 TB/s.  Removed: profiles/r05_pw_lab_f32_family.txt)
 
+// ================================================================================================ small calls: the long-K layers as a latency problem
+// One clip per Predict is the product's own call pattern (cmd/benchmark/benchmark.go:99-133, orchestrator.go:531).  There the
+// projections (K = 480 .. 1152) and the dense head (K = 1024) are a handful of tiles whose K loop is a chain of memory latencies: the
+// tiled kernels fetch a slab one or two ahead and meet at a barrier per slab - 36 slabs x ~0.8 us = 28.5 us for 1.4 MFLOP at one clip, the
+// same at eight (tools/latency_small.py).  k_pw_lat: a block is one 16-row tile x four column groups of 16 NT columns (one per wave).
+//   * weight fragments come straight from the plan-time image (which is in fragment order) into a per-wave ring of DW register stages
+//     that runs DW slabs ahead - no LDS, nobody to wait for;
+//   * the rows' operand work is shared: K is walked in groups of four slabs, wave w loads (two groups ahead), scales and splits slab
+//     4 g + w of the group and publishes its three bf16 planes to LDS, ONE barrier per group, then every wave runs the group's
+//     4 x 6 NT MFMAs from those fragments (the first form of this kernel had every wave split every slab: 52 VALU per 6 MFMAs on
+//     one in-order wave - 16 us a projection; tools/ubench/pw_lab '@' shapes);
+//   * epilogue straight from the accumulators.
+// Same image, same K order, same six products per accumulator in the same order: bit-identical to k_pw_bx3 - a clip's logits still
+// do not depend on the call's size.
+template <int NT, bool SC, int DW>
+__global__ __launch_bounds__(256) void k_pw_lat(PwParams p, const uint16_t* __restrict__ Wimg, int Npad, int ngroups, FDiv dhw) {
+    __shared__ __attribute__((aligned(16))) u32v4 frl[2][4][3][64];       // [group parity][slab of the group][plane][lane]
+    const int lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int gblocks = (ngroups + 3) >> 2;                  // blocks per row tile
+    const int rt = (int)blockIdx.x / gblocks;
+    const int cg = min(((int)blockIdx.x - rt * gblocks) * 4 + wave, ngroups - 1);       // (a surplus wave repeats the last group: it shares the split work)
+    const bool live = ((int)blockIdx.x - rt * gblocks) * 4 + wave < ngroups;
+    const int K = p.K, nslab = (K + 31) >> 5, ngrp = (nslab + 3) >> 2;
+    const int m = min(16 * rt + li, p.M - 1), n0 = 16 * NT * cg;
+    const float* arow = p.A + (size_t)m * K + 4 * kq;
+    const float* srow = SC ? p.ascale + (size_t)fdiv((unsigned)m, dhw) * K + 4 * kq : nullptr;
+    const u32v4* W16 = reinterpret_cast<const u32v4*>(Wimg);
+    unsigned wcol[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) wcol[t] = (unsigned)kq * (unsigned)Npad + (unsigned)min(n0 + 16 * t + li, Npad - 1);
+
+    struct AStage { float4 alo, ahi, slo, shi; };
+    AStage ast[2];                                           // this wave's slab of groups g and g + 1 (loaded two groups ahead)
+    auto aload = [&](int sl, AStage& s_) {
+        // (a slab beyond K, or the missing quads of a short last slab: read the row's first quad instead and zero by a select)
+        const bool inlo = 32 * sl + 4 * kq < K, inhi = 32 * sl + 16 + 4 * kq < K;
+        const int klo = inlo ? 32 * sl : -4 * kq, khi = inhi ? 32 * sl + 16 : -4 * kq;
+        const float4 lo = *reinterpret_cast<const float4*>(arow + klo), hi = *reinterpret_cast<const float4*>(arow + khi);
+        s_.alo = inlo ? lo : make_float4(0.f, 0.f, 0.f, 0.f);
+        s_.ahi = inhi ? hi : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (SC) {
+            s_.slo = *reinterpret_cast<const float4*>(srow + klo);
+            s_.shi = *reinterpret_cast<const float4*>(srow + khi);
+        }
+    };
+    u32v4 wst[DW][NT][3];
+    auto wload = [&](int sl, u32v4 (&dst)[NT][3]) {
+        const u32v4* Ws = W16 + (size_t)sl * 12 * Npad;
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) dst[t][pl] = Ws[wcol[t] + (unsigned)(pl * 4) * (unsigned)Npad];
+    };
+    auto publish = [&](const AStage& s_, int par) {          // scale, split exactly, three planes to LDS
+        float4 v0 = s_.alo, v1 = s_.ahi;
+        if constexpr (SC) {
+            v0.x *= s_.slo.x; v0.y *= s_.slo.y; v0.z *= s_.slo.z; v0.w *= s_.slo.w;
+            v1.x *= s_.shi.x; v1.y *= s_.shi.y; v1.z *= s_.shi.z; v1.w *= s_.shi.w;
+        }
+        WsFrag f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float x0, x1;
+            ws_pair(v0, v1, q, x0, x1);
+            unsigned h, mm, l;
+            ws_split2(x0, x1, h, mm, l);
+            f.h[q] = h; f.m[q] = mm; f.l[q] = l;
+        }
+        frl[par][wave][0][lane] = f.h; frl[par][wave][1][lane] = f.m; frl[par][wave][2][lane] = f.l;
+    };
+    f32x4 acc[NT][1];
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    aload(wave, ast[0]);
+    aload(4 + wave, ast[1]);
+#pragma unroll
+    for (int d = 0; d < DW; d++) if (d < nslab) wload(d, wst[d]);
+    static_assert(DW % 8 == 0, "groups are walked DW / 4 at a time: stage and A-set indices are static when that count is even");
+    // groups are walked DW / 4 at a time so that every register stage index is static
+    for (int g0 = 0; g0 < ngrp; g0 += DW / 4) {
+#pragma unroll
+        for (int gg = 0; gg < DW / 4; gg++) {
+            const int g = g0 + gg;
+            if (g < ngrp) {
+                publish(ast[gg & 1], gg & 1);
+                aload(4 * (g + 2) + wave, ast[gg & 1]);     // (beyond K: zeros from a valid address)
+                __syncthreads();
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const int sl = 4 * g + d;
+                    if (sl < nslab) {
+                        WsFrag f[2];
+                        f[0].h = frl[gg & 1][d][0][lane]; f[0].m = frl[gg & 1][d][1][lane]; f[0].l = frl[gg & 1][d][2][lane];
+#pragma unroll
+                        for (int t = 0; t < NT; t++) ws_mfma<1, true>(acc[t], wst[4 * gg + d][t], f);
+                        if (sl + DW < nslab) wload(sl + DW, wst[4 * gg + d]);
+                    }
+                }
+            }
+        }
+    }
+    const int mrow = 16 * rt + li;
+    if (live && mrow < p.M) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) ws_store(p, acc[t][0], p.bias, mrow, n0 + 16 * t + 4 * kq);
+    }
+}
+
+static std::atomic<long> g_pw_lat_launches{0};
+// calls it takes: six-product engines, fp32 activations, K of at least eight slabs, few enough (row tile, column tile) pairs that the
+// tiled kernels would be a chain of latencies rather than a full chip
+bool pw_lat_ok(const PwParams& p) {
+    if (p.sw & PW_SW_LAT_OFF) return false;
+    if (p.prec != 0 || p.a_bf16 || (p.K & 3) || p.K < 256) return false;
+    if ((p.N & 3) && (p.out_bf16 || p.res_bf16)) return false;
+    return (long)((p.M + 15) / 16) * ((p.N + 15) / 16) <= 2048;      // (every lane reads the scale row of its own clip: any HW)
+}
+void launch_pw_lat(const PwParams& p, const uint16_t* Wimg, int Npad, hipStream_t s) {
+    g_pw_lat_launches.fetch_add(1, std::memory_order_relaxed);
+    const int rt = (p.M + 15) / 16, ct = (p.N + 15) / 16;
+    // two column tiles per wave once one each already gives the chip a wave per SIMD
+    const int nt = (long)rt * ct >= 2048 / 2 ? 2 : 1;
+    const int ngroups = (ct + nt - 1) / nt;
+    const unsigned nblk = (unsigned)rt * (unsigned)((ngroups + 3) / 4);
+    const FDiv dhw = make_fdiv((unsigned)std::max(p.HW, 1));
+    if (p.ascale) {
+        if (nt == 1) hipLaunchKernelGGL((k_pw_lat<1, true, 8>), dim3(nblk), dim3(256), 0, s, p, Wimg, Npad, ngroups, dhw);
+        else hipLaunchKernelGGL((k_pw_lat<2, true, 8>), dim3(nblk), dim3(256), 0, s, p, Wimg, Npad, ngroups, dhw);
+    } else {
+        if (nt == 1) hipLaunchKernelGGL((k_pw_lat<1, false, 8>), dim3(nblk), dim3(256), 0, s, p, Wimg, Npad, ngroups, dhw);
+        else hipLaunchKernelGGL((k_pw_lat<2, false, 8>), dim3(nblk), dim3(256), 0, s, p, Wimg, Npad, ngroups, dhw);
+    }
+}
+
 }  // namespace bnhip
 
 extern "C" long bnhip_debug_pw_ws_launches(void) { return bnhip::g_pw_ws_launches.load(std::memory_order_relaxed); }
+extern "C" long bnhip_debug_pw_lat_launches(void) { return bnhip::g_pw_lat_launches.load(std::memory_order_relaxed); }

@@ -705,3 +705,37 @@ def test_streamed_split_gemm_equals_the_staged_one(full_blob, monkeypatch):
             c.close()
             assert (used >= 15) if mode == "2" else (used == 0), (n, mode, used)
         assert np.array_equal(out["2"], out["0"]), (n, np.abs(out["2"] - out["0"]).max())
+
+
+def test_small_calls_take_the_latency_kernels_and_keep_the_bits(full_blob, monkeypatch):
+    """One clip per Predict is the product's call pattern.  Calls of a few clips route their long-K layers (projections, dense head)
+    to k_pw_lat (one barrier per four K slabs, weight fragments from a register ring, the operand split shared by a block's waves)
+    and their min / max to the 16-blocks-per-clip form with a self-resetting arrival counter.  Both are bit-identical to what a
+    large call runs: the same clips inside a 40-clip call give the same logits, twice in a row (the counter resets), and with
+    the latency kernel switched off."""
+    import ctypes
+    lib = host.load_library()
+    lib.bnhip_debug_pw_lat_launches.restype = ctypes.c_long
+    x = sm.synth_clips(40, 144000, 48000, first=77)
+    x[3] = 0.0                                               # (silence: min == max)
+    c = host.HipClassifier(full_blob, max_batch=64, autotune=False)
+    try:
+        big = c.predict_batch(x.reshape(-1), 40).copy()
+        for n in (1, 3, 8, 16):
+            for rep in range(2):
+                before = lib.bnhip_debug_pw_lat_launches()
+                got = c.predict_batch(x[:n].reshape(-1), n)
+                assert lib.bnhip_debug_pw_lat_launches() - before >= 10, n
+                assert np.array_equal(got, big[:n]), (n, rep, np.abs(got - big[:n]).max())
+            got = c.predict_batch(x[5:5 + n].reshape(-1), n)            # other clips through the same scratch
+            assert np.array_equal(got, big[5:5 + n]), n
+    finally:
+        c.close()
+    monkeypatch.setenv("BNHIP_PW_LAT", "0")
+    c = host.HipClassifier(full_blob, max_batch=64, autotune=False)
+    try:
+        before = lib.bnhip_debug_pw_lat_launches()
+        assert np.array_equal(c.predict_batch(x[:3].reshape(-1), 3), big[:3]) and lib.bnhip_debug_pw_lat_launches() == before
+        assert np.array_equal(c.predict_batch(x[:16].reshape(-1), 16), big[:16])      # (16 clips: the two-column-tiles-per-wave form was behind `big`)
+    finally:
+        c.close()

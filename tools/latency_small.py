@@ -1,5 +1,5 @@
 """Per-launch table of a small call (default one clip) through the device entry: what bounds single-clip latency.
-    python tools/latency_small.py [n_clips] [se_fold_max]
+    python tools/latency_small.py [n_clips]
 """
 import sys, os, time
 import numpy as np
@@ -8,17 +8,16 @@ import birdnet_go_amd  # noqa
 from birdnet_go_amd import host, synth_model as sm
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-fold = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 cfg = sm.SynthConfig()
 blob = sm.build_model(cfg)
-clf = host.HipClassifier(blob, device=0, max_batch=256, se_fold_max=fold)
+clf = host.HipClassifier(blob, device=0, max_batch=256)
 x = sm.synth_clips(n, cfg.n_samples, cfg.sample_rate)
 for _ in range(5):
     clf.predict_batch(x.reshape(-1), n)
 ts = []
 for _ in range(50):
     t0 = time.perf_counter(); clf.predict_batch(x.reshape(-1), n); ts.append(time.perf_counter() - t0)
-print(f"n={n} se_fold_max={fold}: host call median {1e3 * np.median(ts):.3f} ms  min {1e3 * min(ts):.3f} ms")
+print(f"n={n}: host call median {1e3 * np.median(ts):.3f} ms  min {1e3 * min(ts):.3f} ms")
 clf.profile_enable(True)
 for _ in range(5):
     clf.predict_batch(x.reshape(-1), n)

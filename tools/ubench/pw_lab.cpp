@@ -39,6 +39,15 @@ int main(int argc, char** argv) {
         {"b5/project", 196608, 40, 240, 768, ACT_NONE, true, true},
         {"b4/project", 196608, 40, 144, 768, ACT_NONE, true, false},
         {"dense", 256, 6522, 1024, 1, ACT_NONE, false, false},
+        // small calls (one and eight clips): wm = 14 is k_pw_lat (what launch_pw_bx3 takes for them), the others the tiled kernels with shrunk grids
+        {"b13/project@1", 48, 192, 1152, 48, ACT_NONE, true, true},
+        {"b13/project@8", 384, 192, 1152, 48, ACT_NONE, true, true},
+        {"b16/project@1", 48, 320, 1152, 48, ACT_NONE, true, false},
+        {"b10/project@1", 192, 112, 672, 192, ACT_NONE, true, true},
+        {"b10/project@8", 1536, 112, 672, 192, ACT_NONE, true, true},
+        {"b8/project@1", 192, 80, 480, 192, ACT_NONE, true, true},
+        {"dense@1", 1, 6522, 1024, 1, ACT_NONE, false, false},
+        {"dense@8", 8, 6522, 1024, 1, ACT_NONE, false, false},
         // the f32-MFMA family (HBM-bound early projections): wm 1 / 2 k_pw_gemm 64- / 128-row tiles, 3 / 4 k_pw_pipe
         {"b1/project", 3145728, 16, 32, 12288, ACT_NONE, true, false, true},
         {"b2/project", 786432, 24, 96, 3072, ACT_NONE, true, false, true},
@@ -46,7 +55,7 @@ int main(int argc, char** argv) {
     };
     const Cand cands32[] = {{1, 1}, {1, 2}, {2, 1}, {2, 2}, {3, 2}, {4, 2}};
     const Cand cands[] = {{6, 4}, {6, 3}, {6, 6}, {6, 8}, {5, 3}, {5, 5}, {5, 7}, {8, 4}, {9, 4}, {9, 6}, {10, 3}, {10, 5}, {10, 7},
-                          {12, 4}, {12, 6}, {12, 8}};
+                          {12, 4}, {12, 6}, {12, 8}, {14, 0}};
     std::mt19937 rng(1234);
     std::normal_distribution<float> nd(0.f, 1.f);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -65,8 +74,9 @@ int main(int argc, char** argv) {
         float *dref, *dout;
         (void)hipMalloc(&dref, (size_t)M * N * 4); (void)hipMalloc(&dout, (size_t)M * N * 4);
         auto params = [&](int wm, int nt, float* out) {
-            PwParams p{dA, dW, db, ds, dr, out, M, N, K, sh.HW, sh.act, nt, wm};
+            PwParams p{dA, dW, db, ds, dr, out, M, N, K, sh.HW, sh.act, nt, wm == 14 ? 6 : wm};
             p.prec = 0;
+            p.sw = wm == 14 ? 0 : PW_SW_LAT_OFF;          // (the tiled candidates and the reference must not be routed to k_pw_lat)
             return p;
         };
         auto launch = [&](const PwParams& p) { if (sh.f32) launch_pw_gemm(p, 0); else launch_pw_bx3(p, dimg, 0); };
@@ -94,8 +104,9 @@ int main(int argc, char** argv) {
             if (sh.f32 && c.nt <= 8 && c.nt * 16 > (N + 15) / 16 * 16) continue;
             if (sh.f32 && c.wm > 2 && !pw_pipe_ok(c.nt, c.wm - 2, K)) continue;
             if (!sh.f32 && c.wm == 12 && !pw_ws_ok(p)) continue;
+            if (c.wm == 14 && (sh.f32 || !pw_lat_ok(p))) continue;
             if (!sh.f32 && c.wm == 8 && !pw_bx3p_ok(c.nt, 2, K)) continue;
-            if (!sh.f32 && c.wm != 12 && c.nt * 16 > (N + 15) / 16 * 16 * 13 / 10 && c.nt > 1) continue;
+            if (!sh.f32 && c.wm != 12 && c.wm != 14 && c.nt * 16 > (N + 15) / 16 * 16 * 13 / 10 && c.nt > 1) continue;
             (void)hipMemset(dout, 0xff, (size_t)M * N * 4);
             launch(p);
             hipError_t err = hipDeviceSynchronize();
