@@ -24,8 +24,9 @@ static float* dev_f(const std::vector<float>& h) {
 }
 
 int main(int argc, char** argv) {
-    const char* only = argc > 1 ? argv[1] : nullptr;
-    const int only_wm = argc > 3 ? atoi(argv[2]) : 0, only_nt = argc > 3 ? atoi(argv[3]) : 0;      // pw_lab <shape> <wm> <nt>: one candidate
+    const char* only = argc > 1 && strcmp(argv[1], "--fuzz") ? argv[1] : nullptr;
+    const bool fuzz_mode = argc > 1 && !strcmp(argv[1], "--fuzz");
+    const int only_wm = argc > 3 && !fuzz_mode ? atoi(argv[2]) : 0, only_nt = argc > 3 && !fuzz_mode ? atoi(argv[3]) : 0;      // pw_lab <shape> <wm> <nt>: one candidate
     const Shape shapes[] = {
         {"b13/expand", 12288, 1152, 192, 48, ACT_SWISH, false, false},
         {"top", 12288, 1024, 320, 48, ACT_SWISH, false, false},
@@ -59,8 +60,8 @@ int main(int argc, char** argv) {
     std::mt19937 rng(1234);
     std::normal_distribution<float> nd(0.f, 1.f);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (const Shape& sh : shapes) {
-        if (only && !strstr(sh.name, only)) continue;
+    size_t fz_cmp = 0, fz_bad = 0, fz_ws = 0, fz_lat = 0;
+    auto run = [&](const Shape& sh, bool fuzz) {
         const int M = sh.M, N = sh.N, K = sh.K, B = (M + sh.HW - 1) / sh.HW;
         std::vector<float> A((size_t)M * K), W((size_t)N * K), bias(N), sc((size_t)B * K), res((size_t)M * N);
         for (auto& v : A) v = nd(rng);
@@ -94,8 +95,10 @@ int main(int argc, char** argv) {
             if (sh.res) acc += res[(size_t)m * N + n];
             worst = std::max(worst, std::fabs(acc - href[(size_t)m * N + n]));
         }
-        printf("== %-12s M=%d N=%d K=%d HW=%d scale=%d res=%d  (reference tiled kernel vs fp64 on 64 outputs: max |d| %.2e)\n", sh.name, M, N, K, sh.HW,
-               (int)sh.scale, (int)sh.res, worst);
+        if (!fuzz || worst > 1e-3)
+            printf("== %-12s M=%d N=%d K=%d HW=%d scale=%d res=%d  (reference tiled kernel vs fp64 on 64 outputs: max |d| %.2e)\n", sh.name, M, N, K, sh.HW,
+                   (int)sh.scale, (int)sh.res, worst);
+        if (fuzz && worst > 1e-3) fz_bad++;
         std::vector<Cand> cl;
         if (sh.f32) cl.assign(std::begin(cands32), std::end(cands32)); else cl.assign(std::begin(cands), std::end(cands));
         for (const Cand& c : cl) {
@@ -103,10 +106,12 @@ int main(int argc, char** argv) {
             PwParams p = params(c.wm, c.nt, dout);
             if (sh.f32 && c.nt <= 8 && c.nt * 16 > (N + 15) / 16 * 16) continue;
             if (sh.f32 && c.wm > 2 && !pw_pipe_ok(c.nt, c.wm - 2, K)) continue;
+            if (fuzz && c.wm == 12) p.sw |= PW_SW_WS_FORCE;          // (whatever the size: pw_ws_fills is a speed rule)
             if (!sh.f32 && c.wm == 12 && !pw_ws_ok(p)) continue;
             if (c.wm == 14 && (sh.f32 || !pw_lat_ok(p))) continue;
             if (!sh.f32 && c.wm == 8 && !pw_bx3p_ok(c.nt, 2, K)) continue;
-            if (!sh.f32 && c.wm != 12 && c.wm != 14 && c.nt * 16 > (N + 15) / 16 * 16 * 13 / 10 && c.nt > 1) continue;
+            if (!fuzz && !sh.f32 && c.wm != 12 && c.wm != 14 && c.nt * 16 > (N + 15) / 16 * 16 * 13 / 10 && c.nt > 1) continue;
+            if (fuzz && (c.wm == 6 || c.wm == 8) && c.nt != 3) continue;      // (a sample of the tiled forms is enough)
             (void)hipMemset(dout, 0xff, (size_t)M * N * 4);
             launch(p);
             hipError_t err = hipDeviceSynchronize();
@@ -115,6 +120,12 @@ int main(int argc, char** argv) {
             size_t bad = 0, first = 0;
             for (size_t i = 0; i < hout.size(); i++)
                 if (memcmp(&hout[i], &href[i], 4)) { if (!bad) first = i; bad++; }
+            if (fuzz) {
+                fz_cmp++; fz_ws += c.wm == 12; fz_lat += c.wm == 14;
+                if (bad) { fz_bad++; printf("   MISMATCH M=%d N=%d K=%d HW=%d scale=%d res=%d act=%d wm=%d nt=%d: %zu of %zu, first at row %zu col %zu: %g vs %g\n", M, N, K, sh.HW,
+                                            (int)sh.scale, (int)sh.res, sh.act, c.wm, c.nt, bad, hout.size(), first / N, first % N, hout[first], href[first]); }
+                continue;
+            }
             launch(p);
             (void)hipEventRecord(e0, 0);
             for (int r = 0; r < 10; r++) launch(p);
@@ -132,6 +143,36 @@ int main(int argc, char** argv) {
             fflush(stdout);
         }
         hipFree(dimg); hipFree(dA); hipFree(dW); hipFree(db); if (ds) hipFree(ds); if (dr) hipFree(dr); hipFree(dref); hipFree(dout);
+    };
+    if (argc > 1 && !strcmp(argv[1], "--fuzz")) {
+        // pw_lab --fuzz <seed> <count>: random shapes (K tails, ragged N, N % 4 != 0, one row, scale / residual / swish on and off) through
+        // every kernel form of the split-bf16 family - k_pw_ws and k_pw_lat wherever they accept the layer, whatever its size - bitwise
+        // against the tiled k_pw_bx3.  Prints mismatches and one summary line (tests/test_pw_lab.py asserts on it).
+        std::mt19937 fr((unsigned)(argc > 2 ? atoi(argv[2]) : 1));
+        const int count = argc > 3 ? atoi(argv[3]) : 24;
+        for (int i = 0; i < count; i++) {
+            Shape sh{"fuzz", 0, 0, 0, 0, 0, false, false};
+            const int kind = (int)(fr() % 4);
+            sh.HW = 16 * (1 + (int)(fr() % 12)) + (fr() % 3 == 0 ? 7 : 0);
+            sh.M = kind == 0 ? 1 + (int)(fr() % 40) : sh.HW * (1 + (int)(fr() % 12)) + (fr() % 4 == 0 ? 5 : 0);
+            sh.N = kind == 3 ? 2 * (3 + (int)(fr() % 300)) + 1 * (int)(fr() % 2) : 4 * (2 + (int)(fr() % 90));
+            sh.K = 4 * (4 + (int)(fr() % (kind == 1 ? 60 : 320)));
+            sh.act = fr() % 2 ? ACT_SWISH : ACT_NONE;
+            sh.scale = fr() % 2 == 0;
+            sh.res = fr() % 3 == 0;
+            if (kind == 1) {                                 // k_pw_ws territory: 3-6, 8 or 10 slabs (with and without a K tail), wide N, no scale
+                static const int ks[] = {96, 100, 128, 136, 160, 172, 192, 232, 256, 300, 320};
+                sh.K = ks[fr() % 11]; sh.N = 4 * (16 + (int)(fr() % 80)); sh.scale = false;
+                sh.M = 16 * (17 + (int)(fr() % 100)) + (fr() % 3 == 0 ? 9 : 0);
+            }
+            run(sh, true);
+        }
+        printf("fuzz: %d shapes, %zu comparisons (%zu on k_pw_ws, %zu on k_pw_lat), %zu mismatches\n", count, fz_cmp, fz_ws, fz_lat, fz_bad);
+        return fz_bad ? 1 : 0;
+    }
+    for (const Shape& sh : shapes) {
+        if (only && !strstr(sh.name, only)) continue;
+        run(sh, false);
     }
     return 0;
 }
