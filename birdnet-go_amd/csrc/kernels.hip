@@ -354,18 +354,8 @@ size_t frontend_lds_bytes(int Lfft, int Kp, int hop, int NTP) {
 template <int NT, int WN, int FT, int KC>
 static void launch_frontend_shape(const FrontendParams& p, hipStream_t s) {
     size_t lds = fe_lds_bytes(FT, KC, p.Lfft, p.Kp, p.hop, p.NTP);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frontend<NT, WN, FT, KC>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-        if (getenv("BNHIP_DEBUG")) {
-            int nb = -1;
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_frontend<NT, WN, FT, KC>),
-                                                         64 * (FT / 16) * WN, lds);
-            fprintf(stderr, "[bnhip] k_frontend<%d,%d,%d,%d>: lds %zu B, %d block(s)/CU\n", NT, WN, FT, KC, lds, nb);
-        }
-    }
+    // (per launch: the limit is an attribute of the function on the CURRENT device - see launch_stft_bins)
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frontend<NT, WN, FT, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     dim3 grid((p.F + FT - 1) / FT, p.n_clips);
     hipLaunchKernelGGL((k_frontend<NT, WN, FT, KC>), grid, dim3(64 * (FT / 16) * WN), lds, s, p);
 }

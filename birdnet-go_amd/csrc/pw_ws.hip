@@ -327,8 +327,9 @@ void launch_pw_ws(const PwParams& p, const uint16_t* Wimg, int Npad, hipStream_t
     const FDiv dn = make_fdiv((unsigned)nblk_n);
 #define WS_LAUNCH(NT_, NS_, SIX_, ABF_) do { \
         auto kern = &k_pw_ws<NT_, NS_, ws_ring(NS_), SIX_, ABF_, WS_NW>; \
-        static std::atomic<bool> attr{false}; \
-        if (!attr.load(std::memory_order_acquire)) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr.store(true, std::memory_order_release); } \
+        /* (per launch, like k_pw_bx3p: the attribute belongs to the function ON THE CURRENT DEVICE - a process-wide "done" flag would leave the \
+           second device of a multi-device handle at the 64 KB default) */ \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * WS_NW), lds, s, p, Wimg, Npad, nblk_n, nblk, GW, dn); } while (0)
 #define WS_SIX(NT_) switch (ns) { case 3: WS_LAUNCH(NT_, 3, true, false); break; case 4: WS_LAUNCH(NT_, 4, true, false); break; \
                                    case 5: WS_LAUNCH(NT_, 5, true, false); break; default: WS_LAUNCH(NT_, 6, true, false); break; }

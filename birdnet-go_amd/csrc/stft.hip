@@ -457,18 +457,18 @@ void launch_stft_bins(const StftParams& p0, hipStream_t s) {
     const int P = p.Lfft / 128, W = stft_waves(P);
     size_t lds = stft_lds_bytes(P, p.nb_cap);
     dim3 grid((p.F + W * p.fpw - 1) / (W * p.fpw), p.n_clips);
-    static bool attr16 = false;
+    // (the dynamic-LDS limit is an attribute of the function ON THE CURRENT DEVICE: set per launch - the process-wide once-flags that stood here
+    // left every further device of a multi-device handle at the 64 KB default, and were plain bools written by its worker threads)
     if (p.mel) {
         lds += (size_t)p.mel_quads * 16 + (size_t)(p.mel_quads + 3) / 4 * 16;
-        static bool am16 = false, am8 = false, am4 = false;
         if (P == 16) {
-            if (!am16) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<16, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); am16 = true; }
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<16, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipLaunchKernelGGL((k_stft_bins<16, 8, true>), grid, dim3(64 * W), lds, s, p);
         } else if (P == 8) {
-            if (!am8) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); am8 = true; }
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipLaunchKernelGGL((k_stft_bins<8, 4, true>), grid, dim3(64 * W), lds, s, p);
         } else {
-            if (!am4) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<4, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); am4 = true; }
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<4, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipLaunchKernelGGL((k_stft_bins<4, 8, true>), grid, dim3(64 * W), lds, s, p);
         }
         return;
@@ -477,8 +477,7 @@ void launch_stft_bins(const StftParams& p0, hipStream_t s) {
         lds /= 2;
         if (P == 4) hipLaunchKernelGGL((k_stft_bins<4, 8, false, float>), grid, dim3(64 * W), lds, s, p);
         else if (P == 16) {
-            static bool a16f = false;
-            if (!a16f) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<16, 8, false, float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a16f = true; }
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<16, 8, false, float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipLaunchKernelGGL((k_stft_bins<16, 8, false, float>), grid, dim3(64 * W), lds, s, p);
         } else hipLaunchKernelGGL((k_stft_bins<8, 4, false, float>), grid, dim3(64 * W), lds, s, p);
         return;
@@ -486,7 +485,7 @@ void launch_stft_bins(const StftParams& p0, hipStream_t s) {
     if (P == 4) {
         hipLaunchKernelGGL((k_stft_bins<4, 8>), grid, dim3(64 * W), lds, s, p);      // < 64 KB of LDS
     } else if (P == 16) {
-        if (!attr16) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<16, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr16 = true; }
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<16, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL((k_stft_bins<16, 8>), grid, dim3(64 * W), lds, s, p);
     } else {
         hipLaunchKernelGGL((k_stft_bins<8, 4>), grid, dim3(64 * W), lds, s, p);      // 42 KB of LDS
