@@ -467,7 +467,12 @@ bool pw_lat_ok(const PwParams& p) {
     if (p.sw & PW_SW_LAT_OFF) return false;
     if (p.prec != 0 || p.a_bf16 || (p.K & 3) || p.K < 256) return false;
     if ((p.N & 3) && (p.out_bf16 || p.res_bf16)) return false;
-    return (long)((p.M + 15) / 16) * ((p.N + 15) / 16) <= 2048;      // (every lane reads the scale row of its own clip: any HW)
+    // Every row tile streams the whole weight image through its waves' registers, so the call must be small in tiles AND in
+    // re-read weight bytes (measured crossover, tools/ubench/pw_lab '@' shapes: 1152 -> 192 wins up to 32 clips = 96 row tiles x 1.3 MB,
+    // loses at 64; the dense head (40 MB of image) wins at 8 clips = one row tile, loses at 64 = four).  BNHIP_PW_LAT_TILES: lab sweeps, read once.
+    static const long max_tiles = getenv("BNHIP_PW_LAT_TILES") ? atol(getenv("BNHIP_PW_LAT_TILES")) : 2048;
+    const long rt = (p.M + 15) / 16, ct = (p.N + 15) / 16;
+    return rt * ct <= max_tiles && (double)rt * (double)p.K * (double)(16 * ct) * 6.0 <= 130e6 * (double)max_tiles / 2048.0;      // (any HW: every lane reads the scale row of its own clip)
 }
 void launch_pw_lat(const PwParams& p, const uint16_t* Wimg, int Npad, hipStream_t s) {
     g_pw_lat_launches.fetch_add(1, std::memory_order_relaxed);

@@ -47,6 +47,14 @@ int main(int argc, char** argv) {
         {"b10/project@1", 192, 112, 672, 192, ACT_NONE, true, true},
         {"b10/project@8", 1536, 112, 672, 192, ACT_NONE, true, true},
         {"b8/project@1", 192, 80, 480, 192, ACT_NONE, true, true},
+        {"b13/project@16", 768, 192, 1152, 48, ACT_NONE, true, true},
+        {"b13/project@32", 1536, 192, 1152, 48, ACT_NONE, true, true},
+        {"b13/project@64", 3072, 192, 1152, 48, ACT_NONE, true, true},
+        {"b13/project@128", 6144, 192, 1152, 48, ACT_NONE, true, true},
+        {"b10/project@16", 3072, 112, 672, 192, ACT_NONE, true, true},
+        {"b10/project@32", 6144, 112, 672, 192, ACT_NONE, true, true},
+        {"b10/project@64", 12288, 112, 672, 192, ACT_NONE, true, true},
+        {"dense@64", 64, 6522, 1024, 1, ACT_NONE, false, false},
         {"dense@1", 1, 6522, 1024, 1, ACT_NONE, false, false},
         {"dense@8", 8, 6522, 1024, 1, ACT_NONE, false, false},
         // the f32-MFMA family (HBM-bound early projections): wm 1 / 2 k_pw_gemm 64- / 128-row tiles, 3 / 4 k_pw_pipe
