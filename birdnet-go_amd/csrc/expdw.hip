@@ -38,6 +38,8 @@ struct ExpDwParams {
     int xsh = 0, xsw = 1, ysh = 0, ysw = 1, tr = 0;
     int in_bf16 = 0, out_bf16 = 0;      // bf16 activation storage: x (COPY form only) / y hold bf16 values (see bf16x4_load)
     FDiv d_bpc{}, d_cch{}, d_tw{};      // blocks per clip, channel chunks, tiles per row (set by the launcher)
+    int cpp = 0;                        // chunk-loop form: channel chunks per block (0 = all: one block per (clip, tile)); small calls cut the loop into parts
+    FDiv d_part{};                      // ... and the divisor by the parts per tile
 };
 #define ED_ES 36     // E row stride (floats)
 // Phase 1 feeds the MFMA straight from global memory: every footprint pixel row belongs to exactly one wave
@@ -518,8 +520,20 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, PH == 
     const unsigned L = xcd_remap(blockIdx.x, nblk);
     const int tiles = p.tiles_h * p.tiles_w;
     int b, tile, cc0 = 0;
+    int cpp = p.cchunks;
     if constexpr (LOOP) {
-        b = (int)fdiv(L, p.d_bpc); tile = (int)L - b * tiles;               // (d_bpc divides by tiles here)
+        if (p.cpp > 0) {
+            // small calls: a (clip, tile)'s chunk loop cut into parts of cpp chunks, one block each - the same chunks computed the same way
+            // (and their per-tile sums written by whoever computed them), only on more CUs (launch_expand_dw)
+            cpp = p.cpp;
+            const int nparts = (p.cchunks + cpp - 1) / cpp;
+            b = (int)fdiv(L, p.d_bpc);
+            const int rest = (int)L - b * tiles * nparts;
+            tile = (int)fdiv((unsigned)rest, p.d_part);
+            cc0 = (rest - tile * nparts) * cpp;
+        } else {
+            b = (int)fdiv(L, p.d_bpc); tile = (int)L - b * tiles;           // (d_bpc divides by tiles here)
+        }
     } else {
         b = (int)fdiv(L, p.d_bpc);
         const int rest = (int)L - b * tiles * p.cchunks;
@@ -532,7 +546,7 @@ __global__ __launch_bounds__(64 * NW, expdw_sk_waves(K, S, TOH, TOW, TRH, PH == 
     const int nvalid = (vr1 - vr0) * TIW;
     const int jtv = (nvalid + 15) >> 4;
     const int Cin = p.Cin;
-    const int ncc = LOOP ? p.cchunks : 1;
+    const int ncc = LOOP ? min(cpp, p.cchunks - cc0) : 1;
     const size_t tile_index = (size_t)b * tiles + tile;
 
     static_assert(SW * S == 2 || SW * S == 4, "lane permutation tables cover SW*S in {2, 4}");
@@ -953,8 +967,21 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
     if (pipe16) { p.wep = wep; p.Kp = expdw_kp(Cin); p.prec = prec; p.in_bf16 = in_bf16; }     // (the planner marks x bf16 for this form only)
     if (sk && !stem) {
         // small-K form: a block owns (clip, tile) and walks the channel chunks itself
-        nblk = (unsigned)B * p.tiles_h * p.tiles_w;
-        p.d_bpc = make_fdiv((unsigned)(p.tiles_h * p.tiles_w));
+        const int tiles = p.tiles_h * p.tiles_w;
+        nblk = (unsigned)B * tiles;
+        p.d_bpc = make_fdiv((unsigned)tiles);
+        // ... unless the call is so small that the chip would idle behind a few serial chunk loops (one clip: 12-24 blocks walking
+        // five chunks each, 19-24 us): then the loop is cut into parts until the grid has ~256 blocks
+        if (p.cchunks > 1 && (long)B * tiles < 128) {
+            const int want = (int)std::min<long>(p.cchunks, (256 + (long)B * tiles - 1) / ((long)B * tiles));
+            const int cpp = (p.cchunks + want - 1) / want, nparts = (p.cchunks + cpp - 1) / cpp;
+            if (nparts > 1) {
+                p.cpp = cpp;
+                p.d_part = make_fdiv((unsigned)nparts);
+                nblk = (unsigned)B * tiles * nparts;
+                p.d_bpc = make_fdiv((unsigned)(tiles * nparts));
+            }
+        }
     }
     if (stem) {
         p.Hin = stem->Hin; p.Win = stem->Win; p.pts = stem->pt; p.pls = stem->pl;
