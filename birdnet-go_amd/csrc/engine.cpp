@@ -367,6 +367,7 @@ Engine::~Engine() {
     for (auto e : ev_pool) hipEventDestroy(e);
     for (auto& p : step_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     if (mm_scratch) hipFree(mm_scratch);
+    if (d_hand) hipFree(d_hand);
     for (void* p : {(void*)act_arena, (void*)w_arena, (void*)d_stage_in, (void*)d_stage_logits, (void*)d_stage_emb,
                     (void*)d_stage_pcm, (void*)d_post_conf, (void*)d_topk_conf, (void*)d_topk_idx})
         if (p) hipFree(p);
@@ -1650,6 +1651,7 @@ bool Engine::build(TflModel m, int dev, int maxb, bool plan_only, std::string* e
     act_bytes = plan_arena((size_t)max_batch, false);
     lane_bytes = n_lanes > 1 ? align_up(plan_arena((size_t)lane_cap, true), 256) : 0;
     act_bytes = std::max(act_bytes, lane_bytes * (size_t)n_lanes);
+    pick_split();
 
     // ---------------------------------------------------------------- device allocation
     w_bytes = wimg.size() * sizeof(float);
@@ -2159,6 +2161,7 @@ float* Engine::vptr(int v, const float* d_in, float* d_logits, float* d_emb, int
     if (v < 0) return nullptr;
     if (v == v_input) return const_cast<float*>(d_in);
     if (v == v_logits) return d_logits;
+    if (part_hand && v == v_hand) return part_hand;
     (void)d_emb;
     char* base = cur_arena ? cur_arena : act_arena;
     // lane >= 0: that lane's own copy of the lane layout (values are [clip][elems] from the lane's first clip)
@@ -2213,6 +2216,74 @@ bool Engine::run_on_context(int c, hipStream_t st, const float* d_in, int n, flo
     cur_arena = nullptr;
     cur_stream = nullptr;
     return ok;
+}
+// Steps [s0, s1) for n clips in context c's arena on stream st (hostpipe.cpp's two-phase calls); the one value that crosses the cut
+// is read / written at `hand` instead of its arena slot.
+bool Engine::run_part(int c, hipStream_t st, int s0, int s1, const float* d_in, int n, float* hand, float* d_logits, float* d_emb, std::string* err) {
+    if (n <= 0 || n > max_batch) { *err = "batch size out of range"; return false; }
+    if (c < 0 || c >= kMaxDepth || !st || !ctx_arena[c]) { *err = "context does not exist"; return false; }
+    if (v_hand < 0 || !hand || s0 < 0 || s1 > (int)steps.size() || s0 >= s1 || (s0 != 0 && s0 != split_step) || (s1 != (int)steps.size() && s1 != split_step)) {
+        *err = "not a cut of this plan"; return false;
+    }
+    call_idx++;
+    cur_arena = ctx_arena[c];
+    cur_stream = st;
+    cur_ctx = c;
+    part_s0 = s0; part_s1 = s1; part_hand = hand;
+    bool ok = run_eager(d_in, n, d_logits, d_emb, err);
+    part_s0 = 0; part_s1 = -1; part_hand = nullptr;
+    cur_ctx = -1;
+    cur_arena = nullptr;
+    cur_stream = nullptr;
+    return ok;
+}
+bool Engine::ensure_hand(std::string* err) {
+    if (d_hand || v_hand < 0) return v_hand >= 0;
+    if (hipMalloc((void**)&d_hand, std::max<size_t>((size_t)max_batch * hand_clip_bytes(), 256)) != hipSuccess) {
+        (void)hipGetLastError(); d_hand = nullptr; *err = "hand-off allocation failed"; return false;
+    }
+    return true;
+}
+// Where a call that fits one batch is cut in two (run_part): the launch boundaries a single activation crosses are the block
+// boundaries of the stack; of those, the first one whose crossing value has fewer than `rows_min` spatial positions per clip - from
+// there on a quarter-batch chunk has too few rows to fill 256 CUs and the layers are worth running over a larger group (v2.4 stack:
+// the input of b5; cuts from b4 to b7 measured within 2 % of each other, earlier and later ones lose).
+// BNHIP_HOST_SPLIT=<step index> picks a boundary by hand (snapped to the next candidate), -1 disables; read once here, at plan time.
+void Engine::pick_split() {
+    split_step = -1; v_hand = -1; split_candidates.clear();
+    const int ns = (int)steps.size();
+    std::vector<int> crossing(ns, -1);
+    for (int k = 1; k < ns; k++) {
+        int cnt = 0, who = -1; bool bad = false;
+        for (int v = 0; v < (int)vals.size(); v++) {
+            const Value& V = vals[v];
+            if (V.first < 0 || V.first >= k || V.last < k) continue;      // not alive across the boundary before step k
+            if (v == v_input || v == v_logits || v == v_emb || V.external) { bad = true; break; }
+            cnt++; who = v;
+        }
+        if (!bad && cnt == 1) { split_candidates.push_back(k); crossing[k] = who; }
+    }
+    int want = -2;
+    if (const char* e = getenv("BNHIP_HOST_SPLIT")) want = atoi(e);
+    if (want == -1 || split_candidates.empty()) return;
+    int pick = -1;
+    if (want >= 0) {
+        for (int k : split_candidates) if (k >= want) { pick = k; break; }
+    } else {
+        const int rows_min = 1000;
+        for (int k : split_candidates) {
+            const Step& s = steps[k];                                    // the consumer's input geometry = the crossing value's
+            if ((s.kind == S_PW || s.kind == S_EXPAND_DW || s.kind == S_DW) && s.H * s.W < rows_min && s.H * s.W > 0) { pick = k; break; }
+        }
+    }
+    if (pick < 0) return;
+    split_step = pick; v_hand = crossing[pick];
+    if (getenv("BNHIP_DEBUG")) {
+        fprintf(stderr, "[bnhip] host split: step %d (%s), value %d (%zu elems/clip%s); candidates:", split_step, steps[split_step].name.c_str(), v_hand,
+                vals[v_hand].elems, vals[v_hand].half ? ", bf16" : "");
+        for (int k : split_candidates) fprintf(stderr, " %d", k);
+        fprintf(stderr, "\n");
+    }
 }
 void Engine::sync_contexts() {
     for (int i = 0; i < kMaxKStreams; i++) if (kstream[i]) hipStreamSynchronize(kstream[i]);
@@ -2288,7 +2359,8 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
         hipEventRecord(ev_fork, main_stream);
         for (int li = 1; li < nl; li++) hipStreamWaitEvent(lanes[li].st, ev_fork, 0);
     }
-    for (int si = 0; si < (int)steps.size(); si++) {
+    const int s_end = part_s1 < 0 ? (int)steps.size() : part_s1;
+    for (int si = part_s0; si < s_end; si++) {
       for (int li = 0; li < nl; li++) {
         const Step& s = steps[si];
         const float* d_in = lanes[li].d_in; float* d_logits = lanes[li].d_logits; float* d_emb = lanes[li].d_emb;
@@ -2471,7 +2543,7 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
     }
     for (int li = 0; li < nl; li++) {
         const Lane& L = lanes[li];
-        if (L.d_emb && v_emb >= 0) {
+        if (L.d_emb && v_emb >= 0 && s_end == (int)steps.size()) {
             hipError_t e = hipMemcpyAsync(L.d_emb, vptr(v_emb, L.d_in, L.d_logits, L.d_emb, nl > 1 ? li : -1), (size_t)L.n * emb_dim * 4,
                                           hipMemcpyDeviceToDevice, L.st);
             if (e != hipSuccess) { *err = std::string("emb copy: ") + hipGetErrorString(e); return false; }
@@ -2510,7 +2582,7 @@ static void jesc(std::ostringstream& os, const std::string& s) {
 
 std::string Engine::describe() const {
     std::ostringstream os;
-    os << "{\"n_samples\":" << n_samples << ",\"n_classes\":" << n_classes << ",\"emb_dim\":" << emb_dim
+    os << "{\"split_step\":" << split_step << ",\"n_samples\":" << n_samples << ",\"n_classes\":" << n_classes << ",\"emb_dim\":" << emb_dim
        << ",\"max_batch\":" << max_batch << ",\"logits_output\":" << logits_output << ",\"embedding_output\":" << embedding_output << ",\"precision\":\"" << (precision ? "bf16" : "f32") << "\",\"lanes\":" << n_lanes << ",\"lane_min_batch\":" << dual_lane_min << ",\"act_arena_bytes\":" << act_bytes << ",\"weight_bytes\":" << w_bytes
        << ",\"specs\":[";
     for (size_t i = 0; i < specs.size(); i++) {

@@ -131,6 +131,18 @@ class Engine {
     int host_depth = 2;
     bool ensure_contexts(int d, std::string* err, bool with_streams = true);   // host pipeline: arenas only (it runs on kstream[0..1])
     bool run_on_context(int c, hipStream_t st, const float* d_in, int n, float* d_logits, float* d_emb, std::string* err);
+    // Two-phase host calls (hostpipe.cpp, calls that fit one batch): the plan is cut at `split_step`, a launch boundary that exactly
+    // one activation crosses (`v_hand`).  Steps [0, split_step) run per chunk as the chunks arrive and leave that value in hand-off
+    // memory at the chunk's clip offset; steps [split_step, end) run over groups of chunks, where the late layers have the rows to
+    // fill the chip.  Same kernels, same per-clip arithmetic: a clip's outputs do not depend on how the call was cut.
+    int split_step = -1, v_hand = -1;   // chosen at plan time (pick_split); -1: no such cut / disabled
+    float* d_hand = nullptr;            // [max_batch][hand_clip_bytes()], allocated on first use
+    std::vector<int> split_candidates;  // every step index with a single crossing value (diagnostics, describe)
+    void pick_split();
+    size_t hand_clip_bytes() const { return v_hand < 0 ? 0 : vals[v_hand].elems * (vals[v_hand].half ? 2 : 4); }
+    bool ensure_hand(std::string* err);
+    // steps [s0, s1) of the plan for n clips in context c's arena on stream st; `hand` = the hand-off value's rows for these clips
+    bool run_part(int c, hipStream_t st, int s0, int s1, const float* d_in, int n, float* hand, float* d_logits, float* d_emb, std::string* err);
     struct HostPipe* hostpipe = nullptr;
     static constexpr int kMaxLanes = 4;
     int n_lanes = 2;                    // batches of >= dual_lane_min clips are split over this many streams (see run_eager)
@@ -194,6 +206,8 @@ class Engine {
     char* cur_arena = nullptr;          // arena the launches of the current call address (act_arena or a context's)
     hipStream_t cur_stream = nullptr;   // main stream of the current call (stream or a context's)
     int cur_ctx = -1;                   // context index of the current pipelined call (diagnostics)
+    int part_s0 = 0, part_s1 = -1;      // step range of the current call (run_part); -1 = to the end
+    float* part_hand = nullptr;         // where v_hand lives for the current call (run_part)
     size_t act_bytes = 0;
     char* w_arena = nullptr;
     size_t w_bytes = 0;

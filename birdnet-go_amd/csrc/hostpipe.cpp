@@ -139,7 +139,7 @@ struct HostPipe {
         float* d_emb = nullptr; float* h_emb = nullptr;
         float* d_conf = nullptr;                           // [max_batch, n_classes] activation output (top-k jobs)
         float* d_tkc = nullptr; int32_t* d_tki = nullptr; float* h_tkc = nullptr; int32_t* h_tki = nullptr; int tk_cap = 0;
-        hipEvent_t ev_h2d = nullptr, ev_comp = nullptr, ev_done = nullptr;   // input landed / kernels done / results in pinned memory
+        hipEvent_t ev_h2d = nullptr, ev_comp = nullptr, ev_done = nullptr, ev_out = nullptr;   // input landed / kernels done / results in pinned memory
         Ticket fill;
         int chunk = -1;                                    // chunk index in flight, -1 = idle
     };
@@ -157,6 +157,7 @@ void hostpipe_free(HostPipe* hp) {
         if (s.ev_h2d) hipEventDestroy(s.ev_h2d);
         if (s.ev_done) hipEventDestroy(s.ev_done);
         if (s.ev_comp) hipEventDestroy(s.ev_comp);
+        if (s.ev_out) hipEventDestroy(s.ev_out);
     }
     if (hp->xfer) hipStreamSynchronize(hp->xfer);       // (owned by the device's stream pool)
     delete hp;
@@ -193,6 +194,7 @@ int ensure_pipe(Engine& e, const HostJob& j, size_t chunk_bytes, std::string& er
         if (!s.ev_h2d) HP_TRY(hipEventCreateWithFlags(&s.ev_h2d, hipEventDisableTiming), "event");
         if (!s.ev_done) HP_TRY(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming), "event");
         if (!s.ev_comp) HP_TRY(hipEventCreateWithFlags(&s.ev_comp, hipEventDisableTiming), "event");
+        if (!s.ev_out) HP_TRY(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming), "event");
         if (s.h_in_cap < chunk_bytes) {
             if (s.h_in) { hipHostFree(s.h_in); s.h_in = nullptr; s.h_in_cap = 0; }
             HP_TRY(hipHostMalloc((void**)&s.h_in, chunk_bytes, hipHostMallocDefault), "pinned staging allocation");
@@ -299,6 +301,185 @@ int small_run(Engine& e, const HostJob& j, std::string& err) {
     return BNHIP_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ two-phase call
+// A blocking call that fits one batch starts on an idle GPU and ends on one: cut into whole-plan chunks, its first chunk runs alone,
+// its last one runs alone, and every chunk runs the late layers of the stack with a quarter of the rows they need to fill the chip
+// (a plan tuned for the chunk size does not change that: measured).  Here the PLAN is cut as well (Engine::pick_split):
+// the front of the plan (front-end, early blocks: plenty of rows per clip) runs chunk by chunk on stream A as the copies land and
+// leaves the one activation that crosses the cut in hand-off memory; the back of the plan runs on stream B over GROUPS of chunks -
+// the first group under the later chunks' copies and front halves, the last one alone but over half the call's rows.
+// Same kernels and per-clip arithmetic as any other cut: results are bit-identical to the serial path.
+static std::atomic<long> g_split_calls{0};
+int host_run_split(Engine& e, const HostJob& j, const std::vector<int>& csize, std::string& err) {
+    const int nch = (int)csize.size();
+    constexpr int K = HostPipe::K;
+    std::vector<int> cfirst(nch + 1, 0);
+    for (int c = 0; c < nch; c++) cfirst[c + 1] = cfirst[c] + csize[c];
+    const size_t bps = j.pcm_bits ? (size_t)j.pcm_bits / 8 : 4;
+    const size_t clip_bytes = (size_t)e.n_samples * bps;
+    const int kk = j.topk > 0 ? std::min(j.topk, e.n_classes) : 0;
+    HostJob jj = j; jj.topk = kk;
+    int rc = ensure_pipe(e, jj, (size_t)e.max_batch * clip_bytes, err);
+    if (rc) return rc;
+    if (!e.ensure_contexts(2, &err, false) || !e.ensure_hand(&err)) return BNHIP_E_NOMEM;
+    HostPipe& hp = *e.hostpipe;
+    hipStream_t sa = e.kernel_stream(0), sb = e.kernel_stream(1);
+    if (!sa || !sb) { err = "hipStreamCreate failed"; return BNHIP_E_RUNTIME; }
+    e.sync_contexts();
+    if (e.stream) hipStreamSynchronize(e.stream);
+    for (int c = 0; c < Engine::kMaxDepth; c++) if (e.ctx_stream[c]) hipStreamSynchronize(e.ctx_stream[c]);
+    g_split_calls.fetch_add(1, std::memory_order_relaxed);
+
+    const bool src_pinned = is_pinned(j.src, (size_t)j.n_clips * clip_bytes);
+    if (src_pinned) g_pinned_inputs.fetch_add(1, std::memory_order_relaxed);
+    const bool logits_pinned = j.logits && is_pinned(j.logits, (size_t)j.n_clips * e.n_classes * 4);
+    const bool emb_pinned = j.emb && is_pinned(j.emb, (size_t)j.n_clips * e.emb_dim * 4);
+    auto abort_all = [&]() {
+        for (auto& s : hp.s) pool().wait(&s.fill);
+        hipStreamSynchronize(hp.xfer);
+        for (int q = 0; q < 3; q++) if (e.kstream[q]) hipStreamSynchronize(e.kstream[q]);
+        hipStreamSynchronize(hp.xfer);
+        (void)hipGetLastError();
+    };
+#define HP_PIPE(call, what)                                                                \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            abort_all();                                                                   \
+            err = std::string(what) + ": " + hipGetErrorString(e_);                        \
+            return BNHIP_E_RUNTIME;                                                        \
+        }                                                                                  \
+    } while (0)
+    // The schedule: fronts ('f') in chunk order and backs ('b'), each with the kernel stream it runs on (= the context arena it
+    // uses: launches that may overlap never share an arena); a back covers the chunks whose fronts were queued since the previous
+    // back and waits for exactly those.
+    struct Op { char kind; int st; };
+    std::vector<Op> ops;
+    {
+        std::string plan;
+        if (const char* pe = getenv("BNHIP_HOST_PLAN")) plan = pe;      // experiments: "f0 f0 b1 f0 f0 b1" (read per call)
+        int nf = 0; bool ok = !plan.empty(), open = false;
+        for (size_t i = 0; ok && i < plan.size(); i++) {
+            if (plan[i] == ' ' || plan[i] == ',') continue;
+            if ((plan[i] != 'f' && plan[i] != 'b') || i + 1 >= plan.size() || plan[i + 1] < '0' || plan[i + 1] > '2') { ok = false; break; }
+            if (plan[i] == 'f') { nf++; open = true; } else { if (!open) ok = false; open = false; }
+            ops.push_back(Op{plan[i], plan[i + 1] - '0'});
+            i++;
+        }
+        int nb = 0; for (const Op& o : ops) nb += o.kind == 'b';
+        if (!ok || nf != nch || open || nb > K) {
+            // default: every front on stream 0; the back of all chunks but the last on stream 1 as soon as their fronts are queued, the
+            // last chunk's back behind its front on stream 0 - the call ends with two backs overlapping instead of one running alone
+            // (measured against even halves, three groups, fronts alternating over two streams and uneven chunks: profiles/r05_host_split.txt)
+            ops.clear();
+            for (int c = 0; c < nch; c++) {
+                ops.push_back(Op{'f', 0});
+                if (c + 2 == nch) ops.push_back(Op{'b', 1});
+                if (c + 1 == nch) ops.push_back(Op{'b', 0});
+            }
+        }
+    }
+    int n_streams = 1;
+    for (const Op& o : ops) n_streams = std::max(n_streams, o.st + 1);
+    if (!e.ensure_contexts(n_streams, &err, false)) return BNHIP_E_NOMEM;
+    hipStream_t ks[3] = {sa, sb, n_streams > 2 ? e.kernel_stream(2) : nullptr};
+    if (n_streams > 2 && !ks[2]) { err = "hipStreamCreate failed"; return BNHIP_E_RUNTIME; }
+    int ng = 0; for (const Op& o : ops) ng += o.kind == 'b';
+    std::vector<int> gfirst, gcount;                      // per group: first clip, clips
+    auto start_fill = [&](int c) {
+        HostPipe::Slot& s = hp.s[c % K];
+        if (j.prepare) j.prepare(cfirst[c], csize[c]);
+        if (!src_pinned) pool().submit(s.h_in, (const char*)j.src + (size_t)cfirst[c] * clip_bytes, (size_t)csize[c] * clip_bytes, &s.fill);
+    };
+    static const bool trace = getenv("BNHIP_HOST_TRACE") != nullptr;
+    std::vector<hipEvent_t> tev;                          // trace: [base][per chunk: h2d done, front start, front done][per group: back start, back done]
+    if (trace) {
+        tev.resize(1 + 3 * (size_t)nch + 2 * (size_t)ng);
+        for (auto& ev : tev) hipEventCreate(&ev);
+        hipEventRecord(tev[0], hp.xfer);
+    }
+    char* hand = reinterpret_cast<char*>(e.d_hand);
+    const size_t hcb = e.hand_clip_bytes();
+    const int ns = (int)e.steps.size();
+    start_fill(0);
+    int c = 0, g = 0, gopen = 0;                          // next chunk, next group, first chunk of the open group
+    for (const Op& op : ops) {
+        hipStream_t st = ks[op.st];
+        if (op.kind == 'f') {
+            HostPipe::Slot& s = hp.s[c % K];
+            const int n = csize[c];
+            const size_t cnt = (size_t)n * e.n_samples;
+            if (!src_pinned) pool().wait(&s.fill);
+            const void* h_src = src_pinned ? (const void*)((const char*)j.src + (size_t)cfirst[c] * clip_bytes) : (const void*)s.h_in;
+            HP_PIPE(hipMemcpyAsync(j.pcm_bits ? (void*)s.d_raw : (void*)s.d_in, h_src, cnt * bps, hipMemcpyHostToDevice, hp.xfer), "H2D copy");
+            HP_PIPE(hipEventRecord(s.ev_h2d, hp.xfer), "event record");
+            if (trace) hipEventRecord(tev[1 + 3 * c], hp.xfer);
+            HP_PIPE(hipStreamWaitEvent(st, s.ev_h2d, 0), "stream wait");
+            if (trace) hipEventRecord(tev[2 + 3 * c], st);
+            if (j.pcm_bits) launch_pcm_to_f32(s.d_raw, j.pcm_bits, s.d_in, cnt, st);
+            if (!e.run_part(op.st, st, 0, e.split_step, s.d_in, n, reinterpret_cast<float*>(hand + (size_t)cfirst[c] * hcb), s.d_logits, nullptr, &err)) { abort_all(); return BNHIP_E_RUNTIME; }
+            HP_PIPE(hipEventRecord(s.ev_comp, st), "event record");      // (front of chunk c done)
+            if (trace) hipEventRecord(tev[3 + 3 * c], st);
+            c++;
+            if (c < nch) start_fill(c);
+        } else {
+            HostPipe::Slot& o = hp.s[g];                              // (output side of slot g: logits / top-k / embedding staging)
+            const int first = cfirst[gopen], gn = cfirst[c] - first;
+            for (int q = gopen; q < c; q++) HP_PIPE(hipStreamWaitEvent(st, hp.s[q % K].ev_comp, 0), "stream wait");
+            if (trace) hipEventRecord(tev[1 + 3 * nch + 2 * g], st);
+            if (!e.run_part(op.st, st, e.split_step, ns, o.d_in, gn, reinterpret_cast<float*>(hand + (size_t)first * hcb), o.d_logits, j.emb ? o.d_emb : nullptr, &err)) { abort_all(); return BNHIP_E_RUNTIME; }
+            if (kk) {
+                launch_activation(o.d_logits, o.d_conf, gn, e.n_classes, j.activation, j.sensitivity, st);
+                launch_topk(o.d_conf, gn, e.n_classes, kk, o.d_tkc, o.d_tki, st);
+            }
+            HP_PIPE(hipEventRecord(o.ev_done, st), "event record");   // (back phase of group g done)
+            if (trace) hipEventRecord(tev[2 + 3 * nch + 2 * g], st);
+            gfirst.push_back(first); gcount.push_back(gn);
+            gopen = c; g++;
+        }
+    }
+    // copy-out, behind every H2D on the copy stream
+    for (int q = 0; q < ng; q++) {
+        HostPipe::Slot& o = hp.s[q];
+        const size_t off = (size_t)gfirst[q], gn = (size_t)gcount[q];
+        HP_PIPE(hipStreamWaitEvent(hp.xfer, o.ev_done, 0), "stream wait");
+        if (kk) {
+            HP_PIPE(hipMemcpyAsync(o.h_tkc, o.d_tkc, gn * kk * 4, hipMemcpyDeviceToHost, hp.xfer), "D2H copy");
+            HP_PIPE(hipMemcpyAsync(o.h_tki, o.d_tki, gn * kk * 4, hipMemcpyDeviceToHost, hp.xfer), "D2H copy");
+        }
+        if (j.logits) HP_PIPE(hipMemcpyAsync(logits_pinned ? (void*)(j.logits + off * e.n_classes) : (void*)o.h_logits, o.d_logits, gn * e.n_classes * 4, hipMemcpyDeviceToHost, hp.xfer), "D2H copy");
+        if (j.emb) HP_PIPE(hipMemcpyAsync(emb_pinned ? (void*)(j.emb + off * e.emb_dim) : (void*)o.h_emb, o.d_emb, gn * e.emb_dim * 4, hipMemcpyDeviceToHost, hp.xfer), "D2H copy");
+        HP_PIPE(hipEventRecord(o.ev_out, hp.xfer), "event record");
+    }
+    for (int q = 0; q < ng; q++) {
+        HostPipe::Slot& o = hp.s[q];
+        const size_t off = (size_t)gfirst[q], gn = (size_t)gcount[q];
+        HP_PIPE(hipEventSynchronize(o.ev_out), "D2H copy/sync");
+        if (j.logits && !logits_pinned) parallel_copy(j.logits + off * e.n_classes, o.h_logits, gn * e.n_classes * 4);
+        if (j.emb && !emb_pinned) memcpy(j.emb + off * e.emb_dim, o.h_emb, gn * e.emb_dim * 4);
+        if (kk) {
+            memcpy(j.out_conf + off * kk, o.h_tkc, gn * kk * 4);
+            memcpy(j.out_idx + off * kk, o.h_tki, gn * kk * 4);
+        }
+    }
+    if (trace) {
+        for (int c = 0; c < nch; c++) {
+            float a = 0, b = 0, d = 0;
+            hipEventElapsedTime(&a, tev[0], tev[1 + 3 * c]); hipEventElapsedTime(&b, tev[0], tev[2 + 3 * c]); hipEventElapsedTime(&d, tev[0], tev[3 + 3 * c]);
+            fprintf(stderr, "[bnhip] host trace: chunk %d (%d clips) GPU: h2d done %.3f, front start %.3f, done %.3f ms\n", c, csize[c], a, b, d);
+        }
+        for (int q = 0; q < ng; q++) {
+            float a = 0, b = 0;
+            hipEventElapsedTime(&a, tev[0], tev[1 + 3 * nch + 2 * q]); hipEventElapsedTime(&b, tev[0], tev[2 + 3 * nch + 2 * q]);
+            fprintf(stderr, "[bnhip] host trace: group %d (%d clips from %d) GPU: back start %.3f, done %.3f ms\n", q, gcount[q], gfirst[q], a, b);
+        }
+        for (auto& ev : tev) hipEventDestroy(ev);
+    }
+#undef HP_PIPE
+    return BNHIP_OK;
+}
+
 }  // namespace
 
 int host_run(Engine& e, const HostJob& j, std::string& err) {
@@ -349,6 +530,9 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
         if (!want.empty() && sum == j.n_clips) csize = want;
     }
     const int nch = (int)csize.size();
+    // a call that fits one batch: cut the plan as well as the batch (host_run_split)
+    if (e.split_step > 0 && D >= 2 && j.n_clips <= e.max_batch && nch >= 2 && nch <= HostPipe::K && !getenv("BNHIP_HOST_SERIAL") && !getenv("BNHIP_HOST_NOSPLIT"))      // (diagnostics, read per call)
+        return host_run_split(e, j, csize, err);
     std::vector<int> cfirst(nch + 1, 0);
     for (int c = 0; c < nch; c++) cfirst[c + 1] = cfirst[c] + csize[c];
     const size_t bps = j.pcm_bits ? (size_t)j.pcm_bits / 8 : 4;
@@ -492,4 +676,5 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
 
 }  // namespace bnhip
 
+extern "C" long bnhip_debug_split_calls(void) { return bnhip::g_split_calls.load(std::memory_order_relaxed); }
 extern "C" long bnhip_debug_pinned_inputs(void) { return bnhip::g_pinned_inputs.load(std::memory_order_relaxed); }

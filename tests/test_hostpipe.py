@@ -202,3 +202,71 @@ def test_pinned_caller_buffers_are_bit_identical_and_skip_the_staging(gpu, full_
         clf.close()
     with pytest.raises(host.HipError):
         host.PinnedArray((0,), np.float32)
+
+
+def test_plan_cut_of_the_two_phase_call_is_a_block_boundary():
+    """CPU: Engine::pick_split cuts the v2.4 plan where exactly one activation crosses (a block boundary) - the input of b5, the first
+    block whose input has fewer than 1000 positions per clip; BNHIP_HOST_SPLIT=-1 (read at plan time) disables it."""
+    import os
+    blob = sm.build_model()
+    clf = host.HipClassifier(blob, plan_only=True)
+    d = clf.describe()
+    clf.close()
+    k = d["split_step"]
+    assert k > 0 and d["steps"][k]["name"] == "b5/expand+dw" and d["steps"][k - 1]["name"] == "b4/project"
+    os.environ["BNHIP_HOST_SPLIT"] = "-1"
+    try:
+        clf = host.HipClassifier(blob, plan_only=True)
+        assert clf.describe()["split_step"] == -1
+        clf.close()
+    finally:
+        os.environ.pop("BNHIP_HOST_SPLIT")
+
+
+@pytest.mark.gpu
+def test_two_phase_call_equals_whole_plan_chunks_bit_for_bit(gpu, full_blob):
+    """A blocking call that fits one batch cuts the PLAN as well as the batch (hostpipe.cpp host_run_split): fronts per chunk, backs over
+    groups of chunks, the crossing activation through hand-off memory.  Same kernels, same per-clip arithmetic: logits, embeddings and
+    top-k equal the whole-plan chunk schedule (BNHIP_HOST_NOSPLIT, read per call) bit for bit - float32 and int16 input, pageable and
+    page-locked, clip counts that do not divide, fp32 and bf16-storage engines - and the path is the one taken (counter)."""
+    import ctypes
+    import os
+    lib = host.load_library()
+    lib.bnhip_debug_split_calls.restype = ctypes.c_long
+    x = sm.synth_clips(256, 144000, 48000)
+    pcm = (np.clip(x, -1, 1) * 32767).astype(np.int16)
+    for kw in ({}, {"precision": "bf16", "autotune": False}):
+        clf = host.HipClassifier(full_blob, max_batch=256, **kw)
+        try:
+            assert clf.describe()["split_step"] > 0
+            for n in (256, 200, 129):
+                got, ref = {}, {}
+                for dst, env in ((got, None), (ref, "1")):
+                    if env:
+                        os.environ["BNHIP_HOST_NOSPLIT"] = env
+                    try:
+                        before = lib.bnhip_debug_split_calls()
+                        if clf.emb_dim:
+                            dst["f32"], dst["emb"] = clf.predict_batch(x[:n].reshape(-1), n, want_embeddings=True)
+                        else:
+                            dst["f32"] = clf.predict_batch(x[:n].reshape(-1), n).copy()
+                        dst["pcm"] = clf.predict_pcm16(pcm[:n].reshape(-1), n).copy()
+                        dst["topk"] = clf.predict_topk(x[:n].reshape(-1), n, k=10, activation=0, sensitivity=1.0)
+                        assert lib.bnhip_debug_split_calls() - before == (0 if env else 3), (n, env)
+                    finally:
+                        os.environ.pop("BNHIP_HOST_NOSPLIT", None)
+                assert np.isfinite(got["f32"]).all()
+                assert np.array_equal(got["f32"], ref["f32"]) and np.array_equal(got["pcm"], ref["pcm"]), (n, kw)
+                if "emb" in got:
+                    assert np.array_equal(got["emb"], ref["emb"]), (n, kw)
+                assert np.array_equal(got["topk"][0], ref["topk"][0]) and np.array_equal(got["topk"][1], ref["topk"][1]), (n, kw)
+            if not kw:
+                with host.PinnedArray((256, 144000), np.float32) as pi, host.PinnedArray((256, clf.num_species()), np.float32) as po:
+                    pi.array[:] = x
+                    assert np.array_equal(clf.predict_batch(pi.array.reshape(-1), 256, out=po.array), got["f32"] if n == 256 else clf.predict_batch(x.reshape(-1), 256))
+                # the oracle on sampled rows of the two-phase call
+                rows = [0, 63, 64, 191, 192, 255]
+                full = clf.predict_batch(x.reshape(-1), 256)
+                assert_parity(full[rows], Interpreter(full_blob).invoke(x[rows])[0])
+        finally:
+            clf.close()
