@@ -842,10 +842,10 @@ static ExpDwGeo expdw_oriented(int idx, const ExpDwGeo& g) {
     t.H = g.W; t.W = g.H; t.Ho = g.Wo; t.Wo = g.Ho; t.pt = g.pl; t.pl = g.pt;
     return t;
 }
-bool expdw_shape_fits(int idx, const ExpDwGeo& g0) {
+bool expdw_shape_fits(int idx, const ExpDwGeo& g0, bool planning) {
     if (idx < 0 || idx >= 2 * kNumExpDwShapes) return false;
     if (idx >= kNumExpDwShapes && g0.stem) return false;
-    if (!g0.stem) {                                      // BNHIP_EXPDW_ORIENT = n | t: one orientation only (tests, A/B runs)
+    if (!g0.stem && planning) {                          // BNHIP_EXPDW_ORIENT = n | t: one orientation only (tests, A/B runs; plan / tune time only)
         const char* oe = getenv("BNHIP_EXPDW_ORIENT");
         if (oe && ((oe[0] == 'n' && idx >= kNumExpDwShapes) || (oe[0] == 't' && idx < kNumExpDwShapes))) return false;
     }
@@ -940,7 +940,7 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
     // the arithmetic of a layer does not depend on which tile the tuner preferred: skw = 0 withholds them)
     const bool pipe16 = expdw_sk_pipe16(Cin, act_e, stem != nullptr, prec, wep != nullptr);
     const ExpDwGeo g0{k, s, H, W, Ho, Wo, pt, pl, stem != nullptr, pipe16 ? 0 : expdw_skw(Cin, act_e, stem != nullptr)};
-    if (!expdw_shape_fits(shape, g0)) shape = expdw_default_shape(g0);
+    if (!expdw_shape_fits(shape, g0, false)) shape = expdw_default_shape(g0);
     if (shape < 0) return;                             // the planner only fuses layers some shape accepts
     const ExpDwShape* sh = &kExpDwShapes[shape % kNumExpDwShapes];
     const bool tr = shape >= kNumExpDwShapes;
@@ -1036,7 +1036,7 @@ bool dwconv_lds_supported(const DwParams& p) {
 }
 void launch_dwconv_lds(const DwParams& q, float* partial, int shape, hipStream_t st) {
     const ExpDwGeo g0{q.kh, q.sh, q.H, q.W, q.Ho, q.Wo, q.pt, q.pl, false};
-    if (!expdw_shape_fits(shape, g0)) shape = expdw_default_shape(g0);
+    if (!expdw_shape_fits(shape, g0, false)) shape = expdw_default_shape(g0);
     if (shape < 0) return;
     const ExpDwShape* sh = &kExpDwShapes[shape % kNumExpDwShapes];
     const bool tr = shape >= kNumExpDwShapes;

@@ -302,6 +302,14 @@ int small_run(Engine& e, const HostJob& j, std::string& err) {
 }
 
 
+// Diagnostic switches of the host pipeline (BNHIP_HOST_SERIAL / _NOSPLIT / _PLAN / _CHUNKS / _SCHED) are read per CALL so that one
+// process can compare schedules - but only in a process that started with BNHIP_HOST_DIAG set: a production call never touches the
+// environment (getenv beside another thread's setenv is a data race; multi-device handles run calls on worker threads).
+static const char* diag_env(const char* name) {
+    static const bool on = getenv("BNHIP_HOST_DIAG") != nullptr;
+    return on ? getenv(name) : nullptr;
+}
+
 // ------------------------------------------------------------------------------------------------ two-phase call
 // A blocking call that fits one batch starts on an idle GPU and ends on one: cut into whole-plan chunks, its first chunk runs alone,
 // its last one runs alone, and every chunk runs the late layers of the stack with a quarter of the rows they need to fill the chip
@@ -358,7 +366,7 @@ int host_run_split(Engine& e, const HostJob& j, const std::vector<int>& csize, s
     std::vector<Op> ops;
     {
         std::string plan;
-        if (const char* pe = getenv("BNHIP_HOST_PLAN")) plan = pe;      // experiments: "f0 f0 b1 f0 f0 b1" (read per call)
+        if (const char* pe = diag_env("BNHIP_HOST_PLAN")) plan = pe;      // experiments: "f0 f0 b1 f0 f0 b1" (read per call)
         int nf = 0; bool ok = !plan.empty(), open = false;
         for (size_t i = 0; ok && i < plan.size(); i++) {
             if (plan[i] == ' ' || plan[i] == ',') continue;
@@ -510,7 +518,7 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
         for (int left = j.n_clips; left > 0; left -= ck) csize.push_back(std::min(ck, left));
     } else {
         int h1 = unit, h2 = 2 * unit, t1 = 5 * unit / 2, t2 = std::max(1, unit / 2);   // (the context that frees first takes the larger last piece)
-        if (const char* sc = getenv("BNHIP_HOST_SCHED")) sscanf(sc, "%d,%d,%d,%d", &h1, &h2, &t1, &t2);   // experiments
+        if (const char* sc = diag_env("BNHIP_HOST_SCHED")) sscanf(sc, "%d,%d,%d,%d", &h1, &h2, &t1, &t2);   // experiments
         h1 = std::max(1, std::min(h1, e.max_batch)); h2 = std::max(1, std::min(h2, e.max_batch));
         t1 = std::max(1, std::min(t1, e.max_batch)); t2 = std::max(1, std::min(t2, e.max_batch));
         if (h1 + h2 + t1 + t2 > j.n_clips) { h1 = unit; h2 = 2 * unit; t1 = 5 * unit / 2; t2 = std::max(1, unit / 2); }   // (a BNHIP_HOST_SCHED that does not fit the call)
@@ -519,7 +527,7 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
         for (int k = 0, left = mid; k < nm; k++) { const int c = (left + (nm - k) - 1) / (nm - k); csize.push_back(c); left -= c; }
         csize.push_back(t1); csize.push_back(t2);
     }
-    if (const char* cc = getenv("BNHIP_HOST_CHUNKS")) {    // experiments: an explicit schedule "32,64,96,64" (read per call; must add up)
+    if (const char* cc = diag_env("BNHIP_HOST_CHUNKS")) {    // experiments: an explicit schedule "32,64,96,64" (read per call; must add up)
         std::vector<int> want;
         long sum = 0;
         for (const char* q = cc; *q;) {
@@ -534,7 +542,7 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
     }
     const int nch = (int)csize.size();
     // a call that fits one batch: cut the plan as well as the batch (host_run_split)
-    if (e.split_step > 0 && D >= 2 && j.n_clips <= e.max_batch && nch >= 2 && nch <= HostPipe::K && !getenv("BNHIP_HOST_SERIAL") && !getenv("BNHIP_HOST_NOSPLIT"))      // (diagnostics, read per call)
+    if (e.split_step > 0 && D >= 2 && j.n_clips <= e.max_batch && nch >= 2 && nch <= HostPipe::K && !diag_env("BNHIP_HOST_SERIAL") && !diag_env("BNHIP_HOST_NOSPLIT"))      // (diagnostics, read per call)
         return host_run_split(e, j, csize, err);
     std::vector<int> cfirst(nch + 1, 0);
     for (int c = 0; c < nch; c++) cfirst[c + 1] = cfirst[c] + csize[c];
@@ -607,7 +615,7 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
         for (auto& ev : tev) hipEventCreate(&ev);
         hipEventRecord(tev[0], hp.xfer);
     }
-    const bool serial = getenv("BNHIP_HOST_SERIAL") != nullptr;      // diagnostics: one chunk at a time (read per call)
+    const bool serial = diag_env("BNHIP_HOST_SERIAL") != nullptr;      // diagnostics: one chunk at a time (read per call)
     auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_call = now_ms();
     std::vector<double> tr;

@@ -174,7 +174,7 @@ int expdw_skw(int Cin, int act_e, bool stem);
 bool expdw_sk_pipe16(int Cin, int act_e, bool stem, int prec, bool have_image);   // phase 1 on the bf16 pipe (then no eight-wave shapes: pass skw = 0)
 int expdw_sum_slabs(const ExpDwGeo& g);   // slabs of the cost-model shape; 0 = no tile shape fits (do not fuse)
 int expdw_num_shapes();                   // 2n
-bool expdw_shape_fits(int idx, const ExpDwGeo& g);
+bool expdw_shape_fits(int idx, const ExpDwGeo& g, bool planning = true);   // planning: also honour BNHIP_EXPDW_ORIENT (the launchers pass false: no getenv per launch)
 int expdw_shape_slabs(int idx, const ExpDwGeo& g);
 int expdw_default_shape(const ExpDwGeo& g);
 int expdw_max_slabs(const ExpDwGeo& g);

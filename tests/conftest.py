@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+os.environ.setdefault("BNHIP_HOST_DIAG", "1")      # the host pipeline's per-call diagnostic switches (hostpipe.cpp diag_env) exist in test processes only
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

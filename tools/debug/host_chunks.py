@@ -1,6 +1,8 @@
 """Explicit chunk schedules for the 256-clip blocking call (BNHIP_HOST_CHUNKS, read per call): one engine, every schedule
 timed in turn, twice round (same box, interleaved).  python tools/debug/host_chunks.py"""
 import os
+
+os.environ.setdefault("BNHIP_HOST_DIAG", "1")      # per-call switches of the host pipeline are read only in a process that sets this
 import sys
 import time
 

@@ -1,5 +1,7 @@
 """Blocking calls of 16 ... 192 clips (pageable fp32 / int16): serial path vs the pipelined paths (BNHIP_HOST_PIPE_MIN, BNHIP_HOST_RAMP: read once)."""
 import os
+
+os.environ.setdefault("BNHIP_HOST_DIAG", "1")      # per-call switches of the host pipeline are read only in a process that sets this
 import sys
 import time
 

@@ -1,5 +1,7 @@
 """Two-phase call of n clips: the default chunks (64-clip units) vs four equal chunks (BNHIP_HOST_CHUNKS, read per call)."""
 import os
+
+os.environ.setdefault("BNHIP_HOST_DIAG", "1")      # per-call switches of the host pipeline are read only in a process that sets this
 import sys
 import time
 

@@ -3,6 +3,8 @@ read at create time), under different schedules (BNHIP_HOST_PLAN / BNHIP_HOST_CH
 pinned and pageable caller memory and a digest of the logits (every cut and schedule must give the same bits)."""
 import hashlib
 import os
+
+os.environ.setdefault("BNHIP_HOST_DIAG", "1")      # per-call switches of the host pipeline are read only in a process that sets this
 import sys
 import time
 

@@ -1,5 +1,7 @@
 """Two-phase call vs whole-plan chunks on one engine (BNHIP_HOST_NOSPLIT, read per call): where do the logits differ?"""
 import os
+
+os.environ.setdefault("BNHIP_HOST_DIAG", "1")      # per-call switches of the host pipeline are read only in a process that sets this
 import sys
 
 import numpy as np

@@ -1,5 +1,6 @@
 """Count rows whose logits differ between the serial and the overlapped execution of the same 2048-clip host call."""
 import os, sys
+os.environ.setdefault("BNHIP_HOST_DIAG", "1")      # per-call switches of the host pipeline are read only in a process that sets this
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import birdnet_go_amd
