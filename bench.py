@@ -350,7 +350,7 @@ def host_pointer_rates(clf, x, reps_small=100, reps_mid=12, reps_big=5):
     finally:
         win.close()
     res["note"] = ("blocking C-ABI entries bnhip_predict / bnhip_predict_pcm16, outputs complete on return; calls of >= 128 clips run as chunks "
-                   "on two contexts (csrc/hostpipe.cpp): pageable caller memory is staged through the library's pinned slots by copy threads, "
+                   "on two contexts - a call that fits one batch with the plan cut in two as well: fronts per chunk, backs over groups of chunks (csrc/hostpipe.cpp): pageable caller memory is staged through the library's pinned slots by copy threads, "
                    "`_pinned` legs pass bnhip_host_alloc memory, which the copy engines read and write directly; median of the calls; "
                    "realtime_tick_256: 256 sources written into the window assembler, then ONE bnhip_windows_predict_topk (ms = that call; the two-step "
                    "collect + bnhip_predict_pcm_topk beside it)")
