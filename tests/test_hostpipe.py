@@ -224,6 +224,42 @@ def test_plan_cut_of_the_two_phase_call_is_a_block_boundary():
 
 
 @pytest.mark.gpu
+def test_two_phase_call_on_the_tiny_model_embeddings_and_24_bit(gpu, tiny_blob):
+    """The same contract on the small model (cut right behind the stem, embeddings out of the back phase, 24-bit PCM through the fronts):
+    two-phase == whole-plan chunks, bit for bit, at clip counts that leave ragged chunks."""
+    import ctypes
+    import os
+    lib = host.load_library()
+    lib.bnhip_debug_split_calls.restype = ctypes.c_long
+    cfg = sm.tiny_config()
+    clf = host.HipClassifier(tiny_blob, max_batch=256)
+    try:
+        assert clf.describe()["split_step"] > 0
+        for n in (129, 191, 256):
+            x = sm.synth_clips(n, cfg.n_samples, cfg.sample_rate)
+            i24 = np.clip(np.round(x * 8388607), -8388608, 8388607).astype(np.int32)
+            raw = np.zeros((i24.size, 3), np.uint8)
+            u = i24.reshape(-1).astype(np.uint32)
+            raw[:, 0] = u & 0xff; raw[:, 1] = (u >> 8) & 0xff; raw[:, 2] = (u >> 16) & 0xff
+            res = {}
+            for env in (None, "1"):
+                if env:
+                    os.environ["BNHIP_HOST_NOSPLIT"] = env
+                try:
+                    before = lib.bnhip_debug_split_calls()
+                    a = clf.predict_batch(x.reshape(-1), n, want_embeddings=True) if clf.emb_dim else (clf.predict_batch(x.reshape(-1), n).copy(),)
+                    b = clf.predict_pcm(raw.tobytes(), 24, n).copy()
+                    assert lib.bnhip_debug_split_calls() - before == (0 if env else 2), (n, env)
+                    res[env] = tuple(np.array(v) for v in a) + (b,)
+                finally:
+                    os.environ.pop("BNHIP_HOST_NOSPLIT", None)
+            for u_, v_ in zip(res[None], res["1"]):
+                assert np.isfinite(u_).all() and np.array_equal(u_, v_), n
+    finally:
+        clf.close()
+
+
+@pytest.mark.gpu
 def test_two_phase_call_equals_whole_plan_chunks_bit_for_bit(gpu, full_blob):
     """A blocking call that fits one batch cuts the PLAN as well as the batch (hostpipe.cpp host_run_split): fronts per chunk, backs over
     groups of chunks, the crossing activation through hand-off memory.  Same kernels, same per-clip arithmetic: logits, embeddings and
