@@ -636,6 +636,10 @@ int bnhip_model_create(const void* blob, size_t n_bytes, const char* opts_json, 
         std::unique_ptr<Engine> e(new Engine());
         e->no_reuse = json_int(opts_json, "debug_no_reuse", 0) != 0;
         e->autotune = json_int(opts_json, "autotune", 1) != 0;
+        {
+            const char* tenv = getenv("BNHIP_TUNE_DIR");
+            e->tune_dir = json_str(opts_json, "tune_dir", tenv ? tenv : "");
+        }
         e->n_lanes = (int)json_int(opts_json, "lanes", lenv ? atoi(lenv) : 2);
         e->depth = (int)json_int(opts_json, "depth", denv ? atoi(denv) : 1);
         {
@@ -1267,7 +1271,17 @@ int bnhip_model_describe(const bnhip_model* m, char* buf, size_t cap) {
     std::string devs = "[";
     for (size_t i = 0; i < m->engs.size(); i++) devs += (i ? "," : "") + std::to_string(m->engs[i]->device);
     devs += "]";
-    std::string head = "{\"devices\":" + devs + ",\"weight_replication\":\"" + m->replication + "\",";
+    // (what every engine of the handle runs: one tuning adopted by all of them, or their own - "tune_sources"; "plans_identical":
+    // every engine picked the same tile / kernel form for every step, so a clip's bits do not depend on the shard it lands on)
+    std::string srcs = "[";
+    bool same = true;
+    for (size_t i = 0; i < m->engs.size(); i++) {
+        srcs += std::string(i ? "," : "") + "\"" + m->engs[i]->tune_source + "\"";
+        same = same && m->engs[i]->tuning_text() == m->engs[0]->tuning_text();
+    }
+    srcs += "]";
+    std::string head = "{\"devices\":" + devs + ",\"weight_replication\":\"" + m->replication + "\",\"tune_sources\":" + srcs +
+                       ",\"plans_identical\":" + (same ? "true" : "false") + ",";
     if (!d.empty() && d[0] == '{') d = head + d.substr(1);
     return copy_out(d, buf, cap);
     BN_GUARD_END((void)0)

@@ -1785,47 +1785,129 @@ void Engine::finish_deferred() {
     defer_weights = false;
 }
 
+// Where a plan's tuning comes from, in this order (round 6: "one plan per library"):
+//   1. BNHIP_TUNE_FILE          an experiment's own file (tools/profile_round.sh: bench, kernel trace and every PMC pass of one round)
+//   2. the process cache        an engine of the same plan (model geometry, batch, depth, precision, switches, architecture) was
+//                               already tuned in this process - the other shards of a multi-device handle, a second handle on the same
+//                               model: they adopt its decisions, so a clip's bits do not depend on which engine it lands on
+//   3. "tune_dir" / BNHIP_TUNE_DIR   a directory of recorded tunings named by that key (birdnet-go_amd/tune/ holds the ones the
+//                               committed PMC passes ran on): the counters under profiles/ then describe the plan that is timed
+//   4. the three create-time tuners (timing races: no two runs agree on every tile); recorded into 1 / 3 on request
+// Switches that change what the tuners may pick (BNHIP_EXPDW_FORCE, BNHIP_DW_LDS, BNHIP_NO_DW_LDS, BNHIP_TUNE_BY_TIME) bypass 2 and 3;
+// BNHIP_TUNE_CACHE=0 bypasses 2 only.
+namespace {
+std::mutex g_tune_mu;
+std::map<std::string, std::string> g_tune_cache;
+bool tune_experiment_env() {
+    for (const char* n : {"BNHIP_EXPDW_FORCE", "BNHIP_DW_LDS", "BNHIP_NO_DW_LDS", "BNHIP_TUNE_BY_TIME"}) if (getenv(n)) return true;
+    return false;
+}
+bool tune_cache_off() {                                     // BNHIP_TUNE_CACHE=0: tests of the directory path, A/B runs of the tuners themselves
+    const char* e = getenv("BNHIP_TUNE_CACHE");
+    return e && atoi(e) == 0;
+}
+bool read_text_file(const std::string& path, std::string* out) {
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    char buf[4096]; size_t n;
+    out->clear();
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) { out->append(buf, n); if (out->size() > (1u << 22)) break; }
+    fclose(f);
+    return true;
+}
+}  // namespace
+
 void Engine::tune_or_load() {
-    {
-        // BNHIP_TUNE_FILE: reuse a recorded tuning instead of timing again, so that separate processes (the bench, a rocprofv3
-        // kernel trace, every PMC pass) run the SAME kernel instantiations; written after a timed tuning when the file does not
-        // exist yet (a file that describes another plan - other batch size, depth, precision - is ignored and left alone).
-        const char* tf = getenv("BNHIP_TUNE_FILE");
-        if (!(tf && *tf && load_tuning(tf))) {
-            autotune_pw(); autotune_expdw(); autotune_dw();
-            if (tf && *tf) { FILE* ex = fopen(tf, "r"); if (ex) fclose(ex); else save_tuning(tf); }     // (never overwritten: another engine of the process may own it)
+    const char* tf = getenv("BNHIP_TUNE_FILE");
+    const bool experiment = tune_experiment_env();
+    const std::string key = tune_key();
+    std::string text;
+    auto adopted = [&](const std::string& src) {
+        tune_source = src;
+        if (getenv("BNHIP_DEBUG")) fprintf(stderr, "[bnhip] tuning %s: %s\n", key.c_str(), src.c_str());
+    };
+    if (tf && *tf && read_text_file(tf, &text) && apply_tuning_text(text)) { adopted(std::string("file:") + tf); }
+    else {
+        bool done = false;
+        if (!experiment) {
+            if (!tune_cache_off()) {
+                std::lock_guard<std::mutex> lk(g_tune_mu);
+                auto it = g_tune_cache.find(key);
+                if (it != g_tune_cache.end()) text = it->second; else text.clear();
+            }
+            else text.clear();
+            if (!text.empty() && apply_tuning_text(text)) { adopted("process-cache"); done = true; }
+            if (!done && !tune_dir.empty() && read_text_file(tune_dir + "/" + key + ".tune", &text) && apply_tuning_text(text)) {
+                adopted("dir:" + key + ".tune"); done = true;
+            }
         }
+        if (!done) {
+            autotune_pw(); autotune_expdw(); autotune_dw();
+            adopted("self-tuned");
+            if (tf && *tf) { FILE* ex = fopen(tf, "r"); if (ex) fclose(ex); else save_tuning(tf); }     // (never overwritten: another engine of the process may own it)
+            if (!experiment && !tune_dir.empty() && getenv("BNHIP_TUNE_RECORD")) {
+                const std::string path = tune_dir + "/" + key + ".tune";
+                FILE* ex = fopen(path.c_str(), "r");
+                if (ex) fclose(ex); else save_tuning(path.c_str());
+            }
+        }
+    }
+    if (!experiment && !tune_cache_off()) {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        g_tune_cache.emplace(key, tuning_text());          // (first writer wins: every later engine of this plan adopts it)
     }
 }
 
 // One line per step: what the three create-time tuners decide (tile shapes, kernel flavour, LDS-staged depthwise, slab counts).
 static const char* kTuneMagic = "bnhip-tuning-2";
 // what a tuning was made FOR, beyond the step names: every step's geometry, the clip length and the device architecture
-// (the header of version 1 carried none of them)
+// (the header of version 1 carried none of them), the device's CU count (the fill rules depend on it)
 static unsigned long long tune_plan_hash(const Engine& e) {
     unsigned long long h = 1469598103934665603ull;
     auto mix = [&](long long v) { for (int b = 0; b < 8; b++) { h ^= (unsigned long long)(v >> (8 * b)) & 0xff; h *= 1099511628211ull; } };
     mix(e.n_samples); mix(e.n_classes);
     for (const Step& s : e.steps) { mix((int)s.kind); mix(s.H); mix(s.W); mix(s.C); mix(s.Co); mix(s.Ho); mix(s.Wo); mix(s.kh); mix(s.kw); mix(s.sh); mix(s.sw); mix(s.act); }
     hipDeviceProp_t pr{};
-    if (e.device >= 0 && hipGetDeviceProperties(&pr, e.device) == hipSuccess)
+    if (e.device >= 0 && hipGetDeviceProperties(&pr, e.device) == hipSuccess) {
         for (const char* c = pr.gcnArchName; *c && *c != ':'; c++) mix(*c);
-    else (void)hipGetLastError();
+        mix(pr.multiProcessorCount);
+    } else (void)hipGetLastError();
     return h;
+}
+// file name / cache key of a plan's tuning: everything the header line checks
+std::string Engine::tune_key() const {
+    char b[160];
+    snprintf(b, sizeof b, "%016llx_b%d_d%d_h%d_p%d_x%d_l%d_s%x", tune_plan_hash(*this), max_batch, depth, host_depth, precision, bf16x3, n_lanes, (unsigned)pw_sw);
+    return b;
+}
+std::string Engine::tuning_text() const {
+    std::ostringstream os;
+    char b[1024];
+    snprintf(b, sizeof b, "%s %zu %d %d %d %d %d %llx\n", kTuneMagic, steps.size(), max_batch, depth, host_depth, precision, bf16x3, tune_plan_hash(*this));
+    os << b;
+    for (size_t i = 0; i < steps.size(); i++) {
+        const Step& s = steps[i];
+        snprintf(b, sizeof b, "%zu %d %d %d %d %d %d %d %d %d ", i, (int)s.kind, s.nt, s.wm, s.nt_full, s.wm_full, s.shape, s.dwl, s.bx, s.S);
+        os << b << s.name << "\n";
+    }
+    return os.str();
 }
 bool Engine::save_tuning(const char* path) const {
     FILE* f = fopen(path, "w");
     if (!f) return false;
-    fprintf(f, "%s %zu %d %d %d %d %d %llx\n", kTuneMagic, steps.size(), max_batch, depth, host_depth, precision, bf16x3, tune_plan_hash(*this));
-    for (size_t i = 0; i < steps.size(); i++) {
-        const Step& s = steps[i];
-        fprintf(f, "%zu %d %d %d %d %d %d %d %d %d %s\n", i, (int)s.kind, s.nt, s.wm, s.nt_full, s.wm_full, s.shape, s.dwl, s.bx, s.S, s.name.c_str());
-    }
+    const std::string t = tuning_text();
+    fwrite(t.data(), 1, t.size(), f);
     fclose(f);
     return true;
 }
 bool Engine::load_tuning(const char* path) {
-    FILE* f = fopen(path, "r");
+    std::string text;
+    if (!read_text_file(path, &text) || !apply_tuning_text(text)) return false;
+    if (getenv("BNHIP_DEBUG")) fprintf(stderr, "[bnhip] tuning read from %s\n", path);
+    return true;
+}
+bool Engine::apply_tuning_text(const std::string& text) {
+    FILE* f = fmemopen(const_cast<char*>(text.data()), text.size(), "r");
     if (!f) return false;
     char magic[32] = {0}; size_t n = 0; int mb = 0, dp = 0, hd = 0, pr = 0, bx = 0; unsigned long long ph = 0;
     bool ok = fscanf(f, "%31s %zu %d %d %d %d %d %llx", magic, &n, &mb, &dp, &hd, &pr, &bx, &ph) == 8 && !strcmp(magic, kTuneMagic) && n == steps.size() &&
@@ -1872,7 +1954,6 @@ bool Engine::load_tuning(const char* path) {
         s.S = expdw_shape_slabs(s.shape, g);
         for (auto& c : steps) if (&c != &s && c.in0 == s.out2) c.S = s.S;
     }
-    if (getenv("BNHIP_DEBUG")) fprintf(stderr, "[bnhip] tuning read from %s\n", path);
     return true;
 }
 
@@ -2582,7 +2663,9 @@ static void jesc(std::ostringstream& os, const std::string& s) {
 
 std::string Engine::describe() const {
     std::ostringstream os;
-    os << "{\"split_step\":" << split_step << ",\"n_samples\":" << n_samples << ",\"n_classes\":" << n_classes << ",\"emb_dim\":" << emb_dim
+    os << "{\"tune_source\":\"";
+    jesc(os, tune_source);
+    os << "\",\"tune_key\":\"" << (device >= 0 ? tune_key() : std::string()) << "\",\"split_step\":" << split_step << ",\"n_samples\":" << n_samples << ",\"n_classes\":" << n_classes << ",\"emb_dim\":" << emb_dim
        << ",\"max_batch\":" << max_batch << ",\"logits_output\":" << logits_output << ",\"embedding_output\":" << embedding_output << ",\"precision\":\"" << (precision ? "bf16" : "f32") << "\",\"lanes\":" << n_lanes << ",\"lane_min_batch\":" << dual_lane_min << ",\"act_arena_bytes\":" << act_bytes << ",\"weight_bytes\":" << w_bytes
        << ",\"specs\":[";
     for (size_t i = 0; i < specs.size(); i++) {

@@ -153,6 +153,11 @@ class Engine {
     void tune_or_load();                            // the three create-time tuners, or their recorded result (BNHIP_TUNE_FILE)
     bool save_tuning(const char* path) const;      // BNHIP_TUNE_FILE: the create-time tuners' decisions, one line per step
     bool load_tuning(const char* path);             // false (and nothing changed) unless the file describes exactly this plan
+    std::string tuning_text() const;                // the same decisions as text (what the file holds)
+    bool apply_tuning_text(const std::string& text);
+    std::string tune_key() const;                   // plan hash + batch / depth / precision / switches: cache key and file name of a recorded tuning
+    std::string tune_dir;                           // "tune_dir" option / BNHIP_TUNE_DIR: directory of recorded tunings (<tune_key>.tune)
+    std::string tune_source;                        // where this engine's tuning came from: file:… | process-cache | dir:… | self-tuned | (empty: autotune off)
     std::map<int, int> tensor_value;    // tflite tensor index -> value id (diagnostics)
     const float* value_ptr(int v) const { return reinterpret_cast<const float*>(act_arena + vals[v].offset); }
     int n_samples = 0, n_classes = 0, emb_dim = 0, C_spec = 0;

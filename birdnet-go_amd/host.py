@@ -19,6 +19,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+TUNE_DIR = os.path.join(_HERE, "tune")             # recorded create-time tunings shipped with the package (bnhip.h "tune_dir")
 LIB_PATH = os.environ.get("BNHIP_LIB") or os.path.join(_HERE, "lib", "libbnhip.so")   # BNHIP_LIB: A/B a second build
 
 BNHIP_OK, E_INVALID, E_NO_DEVICE, E_MODEL, E_UNSUPPORTED, E_RUNTIME, E_NOMEM = 0, -1, -2, -3, -4, -5, -6
@@ -138,7 +139,7 @@ class HipClassifier:
 
     def __init__(self, model_bytes: bytes, device=0, max_batch=256, plan_only=False, debug_no_reuse=False,
                  graphs=None, frontend_fft=None, depth=None, lanes=None, autotune=None, devices=None, replicate=None,
-                 bf16x3=None, precision=None, logits_output=None, embedding_output=None, host_depth=None):
+                 bf16x3=None, precision=None, logits_output=None, embedding_output=None, host_depth=None, tune_dir=None):
         self._lib = load_library()
         self._h = C.c_void_p()
         o = {"device": device, "max_batch": max_batch, "plan_only": int(plan_only), "debug_no_reuse": int(debug_no_reuse)}
@@ -166,6 +167,12 @@ class HipClassifier:
             o["lanes"] = int(lanes)
         if autotune is not None:
             o["autotune"] = int(autotune)
+        # recorded tunings (bnhip.h "tune_dir"): the package's own directory unless the caller or BNHIP_TUNE_DIR says otherwise
+        # ("" = none: always time the candidates)
+        if tune_dir is None and "BNHIP_TUNE_DIR" not in os.environ and os.path.isdir(TUNE_DIR):
+            tune_dir = TUNE_DIR
+        if tune_dir:
+            o["tune_dir"] = str(tune_dir)
         opts = json.dumps(o).encode()
         buf = (C.c_char * len(model_bytes)).from_buffer_copy(model_bytes)
         _check(self._lib, self._lib.bnhip_model_create(C.cast(buf, C.c_void_p), len(model_bytes), opts, C.byref(self._h)))

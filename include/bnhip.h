@@ -57,7 +57,7 @@ void bnhip_shutdown(void);
  * call and may be freed afterwards (classifier.go:37).
  * opts_json (nullable): {"device":0,"devices":[0,1,..],"replicate":"auto","max_batch":256,"plan_only":0,"debug_no_reuse":0,
  *                        "autotune":1,"graphs":0,"lanes":2,"frontend_fft":-1,"depth":1,"host_depth":2,"bf16x3":1,
- *                        "precision":"f32","logits_output":0,"embedding_output":1}
+ *                        "precision":"f32","logits_output":0,"embedding_output":1,"tune_dir":"/path"}
  * "devices": one handle over several GPUs: one engine per listed device, the clips of every host-
  *          pointer call are sharded index-contiguously over them and run concurrently (one worker thread per device, own
  *          streams and pinned-order staging per device).  The frozen weights are uploaded to the first device only and
@@ -65,6 +65,11 @@ void bnhip_shutdown(void);
  *          and the devices are distinct, hipMemcpyPeer otherwise; "rccl" / "peer" force one (the same device may be listed
  *          twice with "peer": two shards on one GPU, used by the 1-GPU test of the sharding code).  The device-pointer entry
  *          bnhip_predict_device needs a single-device handle.
+ * "tune_dir": directory of recorded create-time tunings (env BNHIP_TUNE_DIR; files <plan key>.tune).  The
+ *          create-time tuners choose tiles by timing, so two processes need not agree on every tile; a recorded tuning makes the
+ *          plan - and with it a clip's last bits - reproducible.  Inside one process every engine of the same plan (the shards
+ *          of a "devices" handle, a second handle on the same model) adopts the first one's decisions whatever this option says.
+ *          A file that describes another plan is ignored; BNHIP_TUNE_RECORD=1 writes a missing one after a timed tuning.
  * "plan_only": builds the kernel plan on the CPU without touching a device (info/describe work, predict is rejected).
  * "lanes": batches of >= 32 clips are split over this many concurrent streams inside one call (default 2).
  * "depth": > 1 lets successive bnhip_predict_device calls overlap on alternating contexts (own stream and activation

@@ -3,6 +3,7 @@
 // them; every collected row is checked against the stream it was cut from.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <thread>
@@ -115,6 +116,14 @@ static int run_overwrite(int seed) {
             for (size_t i = 0; i < ov + rd; i++) if (row[i] != (uint8_t)(k + 1) && !(i < ov && row[i] == 0)) bad++;   // own bytes, or the zero prefix
         }
         if (it % 997 == 0) w.reset(ids[(size_t)it % nsrc]);
+    }
+    // (a reset zeroes the counters: on a loaded box a writer may not have been scheduled since the last one - wait for every
+    // writer to have overwritten at least once before the accounting below is read, instead of betting on the scheduler)
+    for (int spin = 0; spin < 200000; spin++) {
+        bool all = true;
+        for (int k = 0; k < nsrc; k++) { uint64_t wr = 0, ovw = 0; size_t bf = 0; w.stats(ids[k], &wr, &ovw, &bf); all = all && ovw > 0; }
+        if (all) break;
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
     stop = true;
     for (auto& t : th) t.join();

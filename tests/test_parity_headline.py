@@ -96,6 +96,95 @@ def test_batch256_depth2_sampled_rows_vs_oracle(gpu, full_blob):
         clf.close(); x.free(); out.free()
 
 
+@pytest.mark.gpu
+def test_batch1024_depth2_sampled_rows_vs_oracle(gpu, full_blob):
+    """BASELINE configs[2] at its per-GPU shard size (8 192 clips over 8 GPUs = 1 024 per GPU): `max_batch` 1 024, depth 2, inputs
+    resident in HBM, three calls in flight over the two contexts; rows {0, 511, 512, 1023} vs the oracle, both contexts
+    bit-identical, the last 256 clips against what a 256-clip engine computes for them (its own tiles: summation-order
+    tolerance) - then the same 1 024 clips through the blocking host-pointer entry of a default engine.
+    VERDICT r5 item 1: round 1's logits-off-by-2.0 bug lived exactly in "only at full size", and nothing ran at 1 024."""
+    B = 1024
+    xh = sm.synth_clips(B, 144000, 48000)
+    rows = [0, 511, 512, 1023]
+    ref = Interpreter(full_blob).invoke(xh[rows])[0]
+    clf = host.HipClassifier(full_blob, max_batch=B, depth=2, lanes=1)
+    x, out = _DevBuf(xh.nbytes), _DevBuf(2 * B * 6522 * 4)
+    try:
+        x.upload(xh)
+        for i in range(3):
+            clf.predict_device(x.at(0), B, out.at((i & 1) * B * 6522 * 4))
+        clf.synchronize()
+        o0 = out.download((2, B, 6522))
+        assert np.isfinite(o0).all()
+        assert np.array_equal(o0[0], o0[1])
+        got = o0[0][rows]
+        assert_parity(got, ref)
+        assert np.abs(got - ref).max() < 1e-3
+        # the last 256 clips through a 256-clip engine (other tiles, other grid fill): within the summation-order tolerance
+        c256 = host.HipClassifier(full_blob, max_batch=256, depth=2, lanes=1)
+        try:
+            o256 = _DevBuf(256 * 6522 * 4)
+            c256.predict_device(x.at(768 * 144000 * 4), 256, o256.at(0))
+            c256.synchronize()
+            assert np.abs(o256.download((256, 6522)) - o0[0][768:]).max() < 1e-4
+            o256.free()
+        finally:
+            c256.close()
+    finally:
+        clf.close(); x.free(); out.free()
+    d = host.HipClassifier(full_blob, max_batch=B)
+    try:
+        h = d.predict_batch(xh.reshape(-1), B)
+        assert np.abs(h - o0[0]).max() < 1e-4
+        assert_parity(h[rows], ref)
+    finally:
+        d.close()
+
+
+def _softmax64(v):
+    z = np.asarray(v, np.float64)
+    e = np.exp(z - z.max(axis=-1, keepdims=True))
+    return e / e.sum(axis=-1, keepdims=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("bf16", 2e-2)])
+def test_perch_batch512_depth2_sampled_rows_vs_oracle(gpu, prec, tol):
+    """BASELINE configs[4] at its per-GPU shard size (4 096 clips over 8 GPUs = 512 per GPU), fp32 and bf16 engines: 512 clips of
+    5 s @ 32 kHz resident in HBM, depth 2, three calls in flight; rows {0, 255, 256, 511}: softmax vs the fp32 oracle (1e-4 fp32;
+    2e-2 bf16 - the reference accepts 0.08 on an f16 GPU, openvino_parity_functional_test.go:156-158), top-1 identical, the 1536-d
+    embedding output too (2e-3 relative fp32, the reference's own cross-runtime expectation model_openvino.go:263-265; 5e-2 bf16),
+    both contexts bit-identical."""
+    cfg = sm.perch_config()
+    blob = sm.build_model(cfg)
+    B = 512
+    xh = sm.synth_clips(B, cfg.n_samples, cfg.sample_rate)
+    rows = [0, 255, 256, 511]
+    outs = Interpreter(blob).invoke(xh[rows])
+    ref, ref_emb = outs[3], outs[0]
+    clf = host.HipClassifier(blob, max_batch=B, depth=2, lanes=1, precision=prec)
+    nc, ed = clf.num_species(), clf.emb_dim
+    assert (nc, ed) == (14795, 1536)
+    x, out, emb = _DevBuf(xh.nbytes), _DevBuf(2 * B * nc * 4), _DevBuf(2 * B * ed * 4)
+    try:
+        x.upload(xh)
+        for i in range(3):
+            clf.predict_device(x.at(0), B, out.at((i & 1) * B * nc * 4), emb.at((i & 1) * B * ed * 4))
+        clf.synchronize()
+        o, e = out.download((2, B, nc)), emb.download((2, B, ed))
+        assert np.isfinite(o).all() and np.isfinite(e).all()
+        assert np.array_equal(o[0], o[1]) and np.array_equal(e[0], e[1])
+        got = o[0][rows]
+        assert (got.argmax(1) == ref.argmax(1)).all()
+        d = float(np.abs(_softmax64(got) - _softmax64(ref)).max())
+        assert d <= tol, d
+        scale = float(np.abs(ref_emb).max())
+        de = float(np.abs(e[0][rows] - ref_emb).max()) / scale
+        assert de <= (2e-3 if prec == "f32" else 5e-2), de
+    finally:
+        clf.close(); x.free(); out.free(); emb.free()
+
+
 # ------------------------------------------------------------------------------------------------ real artefacts (env-gated)
 REAL_MODEL = os.environ.get("BNHIP_REAL_MODEL")
 
