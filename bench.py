@@ -3,9 +3,11 @@
 
 Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under torch.distributed.run, one rank
 per GPU).  A *step* = one pass of the whole hot path (per-clip normalise -> fused mel front-end ->
-CNN -> species head, raw logits out) over one batch of 256 synthetic 3 s / 48 kHz clips per GPU
-(BASELINE.json configs[1]: "BirdNET v2.4 fp32, batch 256x3s@48kHz synthetic sine+noise").  Inputs are
-resident in HBM before the timed region.  Prints ONE JSON line on rank 0 with `roofline` (dominant
+CNN -> species head, raw logits out) over one batch of synthetic 3 s / 48 kHz clips per GPU: at N = 1 the
+256 clips of BASELINE.json configs[1] ("BirdNET v2.4 fp32, batch 256x3s@48kHz synthetic sine+noise"), at
+N > 1 the 1024 clips per GPU of configs[2] ("batch 8192 clips sharded 8xMI355X"; a `weak_256` leg keeps
+the 256-per-GPU figure comparable with the N = 1 line, `host_pointer_per_rank` measures the PCIe- and
+host-staging-inclusive rate with every rank ingesting at once).  Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0 with `roofline` (dominant
 kernel, measured with HIP events on the launch stream inside the timed region) and `cpu_baseline`
 (the numpy/BLAS oracle restatement timed on this box's host cores; N=1 only).
 """
@@ -31,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (0: the workload's BASELINE value: 256 / 512)")
+    ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (0: the workload's BASELINE value: 256 at N = 1 / 1024 at N > 1 (configs[1] / [2]); Perch 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--input-sets", type=int, default=4, help="distinct resident input batches rotated over the steps")
     ap.add_argument("--bf16x3", type=int, default=None, help="split-bf16 MFMA path for the pointwise layers: 0 off, 1 where the "
@@ -341,11 +343,15 @@ def host_pointer_rates(clf, x, reps_small=100, reps_mid=12, reps_big=5):
                 parts["collect"].append(t2 - t1); parts["predict"].append(time.perf_counter() - t2)
             return len(idxs)
         assert tick(False) == 256 and tick(True) == 256
-        for _ in range(reps_mid):
+        n_ticks = 30                                          # (a distribution, not one median of 12)
+        for _ in range(n_ticks):
             tick(False); tick(True)
-        med = {k: sorted(v[-reps_mid:])[reps_mid // 2] * 1e3 for k, v in parts.items()}
-        res["realtime_tick_256"] = {"ms": med["one_call"], "windows_per_s": 256 / (med["one_call"] * 1e-3),
+        pct = lambda k, q: float(np.percentile(np.asarray(parts[k][-n_ticks:]) * 1e3, q))
+        med = {k: pct(k, 50) for k in parts}
+        res["realtime_tick_256"] = {"ms": med["one_call"], "ms_p95": pct("one_call", 95), "ms_min": float(min(parts["one_call"][-n_ticks:]) * 1e3),
+                                    "ticks": n_ticks, "windows_per_s": 256 / (med["one_call"] * 1e-3),
                                     "two_step_collect_ms": med["collect"], "two_step_predict_pcm_topk_ms": med["predict"],
+                                    "two_step_sum_ms_p50": float(np.percentile((np.asarray(parts["collect"][-n_ticks:]) + np.asarray(parts["predict"][-n_ticks:])) * 1e3, 50)),
                                     "capture_side_write_ms": med["write"], "batch_buffer_pinned": win.pinned}
     finally:
         win.close()
@@ -480,10 +486,13 @@ def dist_env():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def dist_begin(dev, backend="nccl"):
+def dist_begin(dev, backend=None):
     """Process-group set-up of the N-rank run: one process per GPU, backend nccl (= RCCL over xGMI); the CPU test of this very
-    code path substitutes gloo (tests/test_dist_cpu.py).  BENCH_FORCE_DIST=1 exercises it on one GPU.  Returns use_dist."""
+    code path substitutes gloo (tests/test_dist_cpu.py).  BENCH_FORCE_DIST=1 exercises it on one GPU; BENCH_DIST_BACKEND=gloo lets
+    several ranks share ONE GPU (RCCL refuses two ranks on a device) - the record of the per-rank ingest leg on a one-GPU box.
+    Returns use_dist."""
     import torch.distributed as dist
+    backend = backend or os.environ.get("BENCH_DIST_BACKEND", "nccl")
     world, rank, _ = dist_env()
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
     if use_dist:
@@ -525,6 +534,107 @@ def dist_timing(dt, clips_per_rank_step, steps, use_dist, dev):
     return float(t.item()), [clips_per_rank_step * steps / float(e.item()) for e in every], dist.get_world_size()
 
 
+def dist_gather(vals, use_dist, dev):
+    """Every rank's list of floats on every rank: [[rank 0's], [rank 1's], ...] (one all_gather; [vals] without a group)."""
+    import torch
+    import torch.distributed as dist
+    if not use_dist:
+        return [[float(v) for v in vals]]
+    t = torch.tensor([float(v) for v in vals], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, t)
+    return [[float(q) for q in e.cpu().tolist()] for e in every]
+
+
+def ranks_ingest_leg(calls, reps, use_dist, dev):
+    """The N-rank ingest measurement: `calls` = {name: (fn, n_clips)}, fn one BLOCKING host-pointer call on this
+    rank.  Every repetition starts behind a barrier, so all ranks stage, copy and compute AT THE SAME TIME - what a node-wide
+    deployment does to the host's memory system and PCIe roots, and what a resident-input bench cannot show.  Per call: each rank's
+    median time; the job's figure is n_clips x ranks / the slowest rank's median (the contract's max-over-ranks rule)."""
+    import torch.distributed as dist
+    out = {}
+    for name, (fn, n_clips) in calls.items():
+        fn()                                                         # warm-up (first use allocates the pinned slots)
+        ts = []
+        for _ in range(reps):
+            if use_dist:
+                dist.barrier()
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        ts.sort()
+        med = ts[len(ts) // 2]
+        per_rank = [r[0] for r in dist_gather([med], use_dist, dev)]
+        out[name] = {"n_clips_per_rank": n_clips, "ms_per_rank": [t * 1e3 for t in per_rank], "ms_max": max(per_rank) * 1e3,
+                     "clips_per_s_whole_job": n_clips * len(per_rank) / max(per_rank),
+                     "clips_per_s_per_rank": [n_clips / t for t in per_rank]}
+    return out
+
+
+def weak_leg(blob, gpu, depth, args, xs, n, use_dist, dev, stream):
+    """`n` clips per GPU (BASELINE configs[1]'s batch) through an engine planned for n, on the first n clips of each resident input
+    set: the figure that compares with the N = 1 line when the N-rank workload is configs[2]'s 1 024 per GPU.  Same bracket as the
+    contract's: warm-up, barrier + synchronize, K steps, synchronize + barrier, max over ranks."""
+    import torch
+    import torch.distributed as dist
+    from birdnet_go_amd import host
+    clf = host.HipClassifier(blob, device=gpu, max_batch=n, depth=depth, lanes=1 if depth > 1 else None, bf16x3=args.bf16x3, precision=args.precision)
+    clf.set_stream(stream.cuda_stream)
+    outs = [torch.empty((n, clf.num_species()), dtype=torch.float32, device=dev) for _ in xs]
+    k = [0]
+
+    def step():
+        i = k[0] % len(xs); k[0] += 1
+        clf.predict_device(xs[i].data_ptr(), n, outs[i].data_ptr())
+    for _ in range(max(args.warmup, 1)):
+        step()
+    clf.synchronize(); torch.cuda.synchronize(dev)
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    clf.synchronize(); torch.cuda.synchronize(dev)
+    if use_dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    clf.close()
+    world = dist.get_world_size() if use_dist else 1
+    dt, rates, _ = dist_timing(dt, n, args.steps, use_dist, dev)
+    return {"value": n * world * args.steps / dt, "unit": "clips/s", "batch_per_gpu": n, "ms_per_step": dt / args.steps * 1e3,
+            "per_rank_clips_per_s": rates, "workload": "BASELINE configs[1]'s batch on every GPU (weak scaling of the N = 1 line)"}
+
+
+def ranks_host_pointer(blob, gpu, args, x256, use_dist, dev):
+    """Every rank at once through the blocking host-pointer entries (bnhip_predict_pcm16: the int16 capture format, 74 MB per 256
+    clips): 256 and 2 048 clips, from pageable caller memory (staged by the rank's NUMA-bound copy pool through pinned slots) and from
+    page-locked memory (bnhip_host_alloc, placed on the GPU's node)."""
+    from birdnet_go_amd import host
+    clf = host.HipClassifier(blob, device=gpu, max_batch=256, bf16x3=args.bf16x3, precision=args.precision)
+    ncls = clf.num_species()
+    pcm = (np.clip(x256, -1, 1) * 32767).astype(np.int16)
+    big = np.tile(pcm, (8, 1))
+    out256, out2048 = np.zeros((256, ncls), np.float32), np.zeros((2048, ncls), np.float32)
+    import ctypes as C
+    pool = [C.c_int(-9) for _ in range(4)]
+    host.load_library().bnhip_debug_copy_pool(gpu, *[C.byref(q) for q in pool])
+    with host.PinnedArray((2048, x256.shape[1]), np.int16) as pp, host.PinnedArray((2048, ncls), np.float32) as po:
+        pp.array[:] = big
+        calls = {
+            "pcm16_256": (lambda: clf.predict_pcm16(pcm.reshape(-1), 256, out=out256), 256),
+            "pcm16_256_pinned": (lambda: clf.predict_pcm16(pp.array[:256].reshape(-1), 256, out=po.array[:256]), 256),
+            "pcm16_2048": (lambda: clf.predict_pcm16(big.reshape(-1), 2048, out=out2048), 2048),
+            "pcm16_2048_pinned": (lambda: clf.predict_pcm16(pp.array.reshape(-1), 2048, out=po.array), 2048),
+        }
+        res = ranks_ingest_leg(calls, 7, use_dist, dev)
+    clf.close()
+    placement = dist_gather([q.value for q in pool], use_dist, dev)
+    res["numa"] = {"per_rank": [{"node": int(q[0]), "copy_threads": int(q[1]), "bound": int(q[2]), "node_cpus_usable": int(q[3])} for q in placement],
+                   "note": "copy threads and pinned staging slots of a rank live on its GPU's NUMA node (csrc/numa.cpp; BNHIP_NUMA=0 turns it off)"}
+    res["note"] = ("all ranks enter each call behind one barrier; ms = each rank's median of 7; whole-job rate = clips x ranks / slowest rank "
+                   "(PCIe + host staging inclusive; bnhip_predict_pcm16, outputs complete on return)")
+    return res
+
+
 def run_model(args):
     """One model workload (birdnet = the contract's line, perch = BASELINE configs[4]); returns the JSON object on rank 0."""
     import torch
@@ -537,20 +647,24 @@ def run_model(args):
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists by design)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    gpu = local_rank % max(1, torch.cuda.device_count())       # (one rank per GPU; ranks > GPUs only in the one-GPU record, BENCH_DIST_BACKEND=gloo)
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
     use_dist = dist_begin(dev)
 
     perch = args.workload == "perch"
     cfg = sm.perch_config() if perch else sm.SynthConfig()
+    default_batch = not args.batch
     if not args.batch:
-        args.batch = 512 if perch else 256          # configs[4]: 4096 clips over 8 GPUs; configs[1]: 256 per GPU
+        # configs[4]: 4096 clips over 8 GPUs = 512 per GPU; configs[1]: 256 on one GPU; configs[2]: 8192 over 8 GPUs = 1024 per GPU
+        args.batch = 512 if perch else (1024 if world > 1 else 256)
     blob = dist_model_bytes(cfg, use_dist, dev)
 
     B = args.batch
     depth = max(1, args.depth)
-    clf = host.HipClassifier(blob, device=local_rank, max_batch=B, depth=depth, lanes=1 if depth > 1 else None, bf16x3=args.bf16x3,
+    clf = host.HipClassifier(blob, device=gpu, max_batch=B, depth=depth, lanes=1 if depth > 1 else None, bf16x3=args.bf16x3,
                              precision=args.precision)
+    local_rank = gpu
     lo, _ = shard.shard_range(B * world, rank, world)       # weak scaling: B clips per rank, distinct seeds
     # NSETS distinct input batches, rotated step by step (round 1 re-ran the same 256 clips every step: 147 MB, small enough
     # to come back from the 256 MiB Infinity Cache; four sets = 590 MB of distinct input do not).  Set 0 is the config-2
@@ -633,6 +747,12 @@ def run_model(args):
                           "method": "one HIP event pair per step on the step's own stream; interval = spacing of step completions "
                                     "`pipeline_depth` apart / pipeline_depth (steps on alternating contexts overlap and finish in bursts)"}
     dt, rank_rates, rccl_ranks = dist_timing(dt, B, args.steps, use_dist, dev)
+    # N > 1 (every rank takes part; rank 0 reports): the 256-per-GPU figure of the N = 1 line, and the ingest legs
+    weak_256 = ingest = None
+    if world > 1 and not perch and default_batch and B != 256:
+        weak_256 = weak_leg(blob, gpu, depth, args, xs, 256, use_dist, dev, stream)
+    if world > 1 and not perch and not args.no_host_pointer:
+        ingest = ranks_host_pointer(blob, gpu, args, x_host[:256], use_dist, dev)
 
     ok = all(bool(torch.isfinite(o).all().item()) for o in outs[:min(NSETS, args.steps + args.warmup)])
     # set 0 was last computed inside (or, for short runs, before) the timed region by the same engine: checks below use it
@@ -684,8 +804,11 @@ def run_model(args):
             "config": {"workload": ("BASELINE configs[4]: Google Perch v2 dimensions (14,795-class head), batch 512 x 5 s @ 32 kHz per GPU "
                                     "(4096 over 8), log-mel front-end + EfficientNet-B3-shaped CNN + head on device, raw logits out")
                                    if perch else
-                                   "BASELINE configs[1]: BirdNET v2.4 fp32, batch 256 x 3 s @ 48 kHz per GPU, "
-                                   "mel front-end + CNN + head on device, raw logits out",
+                                   (f"BASELINE configs[2]: BirdNET v2.4 fp32, batch {B * world} clips sharded over {world} x MI355X ({B} per GPU), "
+                                    "weights broadcast once over RCCL, mel front-end + CNN + head on device, raw logits out"
+                                    if world > 1 and B == 1024 else
+                                    f"BASELINE configs[1]: BirdNET v2.4 fp32, batch {B} x 3 s @ 48 kHz per GPU, "
+                                    "mel front-end + CNN + head on device, raw logits out"),
                        "inputs": "device-resident (device-only): the clips are in HBM when the timed region starts; rates through the "
                                  "blocking host-pointer entries (PCIe-inclusive) are in `host_pointer`",
                        "batch_per_gpu": B, "n_samples": cfg.n_samples, "n_classes": clf.num_species(),
@@ -695,6 +818,10 @@ def run_model(args):
         }
         if dist_stats:
             out["step_distribution"] = dist_stats
+        if weak_256:
+            out["weak_256"] = weak_256
+        if ingest:
+            out["host_pointer_per_rank"] = ingest
         if prof:
             prof = sorted(prof, key=lambda r: -r["ms"])
             dom = prof[0]
@@ -774,6 +901,7 @@ def run_model(args):
             if mu:
                 out["mfma_util"] = mu
             out["evidence"] = {"lib_digest": cur_dig, "plan_signature": cur_plan, "tune_file": os.environ.get("BNHIP_TUNE_FILE") or None,
+                               "tune_source": clf.describe().get("tune_source"), "tune_key": clf.describe().get("tune_key"),
                                "note": "counter files under profiles/ are quoted only when they were collected on this library digest"}
             wsum = sum(r["ms"] for r in warm_prof) or 1.0
             roof["share_of_kernel_time"] = next((r["ms"] for r in warm_prof if r["kernel"] == dom["kernel"]), 0.0) / wsum

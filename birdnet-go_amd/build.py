@@ -9,8 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.environ.get("BNHIP_LIBDIR") or os.path.join(HERE, "lib")      # (BNHIP_LIBDIR + BNHIP_EXTRA_FLAGS: an A/B build beside the shipped one)
 LIB = os.path.join(LIBDIR, "libbnhip.so")
-SOURCES = ["kernels.hip", "expdw.hip", "pw_b16.hip", "pw_ws.hip", "generic.hip", "resample.hip", "stft.hip", "engine.cpp", "graph_passes.cpp", "tflite_model.cpp", "model_onnx.cpp", "hostpipe.cpp", "windows.cpp", "api.cpp"]
-HEADERS = ["kernels.h", "pw_common.h", "pw_split.h", "engine.h", "tflite_model.h", "model_onnx.h", "hostpipe.h", "windows.h", "fft_r8.h", os.path.join("..", "..", "include", "bnhip.h")]
+SOURCES = ["kernels.hip", "expdw.hip", "pw_b16.hip", "pw_ws.hip", "generic.hip", "resample.hip", "stft.hip", "engine.cpp", "graph_passes.cpp", "tflite_model.cpp", "model_onnx.cpp", "hostpipe.cpp", "numa.cpp", "windows.cpp", "api.cpp"]
+HEADERS = ["kernels.h", "pw_common.h", "pw_split.h", "engine.h", "tflite_model.h", "model_onnx.h", "hostpipe.h", "numa.h", "windows.h", "fft_r8.h", os.path.join("..", "..", "include", "bnhip.h")]
 # -fno-slp-vectorize: gfx950 hazard, reproduced standalone (tools/ubench/pkf32_vs_bf16mfma.hip, profiles/r04_pk_hazard.txt): a
 # packed-fp32 VALU instruction whose op_sel bit for src1 is set (v_pk_fma_f32 / v_pk_mul_f32 ... op_sel:[0,1,..]: the LOW result
 # computed from src1's HIGH half) returns a wrong low half in lanes 48-63 while another wave on the same CU executes

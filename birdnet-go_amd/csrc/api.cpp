@@ -22,6 +22,7 @@
 
 #include "engine.h"
 #include "hostpipe.h"
+#include "numa.h"
 #include "model_onnx.h"
 #include "tflite_model.h"
 #include "windows.h"
@@ -424,7 +425,12 @@ int bnhip_host_alloc(size_t n_bytes, void** out) {
     int rc = bnhip_init(nullptr);
     if (rc != BNHIP_OK) return rc;
     void* p = nullptr;
-    hipError_t e = hipHostMalloc(&p, n_bytes, hipHostMallocPortable);      // portable: pinned for every device of a multi-GPU handle
+    // (round 6: from the NUMA node of the calling thread's current device when it has room - the buffer a Go classifier keeps per
+    // model is read by that device's copy engines on every call; portable: pinned for every device of a multi-GPU handle)
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
+    bnhip::NumaPrefer near_gpu(bnhip::device_numa_node(cur));
+    hipError_t e = hipHostMalloc(&p, n_bytes, hipHostMallocPortable);
     if (e != hipSuccess) { (void)hipGetLastError(); return set_err(e == hipErrorOutOfMemory ? BNHIP_E_NOMEM : BNHIP_E_RUNTIME, std::string("pinned host allocation failed: ") + hipGetErrorString(e)); }
     *out = p;
     return BNHIP_OK;

@@ -2351,7 +2351,7 @@ void Engine::pick_split() {
     if (want >= 0) {
         for (int k : split_candidates) if (k >= want) { pick = k; break; }
     } else {
-        const int rows_min = 1000;
+        const int rows_min = (int)((long)(device >= 0 ? device_cus() : 256) * 1000 / 256);      // (1000 on the 256 CUs of an MI355X)
         for (int k : split_candidates) {
             const Step& s = steps[k];                                    // the consumer's input geometry = the crossing value's
             if ((s.kind == S_PW || s.kind == S_EXPAND_DW || s.kind == S_DW) && s.H * s.W < rows_min && s.H * s.W > 0) { pick = k; break; }
@@ -2425,6 +2425,16 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
     Lane lanes[kMaxLanes];
     int nl = 1;
     hipStream_t main_stream = cur_stream ? cur_stream : stream;
+    if (mm_dirty) {
+        //  a call on this engine failed: a launch of k_clip_minmax_parts that did not run to completion leaves its arrival
+        // counter non-zero, and every later small call on that (context, lane) would normalise with stale min / max without any
+        // error.  Error path only: drain the engine's streams and zero the scratch before anything else is queued.
+        for (int i = 0; i < kMaxKStreams; i++) if (kstream[i]) hipStreamSynchronize(kstream[i]);
+        if (stream) hipStreamSynchronize(stream);
+        if (mm_scratch) hipMemset(mm_scratch, 0, (size_t)kMaxDepth * kMaxLanes * kMinMaxScratch * sizeof(float));
+        (void)hipGetLastError();
+        mm_dirty = false;
+    }
     // (an unfiltered profile wants clean per-kernel times and stays single-lane; a class-filtered one measures the
     // kernels as they run in production, overlapped)
     if (n_lanes > 1 && !cur_stream && (!profiling || !profile_filter.empty()) && n_all >= dual_lane_min) nl = std::min(n_lanes, n_all);
@@ -2627,7 +2637,7 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
         if (L.d_emb && v_emb >= 0 && s_end == (int)steps.size()) {
             hipError_t e = hipMemcpyAsync(L.d_emb, vptr(v_emb, L.d_in, L.d_logits, L.d_emb, nl > 1 ? li : -1), (size_t)L.n * emb_dim * 4,
                                           hipMemcpyDeviceToDevice, L.st);
-            if (e != hipSuccess) { *err = std::string("emb copy: ") + hipGetErrorString(e); return false; }
+            if (e != hipSuccess) { *err = std::string("emb copy: ") + hipGetErrorString(e); mm_dirty = true; return false; }
         }
     }
     for (int li = 1; li < nl; li++) {
@@ -2636,7 +2646,7 @@ bool Engine::run_eager(const float* d_in_all, int n_all, float* d_logits_all, fl
     }
     if (step_timing) { hipEventRecord(st_b, main_stream); step_ev.emplace_back(st_a, st_b); }
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { *err = std::string("kernel launch: ") + hipGetErrorString(e); return false; }
+    if (e != hipSuccess) { *err = std::string("kernel launch: ") + hipGetErrorString(e); mm_dirty = true; return false; }
     return true;
 }
 

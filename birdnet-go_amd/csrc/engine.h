@@ -120,6 +120,7 @@ class Engine {
     char* ctx_arena[kMaxDepth] = {nullptr, nullptr, nullptr};
     static constexpr int kMinMaxScratch = 16 * (2 * kMinMaxParts + 2);   // floats: 16 clips x (parts + counter) of k_clip_minmax_parts
     float* mm_scratch = nullptr;        // [context][lane][kMinMaxScratch]: outside the arenas (their layouts overlap), zeroed once
+    bool mm_dirty = false;              // a call failed: the arrival counters in mm_scratch may be non-zero - re-zeroed before the next call
     hipEvent_t ev_ctx_fork = nullptr, ev_ctx_done[kMaxDepth] = {nullptr, nullptr, nullptr};
     unsigned call_idx = 0;
     bool run_pipelined(const float* d_in, int n, float* d_logits, float* d_emb, std::string* err);

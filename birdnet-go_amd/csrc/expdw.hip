@@ -971,9 +971,10 @@ void launch_expand_dw(const float* x, const float* we, const float* be, const fl
         nblk = (unsigned)B * tiles;
         p.d_bpc = make_fdiv((unsigned)tiles);
         // ... unless the call is so small that the chip would idle behind a few serial chunk loops (one clip: 12-24 blocks walking
-        // five chunks each, 19-24 us): then the loop is cut into parts until the grid has ~256 blocks
-        if (p.cchunks > 1 && (long)B * tiles < 128) {
-            const int want = (int)std::min<long>(p.cchunks, (256 + (long)B * tiles - 1) / ((long)B * tiles));
+        // five chunks each, 19-24 us): then the loop is cut into parts until the grid has about one block per CU
+        const int cus = device_cus();
+        if (p.cchunks > 1 && (long)B * tiles < cus / 2) {
+            const int want = (int)std::min<long>(p.cchunks, (cus + (long)B * tiles - 1) / ((long)B * tiles));
             const int cpp = (p.cchunks + want - 1) / want, nparts = (p.cchunks + cpp - 1) / cpp;
             if (nparts > 1) {
                 p.cpp = cpp;

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -22,13 +23,17 @@
 
 #include "../../include/bnhip.h"
 #include "engine.h"
+#include "numa.h"
 
 namespace bnhip {
 
 // ------------------------------------------------------------------------------------------------ copy pool
 // Pageable caller memory -> pinned staging.  One thread moves ~10 GB/s; a 256-clip int16 chunk is 74 MB and has to be
 // staged in well under the 3.6 ms the GPU needs for it, so the copy is cut into 2 MB pieces served by a few threads (the
-// calling thread helps).  Process-wide, shared by every engine and every worker thread of a multi-device handle.
+// calling thread helps).  One pool per NUMA node that has a GPU (round 6): its threads are bound to that node's CPUs, so the
+// staging pass of a GPU's chunks reads the caller's pages and writes the pinned slot from the socket the GPU hangs off; engines
+// on GPUs of one node (and every worker thread of a multi-device handle that serves them) share the node's pool.  A box
+// without NUMA information has one unbound pool, as before.
 namespace {
 
 // `remaining` is only touched under `mu`: the waiter may own the Ticket on its stack (parallel_copy), so the last worker must
@@ -42,7 +47,7 @@ struct Ticket {
 class CopyPool {
   public:
     struct Task { char* dst; const char* src; size_t n; Ticket* t; };
-    CopyPool() {
+    explicit CopyPool(const std::vector<int>& cpus = {}) : cpus_(cpus) {
         int n = 0;
         if (const char* e = getenv("BNHIP_COPY_THREADS")) n = atoi(e);
         else {
@@ -50,7 +55,8 @@ class CopyPool {
             n = (int)std::min(8u, std::max(1u, hw / 4));
         }
         n = std::max(0, std::min(n, 64));
-        for (int i = 0; i < n; i++) th_.emplace_back([this] { loop(); });
+        if (!cpus_.empty()) n = std::min<int>(n, (int)cpus_.size());       // (never more threads than CPUs they may run on)
+        for (int i = 0; i < n; i++) th_.emplace_back([this] { bound_ += bind_this_thread(cpus_) ? 1 : 0; loop(); });
     }
     ~CopyPool() {
         { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
@@ -58,6 +64,8 @@ class CopyPool {
         for (auto& t : th_) if (t.joinable()) t.join();
     }
     int threads() const { return (int)th_.size(); }
+    int bound_threads() const { return bound_.load(); }
+    int cpus() const { return (int)cpus_.size(); }
     // enqueue the copy; the ticket reaches zero when every piece has landed
     void submit(void* dst, const void* src, size_t bytes, Ticket* t) {
         const size_t piece = 2u << 20;
@@ -106,6 +114,8 @@ class CopyPool {
             lk.lock();
         }
     }
+    const std::vector<int> cpus_;
+    std::atomic<int> bound_{0};
     std::vector<std::thread> th_;
     std::mutex mu_;
     std::condition_variable cv_;
@@ -113,20 +123,64 @@ class CopyPool {
     bool stop_ = false;
 };
 
-CopyPool& pool() {
-    static CopyPool* p = new CopyPool();     // never destroyed: a Go host exits without static destructors anyway, and a
-    return *p;                               // destructor joining threads at dlclose time can deadlock under a loader lock
+// BNHIP_NUMA=0 turns the placement off (one unbound pool, default page placement): the A/B switch of the records under profiles/
+bool numa_on() {
+    static const bool on = !(getenv("BNHIP_NUMA") && atoi(getenv("BNHIP_NUMA")) == 0);
+    return on;
 }
 
+std::mutex g_pool_mu;
+std::map<int, CopyPool*> g_pools;            // by NUMA node; -1 = unbound.  Never destroyed: a Go host exits without static
+                                             // destructors anyway, and a destructor joining threads at dlclose time can deadlock
+                                             // under a loader lock
+CopyPool& pool_for_node(int node) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    std::vector<int> cpus;
+    if (node >= 0) { cpus = numa_usable_cpus(node); if (cpus.empty()) node = -1; }
+    auto it = g_pools.find(node);
+    if (it != g_pools.end()) return *it->second;
+    CopyPool* p = new CopyPool(cpus);
+    g_pools[node] = p;
+    return *p;
+}
+
+std::mutex g_devnode_mu;
+std::map<int, int> g_devnode;
 }  // namespace
 
-void parallel_copy(void* dst, const void* src, size_t bytes) {
+// NUMA node of a HIP device (from its PCI address), -1 when unknown or placement is off; cached
+int device_numa_node(int device) {
+    if (device < 0 || !numa_on()) return -1;
+    std::lock_guard<std::mutex> lk(g_devnode_mu);
+    auto it = g_devnode.find(device);
+    if (it != g_devnode.end()) return it->second;
+    char bdf[64] = {0};
+    int node = -1;
+    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) == hipSuccess) node = pci_numa_node(bdf);
+    else (void)hipGetLastError();
+    g_devnode[device] = node;
+    return node;
+}
+
+namespace {
+CopyPool& pool_for_device(int device) { return pool_for_node(device_numa_node(device)); }
+}  // namespace
+
+void parallel_copy(void* dst, const void* src, size_t bytes, int device) {
     if (bytes < (4u << 20)) { if (bytes) memcpy(dst, src, bytes); return; }
     Ticket t;
-    pool().submit(dst, src, bytes, &t);
-    pool().wait(&t);
+    CopyPool& p = pool_for_device(device);
+    p.submit(dst, src, bytes, &t);
+    p.wait(&t);
 }
-int copy_pool_threads() { return pool().threads(); }
+int copy_pool_threads(int device) { return pool_for_device(device).threads(); }
+void copy_pool_info(int device, int* node, int* threads, int* bound, int* cpus) {
+    CopyPool& p = pool_for_device(device);
+    if (node) *node = device_numa_node(device);
+    if (threads) *threads = p.threads();
+    if (bound) *bound = p.bound_threads();
+    if (cpus) *cpus = p.cpus();
+}
 
 // ------------------------------------------------------------------------------------------------ staging ring
 struct HostPipe {
@@ -145,6 +199,8 @@ struct HostPipe {
     };
     Slot s[K];
     hipStream_t xfer = nullptr;              // the one copy stream, both directions (see ensure_pipe)
+    int numa_node = -1;                      // the device's NUMA node: where the pinned slots live and the copy threads run
+    CopyPool* cp = nullptr;                  // that node's pool
 };
 
 void hostpipe_free(HostPipe* hp) {
@@ -189,6 +245,8 @@ int ensure_pipe(Engine& e, const HostJob& j, size_t chunk_bytes, std::string& er
     // for its chunk's kernels, which are done long before the input issued behind it is needed).
     hp.xfer = e.copy_stream();
     if (!hp.xfer) { err = "copy stream creation failed"; return BNHIP_E_RUNTIME; }
+    if (!hp.cp) { hp.numa_node = device_numa_node(e.device); hp.cp = &pool_for_node(hp.numa_node); }
+    NumaPrefer near_gpu(hp.numa_node);       // the pinned slots below are allocated from the GPU's own node when it has room
     const size_t mb = (size_t)e.max_batch;
     for (auto& s : hp.s) {
         if (!s.ev_h2d) HP_TRY(hipEventCreateWithFlags(&s.ev_h2d, hipEventDisableTiming), "event");
@@ -307,8 +365,32 @@ int small_run(Engine& e, const HostJob& j, std::string& err) {
 // environment (getenv beside another thread's setenv is a data race; multi-device handles run calls on worker threads).
 static const char* diag_env(const char* name) {
     static const bool on = getenv("BNHIP_HOST_DIAG") != nullptr;
+    // (a diagnostic switch set WITHOUT BNHIP_HOST_DIAG used to be ignored silently - an A/B script then measured the
+    // default path twice.  Say so once, at the first call, from the state of the environment at process start.)
+    static const bool warned = [] {
+        if (on) return false;
+        bool any = false;
+        for (const char* n : {"BNHIP_HOST_SERIAL", "BNHIP_HOST_NOSPLIT", "BNHIP_HOST_PLAN", "BNHIP_HOST_CHUNKS", "BNHIP_HOST_SCHED"})
+            if (getenv(n)) { fprintf(stderr, "[bnhip] %s is set but BNHIP_HOST_DIAG is not: the host pipeline's diagnostic switches are ignored\n", n); any = true; }
+        return any;
+    }();
+    (void)warned;
     return on ? getenv(name) : nullptr;
 }
+
+// BNHIP_HOST_TRACE events: created checked, destroyed on every way out of the call (leaked on the early returns)
+struct TraceEvents {
+    std::vector<hipEvent_t> ev;
+    bool create(size_t n) {
+        ev.assign(n, nullptr);
+        for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); e = nullptr; destroy(); return false; }
+        return true;
+    }
+    void destroy() { for (auto& e : ev) if (e) hipEventDestroy(e); ev.clear(); }
+    hipEvent_t& operator[](size_t i) { return ev[i]; }
+    bool on() const { return !ev.empty(); }
+    ~TraceEvents() { destroy(); }
+};
 
 // ------------------------------------------------------------------------------------------------ two-phase call
 // A blocking call that fits one batch starts on an idle GPU and ends on one: cut into whole-plan chunks, its first chunk runs alone,
@@ -330,7 +412,10 @@ int host_run_split(Engine& e, const HostJob& j, const std::vector<int>& csize, s
     HostJob jj = j; jj.topk = kk;
     int rc = ensure_pipe(e, jj, (size_t)e.max_batch * clip_bytes, err);
     if (rc) return rc;
-    if (!e.ensure_contexts(2, &err, false) || !e.ensure_hand(&err)) return BNHIP_E_NOMEM;
+    if (!e.ensure_contexts(2, &err, false) || !e.ensure_hand(&err)) {
+        if (err.empty()) err = "two-phase host call: context arena / hand-off buffer allocation failed";
+        return BNHIP_E_NOMEM;
+    }
     HostPipe& hp = *e.hostpipe;
     hipStream_t sa = e.kernel_stream(0), sb = e.kernel_stream(1);
     if (!sa || !sb) { err = "hipStreamCreate failed"; return BNHIP_E_RUNTIME; }
@@ -344,7 +429,7 @@ int host_run_split(Engine& e, const HostJob& j, const std::vector<int>& csize, s
     const bool logits_pinned = j.logits && is_pinned(j.logits, (size_t)j.n_clips * e.n_classes * 4);
     const bool emb_pinned = j.emb && is_pinned(j.emb, (size_t)j.n_clips * e.emb_dim * 4);
     auto abort_all = [&]() {
-        for (auto& s : hp.s) pool().wait(&s.fill);
+        for (auto& s : hp.s) hp.cp->wait(&s.fill);
         hipStreamSynchronize(hp.xfer);
         for (int q = 0; q < 3; q++) if (e.kstream[q]) hipStreamSynchronize(e.kstream[q]);
         hipStreamSynchronize(hp.xfer);
@@ -390,23 +475,25 @@ int host_run_split(Engine& e, const HostJob& j, const std::vector<int>& csize, s
     }
     int n_streams = 1;
     for (const Op& o : ops) n_streams = std::max(n_streams, o.st + 1);
-    if (!e.ensure_contexts(n_streams, &err, false)) return BNHIP_E_NOMEM;
+    if (!e.ensure_contexts(n_streams, &err, false)) { if (err.empty()) err = "two-phase host call: context arena allocation failed"; return BNHIP_E_NOMEM; }
     hipStream_t ks[3] = {sa, sb, n_streams > 2 ? e.kernel_stream(2) : nullptr};
     if (n_streams > 2 && !ks[2]) { err = "hipStreamCreate failed"; return BNHIP_E_RUNTIME; }
     int ng = 0; for (const Op& o : ops) ng += o.kind == 'b';
     std::vector<int> gfirst, gcount;                      // per group: first clip, clips
+    // A producer behind page-locked memory (bnhip_windows_predict_topk: rows assembled on demand): the call's FIRST chunk is on the
+    // critical path - nothing runs on the GPU until it has landed - so it is produced and copied in quarters, the DMA of one quarter
+    // under the assembly of the next (round 6: first kernel at 0.65 ms instead of 0.95).  Later chunks are produced whole, under the
+    // previous chunk's kernels.
+    const bool piecewise = j.prepare && src_pinned;
     auto start_fill = [&](int c) {
         HostPipe::Slot& s = hp.s[c % K];
-        if (j.prepare) j.prepare(cfirst[c], csize[c]);
-        if (!src_pinned) pool().submit(s.h_in, (const char*)j.src + (size_t)cfirst[c] * clip_bytes, (size_t)csize[c] * clip_bytes, &s.fill);
+        if (j.prepare && !(piecewise && c == 0)) j.prepare(cfirst[c], csize[c]);
+        if (!src_pinned) hp.cp->submit(s.h_in, (const char*)j.src + (size_t)cfirst[c] * clip_bytes, (size_t)csize[c] * clip_bytes, &s.fill);
     };
-    static const bool trace = getenv("BNHIP_HOST_TRACE") != nullptr;
-    std::vector<hipEvent_t> tev;                          // trace: [base][per chunk: h2d done, front start, front done][per group: back start, back done]
-    if (trace) {
-        tev.resize(1 + 3 * (size_t)nch + 2 * (size_t)ng);
-        for (auto& ev : tev) hipEventCreate(&ev);
-        hipEventRecord(tev[0], hp.xfer);
-    }
+    static const bool trace_env = getenv("BNHIP_HOST_TRACE") != nullptr;
+    TraceEvents tev;                                      // trace: [base][per chunk: h2d done, front start, front done][per group: back start, back done]
+    const bool trace = trace_env && tev.create(1 + 3 * (size_t)nch + 2 * (size_t)ng);
+    if (trace) hipEventRecord(tev[0], hp.xfer);
     char* hand = reinterpret_cast<char*>(e.d_hand);
     const size_t hcb = e.hand_clip_bytes();
     const int ns = (int)e.steps.size();
@@ -418,9 +505,20 @@ int host_run_split(Engine& e, const HostJob& j, const std::vector<int>& csize, s
             HostPipe::Slot& s = hp.s[c % K];
             const int n = csize[c];
             const size_t cnt = (size_t)n * e.n_samples;
-            if (!src_pinned) pool().wait(&s.fill);
+            if (!src_pinned) hp.cp->wait(&s.fill);
             const void* h_src = src_pinned ? (const void*)((const char*)j.src + (size_t)cfirst[c] * clip_bytes) : (const void*)s.h_in;
-            HP_PIPE(hipMemcpyAsync(j.pcm_bits ? (void*)s.d_raw : (void*)s.d_in, h_src, cnt * bps, hipMemcpyHostToDevice, hp.xfer), "H2D copy");
+            char* d_dst = j.pcm_bits ? (char*)s.d_raw : (char*)s.d_in;
+            if (piecewise && c == 0 && n >= 16) {
+                const int pc = (n + 3) / 4;
+                for (int q = 0; q < n; q += pc) {
+                    const int m = std::min(pc, n - q);
+                    j.prepare(cfirst[0] + q, m);
+                    HP_PIPE(hipMemcpyAsync(d_dst + (size_t)q * clip_bytes, (const char*)h_src + (size_t)q * clip_bytes, (size_t)m * clip_bytes, hipMemcpyHostToDevice, hp.xfer), "H2D copy");
+                }
+            } else {
+                if (piecewise && c == 0) j.prepare(cfirst[0], n);
+                HP_PIPE(hipMemcpyAsync(d_dst, h_src, cnt * bps, hipMemcpyHostToDevice, hp.xfer), "H2D copy");
+            }
             HP_PIPE(hipEventRecord(s.ev_h2d, hp.xfer), "event record");
             if (trace) hipEventRecord(tev[1 + 3 * c], hp.xfer);
             HP_PIPE(hipStreamWaitEvent(st, s.ev_h2d, 0), "stream wait");
@@ -464,7 +562,7 @@ int host_run_split(Engine& e, const HostJob& j, const std::vector<int>& csize, s
         HostPipe::Slot& o = hp.s[q];
         const size_t off = (size_t)gfirst[q], gn = (size_t)gcount[q];
         HP_PIPE(hipEventSynchronize(o.ev_out), "D2H copy/sync");
-        if (j.logits && !logits_pinned) parallel_copy(j.logits + off * e.n_classes, o.h_logits, gn * e.n_classes * 4);
+        if (j.logits && !logits_pinned) parallel_copy(j.logits + off * e.n_classes, o.h_logits, gn * e.n_classes * 4, e.device);
         if (j.emb && !emb_pinned) memcpy(j.emb + off * e.emb_dim, o.h_emb, gn * e.emb_dim * 4);
         if (kk) {
             memcpy(j.out_conf + off * kk, o.h_tkc, gn * kk * 4);
@@ -482,7 +580,6 @@ int host_run_split(Engine& e, const HostJob& j, const std::vector<int>& csize, s
             hipEventElapsedTime(&a, tev[0], tev[1 + 3 * nch + 2 * q]); hipEventElapsedTime(&b, tev[0], tev[2 + 3 * nch + 2 * q]);
             fprintf(stderr, "[bnhip] host trace: group %d (%d clips from %d) GPU: back start %.3f, done %.3f ms\n", q, gcount[q], gfirst[q], a, b);
         }
-        for (auto& ev : tev) hipEventDestroy(ev);
     }
 #undef HP_PIPE
     return BNHIP_OK;
@@ -552,7 +649,7 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
     HostJob jj = j; jj.topk = kk;
     int rc = ensure_pipe(e, jj, (size_t)e.max_batch * clip_bytes, err);
     if (rc) return rc;
-    if (!e.ensure_contexts(D, &err, false)) return BNHIP_E_NOMEM;
+    if (!e.ensure_contexts(D, &err, false)) { if (err.empty()) err = "host pipeline: context arena allocation failed"; return BNHIP_E_NOMEM; }
     HostPipe& hp = *e.hostpipe;
     constexpr int K = HostPipe::K;
     // The chunks run in the context arenas on the device's kernel streams; context 0's arena is the engine's own.  Anything an
@@ -568,7 +665,7 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
     const bool emb_pinned = j.emb && is_pinned(j.emb, (size_t)j.n_clips * e.emb_dim * 4);
     auto chunk_n = [&](int c) { return csize[c]; };
     auto abort_all = [&]() {
-        for (auto& s : hp.s) { pool().wait(&s.fill); s.chunk = -1; }
+        for (auto& s : hp.s) { hp.cp->wait(&s.fill); s.chunk = -1; }
         hipStreamSynchronize(hp.xfer);
         for (int c = 0; c < D; c++) if (e.kstream[c]) hipStreamSynchronize(e.kstream[c]);
         hipStreamSynchronize(hp.xfer);
@@ -580,7 +677,7 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
         hipError_t he = hipEventSynchronize(s.ev_done);
         if (he != hipSuccess) return he;
         const size_t off = (size_t)cfirst[s.chunk], n = (size_t)chunk_n(s.chunk);
-        if (j.logits && !logits_pinned) parallel_copy(j.logits + off * e.n_classes, s.h_logits, n * e.n_classes * 4);
+        if (j.logits && !logits_pinned) parallel_copy(j.logits + off * e.n_classes, s.h_logits, n * e.n_classes * 4, e.device);
         if (j.emb && !emb_pinned) memcpy(j.emb + off * e.emb_dim, s.h_emb, n * e.emb_dim * 4);
         if (kk) {
             memcpy(j.out_conf + off * kk, s.h_tkc, n * kk * 4);
@@ -595,7 +692,7 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
         if (he != hipSuccess) return he;
         s.chunk = c;
         if (j.prepare) j.prepare(cfirst[c], chunk_n(c));   // (the producer's own threads; returns with the clips in place)
-        if (!src_pinned) pool().submit(s.h_in, (const char*)j.src + (size_t)cfirst[c] * clip_bytes, (size_t)chunk_n(c) * clip_bytes, &s.fill);
+        if (!src_pinned) hp.cp->submit(s.h_in, (const char*)j.src + (size_t)cfirst[c] * clip_bytes, (size_t)chunk_n(c) * clip_bytes, &s.fill);
         return hipSuccess;
     };
 #define HP_PIPE(call, what)                                                                \
@@ -608,13 +705,10 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
         }                                                                                  \
     } while (0)
 
-    static const bool trace = getenv("BNHIP_HOST_TRACE") != nullptr;
-    std::vector<hipEvent_t> tev;                          // trace: [base][per chunk: h2d done, compute start, done]
-    if (trace) {
-        tev.resize(1 + 3 * (size_t)nch);
-        for (auto& ev : tev) hipEventCreate(&ev);
-        hipEventRecord(tev[0], hp.xfer);
-    }
+    static const bool trace_env = getenv("BNHIP_HOST_TRACE") != nullptr;
+    TraceEvents tev;                                      // trace: [base][per chunk: h2d done, compute start, done]
+    const bool trace = trace_env && tev.create(1 + 3 * (size_t)nch);
+    if (trace) hipEventRecord(tev[0], hp.xfer);
     const bool serial = diag_env("BNHIP_HOST_SERIAL") != nullptr;      // diagnostics: one chunk at a time (read per call)
     auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_call = now_ms();
@@ -641,7 +735,7 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
         const size_t cnt = (size_t)n * e.n_samples;
         hipStream_t cs = e.kernel_stream(ctx);
         if (!cs) { abort_all(); err = "hipStreamCreate failed"; return BNHIP_E_RUNTIME; }
-        if (!src_pinned) pool().wait(&s.fill);
+        if (!src_pinned) hp.cp->wait(&s.fill);
         if (trace) tr.push_back(now_ms() - t_call);
         const void* h_src = src_pinned ? (const void*)((const char*)j.src + (size_t)cfirst[c] * clip_bytes) : (const void*)s.h_in;
         HP_PIPE(hipMemcpyAsync(j.pcm_bits ? (void*)s.d_raw : (void*)s.d_in, h_src, cnt * bps, hipMemcpyHostToDevice, hp.xfer), "H2D copy");
@@ -675,7 +769,6 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
             hipEventElapsedTime(&a, tev[0], tev[1 + 3 * c]); hipEventElapsedTime(&b, tev[0], tev[2 + 3 * c]); hipEventElapsedTime(&d, tev[0], tev[3 + 3 * c]);
             fprintf(stderr, "[bnhip] host trace: chunk %d (%d clips, ctx %d) GPU: h2d done %.3f, compute start %.3f, done %.3f ms\n", c, csize[c], c % D, a, b, d);
         }
-        for (auto& ev : tev) hipEventDestroy(ev);
     }
     if (trace)
         for (int c = 0; c < nch; c++)
@@ -687,5 +780,27 @@ int host_run(Engine& e, const HostJob& j, std::string& err) {
 
 }  // namespace bnhip
 
+// Diagnostics of the NUMA placement (numa.h; not part of the boundary): what a device's copy pool looks like, and the sysfs parsing
+// on a tree of the caller's choosing (CPU tests build a fake /sys).
+extern "C" int bnhip_debug_copy_pool(int device, int* node, int* threads, int* bound, int* cpus) {
+    try { bnhip::copy_pool_info(device, node, threads, bound, cpus); return 0; } catch (...) { return -1; }
+}
+extern "C" int bnhip_debug_numa_probe(const char* sysroot, const char* bdf, int* node, int* cpus, int cap) {
+    try {
+        const std::string root = sysroot ? sysroot : "/sys";
+        const int nd = bnhip::pci_numa_node(bdf ? bdf : "", root);
+        if (node) *node = nd;
+        const std::vector<int> c = bnhip::numa_node_cpus(nd, root);
+        for (size_t i = 0; i < c.size() && (int)i < cap && cpus; i++) cpus[i] = c[i];
+        return (int)c.size();
+    } catch (...) { return -1; }
+}
+extern "C" int bnhip_debug_parse_cpulist(const char* text, int* cpus, int cap) {
+    try {
+        const std::vector<int> c = bnhip::parse_cpulist(text ? text : "");
+        for (size_t i = 0; i < c.size() && (int)i < cap && cpus; i++) cpus[i] = c[i];
+        return (int)c.size();
+    } catch (...) { return -1; }
+}
 extern "C" long bnhip_debug_split_calls(void) { return bnhip::g_split_calls.load(std::memory_order_relaxed); }
 extern "C" long bnhip_debug_pinned_inputs(void) { return bnhip::g_pinned_inputs.load(std::memory_order_relaxed); }

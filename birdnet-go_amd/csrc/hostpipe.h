@@ -37,8 +37,12 @@ struct HostJob {
 int host_run(Engine& e, const HostJob& j, std::string& err);
 void hostpipe_free(struct HostPipe* hp);
 
-// memcpy spread over the process-wide copy pool (BNHIP_COPY_THREADS, default min(8, cores / 4)); callable concurrently.
-void parallel_copy(void* dst, const void* src, size_t bytes);
-int copy_pool_threads();
+// memcpy spread over the copy pool of `device`'s NUMA node (BNHIP_COPY_THREADS per pool, default min(8, cores / 4), never more
+// than the node's usable CPUs; device < 0 or no NUMA information: the unbound pool); callable concurrently.
+void parallel_copy(void* dst, const void* src, size_t bytes, int device = -1);
+int copy_pool_threads(int device = -1);
+// NUMA node of a HIP device from its PCI address (-1: unknown, or BNHIP_NUMA=0), and what its pool looks like
+int device_numa_node(int device);
+void copy_pool_info(int device, int* node, int* threads, int* bound, int* cpus);
 
 }  // namespace bnhip

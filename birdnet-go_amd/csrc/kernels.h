@@ -1,11 +1,44 @@
 // Launch wrappers for the gfx950 kernels in kernels.hip.  All tensors are fp32, activations NHWC.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <vector>
 #include <cstdint>
 
 namespace bnhip {
+
+// The dynamic-LDS limit of a kernel is an attribute of the function ON THE CURRENT DEVICE (round 5: process-wide once-flags left every
+// further device of a multi-device handle at the 64 KB default; setting it per launch cost a runtime call on the one-clip path,
+// ADVICE r5).  Once per (function, device): one bit per device ordinal in a flag that belongs to this instantiation.
+// Compute units of the CURRENT device (cached per ordinal; 256 when no device answers - plan-only engines, the MI355X figure).
+// The grid-fill rules (pw_fill_grid, pw_ws_fills, the parted chunk loops of k_expand_dw_sk, Engine::pick_split) are stated in
+// CUs, not as MI355X literals.
+inline int device_cus() {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+    if (dev < 0 || dev >= 64) return 256;
+    int c = cus[dev].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+    hipDeviceProp_t pr{};
+    if (hipGetDeviceProperties(&pr, dev) != hipSuccess || pr.multiProcessorCount <= 0) { (void)hipGetLastError(); return 256; }
+    cus[dev].store(pr.multiProcessorCount, std::memory_order_relaxed);
+    return pr.multiProcessorCount;
+}
+
+template <auto Kern>
+inline void lds_limit_once(int bytes) {
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    if (dev < 0 || dev >= 64) { hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); return; }
+    const unsigned long long bit = 1ull << dev;
+    if (done.load(std::memory_order_acquire) & bit) return;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess)
+        done.fetch_or(bit, std::memory_order_release);
+    else (void)hipGetLastError();
+}
 
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU_N1_TO_1 = 2, ACT_RELU6 = 3, ACT_TANH = 4, ACT_SWISH = 100, ACT_SIGMOID = 101, ACT_HARD_SWISH = 102 };
 

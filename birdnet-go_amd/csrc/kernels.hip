@@ -355,7 +355,7 @@ template <int NT, int WN, int FT, int KC>
 static void launch_frontend_shape(const FrontendParams& p, hipStream_t s) {
     size_t lds = fe_lds_bytes(FT, KC, p.Lfft, p.Kp, p.hop, p.NTP);
     // (per launch: the limit is an attribute of the function on the CURRENT device - see launch_stft_bins)
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frontend<NT, WN, FT, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    lds_limit_once<&k_frontend<NT, WN, FT, KC>>(160 * 1024);
     dim3 grid((p.F + FT - 1) / FT, p.n_clips);
     hipLaunchKernelGGL((k_frontend<NT, WN, FT, KC>), grid, dim3(64 * (FT / 16) * WN), lds, s, p);
 }
@@ -1408,7 +1408,8 @@ std::vector<uint16_t> pw_bx3_image(const float* W, int N, int K) {
 // then narrower column tiles - until the grid has at least one workgroup per CU or the smallest tile is reached.  Pipelined
 // kernel forms keep their own constraints, so they fall back to the plain form when the tile changes.
 static inline bool pw_fill_grid(int M, int N, int* nt, int* wm, unsigned* nblk, int* nblk_n) {
-    static const int target = getenv("BNHIP_PW_FILL") ? atoi(getenv("BNHIP_PW_FILL")) : 256;
+    static const int target_env = getenv("BNHIP_PW_FILL") ? atoi(getenv("BNHIP_PW_FILL")) : -1;
+    const int target = target_env >= 0 ? target_env : device_cus();
     bool changed = false;
     auto count = [&]() { *nblk_n = (N + *nt * 16 - 1) / (*nt * 16); *nblk = (unsigned)((M + 64 * *wm - 1) / (64 * *wm)) * (unsigned)*nblk_n; };
     count();
@@ -1449,7 +1450,7 @@ void launch_pw_bx3(const PwParams& p, const uint16_t* Wimg, hipStream_t s) {
                      else { if (wm == 1) BX_LAUNCH(NT_, false, 1); else BX_LAUNCH(NT_, false, 2); } break;
     if (pipe) {
         const size_t ldsb = bx3p_lds_bytes(nt, wm);
-#define BP_LAUNCH(NT_, SC_, WM_) do { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_bx3p<NT_, SC_, WM_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+#define BP_LAUNCH(NT_, SC_, WM_) do { lds_limit_once<&k_pw_bx3p<NT_, SC_, WM_>>(80 * 1024); \
         hipLaunchKernelGGL((k_pw_bx3p<NT_, SC_, WM_>), grid, dim3(256), ldsb, s, p, Wimg, Npad, nblk_n, nblk, dn, dhw); } while (0)
 #define BP_CASE(NT_) case NT_: if (sc) { if (wm == 1) BP_LAUNCH(NT_, true, 1); else BP_LAUNCH(NT_, true, 2); } \
                      else { if (wm == 1) BP_LAUNCH(NT_, false, 1); else BP_LAUNCH(NT_, false, 2); } break;
@@ -2082,7 +2083,7 @@ __global__ __launch_bounds__(256) void k_topk(const float* __restrict__ conf, in
 void launch_topk(const float* conf, int n_clips, int n_classes, int k, float* out_conf, int32_t* out_idx,
                  hipStream_t s) {
     if ((size_t)n_classes * sizeof(float) > 48 * 1024)      // class counts above 12 K need more than the default dynamic LDS (per device: not cached)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        lds_limit_once<&k_topk>(160 * 1024 - 256);
     hipLaunchKernelGGL(k_topk, dim3(n_clips), dim3(256), (size_t)n_classes * sizeof(float), s, conf, n_classes, k,
                        out_conf, out_idx);
 }
@@ -2239,11 +2240,11 @@ void launch_us_frame_power(const void* samples, int pcm16, int n_clips, int n, i
     if (fft_size == 8192 && !no8) {
         const size_t lds8 = (size_t)2 * US8_PHYS(US8_N2) * sizeof(double);
         if (pcm16) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_us_frame_power8<int16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            lds_limit_once<&k_us_frame_power8<int16_t>>(80 * 1024);
             hipLaunchKernelGGL(k_us_frame_power8<int16_t>, dim3(frames, n_clips), dim3(512), lds8, s, static_cast<const int16_t*>(samples), n, hop,
                                frames, split_bin, tw, powers);
         } else {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_us_frame_power8<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            lds_limit_once<&k_us_frame_power8<double>>(80 * 1024);
             hipLaunchKernelGGL(k_us_frame_power8<double>, dim3(frames, n_clips), dim3(512), lds8, s, static_cast<const double*>(samples), n, hop,
                                frames, split_bin, tw, powers);
         }
@@ -2253,11 +2254,11 @@ void launch_us_frame_power(const void* samples, int pcm16, int n_clips, int n, i
     size_t lds = (size_t)fft_size * 2 * sizeof(double);
     int threads = fft_size / 2 < 1024 ? (fft_size / 2 < 64 ? 64 : fft_size / 2) : 1024;
     if (pcm16) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_us_frame_power<int16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        lds_limit_once<&k_us_frame_power<int16_t>>(160 * 1024 - 256);
         hipLaunchKernelGGL(k_us_frame_power<int16_t>, dim3(frames, n_clips), dim3(threads), lds, s, static_cast<const int16_t*>(samples), n,
                            fft_size, hop, frames, split_bin, log2n, tw, powers);
     } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_us_frame_power<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        lds_limit_once<&k_us_frame_power<double>>(160 * 1024 - 256);
         hipLaunchKernelGGL(k_us_frame_power<double>, dim3(frames, n_clips), dim3(threads), lds, s, static_cast<const double*>(samples), n,
                            fft_size, hop, frames, split_bin, log2n, tw, powers);
     }

@@ -309,8 +309,9 @@ bool pw_ws_fills(const PwParams& p) {
     const int nt = ws_pick_nt(p);
     if (!nt) return false;
     const int nblk_n = (p.N + 16 * nt - 1) / (16 * nt), mt16 = (p.M + 15) / 16;
-    const int G = std::min(std::max(1, 256 / nblk_n), mt16 / (2 * WS_NW));
-    return G * nblk_n >= 128;
+    const int cus = device_cus();
+    const int G = std::min(std::max(1, cus / nblk_n), mt16 / (2 * WS_NW));
+    return G * nblk_n >= cus / 2;
 }
 void launch_pw_ws(const PwParams& p, const uint16_t* Wimg, int Npad, hipStream_t s) {
     g_pw_ws_launches.fetch_add(1, std::memory_order_relaxed);
@@ -320,16 +321,15 @@ void launch_pw_ws(const PwParams& p, const uint16_t* Wimg, int Npad, hipStream_t
     const int BN = 16 * nt;
     const size_t lds = ws_lds_bytes(ns, nt, six);
     const int nblk_n = (p.N + BN - 1) / BN, mt16 = (p.M + 15) / 16;
-    int G = std::max(1, 256 / nblk_n);                       // one resident generation of blocks (one per CU: 512 threads at up to 256 registers): each loads its columns once
+    int G = std::max(1, device_cus() / nblk_n);              // one resident generation of blocks (one per CU: 512 threads at up to 256 registers): each loads its columns once
     G = std::min(G, std::max(1, mt16 / (2 * WS_NW)));        // (at least one tile pair per wave)
     const unsigned nblk = (unsigned)G * (unsigned)nblk_n;
     const unsigned GW = (unsigned)G * WS_NW;
     const FDiv dn = make_fdiv((unsigned)nblk_n);
 #define WS_LAUNCH(NT_, NS_, SIX_, ABF_) do { \
-        auto kern = &k_pw_ws<NT_, NS_, ws_ring(NS_), SIX_, ABF_, WS_NW>; \
-        /* (per launch, like k_pw_bx3p: the attribute belongs to the function ON THE CURRENT DEVICE - a process-wide "done" flag would leave the \
-           second device of a multi-device handle at the 64 KB default) */ \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        constexpr auto kern = &k_pw_ws<NT_, NS_, ws_ring(NS_), SIX_, ABF_, WS_NW>; \
+        /* (the attribute belongs to the function ON THE CURRENT DEVICE: once per function and device, kernels.h lds_limit_once) */ \
+        lds_limit_once<kern>(160 * 1024); \
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * WS_NW), lds, s, p, Wimg, Npad, nblk_n, nblk, GW, dn); } while (0)
 #define WS_SIX(NT_) switch (ns) { case 3: WS_LAUNCH(NT_, 3, true, false); break; case 4: WS_LAUNCH(NT_, 4, true, false); break; \
                                    case 5: WS_LAUNCH(NT_, 5, true, false); break; default: WS_LAUNCH(NT_, 6, true, false); break; }

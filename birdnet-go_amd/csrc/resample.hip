@@ -19,6 +19,8 @@
 #include <cstdint>
 #include <vector>
 
+#include "kernels.h"
+
 namespace bnhip {
 
 static double bessel_i0(double x) {
@@ -113,7 +115,7 @@ int launch_resample(const void* d_in, void* d_out, const float* d_table, int in_
     dim3 grid((n_out + 255) / 256, n_clips);
 #define BN_RS(IP, OP)                                                                                                        \
     do {                                                                                                                     \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample<IP, OP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        lds_limit_once<&k_resample<IP, OP>>(160 * 1024); \
         hipLaunchKernelGGL((k_resample<IP, OP>), grid, dim3(256), lds, s, d_in, d_out, d_table, n_in, n_out, L, M, T, half, i_base, n_base); \
     } while (0)
     if (in_pcm16 && out_pcm16) BN_RS(true, true);

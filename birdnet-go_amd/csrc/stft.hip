@@ -462,13 +462,13 @@ void launch_stft_bins(const StftParams& p0, hipStream_t s) {
     if (p.mel) {
         lds += (size_t)p.mel_quads * 16 + (size_t)(p.mel_quads + 3) / 4 * 16;
         if (P == 16) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<16, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            lds_limit_once<&k_stft_bins<16, 8, true>>(160 * 1024);
             hipLaunchKernelGGL((k_stft_bins<16, 8, true>), grid, dim3(64 * W), lds, s, p);
         } else if (P == 8) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            lds_limit_once<&k_stft_bins<8, 4, true>>(160 * 1024);
             hipLaunchKernelGGL((k_stft_bins<8, 4, true>), grid, dim3(64 * W), lds, s, p);
         } else {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<4, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            lds_limit_once<&k_stft_bins<4, 8, true>>(160 * 1024);
             hipLaunchKernelGGL((k_stft_bins<4, 8, true>), grid, dim3(64 * W), lds, s, p);
         }
         return;
@@ -477,7 +477,7 @@ void launch_stft_bins(const StftParams& p0, hipStream_t s) {
         lds /= 2;
         if (P == 4) hipLaunchKernelGGL((k_stft_bins<4, 8, false, float>), grid, dim3(64 * W), lds, s, p);
         else if (P == 16) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<16, 8, false, float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            lds_limit_once<&k_stft_bins<16, 8, false, float>>(160 * 1024);
             hipLaunchKernelGGL((k_stft_bins<16, 8, false, float>), grid, dim3(64 * W), lds, s, p);
         } else hipLaunchKernelGGL((k_stft_bins<8, 4, false, float>), grid, dim3(64 * W), lds, s, p);
         return;
@@ -485,7 +485,7 @@ void launch_stft_bins(const StftParams& p0, hipStream_t s) {
     if (P == 4) {
         hipLaunchKernelGGL((k_stft_bins<4, 8>), grid, dim3(64 * W), lds, s, p);      // < 64 KB of LDS
     } else if (P == 16) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bins<16, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        lds_limit_once<&k_stft_bins<16, 8>>(160 * 1024);
         hipLaunchKernelGGL((k_stft_bins<16, 8>), grid, dim3(64 * W), lds, s, p);
     } else {
         hipLaunchKernelGGL((k_stft_bins<8, 4>), grid, dim3(64 * W), lds, s, p);      // 42 KB of LDS

@@ -4,12 +4,45 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <thread>
 
+#if defined(__x86_64__) || defined(_M_X64)
+#include <emmintrin.h>
+#endif
+
 namespace bnhip {
+
+// Row bytes go into the (page-locked) batch buffer the copy engines read next and the CPU never reads again: streaming stores keep
+// them out of the caches (no read-for-ownership of the destination lines, and the DMA does not have to snoop dirty lines out of
+// 256 rows' worth of L2 - measured round 6: H2D of a freshly assembled 64-row chunk 0.43 ms against 0.35 ms from memory the CPU
+// had not just written).  x86-64 only; elsewhere (and for the unaligned head / tail) plain memcpy.
+static inline void copy_to_row(uint8_t* dst, const uint8_t* src, size_t n) {
+#if defined(__x86_64__) || defined(_M_X64)
+    if (n >= 4096) {
+        const size_t head = (16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15;
+        if (head) { std::memcpy(dst, src, head); dst += head; src += head; n -= head; }
+        size_t i = 0;
+        for (; i + 64 <= n; i += 64) {
+            const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i));
+            const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 16));
+            const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 32));
+            const __m128i d = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 48));
+            _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i), a);
+            _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 16), b);
+            _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 32), c);
+            _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 48), d);
+        }
+        _mm_sfence();
+        if (i < n) std::memcpy(dst + i, src + i, n - i);
+        return;
+    }
+#endif
+    std::memcpy(dst, src, n);
+}
 
 WindowAssembler::WindowAssembler(size_t overlap_bytes, size_t read_bytes, int max_batch)
     : overlap_(overlap_bytes), read_(read_bytes), max_batch_(std::max(1, max_batch)) {}
@@ -73,22 +106,29 @@ bool WindowAssembler::read_window(Source& s, uint8_t* win) {
     std::lock_guard<std::mutex> g(s.mu);
     if (s.removed || s.n < read_) return false;
     if (overlap_) {
-        if (s.have_prev) std::memcpy(win, s.prev.data(), overlap_);
+        if (s.have_prev) copy_to_row(win, s.prev.data(), overlap_);
         else std::memset(win, 0, overlap_);
     }
     const size_t cap = s.ring.size(), first = std::min(read_, cap - s.r);
-    std::memcpy(win + overlap_, s.ring.data() + s.r, first);
-    if (read_ > first) std::memcpy(win + overlap_ + first, s.ring.data(), read_ - first);
-    s.r = (s.r + read_) % cap; s.n -= read_;
+    copy_to_row(win + overlap_, s.ring.data() + s.r, first);
+    if (read_ > first) copy_to_row(win + overlap_ + first, s.ring.data(), read_ - first);
     if (overlap_) {
-        // (read >= overlap is part of the geometry's validation; a shorter read would keep the end of the old tail as well)
-        if (read_ >= overlap_) std::memcpy(s.prev.data(), win + overlap_ + read_ - overlap_, overlap_);
-        else {
+        // the new tail = the window's last `overlap` bytes, taken from where they still sit in the CPU's caches (the ring; the old
+        // tail), not read back from the row that was just streamed past them
+        // (read >= overlap is part of the geometry's validation; a shorter read keeps the end of the old tail as well)
+        if (read_ >= overlap_) {
+            const size_t t0 = (s.r + read_ - overlap_) % cap, f2 = std::min(overlap_, cap - t0);
+            std::memcpy(s.prev.data(), s.ring.data() + t0, f2);
+            if (overlap_ > f2) std::memcpy(s.prev.data() + f2, s.ring.data(), overlap_ - f2);
+        } else {
             std::memmove(s.prev.data(), s.prev.data() + read_, overlap_ - read_);
-            std::memcpy(s.prev.data() + overlap_ - read_, win + overlap_, read_);
+            const size_t f2 = std::min(read_, cap - s.r);
+            std::memcpy(s.prev.data() + overlap_ - read_, s.ring.data() + s.r, f2);
+            if (read_ > f2) std::memcpy(s.prev.data() + overlap_ - read_ + f2, s.ring.data(), read_ - f2);
         }
         s.have_prev = true;
     }
+    s.r = (s.r + read_) % cap; s.n -= read_;
     return true;
 }
 

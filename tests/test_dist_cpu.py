@@ -100,7 +100,12 @@ def _bench_worker(rank, world, port, q):
     dist.barrier()
     dt, rates, ranks = bench.dist_timing(0.5 + 0.25 * rank, 4, 10, use_dist, dev)     # rank 1 pretends to be slower
     dist.barrier()
-    q.put((rank, use_dist, len(blob), (lo, hi), plan, dt, rates, ranks))
+    # the per-rank ingest leg (round 6): every repetition behind one barrier, each rank's median gathered, the job's rate from the
+    # slowest rank - here with a stand-in for the blocking device call (rank 1 twice as slow)
+    import time
+    gathered = bench.dist_gather([rank, 10.0 * rank + 1], use_dist, dev)
+    leg = bench.ranks_ingest_leg({"fake_256": (lambda: time.sleep(0.02 * (rank + 1)), 256)}, 3, use_dist, dev)
+    q.put((rank, use_dist, len(blob), (lo, hi), plan, dt, rates, ranks, gathered, leg))
     dist.destroy_process_group()
 
 
@@ -119,7 +124,12 @@ def test_bench_n_rank_path_under_gloo():
         p.join(60)
         assert p.exitcode == 0
     blob = sm.build_model(sm.tiny_config())
-    for rank, use_dist, n, rng, plan, dt, rates, ranks in res:
+    for rank, use_dist, n, rng, plan, dt, rates, ranks, gathered, leg in res:
+        assert gathered == [[0.0, 1.0], [1.0, 11.0]]
+        f = leg["fake_256"]
+        assert f["n_clips_per_rank"] == 256 and len(f["ms_per_rank"]) == 2 and f["ms_per_rank"] == res[0][9]["fake_256"]["ms_per_rank"]
+        assert 19 <= f["ms_per_rank"][0] <= 35 and 39 <= f["ms_per_rank"][1] <= 60 and f["ms_max"] == max(f["ms_per_rank"])
+        assert abs(f["clips_per_s_whole_job"] - 512 / (f["ms_max"] * 1e-3)) < 1e-6
         assert use_dist and n == len(blob) and ranks == 2
         assert rng == (4 * rank, 4 * rank + 4)
         assert plan == res[0][4]
