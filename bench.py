@@ -615,8 +615,6 @@ def ranks_host_pointer(blob, gpu, args, x256, use_dist, dev):
     big = np.tile(pcm, (8, 1))
     out256, out2048 = np.zeros((256, ncls), np.float32), np.zeros((2048, ncls), np.float32)
     import ctypes as C
-    pool = [C.c_int(-9) for _ in range(4)]
-    host.load_library().bnhip_debug_copy_pool(gpu, *[C.byref(q) for q in pool])
     with host.PinnedArray((2048, x256.shape[1]), np.int16) as pp, host.PinnedArray((2048, ncls), np.float32) as po:
         pp.array[:] = big
         calls = {
@@ -626,6 +624,8 @@ def ranks_host_pointer(blob, gpu, args, x256, use_dist, dev):
             "pcm16_2048_pinned": (lambda: clf.predict_pcm16(pp.array.reshape(-1), 2048, out=po.array), 2048),
         }
         res = ranks_ingest_leg(calls, 7, use_dist, dev)
+    pool = [C.c_int(-9) for _ in range(4)]
+    host.load_library().bnhip_debug_copy_pool(gpu, *[C.byref(q) for q in pool])          # (after the calls: the pool's threads have started and bound themselves)
     clf.close()
     placement = dist_gather([q.value for q in pool], use_dist, dev)
     res["numa"] = {"per_rank": [{"node": int(q[0]), "copy_threads": int(q[1]), "bound": int(q[2]), "node_cpus_usable": int(q[3])} for q in placement],

@@ -1844,7 +1844,6 @@ void Engine::tune_or_load() {
         if (!done) {
             autotune_pw(); autotune_expdw(); autotune_dw();
             adopted("self-tuned");
-            if (tf && *tf) { FILE* ex = fopen(tf, "r"); if (ex) fclose(ex); else save_tuning(tf); }     // (never overwritten: another engine of the process may own it)
             if (!experiment && !tune_dir.empty() && getenv("BNHIP_TUNE_RECORD")) {
                 const std::string path = tune_dir + "/" + key + ".tune";
                 FILE* ex = fopen(path.c_str(), "r");
@@ -1852,6 +1851,9 @@ void Engine::tune_or_load() {
             }
         }
     }
+    // BNHIP_TUNE_FILE records whatever this engine ended up with (timed here, or adopted from the cache / the directory) when the
+    // file does not exist yet; never overwritten: another engine of the process may own it
+    if (tf && *tf && tune_source.rfind("file:", 0) != 0) { FILE* ex = fopen(tf, "r"); if (ex) fclose(ex); else save_tuning(tf); }
     if (!experiment && !tune_cache_off()) {
         std::lock_guard<std::mutex> lk(g_tune_mu);
         g_tune_cache.emplace(key, tuning_text());          // (first writer wins: every later engine of this plan adopts it)
