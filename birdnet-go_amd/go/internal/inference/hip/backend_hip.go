@@ -155,6 +155,7 @@ import (
 	"fmt"
 	"math"
 	"runtime"
+	"strings"
 	"sync"
 	"unsafe"
 )
@@ -232,6 +233,10 @@ type Options struct {
 	// StrictF32 keeps every contraction on the f32-input MFMA ("bf16x3":0) instead of letting compute-bound layers run as
 	// six exact bf16 products per fp32 product (fp32-equivalent to 2^-23, include/bnhip.h): for hosts that want one kernel family.
 	StrictF32 bool
+	// TuneDir is a directory of recorded create-time tunings (include/bnhip.h "tune_dir": files <plan key>.tune as shipped under
+	// birdnet-go_amd/tune/): an engine whose plan matches a file adopts it instead of timing its kernel candidates, which makes
+	// the plan - and a clip's last bits - reproducible from process to process. Empty: the BNHIP_TUNE_DIR environment, else none.
+	TuneDir string
 }
 
 // NewClassifierWithOptions is NewClassifier with explicit creation options (e.g. Perch v2 on bf16 operands).
@@ -268,6 +273,12 @@ func NewClassifierWithOptions(modelData []byte, o Options) (*Classifier, error) 
 	}
 	if o.EmbeddingOutput > 0 {
 		js += fmt.Sprintf(`,"embedding_output":%d`, o.EmbeddingOutput-1)
+	}
+	if o.TuneDir != "" {
+		if strings.ContainsAny(o.TuneDir, "\"\\") {
+			return nil, fmt.Errorf("hip: tune directory %q cannot be passed (quote or backslash in the path)", o.TuneDir)
+		}
+		js += fmt.Sprintf(`,"tune_dir":"%s"`, o.TuneDir)
 	}
 	opts := C.CString(js + "}")
 	defer C.free(unsafe.Pointer(opts))

@@ -235,6 +235,9 @@ def test_two_phase_call_on_the_tiny_model_embeddings_and_24_bit(gpu, tiny_blob):
     clf = host.HipClassifier(tiny_blob, max_batch=256)
     try:
         assert clf.describe()["split_step"] > 0
+        #  the per-call diagnostic switches only exist in a process that started with BNHIP_HOST_DIAG (conftest sets it):
+        # without it the NOSPLIT leg below would silently measure the split path twice
+        assert os.environ.get("BNHIP_HOST_DIAG"), "tests/conftest.py must export BNHIP_HOST_DIAG before the library is loaded"
         for n in (129, 191, 256):
             x = sm.synth_clips(n, cfg.n_samples, cfg.sample_rate)
             i24 = np.clip(np.round(x * 8388607), -8388608, 8388607).astype(np.int32)
