@@ -27,3 +27,17 @@ def test_build_keeps_the_slp_vectoriser_off():
     import birdnet_go_amd  # noqa: F401
     from birdnet_go_amd import build
     assert "-fno-slp-vectorize" in build.FLAGS
+
+
+@pytest.mark.skipif(not os.path.exists(isa_audit.OBJDUMP), reason="llvm-objdump not found")
+def test_instruction_class_listing_of_a_fused_kernel(built_lib):
+    """tools/isa_audit.py --classes (round 6: the audit of the small-K fused kernels): the static listing finds the
+    instantiation b2 runs on the recorded plan, and its classes are what the source says the kernel is made of - f32 MFMAs,
+    transcendentals in exp / rcp pairs for the swish, LDS traffic for the expanded footprint."""
+    got = isa_audit.classes(built_lib, "k_expand_dw_sk<3, 2, 8, 8, 17, false, 16, true, 4, 0, 1>")
+    assert len(got) == 1, list(got)
+    c = next(iter(got.values()))
+    assert c["mfma"] >= 40 and c["valu:transcendental"] >= 2 * c["mfma"] and c["lds"] >= 50 and c["barrier"] >= 2
+    assert c["valu:transcendental"] % 2 == 0 or c["valu:transcendental"] > 100       # exp + rcp per element (plus the cold activation switch)
+    assert isa_audit.insn_class("v_pk_mul_f32") == "valu:mul_f32" and isa_audit.insn_class("ds_read_b128") == "lds"
+    assert isa_audit.insn_class("v_lshl_add_u64") == "valu:integer" and isa_audit.insn_class("s_cbranch_scc1") == "branch"

@@ -264,3 +264,26 @@ def test_specific_malformations_name_the_problem(built_lib):
         with pytest.raises(host.HipError, match=needle) as e:
             host.HipClassifier(conv_graph(mut), plan_only=True)
         assert e.value.code == host.E_MODEL, needle
+
+
+def test_shipped_tunings_are_well_formed():
+    """birdnet-go_amd/tune/<plan key>.tune (bnhip.h "tune_dir"): the header repeats what the file name says (plan hash, batch, depth,
+    host depth, precision, split-bf16 mode), one row per step, rows in step order - a stale or hand-edited file is ignored by the
+    engine anyway, but the package should not ship one."""
+    import glob
+    import os
+    import re
+    from birdnet_go_amd import host
+    files = sorted(glob.glob(os.path.join(host.TUNE_DIR, "*.tune")))
+    assert len(files) >= 5, files
+    for f in files:
+        m = re.match(r"([0-9a-f]{16})_b(\d+)_d(\d+)_h(\d+)_p(\d+)_x(\d+)_l(\d+)_s([0-9a-f]+)\.tune$", os.path.basename(f))
+        assert m, f
+        lines = open(f).read().splitlines()
+        hd = lines[0].split()
+        assert hd[0] == "bnhip-tuning-2" and int(hd[1]) == len(lines) - 1, f
+        assert (int(hd[2]), int(hd[3]), int(hd[4]), int(hd[5]), int(hd[6])) == tuple(int(m.group(i)) for i in (2, 3, 4, 5, 6)), f
+        assert int(hd[7], 16) == int(m.group(1), 16), f
+        for i, row in enumerate(lines[1:]):
+            q = row.split(" ", 10)
+            assert len(q) == 11 and int(q[0]) == i and 0 <= int(q[2]) <= 8 and 0 <= int(q[3]) <= 12, (f, row)
