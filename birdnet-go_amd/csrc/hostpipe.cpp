@@ -135,10 +135,16 @@ std::map<int, CopyPool*> g_pools;            // by NUMA node; -1 = unbound.  Nev
                                              // under a loader lock
 CopyPool& pool_for_node(int node) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    std::vector<int> cpus;
-    if (node >= 0) { cpus = numa_usable_cpus(node); if (cpus.empty()) node = -1; }
     auto it = g_pools.find(node);
-    if (it != g_pools.end()) return *it->second;
+    if (it != g_pools.end()) return *it->second;          // (every later call: no sysfs, no allocation)
+    std::vector<int> cpus;
+    if (node >= 0) cpus = numa_usable_cpus(node);
+    if (node >= 0 && cpus.empty()) {                      // the node's CPUs are outside this process' cpuset: the unbound pool serves it
+        auto un = g_pools.find(-1);
+        CopyPool* p = un != g_pools.end() ? un->second : (g_pools[-1] = new CopyPool());
+        g_pools[node] = p;
+        return *p;
+    }
     CopyPool* p = new CopyPool(cpus);
     g_pools[node] = p;
     return *p;
@@ -246,7 +252,10 @@ int ensure_pipe(Engine& e, const HostJob& j, size_t chunk_bytes, std::string& er
     hp.xfer = e.copy_stream();
     if (!hp.xfer) { err = "copy stream creation failed"; return BNHIP_E_RUNTIME; }
     if (!hp.cp) { hp.numa_node = device_numa_node(e.device); hp.cp = &pool_for_node(hp.numa_node); }
-    NumaPrefer near_gpu(hp.numa_node);       // the pinned slots below are allocated from the GPU's own node when it has room
+    // pinned slots come from the GPU's own NUMA node when it has room (the preference lasts for the allocation only: a steady-state
+    // call allocates nothing and touches no policy)
+    const int node = hp.numa_node;
+    auto pinned = [node](void** p, size_t bytes) { NumaPrefer near_gpu(node); return hipHostMalloc(p, bytes, hipHostMallocDefault); };
     const size_t mb = (size_t)e.max_batch;
     for (auto& s : hp.s) {
         if (!s.ev_h2d) HP_TRY(hipEventCreateWithFlags(&s.ev_h2d, hipEventDisableTiming), "event");
@@ -255,15 +264,15 @@ int ensure_pipe(Engine& e, const HostJob& j, size_t chunk_bytes, std::string& er
         if (!s.ev_out) HP_TRY(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming), "event");
         if (s.h_in_cap < chunk_bytes) {
             if (s.h_in) { hipHostFree(s.h_in); s.h_in = nullptr; s.h_in_cap = 0; }
-            HP_TRY(hipHostMalloc((void**)&s.h_in, chunk_bytes, hipHostMallocDefault), "pinned staging allocation");
+            HP_TRY(pinned((void**)&s.h_in, chunk_bytes), "pinned staging allocation");
             s.h_in_cap = chunk_bytes;
         }
         if (!s.d_in) HP_TRY(hipMalloc((void**)&s.d_in, mb * e.n_samples * 4), "device staging allocation");
         if (j.pcm_bits && !s.d_raw) HP_TRY(hipMalloc((void**)&s.d_raw, mb * e.n_samples * 4), "device PCM staging allocation");
         if (!s.d_logits) HP_TRY(hipMalloc((void**)&s.d_logits, mb * e.n_classes * 4), "device logits staging allocation");
-        if (j.logits && !s.h_logits) HP_TRY(hipHostMalloc((void**)&s.h_logits, mb * e.n_classes * 4, hipHostMallocDefault), "pinned logits staging allocation");
+        if (j.logits && !s.h_logits) HP_TRY(pinned((void**)&s.h_logits, mb * e.n_classes * 4), "pinned logits staging allocation");
         if (j.emb && !s.d_emb) HP_TRY(hipMalloc((void**)&s.d_emb, mb * e.emb_dim * 4), "device embedding staging allocation");
-        if (j.emb && !s.h_emb) HP_TRY(hipHostMalloc((void**)&s.h_emb, mb * e.emb_dim * 4, hipHostMallocDefault), "pinned embedding staging allocation");
+        if (j.emb && !s.h_emb) HP_TRY(pinned((void**)&s.h_emb, mb * e.emb_dim * 4), "pinned embedding staging allocation");
         if (j.topk > 0) {
             if (!s.d_conf) HP_TRY(hipMalloc((void**)&s.d_conf, mb * e.n_classes * 4), "device confidence allocation");
             if (s.tk_cap < j.topk) {
@@ -272,8 +281,8 @@ int ensure_pipe(Engine& e, const HostJob& j, size_t chunk_bytes, std::string& er
                 s.d_tkc = nullptr; s.d_tki = nullptr; s.h_tkc = nullptr; s.h_tki = nullptr; s.tk_cap = 0;
                 HP_TRY(hipMalloc((void**)&s.d_tkc, mb * j.topk * 4), "device top-k allocation");
                 HP_TRY(hipMalloc((void**)&s.d_tki, mb * j.topk * 4), "device top-k allocation");
-                HP_TRY(hipHostMalloc((void**)&s.h_tkc, mb * j.topk * 4, hipHostMallocDefault), "pinned top-k allocation");
-                HP_TRY(hipHostMalloc((void**)&s.h_tki, mb * j.topk * 4, hipHostMallocDefault), "pinned top-k allocation");
+                HP_TRY(pinned((void**)&s.h_tkc, mb * j.topk * 4), "pinned top-k allocation");
+                HP_TRY(pinned((void**)&s.h_tki, mb * j.topk * 4), "pinned top-k allocation");
                 s.tk_cap = j.topk;
             }
         }

@@ -91,7 +91,8 @@ bool bind_this_thread(const std::vector<int>& cpus) {
 
 namespace {
 // <linux/mempolicy.h> values; the syscalls are reached directly (glibc has no wrappers, libnuma is not in the image)
-constexpr int kMpolDefault = 0, kMpolPreferred = 1;
+constexpr int kMpolPreferred = 1;
+constexpr unsigned long kMaxNode = 1024;
 long set_mempolicy_raw(int mode, const unsigned long* mask, unsigned long maxnode) {
 #ifdef SYS_set_mempolicy
     return syscall(SYS_set_mempolicy, mode, mask, maxnode);
@@ -100,17 +101,33 @@ long set_mempolicy_raw(int mode, const unsigned long* mask, unsigned long maxnod
     return -1;
 #endif
 }
+long get_mempolicy_raw(int* mode, unsigned long* mask, unsigned long maxnode) {
+#ifdef SYS_get_mempolicy
+    return syscall(SYS_get_mempolicy, mode, mask, maxnode, nullptr, 0ul);
+#else
+    (void)mode; (void)mask; (void)maxnode;
+    return -1;
+#endif
+}
 }  // namespace
 
+// The calling thread's own policy is SAVED and put back: a host started under `numactl --interleave` / `--membind` (or a Go
+// runtime thread whose policy somebody set) keeps it - only the allocation inside the scope sees the preference.  If the old
+// policy cannot be read, nothing is changed at all.
 NumaPrefer::NumaPrefer(int node) {
-    if (node < 0 || node >= 1024) return;
-    unsigned long mask[1024 / (8 * sizeof(unsigned long))] = {0};
+    if (node < 0 || node >= (int)kMaxNode) return;
+    saved_mask_.assign(kMaxNode / (8 * sizeof(unsigned long)) + 1, 0ul);
+    if (get_mempolicy_raw(&saved_mode_, saved_mask_.data(), kMaxNode + 1) != 0) return;
+    unsigned long mask[kMaxNode / (8 * sizeof(unsigned long)) + 1] = {0};
     mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
-    active_ = set_mempolicy_raw(kMpolPreferred, mask, 1024 + 1) == 0;
+    active_ = set_mempolicy_raw(kMpolPreferred, mask, kMaxNode + 1) == 0;
 }
 
 NumaPrefer::~NumaPrefer() {
-    if (active_) set_mempolicy_raw(kMpolDefault, nullptr, 0);
+    if (!active_) return;
+    bool any = false;
+    for (unsigned long w : saved_mask_) any = any || w != 0;
+    set_mempolicy_raw(saved_mode_, any ? saved_mask_.data() : nullptr, any ? kMaxNode + 1 : 0);
 }
 
 }  // namespace bnhip

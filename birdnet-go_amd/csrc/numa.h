@@ -35,6 +35,8 @@ class NumaPrefer {
 
   private:
     bool active_ = false;
+    int saved_mode_ = 0;                       // the thread's policy before the scope (put back by the destructor)
+    std::vector<unsigned long> saved_mask_;
 };
 
 }  // namespace bnhip

@@ -93,3 +93,17 @@ def test_copy_pool_of_the_device_and_placement_changes_no_bit(gpu, tiny_blob, ti
         assert bound == 0
     assert off["pool"][0] == -1 and off["pool"][2] == 0
     assert on["y"] == off["y"]
+
+
+def test_numa_preference_scope_restores_the_threads_own_policy(tmp_path):
+    """csrc/numa.cpp NumaPrefer (g++, no GPU): inside the scope the thread prefers the node, afterwards its own policy is back -
+    MPOL_DEFAULT here, an interleave policy set by the host in the second half - and a refused syscall changes nothing."""
+    import shutil
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "numa_policy")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "birdnet-go_amd", "csrc"),
+                           os.path.join(root, "tests", "native", "numa_policy.cpp"), os.path.join(root, "birdnet-go_amd", "csrc", "numa.cpp"), "-o", exe, "-lpthread"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60).stdout.strip()
+    assert out.startswith("OK") or out.startswith("SKIP"), out
