@@ -53,3 +53,11 @@ def test_plan_signature_follows_the_tuners_decisions():
     assert s0 == b.plan_signature({"steps": [dict(s) for s in steps]})
     steps[1]["wm_full"] = 6
     assert s0 != b.plan_signature({"steps": steps})
+
+
+def test_baseline_batch_per_gpu():
+    """bench.py: the per-GPU batch of the BASELINE configuration a run stands for - configs[1] at N = 1, the 1 024-clip shard of
+    configs[2] at any N > 1 (the N-rank run used to measure 256 per rank), Perch's 512 at every N."""
+    import bench
+    assert [bench.baseline_batch("birdnet", n) for n in (1, 2, 4, 8)] == [256, 1024, 1024, 1024]
+    assert [bench.baseline_batch("perch", n) for n in (1, 8)] == [512, 512]
