@@ -215,3 +215,18 @@ def test_random_onnx_cnn_hip_vs_oracle(gpu, seed):
     finally:
         c.close()
     assert np.abs(got - ref).max() <= 2e-5 * max(1.0, float(np.abs(ref).max())), (seed, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("op", ["QuantizeLinear", "DequantizeLinear", "QLinearConv", "QLinearMatMul", "MatMulInteger", "ConvInteger", "DynamicQuantizeLinear"])
+def test_onnx_quantized_operators_are_reported_unsupported_by_name(built_lib, op):
+    """The reference's INT8 ONNX variants (`int8-arm`, `int8-arm-dfttrunc`: internal/classifier/model_catalog.go:315-318,430-433) are
+    aarch64-only builds (`Requirements.Arch`) and not a deployment an MI355X host sees; a file of that family handed to the engine
+    anyway is refused with BNHIP_E_UNSUPPORTED and the operator's name, which the Go shim turns into "fall back to the existing
+    backend" (model_openvino.go:227-230) - never a crash, never a silent float reinterpretation of quantised tensors."""
+    b = ob.OnnxBuilder()
+    x = b.input("x", ["N", 8])
+    y = b.node(op, [x, b.init(np.asarray([0.1], np.float32))])
+    b.output(y, ["N", 8])
+    with pytest.raises(host.HipError, match=op) as e:
+        host.HipClassifier(b.finish(), plan_only=True)
+    assert e.value.code == host.E_UNSUPPORTED
