@@ -22,6 +22,15 @@ __global__ void k(float* out, unsigned long long* cyc, int iters, float seed) {
                 if (KIND == 2) g[i] = g[i] * (f32x2){1.0001f, 0.9999f};
                 if (KIND == 3) f[i] = __builtin_amdgcn_exp2f(f[i]) * 0.0f + f[i];         // exp + fma (the fma keeps the chain finite)
                 if (KIND == 4) f[i] = __builtin_amdgcn_rcpf(f[i]) * 0.0f + f[i];          // rcp + fma
+                if (KIND == 6) {                                   // v_dot2c_f32_bf16: two bf16 products accumulated into fp32 (no builtin selects it: inline asm)
+                    const unsigned a = __float_as_uint(g[i][0]), b = 0x3f803f80u;
+                    asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(f[i]) : "v"(a), "v"(b));
+                }
+                if (KIND == 7) {                                   // v_dot2_f32_f16
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    const h2 a = __builtin_bit_cast(h2, __float_as_uint(g[i][0])), b = __builtin_bit_cast(h2, 0x3c003c00u);
+                    f[i] = __builtin_amdgcn_fdot2(a, b, f[i], false);
+                }
                 if (KIND == 5) { const float t = f[i] * -1.4426950408889634f; const float e = __builtin_amdgcn_exp2f(t) + 1.0f; f[i] = f[i] * __builtin_amdgcn_rcpf(e) + 1.0f; }
             }
     }
@@ -59,6 +68,8 @@ int main() {
         run<3>(out, cyc, wps, 2, "v_exp_f32 + v_fma_f32");
         run<4>(out, cyc, wps, 2, "v_rcp_f32 + v_fma_f32");
         run<5>(out, cyc, wps, 5, "swish (mul exp add rcp fma)");
+        run<6>(out, cyc, wps, 1, "v_dot2c_f32_bf16");
+        run<7>(out, cyc, wps, 1, "v_dot2_f32_f16");
     }
     return 0;
 }
